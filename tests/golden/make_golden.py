@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by EXECUTING the reference's own modules.
+
+Run in the build container only (needs /root/reference; the GPU box has neither
+the reference nor any need for this script):
+
+    python tests/golden/make_golden.py
+
+The reference's model/{graph_functions,utils,model,seq2seq}.py are imported
+UNMODIFIED from /root/reference.  Third-party modules that are not installed
+here get small stand-ins:
+  numba.jit -> identity;  torch_geometric.data.Data -> attribute bag;
+  torch_geometric.nn.{ChebConv,GCNConv} -> oracle/qt_oracle.py's restatement of
+  the published PyG 2.2.0 definitions (so conv ARITHMETIC is "parity unpinned";
+  everything around it -- quadtree, adjacency, flatten/unflatten, GConvLSTM,
+  Encoder, Decoder, Seq2Seq control flow -- is the reference's own code);
+  tensorboard / torchviz -> no-ops.
+Only arrays (inputs and expected outputs) are written; no reference source.
+"""
+import os
+import sys
+import types
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'quadtree-mpnnlstm_amd'))
+from oracle import qt_oracle as O          # noqa: E402
+from qtmpnn import synthetic               # noqa: E402
+
+
+def install_standins():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+    mod('numba', jit=jit)
+
+    class Data:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        def to(self, *_a, **_k):
+            return self
+
+    class _Absent(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError('not part of the pinned path')
+
+    class MessagePassing(nn.Module):
+        def __init__(self, **k):
+            super().__init__()
+
+    class Linear(nn.Linear):
+        def __init__(self, i, o, bias=True, **k):
+            super().__init__(i, o, bias=bias)
+
+    pyg = mod('torch_geometric')
+    pyg.data = mod('torch_geometric.data', Data=Data)
+    pyg.nn = mod('torch_geometric.nn', ChebConv=O.ChebConv, GCNConv=O.GCNConv, TransformerConv=_Absent,
+                 GATConv=_Absent, GATv2Conv=_Absent, GraphConv=_Absent, MessagePassing=MessagePassing)
+    pyg.nn.conv = mod('torch_geometric.nn.conv', MessagePassing=MessagePassing)
+    pyg.nn.dense = mod('torch_geometric.nn.dense')
+    pyg.nn.dense.linear = mod('torch_geometric.nn.dense.linear', Linear=Linear)
+    pyg.nn.inits = mod('torch_geometric.nn.inits', glorot=lambda t: nn.init.xavier_uniform_(t),
+                       zeros=lambda t: nn.init.zeros_(t))
+    pyg.typing = mod('torch_geometric.typing', Adj=object, OptTensor=object, PairTensor=object)
+    pyg.utils = mod('torch_geometric.utils', add_self_loops=None, degree=None)
+    mod('torchviz', make_dot=lambda *a, **k: None)
+    try:
+        import torch.utils.tensorboard  # noqa: F401
+    except Exception:
+        mod('torch.utils.tensorboard', SummaryWriter=type('SummaryWriter', (), {
+            '__init__': lambda s, *a, **k: None, 'add_scalar': lambda s, *a, **k: None, 'flush': lambda s: None}))
+
+
+install_standins()
+sys.path.insert(0, '/root/reference')
+from model import graph_functions as RG    # noqa: E402  (the reference)
+from model import utils as RU              # noqa: E402
+from model import model as RM              # noqa: E402
+from model import seq2seq as RS            # noqa: E402
+
+
+def sort_edges(ei, attrs):
+    ei = ei.numpy()
+    order = np.lexsort((ei[1], ei[0]))
+    return ei[:, order].astype(np.int32), attrs.detach().numpy()[order]
+
+
+def dist_from_05(arr):
+    return abs(abs(arr - 0.5) - 0.5)
+
+
+def randomize(module, seed, scale=0.3, bscale=0.2):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in module.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (scale if p.dim() > 1 and p.shape[0] > 1 else bscale))
+        for name, p in module.named_parameters():
+            if 'norm' in name and name.endswith('weight'):
+                p.add_(1.0)
+
+
+def state_arrays(module, prefix):
+    return {prefix + k: v.detach().numpy() for k, v in module.state_dict().items()}
+
+
+# ------------------------------------------------------------------ known-answer tests
+def kats():
+    out = {}
+    img = np.zeros((8, 8), np.float32); img[1, 2] = 1
+    out['kat1_img'], out['kat1_labels'] = img, RG.quadtree_decompose(img, thresh=.5, max_size=4)
+    img = np.zeros((8, 8), np.float32); img[4, 0] = 1
+    out['kat2_img'], out['kat2_labels'] = img, RG.quadtree_decompose(img, thresh=.5, max_size=4)
+    img = np.zeros((6, 6), np.float32); img[5, 5] = 1
+    out['kat3_img'], out['kat3_labels'] = img, RG.quadtree_decompose(img, thresh=.5, max_size=4)
+    lab = np.array([[0, 0, 1], [2, 3, 3], [2, 3, 3]])
+    xx, yy = torch.tensor([.5, 2, 0, 1.5]), torch.tensor([0, 0, 1.5, 1.5])
+    ei, at = RG.get_adj(lab, xx, yy, use_edge_attrs=True)
+    out['kat4_labels'] = lab
+    out['kat4_edges_raw'] = ei.numpy()
+    out['kat4_edges'], out['kat4_attrs'] = sort_edges(ei, at)
+    mp, nodes, npx = RG.get_mapping(lab)
+    out['kat5_mapping'], out['kat5_npix'] = mp.to_dense().numpy(), npx.numpy()
+    for cond in RG.CONDITIONS:
+        rng = np.random.default_rng(7)
+        img = rng.random((16, 24)).astype(np.float32)
+        out['kat6_img'] = img
+        out['kat6_' + cond] = RG.quadtree_decompose(img, thresh=.9 if 'max' in cond else .1, max_size=8, condition=cond)
+    np.savez_compressed(os.path.join(HERE, 'kat.npz'), **out)
+
+
+# ------------------------------------------------------------------ graph-build cases
+def graph_case(name, x, thresh, mask=None, hir=None, transform=None, condition='max_larger_than', attrs=False):
+    """x: (ns, w, h, c) float32 without positional encoding."""
+    xt = RU.add_positional_encoding(torch.from_numpy(x))
+    g = RG.image_to_graph(xt, thresh=thresh, mask=mask, high_interest_region=hir, transform_func=transform,
+                          condition=condition, use_edge_attrs=attrs)
+    mapping = g['mapping'].numpy()
+    labels = np.where(mapping.sum(0) > 0, mapping.argmax(0), -1).reshape(x.shape[1:3])
+    ei, at = sort_edges(g['edge_index'], g['edge_attrs'])
+    out = dict(x=x, thresh=np.float64(thresh), labels=labels.astype(np.int32), npix=g['n_pixels_per_node'].numpy(),
+               data=g['data'].numpy(), edges=ei, attrs=at, condition=np.array(condition),
+               has_transform=np.array(transform is not None), use_attrs=np.array(attrs))
+    if mask is not None:
+        out['mask'] = mask
+    if hir is not None:
+        out['hir'] = hir
+    np.savez_compressed(os.path.join(HERE, f'graph_{name}.npz'), **out)
+    print(name, 'N =', len(out['npix']), 'E =', ei.shape[1])
+
+
+def graphs():
+    c = synthetic.make_clip(11, n_digits=1, n_frames=3, pixel_noise=0.0)
+    graph_case('64_1blob_clean', c, 0.1)
+    c = synthetic.make_clip(12, n_digits=1, n_frames=2, pixel_noise=0.05)
+    graph_case('64_1blob_noise', c, 0.1)
+    c = synthetic.make_clip(13, n_digits=2, n_frames=3, pixel_noise=0.0)
+    graph_case('64_2blob_clean_attrs', c, 0.1, attrs=True)
+    c = synthetic.make_clip(14, canvas=(128, 128), n_digits=2, n_frames=1, pixel_noise=0.0)
+    graph_case('128_2blob_clean', c, 0.1)
+    c = synthetic.make_clip(15, canvas=(100, 100), n_digits=2, n_frames=2, pixel_noise=0.0)
+    graph_case('100_2blob_clean', c, 0.1)
+    c = synthetic.make_clip(16, canvas=(128, 64), n_digits=1, n_frames=1, pixel_noise=0.0)  # swapaxes -> (64,128) wide
+    graph_case('64x128_wide', c, 0.1)
+    f, m = synthetic.make_ice_like(17, shape=(96, 96), channels=5, n_frames=2)
+    hir = np.zeros_like(m); hir[40:50, 60:75] = True
+    graph_case('96_ice_masked', f, 0.15, mask=m, hir=hir, transform=dist_from_05)
+    graph_case('96_ice_minsmaller', f[:1], 0.2, mask=m, condition='min_smaller_than')
+    graph_case('96_ice_maxsmaller', f[:1], 0.6, condition='max_smaller_than')
+
+
+# ------------------------------------------------------------------ flatten / unflatten
+def transfers():
+    c = synthetic.make_clip(21, n_digits=1, n_frames=2, pixel_noise=0.0)
+    xt = RU.add_positional_encoding(torch.from_numpy(c)).requires_grad_(True)
+    g = RG.image_to_graph(xt.detach(), thresh=0.1, use_edge_attrs=False)
+    mapping, npx = g['mapping'], g['n_pixels_per_node']
+    labels = mapping.numpy().argmax(0).reshape(64, 64).astype(np.int32)
+    flat = RG.flatten(xt, mapping, npx)
+    gy = torch.randn(flat.shape, generator=torch.Generator().manual_seed(1))
+    (gx,) = torch.autograd.grad(flat, xt, gy)
+    data = torch.randn(2, len(npx), 5, generator=torch.Generator().manual_seed(2)).requires_grad_(True)
+    img = RG.unflatten(data, mapping, (64, 64))
+    gi = torch.randn(img.shape, generator=torch.Generator().manual_seed(3))
+    (gd,) = torch.autograd.grad(img, data, gi)
+    np.savez_compressed(os.path.join(HERE, 'transfer.npz'), labels=labels, npix=npx.numpy(), img=xt.detach().numpy(),
+                        flat=flat.detach().numpy(), flat_gy=gy.numpy(), flat_gx=gx.numpy(), data=data.detach().numpy(),
+                        unflat=img.detach().numpy(), unflat_gi=gi.numpy(), unflat_gd=gd.numpy())
+
+
+# ------------------------------------------------------------------ cells
+def cells():
+    c = synthetic.make_clip(31, canvas=(64, 64), n_digits=1, n_frames=1, pixel_noise=0.0)
+    g = RG.image_to_graph(RU.add_positional_encoding(torch.from_numpy(c)), thresh=0.1, use_edge_attrs=False)
+    ei, ew = g['edge_index'], g['edge_attrs']
+    n = g['data'].shape[1]
+    labels = g['mapping'].numpy().argmax(0).reshape(64, 64).astype(np.int32)
+    sei, sew = sort_edges(ei, ew)
+    gen = torch.Generator().manual_seed(5)
+    out = dict(labels=labels, edges=sei, dist=sew)
+    for tag, n_conv in (('nc1', 1), ('nc2', 2), ('nc3', 3)):
+        cell = RM.GConvLSTM(4, 8, n_conv_layers=n_conv, convolution_type='ChebConv')
+        randomize(cell, 40 + n_conv)
+        X = torch.randn(n, 4, generator=gen).requires_grad_(True)
+        H = torch.randn(n, 8, generator=gen).requires_grad_(True)
+        C = torch.randn(n, 8, generator=gen).requires_grad_(True)
+        Oo, Hn, Cn = cell(X, ei, ew, H, C)
+        gO, gH, gC = (torch.randn(n, 8, generator=gen) for _ in range(3))
+        params = list(cell.parameters())
+        grads = torch.autograd.grad([Oo, Hn, Cn], [X, H, C] + params, [gO, gH, gC])
+        out.update({f'{tag}_X': X.detach().numpy(), f'{tag}_H': H.detach().numpy(), f'{tag}_C': C.detach().numpy(),
+                    f'{tag}_O': Oo.detach().numpy(), f'{tag}_Hn': Hn.detach().numpy(), f'{tag}_Cn': Cn.detach().numpy(),
+                    f'{tag}_gO': gO.numpy(), f'{tag}_gH': gH.numpy(), f'{tag}_gC': gC.numpy(),
+                    f'{tag}_gX': grads[0].numpy(), f'{tag}_gHin': grads[1].numpy(), f'{tag}_gCin': grads[2].numpy()})
+        out.update(state_arrays(cell, f'{tag}_w/'))
+        for (k, _), gr in zip(cell.named_parameters(), grads[3:]):
+            out[f'{tag}_g/{k}'] = gr.numpy()
+    # one Encoder step (2 layers, 2 conv layers) and one Decoder step with explicit concat
+    enc = RS.Encoder(4, 8, 0.0, n_layers=2, convolution_type='ChebConv', rnn_type='LSTM', n_conv_layers=2)
+    randomize(enc, 50)
+    X = torch.randn(1, n, 4, generator=gen)
+    H = torch.randn(n, 8, generator=gen)
+    C = torch.randn(n, 8, generator=gen)
+    hid, cel = enc(X, ei, ew, H=H, C=C)
+    out.update(enc_X=X.numpy(), enc_H=H.numpy(), enc_C=C.numpy(), enc_hidden=hid.detach().numpy(), enc_cell=cel.detach().numpy())
+    out.update(state_arrays(enc, 'enc_w/'))
+    dec = RS.Decoder(4, 8, 0.0, n_layers=2, concat_layers_dim=1, convolution_type='ChebConv', rnn_type='LSTM')
+    randomize(dec, 51)
+    dec.eval()
+    Xd = torch.randn(n, 4, generator=gen)
+    Hd = torch.randn(2, n, 8, generator=gen)
+    Cd = torch.randn(2, n, 8, generator=gen)
+    cl = torch.randn(n, 1, generator=gen)
+    o, hid, cel = dec(Xd, ei, ew, cl, Hd, Cd)
+    out.update(dec_X=Xd.numpy(), dec_H=Hd.numpy(), dec_C=Cd.numpy(), dec_concat=cl.numpy(), dec_out=o.detach().numpy(),
+               dec_hidden=hid.detach().numpy(), dec_cell=cel.detach().numpy())
+    out.update(state_arrays(dec, 'dec_w/'))
+    np.savez_compressed(os.path.join(HERE, 'cells.npz'), **out)
+
+
+# ------------------------------------------------------------------ full rollouts
+def rollout(name, x, y, concat, mask, hidden, n_layers, n_conv, thresh, t_in, t_out, transform=None, hir=None, seed=60,
+            scale=0.25, bscale=0.2):
+    in_feat = x.shape[-1] + 3
+    model = RS.Seq2Seq(hidden_size=hidden, dropout=0.0, thresh=thresh, input_timesteps=t_in, input_features=in_feat,
+                       output_timesteps=t_out, n_layers=n_layers, n_conv_layers=n_conv, transform_func=transform,
+                       convolution_type='ChebConv')
+    randomize(model, seed, scale=scale, bscale=bscale)
+    model.train()
+    xt, yt, ct = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(concat)
+    step_labels = []
+    orig = RG.image_to_graph
+
+    def spy(img, *a, **k):
+        g = orig(img, *a, **k)
+        mp = g['mapping'].numpy()
+        step_labels.append((np.where(mp.sum(0) > 0, mp.argmax(0), -1).reshape(img.shape[1:3]).astype(np.int32),
+                            img[0, ..., 0].detach().numpy().copy()))
+        return g
+    RS.image_to_graph = spy
+    try:
+        outs, maps = model(xt, yt, ct, teacher_forcing_ratio=0, mask=mask, high_interest_region=hir)
+    finally:
+        RS.image_to_graph = orig
+    shape = x.shape[1:3]
+    y_hat = torch.stack([RG.unflatten(outs[i], maps[i], shape, mask) for i in range(t_out)])   # mpnnlstm.py:243-244
+    mk = torch.from_numpy(mask)
+    loss = torch.nn.MSELoss()(y_hat[:, ~mk], yt[:, ~mk])                                        # mpnnlstm.py:246
+    loss.backward()
+    out = dict(x=x, y=y, concat=concat, mask=mask, thresh=np.float64(thresh), loss=np.float64(loss.item()),
+               y_hat=y_hat.detach().numpy(), hidden=np.int64(hidden), n_layers=np.int64(n_layers),
+               n_conv=np.int64(n_conv), has_transform=np.array(transform is not None))
+    if hir is not None:
+        out['hir'] = hir
+    for i, (lab, img) in enumerate(step_labels):
+        out[f'labels_{i}'] = lab
+        if i > 0:
+            out[f'image_{i}'] = img          # the image the mesh of step i was built from
+    for i, o in enumerate(outs):
+        out[f'out_{i}'] = o.detach().numpy()
+    out.update(state_arrays(model, 'w/'))
+    for k, p in model.named_parameters():
+        out['g/' + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f'rollout_{name}.npz'), **out)
+    print(name, 'loss', loss.item(), 'N per step', [len(o) for o in outs])
+
+
+def rollouts():
+    x, y = synthetic.make_batch(9, 0, 1, 4, 4, n_digits=1, pixel_noise=0.0)
+    mask = np.zeros((64, 64), dtype=bool)
+    concat = np.zeros((4, 64, 64, 1), np.float32)
+    rollout('mnist64_h16', x[0], y[0], concat, mask, hidden=16, n_layers=2, n_conv=2, thresh=0.1, t_in=4, t_out=4, scale=0.06,
+            bscale=0.02)
+    x, y = synthetic.make_batch(9, 5, 1, 3, 3, n_digits=1, pixel_noise=0.02, canvas=(64, 64))
+    concat = (0.1 * np.random.default_rng(3).random((3, 64, 64, 1))).astype(np.float32)
+    rollout('mnist64_noise_h8', x[0], y[0], concat, mask, hidden=8, n_layers=1, n_conv=1, thresh=0.1, t_in=3, t_out=3, seed=61)
+    f, m = synthetic.make_ice_like(18, shape=(64, 64), channels=3, n_frames=5)
+    concat = f[2:5, ..., :1].copy() * 0.5
+    rollout('ice64_masked_h8', f[:2], f[2:5, ..., :1].copy(), concat, m, hidden=8, n_layers=1, n_conv=3, thresh=0.15,
+            t_in=2, t_out=3, transform=dist_from_05, seed=62, scale=0.1)
+
+
+if __name__ == '__main__':
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    kats()
+    graphs()
+    transfers()
+    cells()
+    rollouts()
+    print('golden vectors written to', HERE)

@@ -1,0 +1,161 @@
+"""The CPU oracle against golden vectors captured by executing the reference
+(tests/golden/make_golden.py).  Integer results are compared bit-exactly, fp32
+results at rtol 1e-4 (north_star tolerance)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qt_oracle as O
+
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def dist_from_05(arr):
+    return abs(abs(arr - 0.5) - 0.5)
+
+
+def test_kat_quadtree(golden_dir):
+    k = load(golden_dir, 'kat.npz')
+    for i in (1, 2, 3):
+        lab = O.quadtree_decompose(k[f'kat{i}_img'], thresh=.5, max_size=4)
+        assert np.array_equal(lab, k[f'kat{i}_labels'])
+    # SURVEY.md KAT-1 literal (first rows) as an independent anchor
+    assert k['kat1_labels'][0].tolist() == [12, 10, 7, 5, 2, 2, 2, 2]
+    for cond in O.CONDITIONS:
+        lab = O.quadtree_decompose(k['kat6_img'], thresh=.9 if 'max' in cond else .1, max_size=8, condition=cond)
+        assert np.array_equal(lab, k['kat6_' + cond]), cond
+
+
+def test_kat_adjacency_and_mapping(golden_dir):
+    k = load(golden_dir, 'kat.npz')
+    e = O.adjacency_sorted(k['kat4_labels'])
+    assert np.array_equal(e, k['kat4_edges'])
+    xx, yy = torch.tensor([.5, 2, 0, 1.5]), torch.tensor([0, 0, 1.5, 1.5])
+    et = torch.as_tensor(e)
+    np.testing.assert_allclose(O.edge_angle(et[0], et[1], xx, yy), k['kat4_attrs'][:, 0], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(O.edge_dist(et[0], et[1], xx, yy), k['kat4_attrs'][:, 1], rtol=RTOL, atol=ATOL)
+    assert np.array_equal(O.dense_mapping(k['kat4_labels']), k['kat5_mapping'])
+    assert np.array_equal(O.pixel_counts(k['kat4_labels']), k['kat5_npix'])
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'graph_*.npz'))),
+                         ids=lambda p: os.path.basename(p)[6:-4])
+def test_graph_build(path):
+    g = np.load(path, allow_pickle=False)
+    x = O.add_positional_encoding(torch.from_numpy(g['x']))
+    mask = g['mask'] if 'mask' in g else None
+    hir = g['hir'] if 'hir' in g else None
+    out = O.image_to_graph(x, thresh=float(g['thresh']), mask=mask, high_interest_region=hir,
+                           transform_func=dist_from_05 if bool(g['has_transform']) else None,
+                           condition=str(g['condition']), use_edge_attrs=bool(g['use_attrs']))
+    assert np.array_equal(out['labels'], g['labels'])
+    assert np.array_equal(out['n_pixels_per_node'].numpy(), g['npix'])
+    assert np.array_equal(out['edge_index'].numpy(), g['edges'])
+    np.testing.assert_allclose(out['data'].numpy(), g['data'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out['edge_attrs'].numpy(), g['attrs'], rtol=RTOL, atol=ATOL)
+
+
+def test_flatten_unflatten(golden_dir):
+    t = load(golden_dir, 'transfer.npz')
+    img = torch.from_numpy(t['img']).requires_grad_(True)
+    flat = O.flatten(img, t['labels'], t['npix'])
+    np.testing.assert_allclose(flat.detach().numpy(), t['flat'], rtol=RTOL, atol=ATOL)
+    (gx,) = torch.autograd.grad(flat, img, torch.from_numpy(t['flat_gy']))
+    np.testing.assert_allclose(gx.numpy(), t['flat_gx'], rtol=RTOL, atol=ATOL)
+    data = torch.from_numpy(t['data']).requires_grad_(True)
+    im = O.unflatten(data, t['labels'], (64, 64))
+    np.testing.assert_allclose(im.detach().numpy(), t['unflat'], rtol=RTOL, atol=ATOL)
+    (gd,) = torch.autograd.grad(im, data, torch.from_numpy(t['unflat_gi']))
+    np.testing.assert_allclose(gd.numpy(), t['unflat_gd'], rtol=RTOL, atol=1e-4)
+
+
+def _load_state(module, g, prefix):
+    sd = {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+    module.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.parametrize('n_conv', [1, 2, 3])
+def test_gconvlstm_cell(golden_dir, n_conv):
+    g = load(golden_dir, 'cells.npz')
+    tag = f'nc{n_conv}'
+    cell = O.GConvLSTM(4, 8, n_conv, 'ChebConv')
+    _load_state(cell, g, f'{tag}_w/')
+    ei, ew = torch.from_numpy(g['edges']).long(), torch.from_numpy(g['dist'])
+    X, H, C = (torch.from_numpy(g[f'{tag}_{n}']).requires_grad_(True) for n in 'XHC')
+    Oo, Hn, Cn = cell(X, ei, ew, H, C)
+    for got, name in ((Oo, 'O'), (Hn, 'Hn'), (Cn, 'Cn')):
+        np.testing.assert_allclose(got.detach().numpy(), g[f'{tag}_{name}'], rtol=RTOL, atol=ATOL)
+    names = [k for k, _ in cell.named_parameters()]
+    grads = torch.autograd.grad([Oo, Hn, Cn], [X, H, C] + list(cell.parameters()),
+                                [torch.from_numpy(g[f'{tag}_g{n}']) for n in 'OHC'])
+    for got, name in zip(grads[:3], ('gX', 'gHin', 'gCin')):
+        np.testing.assert_allclose(got.numpy(), g[f'{tag}_{name}'], rtol=1e-3, atol=1e-4)
+    for got, k in zip(grads[3:], names):
+        ref = g[f'{tag}_g/{k}']
+        np.testing.assert_allclose(got.numpy(), ref, rtol=1e-3, atol=1e-4 * max(1.0, np.abs(ref).max()))
+
+
+def test_encoder_decoder_step(golden_dir):
+    g = load(golden_dir, 'cells.npz')
+    ei, ew = torch.from_numpy(g['edges']).long(), torch.from_numpy(g['dist'])
+    enc = O.Encoder(4, 8, 2, 'ChebConv', 2)
+    _load_state(enc, g, 'enc_w/')
+    hid, cel = enc(torch.from_numpy(g['enc_X'])[0], ei, ew, torch.from_numpy(g['enc_H']), torch.from_numpy(g['enc_C']))
+    np.testing.assert_allclose(hid.detach().numpy(), g['enc_hidden'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(cel.detach().numpy(), g['enc_cell'], rtol=RTOL, atol=ATOL)
+    dec = O.Decoder(4, 8, 0.0, 2, 1, 'ChebConv')
+    _load_state(dec, g, 'dec_w/')
+    out, hid, cel = dec(torch.from_numpy(g['dec_X']), ei, ew, torch.from_numpy(g['dec_concat']),
+                        torch.from_numpy(g['dec_H']), torch.from_numpy(g['dec_C']))
+    np.testing.assert_allclose(out.detach().numpy(), g['dec_out'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hid.detach().numpy(), g['dec_hidden'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(cel.detach().numpy(), g['dec_cell'], rtol=RTOL, atol=ATOL)
+
+
+def oracle_rollout(g):
+    x, y, concat = (torch.from_numpy(g[k]) for k in ('x', 'y', 'concat'))
+    model = O.Seq2Seq(int(g['hidden']), 0.0, float(g['thresh']), input_timesteps=x.shape[0], input_features=x.shape[-1] + 3,
+                      output_timesteps=y.shape[0], n_layers=int(g['n_layers']), n_conv_layers=int(g['n_conv']),
+                      transform_func=dist_from_05 if bool(g['has_transform']) else None)
+    _load_state(model, g, 'w/')
+    hir = g['hir'] if 'hir' in g.files else None
+    outs, maps, trace = model(x, concat, mask=g['mask'], high_interest_region=hir)
+    loss = O.clip_loss(outs, maps, y, x.shape[1:3], g['mask'])
+    return model, outs, maps, trace, loss
+
+
+@pytest.mark.parametrize('name', ['mnist64_h16', 'mnist64_noise_h8', 'ice64_masked_h8'])
+def test_rollout(golden_dir, name):
+    g = load(golden_dir, f'rollout_{name}.npz')
+    model, outs, maps, trace, loss = oracle_rollout(g)
+    for i, lab in enumerate(trace['labels']):
+        assert np.array_equal(lab, g[f'labels_{i}']), f'mesh {i}'
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().numpy(), g[f'out_{i}'], rtol=RTOL, atol=ATOL)
+    assert abs(float(loss.detach()) - float(g['loss'])) <= RTOL * abs(float(g['loss']))
+    loss.backward()
+    for k, p in model.named_parameters():
+        ref = g['g/' + k]
+        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=1e-3, atol=1e-4 * max(1e-3, np.abs(ref).max()), err_msg=k)
+
+
+def test_cheb_conv_self_consistency(golden_dir):
+    """PyG arithmetic is parity-unpinned (oracle header): cross-check the restated ChebConv
+    against an independent dense float64 formulation."""
+    g = load(golden_dir, 'cells.npz')
+    ei, ew = torch.from_numpy(g['edges']).long(), torch.from_numpy(g['dist'])
+    n = int(ei.max()) + 1
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(n, 5, generator=gen)
+    ws = [torch.randn(7, 5, generator=gen) for _ in range(3)]
+    b = torch.randn(7, generator=gen)
+    a = O.cheb_conv(x, ei, ew, ws, b)
+    d = O.cheb_conv_dense(x, ei, ew, ws, b)
+    np.testing.assert_allclose(a.numpy(), d.numpy(), rtol=1e-4, atol=1e-4)
