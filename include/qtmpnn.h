@@ -1,0 +1,168 @@
+/*
+ * qtmpnn.h -- C ABI of libqtmpnn_hip.so: the MI355X (gfx950) kernels behind the
+ * Quadtree-MPNNLSTM training hot path.
+ *
+ * The reference (zach-gousseau/Quadtree-MPNNLSTM) is pure Python and has no FFI;
+ * each entry below names the reference function whose arithmetic it replaces
+ * (file:line into the reference tree).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; the caller owns all
+ *     memory, the library never allocates or frees;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
+ *     never synchronises and keeps no global state besides the last-error text;
+ *   - return value 0 = ok, negative = QT_E_* ; qt_last_error() gives the text;
+ *   - fp32 data, int32 indices; node-feature matrices are row-major (N, C);
+ *   - a "mesh" is the block-diagonal quadtree graph of B clips:
+ *       labels (B, n, m) int32   global node id of every pixel, -1 = masked
+ *       level  (B, n, m) uint8   log2(cell size) of the pixel's leaf
+ *       cell   (N, 4)    int32   {row0, col0, size, clip} of every node
+ *       rowptr (N+1), col (E), nrm (E)   CSR of L^ = -D^-1/2 W D^-1/2 (no self loops)
+ */
+#ifndef QTMPNN_H
+#define QTMPNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QT_OK 0
+#define QT_E_ARG (-1)     /* bad argument (shape, alignment, null pointer) */
+#define QT_E_LAUNCH (-2)  /* HIP launch error */
+
+#define QT_COND_MAX_LARGER 0
+#define QT_COND_MAX_SMALLER 1
+#define QT_COND_MIN_LARGER 2
+#define QT_COND_MIN_SMALLER 3
+
+#define QT_ACT_NONE 0
+#define QT_ACT_RELU 1
+#define QT_ACT_TANH_RES 2 /* y = tanh(drop * acc) + res */
+
+const char* qt_last_error(void);
+int qt_abi_version(void);
+
+/* ---------------------------------------------------------------- mesh build
+ * quadtree_decompose, model/graph_functions.py:145-259 (+ get_mapping :555-587).
+ *
+ * Stage 1: one workgroup per base cell.  Criterion value of padded pixel (r, c):
+ *   src != NULL : src[b][min(r, src_rows-1)][min(c, src_cols-1)]          (edge padding, :190)
+ *   src == NULL : nodeval[old_labels[b][r'][c']] (0 where the old label is -1), r' = min(r, n-1) ...
+ *                 i.e. the un-flattened previous output (seq2seq.py:440) without materialising it.
+ * Writes per-pixel local leaf ids / levels and one leaf count per base cell in
+ * DFS order (cnt, length B * nbase).  Stage 2 (qt_scan_i32) turns cnt into
+ * offsets; stage 3 writes labels, level, cell and counts[0] = N.
+ * mask / hir: (n, m) uint8 or NULL, shared by all clips.
+ * Requires ceil(n/max_size) <= ceil(m/max_size) padded sizes n_pad <= m_pad (the reference
+ * raises IndexError otherwise, :222-229).
+ */
+int qt_quadtree_stage1(const float* src, int src_rows, int src_cols,
+                       const float* nodeval, const int32_t* old_labels,
+                       int B, int n, int m, int max_size, float thresh, int condition,
+                       const uint8_t* mask, const uint8_t* hir,
+                       int32_t* local_id /* (B,n,m) */, uint8_t* level /* (B,n,m) */,
+                       int32_t* cnt /* (B*nbase) */, void* stream);
+int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_offsets /* exclusive scan of cnt, length B*nbase+1 */,
+                       int B, int n, int m, int max_size,
+                       int32_t* labels /* (B,n,m) */, const uint8_t* level, int32_t* cell /* (Nmax,4) */,
+                       int32_t* node_off /* (B+1) */, void* stream);
+
+/* exclusive scan: out[0]=0, out[i+1]=sum(in[0..i]); len+1 outputs.  tmp: (len/1024+2) int32. */
+int qt_scan_i32(const int32_t* in, int32_t* out, int64_t len, int32_t* tmp, void* stream);
+
+/* static node features {col centroid / m, row centroid / n, npix / size_norm} (image_to_graph :657-668,
+ * utils.py:37-45) and npix; feat (N, 3), npix (N). */
+int qt_node_features(const int32_t* cell, int N, int n, int m, float size_norm, float* feat, float* npix, void* stream);
+
+/* ---------------------------------------------------------------- adjacency
+ * get_adj + dist, model/graph_functions.py:261-363, and the ChebConv normalisation that PyG
+ * recomputes in every conv call (torch_geometric ChebConv.__norm__, restated in oracle/).
+ * stage1 counts distinct neighbours per (node, side) -> cnt4 (4N); scan; stage2 fills col and
+ * w = centroid distance * resolution; stage3 computes deg, dis and nrm = -dis_i w dis_j.
+ */
+int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, int n, int m, int32_t* cnt4, void* stream);
+int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* off4 /* scan of cnt4, 4N+1 */,
+                  int N, int n, int m, float resolution,
+                  int32_t* rowptr /* N+1 */, int32_t* col, float* w, void* stream);
+int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, int N, float* dis /* N */, float* nrm, void* stream);
+
+/* ---------------------------------------------------------------- mesh <-> image transfers
+ * flatten / unflatten, model/graph_functions.py:391-419, 451-458, by labels instead of the dense
+ * (N, P) mapping.
+ *
+ * qt_gather: img[b,p,:] = scale_p * val[labels[b,p], :]  (0 where label < 0);
+ *            scale_p = 1/npix[label] if inv_npix != NULL (the flatten backward) else 1.
+ * qt_pool:   out[node, coff:coff+C] = sum over the node's pixels of value(p) (* 1/npix[node] if mean)
+ *            value(p) = img[b, s, p, c] (src_labels == NULL; img laid out (B, S, n*m, C), out row = s*N + node)
+ *                     = src_val[src_labels[b,p], c] * (src_inv ? 1/src_npix[..] : 1)     (remesh transfer,
+ *                       seq2seq.py:440-442 + :474-477 fused; its backward swaps the roles of the meshes).
+ * One workgroup per 64x64 tile and clip; deterministic (no atomics).
+ */
+int qt_gather(const float* val, int C, const int32_t* labels, const float* inv_npix,
+              int64_t npixels_total, float* img, void* stream);
+int qt_pool(const float* img, int S, const float* src_val, const int32_t* src_labels, const float* src_npix, int src_inv,
+            int C, const int32_t* labels, const uint8_t* level, const float* npix, int mean,
+            int B, int n, int m, int N, float* out, int out_stride, int out_coff, void* stream);
+
+/* masked MSE, model/mpnnlstm.py:243-246: partial[b*ntile + tile] = sum over the tile's unmasked pixels of
+ * (out[labels[p]] - y[p])^2 ; y (B, n*m).  Pixels with label < 0 are the masked ones. */
+int qt_sse(const float* out, int out_stride, const int32_t* labels, const float* y, int64_t y_clip_stride,
+           int B, int n, int m, float* partial /* B*ceil(P/1024) */, void* stream);
+
+/* ---------------------------------------------------------------- message passing (ChebConv)
+ * qt_spmm (the message-aggregate kernel; PyG MessagePassing.propagate of ChebConv, model/model.py:53,96):
+ *   out[i,:] = alpha * sum_e nrm[e] * x[col[e],:] + beta * p[i,:] + gamma * q[i,:]      (p, q may be NULL)
+ * x, out, p, q: (N, C) contiguous planes; out must not alias x (it may alias p or q).
+ */
+int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, int C,
+            const float* x, float alpha, const float* p, float beta, const float* q, float gamma,
+            float* out, void* stream);
+
+/* qt_dense: out planes = act( [A planes | S] @ [W ; Ws] ), the gate GEMM.
+ *   A: Ka planes, plane k at a0 (k == 0) or a_rest + (k-1)*N*Ca, each (N, Ca)   (T_0 = Z stays in the caller's tensor)
+ *   W: (Ka*Ca, Kb*Cb) row-major;  S: (N, Ks) or NULL with Ws (Ks, Kb*Cb)
+ *   out: Kb planes of (N, Cb) at out + j*N*Cb
+ *   act: QT_ACT_* applied to the result (only with Kb == 1); res (N) / drop (N) for QT_ACT_TANH_RES, drop may be NULL.
+ */
+int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, const float* W,
+             const float* S, int Ks, const float* Ws, int Kb, int Cb, int N,
+             int act, const float* res, int res_stride, const float* drop, float* out, void* stream);
+
+/* qt_wgrad: partial sums of [A planes | S]^T @ G over row blocks, then qt_colsum over the blocks.
+ *   G (N, Co); part (nblk, Ka*Ca + Ks, Co) with nblk = qt_wgrad_blocks(N).  */
+int qt_wgrad_blocks(int N);
+int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, const float* S, int Ks,
+             const float* G, int Co, int N, float* part, void* stream);
+/* out[j] = sum_i part[i*len + j], i < nblk */
+int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream);
+
+/* ---------------------------------------------------------------- GConvLSTM cell + LayerNorm
+ * GConvLSTM gate arithmetic model/model.py:394-428 with the encoder/decoder LayerNorms of
+ * model/seq2seq.py:64-75,140-151 fused (eps 1e-5).
+ *   G (N, 4h) gate pre-activations in the order i, f, c, o (conv_x + conv_h sums);
+ *   Cprev (N, h) or NULL (zeros); wc (3, h) peepholes i, f, o; b (4, h);
+ *   ln (4, h): gamma_h, beta_h, gamma_c, beta_c, or NULL for the bare cell (Hn = H', Cn = C').
+ * Outputs: O (N, h) raw output gate, Hn / Cn (N, h) LayerNorm'ed states,
+ *   gates (N, 4h) activated I, F, T, O and Craw (N, h) saved for the backward.
+ */
+int qt_lstm_fwd(const float* G, const float* Cprev, const float* wc, const float* b, const float* ln,
+                int N, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw, void* stream);
+/* gO may be NULL.  part: (nblk, 11*h) partial sums [g_wc(3h) | g_b(4h) | g_ln(4h)], nblk = qt_lstm_bwd_blocks(N, h) */
+int qt_lstm_bwd_blocks(int N, int h);
+int qt_lstm_bwd(const float* gO, const float* gHn, const float* gCn,
+                const float* gates, const float* Craw, const float* Cprev, const float* wc, const float* ln,
+                int N, int h, float* gG, float* gCprev, float* part, void* stream);
+
+/* decoder head input, model/seq2seq.py:160-165: Z (N, hp) = [relu(LayerNorm_o(O)) | concat | 0...], hp >= h+1 */
+int qt_head_fwd(const float* O, const float* ln_o /* (2,h) */, const float* concat /* (N) or NULL */,
+                int N, int h, int hp, float* Z, void* stream);
+/* gO (N,h), gconcat (N) or NULL; part (nblk, 2h) partial sums of g_ln_o, nblk = qt_lstm_bwd_blocks(N, h) */
+int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, int h, int hp,
+                float* gO, float* gconcat, float* part, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QTMPNN_H */

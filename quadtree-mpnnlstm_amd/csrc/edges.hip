@@ -1,0 +1,131 @@
+// Mesh adjacency as CSR, emitted on the device with no sort.
+// Replaces get_adj + dist (model/graph_functions.py:261-363) and the per-call ChebConv
+// normalisation of PyG (restated in oracle/qt_oracle.py:cheb_norm).
+//
+// A quadtree leaf is a square, so each neighbour touches exactly one of its four sides
+// in one contiguous run: one thread per (node, side) walks the pixels just outside that
+// side and counts label changes.  A prefix sum over the 4N counts is the CSR row
+// pointer, a second walk fills columns and centroid distances.  Self pairs (n, n),
+// which the reference emits for multi-pixel cells, carry weight 0 in every supported
+// convolution and are not stored (the Python mirror re-creates them for edge_index).
+#include "qt_common.h"
+
+namespace {
+
+struct SideWalk {
+    int b, r, c, dr, dc, len;
+};
+
+__device__ __forceinline__ SideWalk side_walk(int4 cl, int side, int n, int m) {
+    SideWalk w;
+    w.b = cl.w;
+    const int hh = min(cl.x + cl.z, n) - cl.x, ww = min(cl.y + cl.z, m) - cl.y;
+    w.len = 0;
+    w.r = w.c = w.dr = w.dc = 0;
+    if (side == 0) {  // row above
+        if (cl.x > 0) { w.r = cl.x - 1; w.c = cl.y; w.dc = 1; w.len = ww; }
+    } else if (side == 1) {  // row below
+        if (cl.x + cl.z < n) { w.r = cl.x + cl.z; w.c = cl.y; w.dc = 1; w.len = ww; }
+    } else if (side == 2) {  // column to the left
+        if (cl.y > 0) { w.r = cl.x; w.c = cl.y - 1; w.dr = 1; w.len = hh; }
+    } else {  // column to the right
+        if (cl.y + cl.z < m) { w.r = cl.x; w.c = cl.y + cl.z; w.dr = 1; w.len = hh; }
+    }
+    return w;
+}
+
+__device__ __forceinline__ void centroid(int4 cl, int n, int m, float res, float* xx, float* yy) {
+    const int hh = min(cl.x + cl.z, n) - cl.x, ww = min(cl.y + cl.z, m) - cl.y;
+    *xx = ((float)cl.y + 0.5f * (float)(ww - 1)) * res;
+    *yy = ((float)cl.x + 0.5f * (float)(hh - 1)) * res;
+}
+
+__global__ void k_edges_count(const int32_t* __restrict__ labels, const int32_t* __restrict__ cell, int N, int n, int m,
+                              int32_t* __restrict__ cnt4) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4 * N) return;
+    const int4 cl = reinterpret_cast<const int4*>(cell)[idx >> 2];
+    const SideWalk w = side_walk(cl, idx & 3, n, m);
+    const int32_t* L = labels + (int64_t)w.b * n * m;
+    int prev = -1, cnt = 0;
+    for (int k = 0; k < w.len; ++k) {
+        const int lab = L[(int64_t)(w.r + k * w.dr) * m + (w.c + k * w.dc)];
+        if (lab >= 0 && lab != prev) ++cnt;
+        prev = lab;
+    }
+    cnt4[idx] = cnt;
+}
+
+__global__ void k_edges_fill(const int32_t* __restrict__ labels, const int32_t* __restrict__ cell,
+                             const int32_t* __restrict__ off4, int N, int n, int m, float res,
+                             int32_t* __restrict__ rowptr, int32_t* __restrict__ col, float* __restrict__ wgt) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) rowptr[N] = off4[4 * N];
+    if (idx >= 4 * N) return;
+    const int node = idx >> 2;
+    const int4 cl = reinterpret_cast<const int4*>(cell)[node];
+    if ((idx & 3) == 0) rowptr[node] = off4[idx];
+    const SideWalk w = side_walk(cl, idx & 3, n, m);
+    const int32_t* L = labels + (int64_t)w.b * n * m;
+    float xx, yy;
+    centroid(cl, n, m, res, &xx, &yy);
+    int prev = -1, e = off4[idx];
+    for (int k = 0; k < w.len; ++k) {
+        const int lab = L[(int64_t)(w.r + k * w.dr) * m + (w.c + k * w.dc)];
+        if (lab >= 0 && lab != prev) {
+            float x2, y2;
+            centroid(reinterpret_cast<const int4*>(cell)[lab], n, m, res, &x2, &y2);
+            col[e] = lab;
+            wgt[e] = sqrtf((yy - y2) * (yy - y2) + (xx - x2) * (xx - x2));
+            ++e;
+        }
+        prev = lab;
+    }
+}
+
+__global__ void k_edges_deg(const int32_t* __restrict__ rowptr, const float* __restrict__ w, int N, float* __restrict__ dis) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float deg = 0.0f;
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) deg += w[e];
+    dis[i] = deg > 0.0f ? 1.0f / sqrtf(deg) : 0.0f;
+}
+
+__global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
+                            const float* __restrict__ dis, int N, float* __restrict__ nrm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float di = dis[i];
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) nrm[e] = -(di * w[e] * dis[col[e]]);
+}
+
+}  // namespace
+
+extern "C" int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, int n, int m, int32_t* cnt4, void* stream) {
+    QT_ARG(labels && cell && cnt4, "null pointer");
+    if (N <= 0) return QT_OK;
+    hipLaunchKernelGGL(k_edges_count, dim3(qt_cdiv(4 * (int64_t)N, 256)), dim3(256), 0, (hipStream_t)stream, labels, cell,
+                       N, n, m, cnt4);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* off4, int N, int n, int m,
+                             float resolution, int32_t* rowptr, int32_t* col, float* w, void* stream) {
+    QT_ARG(labels && cell && off4 && rowptr && col && w, "null pointer");
+    if (N <= 0) return QT_OK;
+    hipLaunchKernelGGL(k_edges_fill, dim3(qt_cdiv(4 * (int64_t)N, 256)), dim3(256), 0, (hipStream_t)stream, labels, cell,
+                       off4, N, n, m, resolution, rowptr, col, w);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, int N, float* dis, float* nrm,
+                             void* stream) {
+    QT_ARG(rowptr && col && w && dis && nrm, "null pointer");
+    if (N <= 0) return QT_OK;
+    hipLaunchKernelGGL(k_edges_deg, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, w, N, dis);
+    hipLaunchKernelGGL(k_edges_nrm, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, w, dis, N, nrm);
+    QT_LAUNCHED();
+    return QT_OK;
+}

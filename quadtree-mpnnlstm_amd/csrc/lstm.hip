@@ -1,0 +1,343 @@
+// Peephole graph-LSTM cell (model/model.py:394-428) fused with the LayerNorms the
+// encoder / decoder apply to H' and C' (model/seq2seq.py:64-75, 140-151), and the decoder
+// head's norm_o + relu + concat (model/seq2seq.py:160-165).
+//
+// A node's h channels are spread over h/4 adjacent lanes (float4 each); LayerNorm
+// statistics are xor-shuffle reductions inside that lane group.  Parameter gradients are
+// accumulated per thread, reduced over the wave with shuffles and over the workgroup
+// through LDS in a fixed order, and leave as one partial row per workgroup.
+#include "qt_common.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int LPN>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int d = 1; d < LPN; d <<= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+struct F4 {
+    float v[4];
+};
+__device__ __forceinline__ F4 ld4(const float* p) {
+    const float4 f = *reinterpret_cast<const float4*>(p);
+    return F4{{f.x, f.y, f.z, f.w}};
+}
+__device__ __forceinline__ void st4(float* p, const F4& a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+
+// y = gamma * xhat + beta over the group's h values; returns xhat and rstd
+template <int LPN>
+__device__ __forceinline__ void layer_norm(const F4& x, int h, F4* xhat, float* rstd) {
+    const float mean = group_sum<LPN>((x.v[0] + x.v[1]) + (x.v[2] + x.v[3])) / (float)h;
+    float sq = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float d = x.v[k] - mean;
+        sq += d * d;
+    }
+    const float var = group_sum<LPN>(sq) / (float)h;
+    *rstd = 1.0f / sqrtf(var + LN_EPS);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xhat->v[k] = (x.v[k] - mean) * (*rstd);
+}
+
+// gx = rstd * (gxh - mean(gxh) - xhat * mean(gxh * xhat)),  gxh = gy * gamma
+template <int LPN>
+__device__ __forceinline__ F4 layer_norm_bwd(const F4& gy, const F4& gamma, const F4& xhat, float rstd, int h) {
+    F4 gxh;
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        gxh.v[k] = gy.v[k] * gamma.v[k];
+        s1 += gxh.v[k];
+        s2 += gxh.v[k] * xhat.v[k];
+    }
+    s1 = group_sum<LPN>(s1) / (float)h;
+    s2 = group_sum<LPN>(s2) / (float)h;
+    F4 gx;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gx.v[k] = rstd * (gxh.v[k] - s1 - xhat.v[k] * s2);
+    return gx;
+}
+
+template <int LPN>
+__global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, const float* __restrict__ Cprev,
+                                                  const float* __restrict__ wc, const float* __restrict__ b,
+                                                  const float* __restrict__ ln, int N, int h, float* __restrict__ O,
+                                                  float* __restrict__ Hn, float* __restrict__ Cn,
+                                                  float* __restrict__ gates, float* __restrict__ Craw) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t node = gid / LPN;
+    if (node >= N) return;
+    const int j0 = (int)(gid % LPN) * 4;
+    const float* g = G + node * 4 * h + j0;
+    const F4 gi = ld4(g), gf = ld4(g + h), gc = ld4(g + 2 * h), go = ld4(g + 3 * h);
+    F4 cp = {{0, 0, 0, 0}};
+    if (Cprev) cp = ld4(Cprev + node * h + j0);
+    const F4 wci = ld4(wc + j0), wcf = ld4(wc + h + j0), wco = ld4(wc + 2 * h + j0);
+    const F4 bi = ld4(b + j0), bf = ld4(b + h + j0), bc = ld4(b + 2 * h + j0), bo = ld4(b + 3 * h + j0);
+    F4 I, F, T, Og, Cr, Hr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        I.v[k] = sigmoidf_(gi.v[k] + wci.v[k] * cp.v[k] + bi.v[k]);
+        F.v[k] = sigmoidf_(gf.v[k] + wcf.v[k] * cp.v[k] + bf.v[k]);
+        T.v[k] = tanhf(gc.v[k] + bc.v[k]);
+        Cr.v[k] = F.v[k] * cp.v[k] + I.v[k] * T.v[k];
+        Og.v[k] = sigmoidf_(go.v[k] + wco.v[k] * Cr.v[k] + bo.v[k]);
+        Hr.v[k] = Og.v[k] * tanhf(Cr.v[k]);
+    }
+    F4 hn = Hr, cn = Cr;
+    if (ln) {
+        F4 xh, xc;
+        float rh, rc;
+        layer_norm<LPN>(Hr, h, &xh, &rh);
+        layer_norm<LPN>(Cr, h, &xc, &rc);
+        const F4 gh = ld4(ln + j0), bh = ld4(ln + h + j0), gcn = ld4(ln + 2 * h + j0), bcn = ld4(ln + 3 * h + j0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hn.v[k] = gh.v[k] * xh.v[k] + bh.v[k];
+            cn.v[k] = gcn.v[k] * xc.v[k] + bcn.v[k];
+        }
+    }
+    st4(O + node * h + j0, Og);
+    st4(Hn + node * h + j0, hn);
+    st4(Cn + node * h + j0, cn);
+    float* gs = gates + node * 4 * h + j0;
+    st4(gs, I);
+    st4(gs + h, F);
+    st4(gs + 2 * h, T);
+    st4(gs + 3 * h, Og);
+    st4(Craw + node * h + j0, Cr);
+}
+
+// reduce NACC*4 per-thread accumulators over the workgroup; lane group layout as above
+template <int LPN, int NACC>
+__device__ __forceinline__ void block_param_reduce(float (&acc)[NACC][4], int h, float* sm, float* part_row) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = acc[a][k];
+#pragma unroll
+            for (int d = LPN; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+            acc[a][k] = v;
+        }
+    if (lane < LPN) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sm[(wave * LPN + lane) * NACC * 4 + a * 4 + k] = acc[a][k];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NACC * h; idx += 256) {
+        const int a = idx / h, j = idx % h;
+        const int li = j >> 2, k = j & 3;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += sm[(w * LPN + li) * NACC * 4 + a * 4 + k];
+        part_row[idx] = s;
+    }
+}
+
+template <int LPN>
+__global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, const float* __restrict__ gHn,
+                                                  const float* __restrict__ gCn, const float* __restrict__ gates,
+                                                  const float* __restrict__ Craw, const float* __restrict__ Cprev,
+                                                  const float* __restrict__ wc, const float* __restrict__ ln, int N, int h,
+                                                  float* __restrict__ gG, float* __restrict__ gCprev,
+                                                  float* __restrict__ part) {
+    __shared__ float sm[4 * LPN * 11 * 4];
+    const int j0 = (threadIdx.x % LPN) * 4;
+    const F4 wci = ld4(wc + j0), wcf = ld4(wc + h + j0), wco = ld4(wc + 2 * h + j0);
+    F4 gam_h = {{1, 1, 1, 1}}, gam_c = {{1, 1, 1, 1}};
+    if (ln) {
+        gam_h = ld4(ln + j0);
+        gam_c = ld4(ln + 2 * h + j0);
+    }
+    float acc[11][4];
+#pragma unroll
+    for (int a = 0; a < 11; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[a][k] = 0.0f;
+
+    const int64_t stride = (int64_t)gridDim.x * (256 / LPN);
+    for (int64_t node = (int64_t)blockIdx.x * (256 / LPN) + threadIdx.x / LPN; node < N; node += stride) {
+        const float* gs = gates + node * 4 * h + j0;
+        const F4 I = ld4(gs), F = ld4(gs + h), T = ld4(gs + 2 * h), Og = ld4(gs + 3 * h);
+        const F4 Cr = ld4(Craw + node * h + j0);
+        F4 cp = {{0, 0, 0, 0}};
+        if (Cprev) cp = ld4(Cprev + node * h + j0);
+        F4 Hr, tc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tc.v[k] = tanhf(Cr.v[k]);
+            Hr.v[k] = Og.v[k] * tc.v[k];
+        }
+        const F4 gyh = ld4(gHn + node * h + j0), gyc = ld4(gCn + node * h + j0);
+        F4 xh = {{0, 0, 0, 0}}, xc = {{0, 0, 0, 0}};
+        F4 gHr = gyh, gCr = gyc;
+        if (ln) {
+            float rh, rc;
+            layer_norm<LPN>(Hr, h, &xh, &rh);
+            layer_norm<LPN>(Cr, h, &xc, &rc);
+            gHr = layer_norm_bwd<LPN>(gyh, gam_h, xh, rh, h);
+            gCr = layer_norm_bwd<LPN>(gyc, gam_c, xc, rc, h);
+        }
+        F4 go_in = {{0, 0, 0, 0}};
+        if (gO) go_in = ld4(gO + node * h + j0);
+        F4 ggi, ggf, ggc, ggo, gcp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[7][k] += gyh.v[k] * xh.v[k];
+            acc[8][k] += gyh.v[k];
+            acc[9][k] += gyc.v[k] * xc.v[k];
+            acc[10][k] += gyc.v[k];
+            const float gOt = go_in.v[k] + gHr.v[k] * tc.v[k];
+            float gc_ = gCr.v[k] + gHr.v[k] * Og.v[k] * (1.0f - tc.v[k] * tc.v[k]);
+            ggo.v[k] = gOt * Og.v[k] * (1.0f - Og.v[k]);
+            gc_ += ggo.v[k] * wco.v[k];
+            ggi.v[k] = gc_ * T.v[k] * I.v[k] * (1.0f - I.v[k]);
+            ggf.v[k] = gc_ * cp.v[k] * F.v[k] * (1.0f - F.v[k]);
+            ggc.v[k] = gc_ * I.v[k] * (1.0f - T.v[k] * T.v[k]);
+            gcp.v[k] = gc_ * F.v[k] + ggi.v[k] * wci.v[k] + ggf.v[k] * wcf.v[k];
+            acc[0][k] += ggi.v[k] * cp.v[k];
+            acc[1][k] += ggf.v[k] * cp.v[k];
+            acc[2][k] += ggo.v[k] * Cr.v[k];
+            acc[3][k] += ggi.v[k];
+            acc[4][k] += ggf.v[k];
+            acc[5][k] += ggc.v[k];
+            acc[6][k] += ggo.v[k];
+        }
+        float* gg = gG + node * 4 * h + j0;
+        st4(gg, ggi);
+        st4(gg + h, ggf);
+        st4(gg + 2 * h, ggc);
+        st4(gg + 3 * h, ggo);
+        if (gCprev) st4(gCprev + node * h + j0, gcp);
+    }
+    block_param_reduce<LPN, 11>(acc, h, sm, part + (int64_t)blockIdx.x * 11 * h);
+}
+
+template <int LPN>
+__global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ O, const float* __restrict__ ln_o,
+                                                  const float* __restrict__ concat, int N, int h, int hp,
+                                                  float* __restrict__ Z) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t node = gid / LPN;
+    if (node >= N) return;
+    const int li = (int)(gid % LPN), j0 = li * 4;
+    const F4 x = ld4(O + node * h + j0);
+    F4 xh;
+    float r;
+    layer_norm<LPN>(x, h, &xh, &r);
+    const F4 gm = ld4(ln_o + j0), bt = ld4(ln_o + h + j0);
+    F4 y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y.v[k] = fmaxf(gm.v[k] * xh.v[k] + bt.v[k], 0.0f);
+    st4(Z + node * hp + j0, y);
+    if (li == 0)
+        for (int j = h; j < hp; ++j) Z[node * hp + j] = (j == h && concat) ? concat[node] : 0.0f;
+}
+
+template <int LPN>
+__global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ gZ, const float* __restrict__ O,
+                                                  const float* __restrict__ ln_o, int N, int h, int hp,
+                                                  float* __restrict__ gO, float* __restrict__ gconcat,
+                                                  float* __restrict__ part) {
+    __shared__ float sm[4 * LPN * 2 * 4];
+    const int li = threadIdx.x % LPN, j0 = li * 4;
+    const F4 gm = ld4(ln_o + j0), bt = ld4(ln_o + h + j0);
+    float acc[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[0][k] = acc[1][k] = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * (256 / LPN);
+    for (int64_t node = (int64_t)blockIdx.x * (256 / LPN) + threadIdx.x / LPN; node < N; node += stride) {
+        const F4 x = ld4(O + node * h + j0);
+        F4 xh;
+        float r;
+        layer_norm<LPN>(x, h, &xh, &r);
+        F4 gy = ld4(gZ + node * hp + j0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (gm.v[k] * xh.v[k] + bt.v[k] <= 0.0f) gy.v[k] = 0.0f;
+            acc[0][k] += gy.v[k] * xh.v[k];
+            acc[1][k] += gy.v[k];
+        }
+        st4(gO + node * h + j0, layer_norm_bwd<LPN>(gy, gm, xh, r, h));
+        if (li == 0 && gconcat) gconcat[node] = gZ[node * hp + h];
+    }
+    block_param_reduce<LPN, 2>(acc, h, sm, part + (int64_t)blockIdx.x * 2 * h);
+}
+
+inline int lanes_per_node(int h) { return h / 4; }
+inline bool h_ok(int h) { return h == 8 || h == 16 || h == 32 || h == 64 || h == 128; }
+
+}  // namespace
+
+#define QT_DISPATCH_LPN(h, KERNEL, grid, stream, ...)                                                          \
+    switch (lanes_per_node(h)) {                                                                               \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;   \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;   \
+        case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;   \
+        case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+        default: hipLaunchKernelGGL(KERNEL<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    }
+
+extern "C" int qt_lstm_fwd(const float* G, const float* Cprev, const float* wc, const float* b, const float* ln, int N,
+                           int h, float* O, float* Hn, float* Cn, float* gates, float* Craw, void* stream) {
+    QT_ARG(G && wc && b && O && Hn && Cn && gates && Craw, "null pointer");
+    QT_ARG(h_ok(h), "hidden size must be 8, 16, 32, 64 or 128");
+    if (N <= 0) return QT_OK;
+    const int grid = qt_cdiv((int64_t)N * lanes_per_node(h), 256);
+    QT_DISPATCH_LPN(h, k_lstm_fwd, grid, stream, G, Cprev, wc, b, ln, N, h, O, Hn, Cn, gates, Craw);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_lstm_bwd_blocks(int N, int h) {
+    if (N <= 0 || !h_ok(h)) return 0;
+    const int need = qt_cdiv((int64_t)N * lanes_per_node(h), 256);
+    return need < 512 ? need : 512;
+}
+
+extern "C" int qt_lstm_bwd(const float* gO, const float* gHn, const float* gCn, const float* gates, const float* Craw,
+                           const float* Cprev, const float* wc, const float* ln, int N, int h, float* gG, float* gCprev,
+                           float* part, void* stream) {
+    QT_ARG(gHn && gCn && gates && Craw && wc && gG && part, "null pointer");
+    QT_ARG(h_ok(h), "hidden size must be 8, 16, 32, 64 or 128");
+    if (N <= 0) return QT_OK;
+    const int grid = qt_lstm_bwd_blocks(N, h);
+    QT_DISPATCH_LPN(h, k_lstm_bwd, grid, stream, gO, gHn, gCn, gates, Craw, Cprev, wc, ln, N, h, gG, gCprev, part);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_head_fwd(const float* O, const float* ln_o, const float* concat, int N, int h, int hp, float* Z,
+                           void* stream) {
+    QT_ARG(O && ln_o && Z, "null pointer");
+    QT_ARG(h_ok(h) && hp >= h && hp % 4 == 0, "bad h / hp");
+    if (N <= 0) return QT_OK;
+    const int grid = qt_cdiv((int64_t)N * lanes_per_node(h), 256);
+    QT_DISPATCH_LPN(h, k_head_fwd, grid, stream, O, ln_o, concat, N, h, hp, Z);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, int h, int hp, float* gO,
+                           float* gconcat, float* part, void* stream) {
+    QT_ARG(gZ && O && ln_o && gO && part, "null pointer");
+    QT_ARG(h_ok(h) && hp >= h && hp % 4 == 0, "bad h / hp");
+    if (N <= 0) return QT_OK;
+    const int grid = qt_lstm_bwd_blocks(N, h);
+    QT_DISPATCH_LPN(h, k_head_bwd, grid, stream, gZ, O, ln_o, N, h, hp, gO, gconcat, part);
+    QT_LAUNCHED();
+    return QT_OK;
+}

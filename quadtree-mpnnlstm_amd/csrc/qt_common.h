@@ -1,0 +1,50 @@
+// Shared helpers for the gfx950 kernels of libqtmpnn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/qtmpnn.h"
+
+void qt_set_error(const char* fmt, ...);
+
+#define QT_ARG(cond, msg)                                   \
+    do {                                                    \
+        if (!(cond)) {                                      \
+            qt_set_error("%s: %s", __func__, msg);          \
+            return QT_E_ARG;                                \
+        }                                                   \
+    } while (0)
+
+#define QT_LAUNCHED()                                                   \
+    do {                                                                \
+        hipError_t qt_e_ = hipGetLastError();                           \
+        if (qt_e_ != hipSuccess) {                                      \
+            qt_set_error("%s: %s", __func__, hipGetErrorString(qt_e_)); \
+            return QT_E_LAUNCH;                                         \
+        }                                                               \
+    } while (0)
+
+static inline int qt_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Exclusive scan of one int per thread over a 256-thread workgroup (4 waves of 64).
+// `red` is 8 ints of LDS.  Returns the exclusive prefix; *total gets the block sum.
+__device__ __forceinline__ int qt_block_excl_scan_256(int v, int* red, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int up = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63) red[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        int s = red[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}

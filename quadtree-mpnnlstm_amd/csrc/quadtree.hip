@@ -1,0 +1,350 @@
+// On-device quadtree decomposition (mesh build, stage 1-3) for B clips at once.
+// Replaces quadtree_decompose + get_mapping, model/graph_functions.py:145-259, :555-587.
+//
+// The reference walks the tree depth-first on the host.  Here every base cell is one
+// workgroup: a max-pyramid over the (size+1)^2 split windows gives all split decisions
+// at once, a pixel's leaf is the first non-splitting ancestor, and the reference's DFS
+// label order is recovered as an exclusive prefix sum over leaf heads laid out in
+// "reversed Morton" order (children are visited (1,1),(0,1),(1,0),(0,0); base cells in
+// reverse row-major order).
+#include "qt_common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <math.h>
+
+static thread_local char g_qt_err[512] = "";
+void qt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_qt_err, sizeof(g_qt_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* qt_last_error(void) { return g_qt_err; }
+extern "C" int qt_abi_version(void) { return 1; }
+
+namespace {
+
+__device__ __forceinline__ unsigned spread_bits(unsigned v) {
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+// child visiting rank: pair value = rowbit + 2*colbit, visited in descending pair order
+__device__ __forceinline__ unsigned morton_rc(unsigned r, unsigned c) { return spread_bits(r) | (spread_bits(c) << 1); }
+
+struct Stage1Args {
+    const float* src;
+    int src_rows, src_cols;
+    const float* nodeval;
+    const int32_t* old_labels;
+    int B, n, m, MS, nbi, nbj;
+    float thresh;
+    int larger, negate;
+    const uint8_t* mask;
+    const uint8_t* hir;
+    int32_t* local_id;
+    uint8_t* level;
+    int32_t* cnt;
+};
+
+constexpr int PITCH = 66;
+
+__global__ __launch_bounds__(256) void k_quadtree_stage1(Stage1Args a) {
+    __shared__ float v[65 * PITCH];
+    __shared__ uint8_t fm[65 * PITCH];
+    __shared__ float D[1365];
+    __shared__ uint8_t Fp[1365];
+    __shared__ uint8_t split[1365];
+    __shared__ uint8_t lvl[4096];
+    __shared__ int flags[4096];
+    __shared__ int red[8];
+
+    const int t = threadIdx.x;
+    const int MS = a.MS, W1 = MS + 1;
+    const int nbase = a.nbi * a.nbj;
+    const int b = blockIdx.x / nbase, base = blockIdx.x % nbase;
+    const int bi = base / a.nbj, bj = base % a.nbj;
+    const int x0 = bi * MS, y0 = bj * MS;
+    const int n_pad = a.nbi * MS, m_pad = a.nbj * MS;
+    const int64_t P = (int64_t)a.n * a.m;
+
+    // ---- 1. criterion window (MS+1)^2 with the reference's clamps
+    for (int idx = t; idx < W1 * W1; idx += 256) {
+        const int r = idx / W1, c = idx % W1;
+        const int gr = x0 + r, gc = y0 + c;
+        float val = -INFINITY;
+        uint8_t f = 0;
+        if (gr < n_pad && gc < m_pad) {
+            if (a.src) {
+                const int rr = min(gr, a.src_rows - 1), cc = min(gc, a.src_cols - 1);
+                val = a.src[((int64_t)b * a.src_rows + rr) * a.src_cols + cc];
+            } else {
+                const int rr = min(gr, a.n - 1), cc = min(gc, a.m - 1);
+                const int lab = a.old_labels[b * P + (int64_t)rr * a.m + cc];
+                val = lab >= 0 ? a.nodeval[lab] : 0.0f;
+            }
+            if (a.negate) val = -val;
+            if (gr < a.n && gc < a.m) {
+                const int64_t p = (int64_t)gr * a.m + gc;
+                if (a.mask && a.mask[p]) f |= 1;
+                if (a.hir && a.hir[p]) f |= 2;
+            }
+        }
+        v[r * PITCH + c] = val;
+        fm[r * PITCH + c] = f;
+    }
+    __syncthreads();
+
+    // ---- 2. window-max pyramid; level l has (MS >> l)^2 cells of size 2^l
+    int L = 0;
+    while ((1 << L) < MS) ++L;
+    const float thr = a.negate ? -a.thresh : a.thresh;
+    int lbase = 0, prev_base = 0;
+    for (int l = 1; l <= L; ++l) {
+        const int nc = MS >> l;
+        for (int idx = t; idx < nc * nc; idx += 256) {
+            const int i = idx / nc, j = idx % nc;
+            float mx;
+            uint8_t fo;
+            if (l == 1) {
+                mx = -INFINITY;
+                fo = 0;
+#pragma unroll
+                for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+                    for (int dc = 0; dc < 3; ++dc) {
+                        const int o = (2 * i + dr) * PITCH + 2 * j + dc;
+                        mx = fmaxf(mx, v[o]);
+                        fo |= fm[o];
+                    }
+            } else {
+                const int pc = nc * 2;
+                const int o = prev_base + (2 * i) * pc + 2 * j;
+                mx = fmaxf(fmaxf(D[o], D[o + 1]), fmaxf(D[o + pc], D[o + pc + 1]));
+                fo = Fp[o] | Fp[o + 1] | Fp[o + pc] | Fp[o + pc + 1];
+            }
+            D[lbase + idx] = mx;
+            Fp[lbase + idx] = fo;
+            const bool s = (a.larger ? (mx > thr) : (mx < thr)) || fo != 0;
+            split[lbase + idx] = s ? 1 : 0;
+        }
+        __syncthreads();
+        prev_base = lbase;
+        lbase += nc * nc;
+    }
+
+    // ---- 3. leaf level of every pixel, head flags in DFS (reversed Morton) order
+    const int MS2 = MS * MS;
+    for (int idx = t; idx < MS2; idx += 256) flags[idx] = 0;
+    __syncthreads();
+    for (int idx = t; idx < MS2; idx += 256) {
+        const int r = idx / MS, c = idx % MS;
+        int leaf = 0, off = lbase;
+        for (int l = L; l >= 1; --l) {
+            const int nc = MS >> l;
+            off -= nc * nc;
+            if (!split[off + (r >> l) * nc + (c >> l)]) {
+                leaf = l;
+                break;
+            }
+        }
+        const int s = 1 << leaf;
+        const int r0 = r & ~(s - 1), c0 = c & ~(s - 1);
+        bool valid = (x0 + r0 < a.n) && (y0 + c0 < a.m);
+        if (leaf == 0 && (fm[r * PITCH + c] & 1)) valid = false;
+        lvl[idx] = (uint8_t)(leaf | (valid ? 0x80 : 0));
+        if (valid && r == r0 && c == c0) flags[MS2 - 1 - (int)morton_rc(r, c)] = 1;
+    }
+    __syncthreads();
+
+    // ---- 4. exclusive scan over the MS^2 keys
+    const int per = (MS2 + 255) / 256;
+    const int k0 = t * per;
+    int sum = 0;
+    for (int k = k0; k < min(k0 + per, MS2); ++k) sum += flags[k];
+    int total;
+    int run = qt_block_excl_scan_256(sum, red, &total);
+    for (int k = k0; k < min(k0 + per, MS2); ++k) {
+        const int f = flags[k];
+        flags[k] = run;
+        run += f;
+    }
+    __syncthreads();
+
+    // ---- 5. per-pixel local leaf id and level (in-image pixels only)
+    for (int idx = t; idx < MS2; idx += 256) {
+        const int r = idx / MS, c = idx % MS;
+        const int gr = x0 + r, gc = y0 + c;
+        if (gr >= a.n || gc >= a.m) continue;
+        const int lv = lvl[idx] & 0x7f;
+        const int s = 1 << lv;
+        const int r0 = r & ~(s - 1), c0 = c & ~(s - 1);
+        const int id = (lvl[idx] & 0x80) ? flags[MS2 - 1 - (int)morton_rc(r0, c0)] : -1;
+        const int64_t p = b * P + (int64_t)gr * a.m + gc;
+        a.local_id[p] = id;
+        a.level[p] = (uint8_t)lv;
+    }
+    if (t == 0) a.cnt[b * nbase + (nbase - 1 - base)] = total;
+}
+
+__global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const int32_t* __restrict__ offs,
+                                  int B, int n, int m, int MS, int nbj, int nbase,
+                                  int32_t* __restrict__ labels, const uint8_t* __restrict__ level,
+                                  int32_t* __restrict__ cell, int32_t* __restrict__ node_off) {
+    const int64_t P = (int64_t)n * m;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx <= B) node_off[idx] = offs[idx * nbase];
+    if (idx >= B * P) return;
+    const int b = (int)(idx / P);
+    const int p = (int)(idx % P);
+    const int r = p / m, c = p % m;
+    const int base = (r / MS) * nbj + (c / MS);
+    const int id = local_id[idx];
+    int lab = -1;
+    if (id >= 0) {
+        lab = id + offs[b * nbase + (nbase - 1 - base)];
+        const int s = 1 << level[idx];
+        if ((r & (s - 1)) == 0 && (c & (s - 1)) == 0) {
+            int4 cl = make_int4(r, c, s, b);
+            reinterpret_cast<int4*>(cell)[lab] = cl;
+        }
+    }
+    labels[idx] = lab;
+}
+
+// ---- three-kernel exclusive scan (2048 items per 256-thread workgroup)
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_CHUNK = 256 * SCAN_ITEMS;
+
+__global__ __launch_bounds__(256) void k_scan_sums(const int32_t* __restrict__ in, int64_t len, int32_t* __restrict__ sums) {
+    __shared__ int red[8];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < len) s += in[base + i];
+    int total;
+    qt_block_excl_scan_256(s, red, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// single workgroup: in-place exclusive scan of sums[0..nblk), sums[nblk] = grand total
+__global__ __launch_bounds__(256) void k_scan_top(int32_t* __restrict__ sums, int nblk) {
+    __shared__ int red[8];
+    int carry = 0;
+    for (int c0 = 0; c0 < nblk; c0 += 256) {
+        const int i = c0 + threadIdx.x;
+        const int vv = i < nblk ? sums[i] : 0;
+        int total;
+        const int ex = qt_block_excl_scan_256(vv, red, &total);
+        if (i < nblk) sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) sums[nblk] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const int32_t* __restrict__ in, int64_t len,
+                                                    const int32_t* __restrict__ sums, int32_t* __restrict__ out) {
+    __shared__ int red[8];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    int vals[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        vals[i] = (base + i < len) ? in[base + i] : 0;
+        s += vals[i];
+    }
+    int total;
+    int run = sums[blockIdx.x] + qt_block_excl_scan_256(s, red, &total);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < len) out[base + i] = run;
+        run += vals[i];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[len] = sums[gridDim.x];
+}
+
+__global__ void k_node_features(const int32_t* __restrict__ cell, int N, int n, int m, float size_norm,
+                                float* __restrict__ feat, float* __restrict__ npix) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int4 cl = reinterpret_cast<const int4*>(cell)[i];
+    const int hh = min(cl.x + cl.z, n) - cl.x, ww = min(cl.y + cl.z, m) - cl.y;
+    const float np_ = (float)(hh * ww);
+    feat[3 * i + 0] = ((float)cl.y + 0.5f * (float)(ww - 1)) / (float)m;
+    feat[3 * i + 1] = ((float)cl.x + 0.5f * (float)(hh - 1)) / (float)n;
+    feat[3 * i + 2] = np_ / size_norm;
+    npix[i] = np_;
+}
+
+}  // namespace
+
+extern "C" int qt_quadtree_stage1(const float* src, int src_rows, int src_cols, const float* nodeval,
+                                  const int32_t* old_labels, int B, int n, int m, int max_size, float thresh,
+                                  int condition, const uint8_t* mask, const uint8_t* hir, int32_t* local_id,
+                                  uint8_t* level, int32_t* cnt, void* stream) {
+    QT_ARG(B > 0 && n > 0 && m > 0, "empty image batch");
+    QT_ARG(max_size >= 2 && max_size <= 64 && (max_size & (max_size - 1)) == 0, "max_size must be a power of two in [2, 64]");
+    QT_ARG(condition >= 0 && condition <= 3, "unknown condition");
+    QT_ARG((src != nullptr) != (nodeval != nullptr && old_labels != nullptr), "give either src or nodeval+old_labels");
+    QT_ARG(local_id && level && cnt, "null output");
+    Stage1Args a;
+    a.src = src;
+    a.src_rows = src_rows;
+    a.src_cols = src_cols;
+    a.nodeval = nodeval;
+    a.old_labels = old_labels;
+    a.B = B;
+    a.n = n;
+    a.m = m;
+    a.MS = max_size;
+    a.nbi = qt_cdiv(n, max_size);
+    a.nbj = qt_cdiv(m, max_size);
+    QT_ARG(a.nbi <= a.nbj, "padded rows exceed padded columns (the reference raises IndexError here)");
+    if (src) QT_ARG(src_rows >= 1 && src_cols >= 1, "bad src shape");
+    a.thresh = thresh;
+    a.larger = (condition == QT_COND_MAX_LARGER || condition == QT_COND_MIN_SMALLER);
+    a.negate = (condition >= 2);
+    a.mask = mask;
+    a.hir = hir;
+    a.local_id = local_id;
+    a.level = level;
+    a.cnt = cnt;
+    hipLaunchKernelGGL(k_quadtree_stage1, dim3(B * a.nbi * a.nbj), dim3(256), 0, (hipStream_t)stream, a);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_offsets, int B, int n, int m,
+                                  int max_size, int32_t* labels, const uint8_t* level, int32_t* cell,
+                                  int32_t* node_off, void* stream) {
+    QT_ARG(local_id && cnt_offsets && labels && level && cell && node_off, "null pointer");
+    const int nbi = qt_cdiv(n, max_size), nbj = qt_cdiv(m, max_size);
+    const int64_t total = (int64_t)B * n * m;
+    hipLaunchKernelGGL(k_quadtree_stage3, dim3(qt_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, local_id,
+                       cnt_offsets, B, n, m, max_size, nbj, nbi * nbj, labels, level, cell, node_off);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_scan_i32(const int32_t* in, int32_t* out, int64_t len, int32_t* tmp, void* stream) {
+    QT_ARG(in && out && tmp && len > 0, "bad scan arguments");
+    const int nblk = qt_cdiv(len, SCAN_CHUNK);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(256), 0, s, in, len, tmp);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tmp, nblk);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(256), 0, s, in, len, tmp, out);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_node_features(const int32_t* cell, int N, int n, int m, float size_norm, float* feat, float* npix,
+                                void* stream) {
+    QT_ARG(cell && feat && npix, "null pointer");
+    if (N <= 0) return QT_OK;
+    hipLaunchKernelGGL(k_node_features, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, cell, N, n, m,
+                       size_norm, feat, npix);
+    QT_LAUNCHED();
+    return QT_OK;
+}

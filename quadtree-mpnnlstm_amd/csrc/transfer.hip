@@ -1,0 +1,280 @@
+// Mesh <-> image transfers by label map: flatten / unflatten
+// (model/graph_functions.py:391-419, 451-458) without the dense (N, P) mapping, the fused
+// remesh transfer of seq2seq.py:440-442 + 474-477, and the masked squared error of
+// mpnnlstm.py:243-246.
+//
+// k_pool: one workgroup per 64x64 image tile.  Each thread owns a 4x4 pixel block and
+// builds the 2x2 / 4x4 sums in registers; 8x8 .. 64x64 sums go through a small LDS
+// pyramid.  A quadtree leaf of level L is exactly one level-L pyramid entry, so every
+// node value is written once, in a fixed order, with no atomics.
+#include "qt_common.h"
+
+namespace {
+
+struct PoolArgs {
+    const float* img;
+    int S;
+    const float* src_val;
+    const int32_t* src_labels;
+    const float* src_npix;
+    int src_inv;
+    int C;
+    const int32_t* labels;
+    const uint8_t* level;
+    const float* npix;
+    int mean;
+    int B, n, m, N;
+    float* out;
+    int out_stride, out_coff;
+    int tiles_r, tiles_c;
+};
+
+template <int VEC>
+struct Vec {
+    float v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> vload(const float* p) {
+    Vec<VEC> r;
+    if constexpr (VEC == 4) {
+        const float4 f = *reinterpret_cast<const float4*>(p);
+        r.v[0] = f.x; r.v[1] = f.y; r.v[2] = f.z; r.v[3] = f.w;
+    } else {
+        r.v[0] = *p;
+    }
+    return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void vstore(float* p, const Vec<VEC>& r, float scale) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) p[k] = r.v[k] * scale;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
+    __shared__ float pyr[(256 + 64 + 16 + 4 + 1) * VEC];
+    const int t = threadIdx.x;
+    const int tiles = a.tiles_r * a.tiles_c;
+    const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int R0 = (tile / a.tiles_c) * 64, C0 = (tile % a.tiles_c) * 64;
+    const int br = t >> 4, bc = t & 15;
+    const int64_t P = (int64_t)a.n * a.m;
+    const int32_t* lab_img = a.labels + b * P;
+    const uint8_t* lvl_img = a.level + b * P;
+
+    int lab[16], slab[16];
+    unsigned lv_pack[4] = {0, 0, 0, 0};
+    float sscale[16];
+    bool big = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = R0 + 4 * br + i, c = C0 + 4 * bc + j;
+            const int q = i * 4 + j;
+            lab[q] = -1;
+            slab[q] = -1;
+            sscale[q] = 1.0f;
+            if (r < a.n && c < a.m) {
+                const int64_t p = (int64_t)r * a.m + c;
+                lab[q] = lab_img[p];
+                const unsigned lv = lvl_img[p];
+                lv_pack[i] |= lv << (8 * j);
+                big |= (lv >= 3);
+                if (a.src_labels) {
+                    slab[q] = a.src_labels[b * P + p];
+                    if (a.src_inv && slab[q] >= 0) sscale[q] = 1.0f / a.src_npix[slab[q]];
+                }
+            }
+        }
+    const bool any_big = __syncthreads_or(big ? 1 : 0) != 0;
+
+    const int nch = a.C / VEC;
+    const int total = (a.src_labels ? 1 : a.S) * nch;
+    for (int it = blockIdx.y; it < total; it += gridDim.y) {
+        const int s = it / nch, ch = it % nch;
+        float* outp = a.out + (int64_t)s * a.N * a.out_stride + a.out_coff + ch * VEC;
+        Vec<VEC> val[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = i * 4 + j;
+                const int r = R0 + 4 * br + i, c = C0 + 4 * bc + j;
+                Vec<VEC> x;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) x.v[k] = 0.0f;
+                if (a.src_labels) {
+                    if (slab[q] >= 0) {
+                        x = vload<VEC>(a.src_val + (int64_t)slab[q] * a.C + ch * VEC);
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) x.v[k] *= sscale[q];
+                    }
+                } else if (lab[q] >= 0) {
+                    x = vload<VEC>(a.img + (((int64_t)b * a.S + s) * P + (int64_t)r * a.m + c) * a.C + ch * VEC);
+                }
+                val[q] = x;
+            }
+        // level 0 leaves
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const unsigned lv = (lv_pack[q >> 2] >> (8 * (q & 3))) & 0xff;
+            if (lab[q] >= 0 && lv == 0) vstore<VEC>(outp + (int64_t)lab[q] * a.out_stride, val[q], 1.0f);
+        }
+        // 2x2 and 4x4 sums in registers
+        Vec<VEC> s2;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) s2.v[k] = 0.0f;
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int q0 = (2 * i2) * 4 + 2 * j2;
+                Vec<VEC> s1;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    s1.v[k] = (val[q0].v[k] + val[q0 + 1].v[k]) + (val[q0 + 4].v[k] + val[q0 + 5].v[k]);
+                    s2.v[k] += s1.v[k];
+                }
+                const unsigned lv = (lv_pack[2 * i2] >> (8 * (2 * j2))) & 0xff;
+                if (lab[q0] >= 0 && lv == 1)
+                    vstore<VEC>(outp + (int64_t)lab[q0] * a.out_stride, s1, a.mean ? 1.0f / a.npix[lab[q0]] : 1.0f);
+            }
+        if (lab[0] >= 0 && (lv_pack[0] & 0xff) == 2)
+            vstore<VEC>(outp + (int64_t)lab[0] * a.out_stride, s2, a.mean ? 1.0f / a.npix[lab[0]] : 1.0f);
+
+        if (any_big) {
+            // LDS pyramid: level 2 (16x16) -> 3 (8x8) -> 4 (4x4) -> 5 (2x2) -> 6 (1)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) pyr[t * VEC + k] = s2.v[k];
+            __syncthreads();
+            int src_off = 0, src_dim = 16, dst_off = 256;
+            for (int L = 3; L <= 6; ++L) {
+                const int dim = src_dim >> 1;
+                if (t < dim * dim) {
+                    const int i = t / dim, j = t % dim;
+                    Vec<VEC> acc;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        const float* sp = pyr + (src_off + (2 * i) * src_dim + 2 * j) * VEC + k;
+                        acc.v[k] = (sp[0] + sp[VEC]) + (sp[src_dim * VEC] + sp[(src_dim + 1) * VEC]);
+                        pyr[(dst_off + t) * VEC + k] = acc.v[k];
+                    }
+                    const int r = R0 + (i << L), c = C0 + (j << L);
+                    if (r < a.n && c < a.m) {
+                        const int64_t p = (int64_t)r * a.m + c;
+                        const int lb = lab_img[p];
+                        if (lb >= 0 && lvl_img[p] == L)
+                            vstore<VEC>(outp + (int64_t)lb * a.out_stride, acc, a.mean ? 1.0f / a.npix[lb] : 1.0f);
+                    }
+                }
+                __syncthreads();
+                src_off = dst_off;
+                src_dim = dim;
+                dst_off += dim * dim;
+            }
+        }
+    }
+}
+
+template <int VEC>
+__global__ void k_gather(const float* __restrict__ val, int C, const int32_t* __restrict__ labels,
+                         const float* __restrict__ inv_npix, int64_t total, float* __restrict__ img) {
+    const int nch = C / VEC;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total * nch) return;
+    const int64_t p = idx / nch;
+    const int ch = (int)(idx % nch);
+    const int lab = labels[p];
+    Vec<VEC> x;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) x.v[k] = 0.0f;
+    float sc = 1.0f;
+    if (lab >= 0) {
+        x = vload<VEC>(val + (int64_t)lab * C + ch * VEC);
+        if (inv_npix) sc = 1.0f / inv_npix[lab];
+    }
+    vstore<VEC>(img + p * C + ch * VEC, x, sc);
+}
+
+__global__ __launch_bounds__(256) void k_sse(const float* __restrict__ out, int out_stride, const int32_t* __restrict__ labels,
+                                             const float* __restrict__ y, int64_t y_clip_stride, int64_t P,
+                                             float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t p = (int64_t)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (p < P) {
+            const int lab = labels[b * P + p];
+            if (lab >= 0) {
+                const float d = out[(int64_t)lab * out_stride] - y[b * y_clip_stride + p];
+                acc += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace
+
+extern "C" int qt_gather(const float* val, int C, const int32_t* labels, const float* inv_npix, int64_t npixels_total,
+                         float* img, void* stream) {
+    QT_ARG(val && labels && img && C > 0, "bad arguments");
+    if (npixels_total <= 0) return QT_OK;
+    const bool v4 = (C % 4 == 0) && (((uintptr_t)val | (uintptr_t)img) % 16 == 0);
+    const int nch = v4 ? C / 4 : C;
+    const int grid = qt_cdiv(npixels_total * nch, 256);
+    if (v4)
+        hipLaunchKernelGGL(k_gather<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, val, C, labels, inv_npix, npixels_total, img);
+    else
+        hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, val, C, labels, inv_npix, npixels_total, img);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_pool(const float* img, int S, const float* src_val, const int32_t* src_labels, const float* src_npix,
+                       int src_inv, int C, const int32_t* labels, const uint8_t* level, const float* npix, int mean,
+                       int B, int n, int m, int N, float* out, int out_stride, int out_coff, void* stream) {
+    QT_ARG(labels && level && out && C > 0 && B > 0, "bad arguments");
+    QT_ARG((img != nullptr) != (src_val != nullptr && src_labels != nullptr), "give either img or src_val+src_labels");
+    QT_ARG(!mean || npix, "mean pooling needs npix");
+    QT_ARG(!src_inv || src_npix, "src_inv needs src_npix");
+    QT_ARG(out_stride >= out_coff + C, "output row too short");
+    if (N <= 0) return QT_OK;
+    PoolArgs a;
+    a.img = img; a.S = img ? S : 1; a.src_val = src_val; a.src_labels = src_labels; a.src_npix = src_npix;
+    a.src_inv = src_inv; a.C = C; a.labels = labels; a.level = level; a.npix = npix; a.mean = mean;
+    a.B = B; a.n = n; a.m = m; a.N = N; a.out = out; a.out_stride = out_stride; a.out_coff = out_coff;
+    a.tiles_r = qt_cdiv(n, 64); a.tiles_c = qt_cdiv(m, 64);
+    const float* srcp = img ? img : src_val;
+    const bool v4 = (C % 4 == 0) && ((uintptr_t)srcp % 16 == 0);
+    const int total = a.S * (v4 ? C / 4 : C);
+    const int blocks = B * a.tiles_r * a.tiles_c;
+    int gy = total;
+    if (blocks * gy > 2048) gy = max(1, 2048 / blocks);
+    if (gy > total) gy = total;
+    if (v4)
+        hipLaunchKernelGGL(k_pool<4>, dim3(blocks, gy), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(k_pool<1>, dim3(blocks, gy), dim3(256), 0, (hipStream_t)stream, a);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_sse(const float* out, int out_stride, const int32_t* labels, const float* y, int64_t y_clip_stride,
+                      int B, int n, int m, float* partial, void* stream) {
+    QT_ARG(out && labels && y && partial, "null pointer");
+    const int64_t P = (int64_t)n * m;
+    hipLaunchKernelGGL(k_sse, dim3(qt_cdiv(P, 1024), B), dim3(256), 0, (hipStream_t)stream, out, out_stride, labels, y,
+                       y_clip_stride, P, partial);
+    QT_LAUNCHED();
+    return QT_OK;
+}

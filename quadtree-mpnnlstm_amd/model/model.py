@@ -1,0 +1,177 @@
+"""Graph-recurrent cells of the hot path: the reference's model/model.py names (GraphConv,
+GConvLSTM, CONVOLUTIONS, CONVOLUTION_KWARGS ...) with the same parameters / state-dict keys, computed
+by fused HIP kernels (qtmpnn.ops) on a `Mesh` instead of per-module PyG calls.
+
+Where the reference passes (edge_index, edge_weight) these modules take the Mesh in the edge_index
+slot; the Mesh already holds the ChebConv normalisation, which PyG recomputes in every call.
+"""
+import torch
+import torch.nn as nn
+
+from qtmpnn import ops
+from qtmpnn.mesh import Mesh
+
+
+class ChebConv(nn.Module):
+    """Parameter layout of torch_geometric ChebConv (lins.{k}.weight (out, in) glorot, bias zeros);
+    reference kwargs K=3, normalization='sym', bias=True (model/model.py:53)."""
+
+    def __init__(self, in_channels, out_channels, K=3, normalization='sym', bias=True):
+        super().__init__()
+        assert normalization == 'sym', 'only the symmetric normalisation is used by the reference'
+        self.in_channels, self.out_channels, self.K = in_channels, out_channels, K
+        self.lins = nn.ModuleList([nn.Linear(in_channels, out_channels, bias=False) for _ in range(K)])
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        for lin in self.lins:
+            nn.init.xavier_uniform_(lin.weight)
+
+    def packed(self, in_pad=None, out_pad=None):
+        """[W_0^T; ...; W_{K-1}^T; bias] as one ((K*in_pad)+1, out_pad) matrix, zero padded."""
+        cin, cout = in_pad or self.in_channels, out_pad or self.out_channels
+        rows = []
+        for lin in self.lins:
+            w = lin.weight.t()
+            rows.append(nn.functional.pad(w, (0, cout - w.shape[1], 0, cin - w.shape[0])))
+        b = self.bias if self.bias is not None else torch.zeros(self.out_channels, device=rows[0].device)
+        rows.append(nn.functional.pad(b, (0, cout - self.out_channels)).unsqueeze(0))
+        return torch.cat(rows, dim=0)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        mesh = _need_mesh(edge_index)
+        pad = (-x.shape[1]) % 4
+        xin = nn.functional.pad(x, (0, pad)) if pad else x
+        opad = (-self.out_channels) % 4
+        y = ops.cheb_poly(xin, self.packed(xin.shape[1], self.out_channels + opad), mesh, self.K, 1)
+        return y[:, :self.out_channels] if opad else y
+
+
+def _need_mesh(edge_index):
+    if not isinstance(edge_index, Mesh):
+        raise TypeError('pass the Mesh (graph_structure["mapping"]) where the reference passes edge_index: '
+                        'the HIP path keeps adjacency and normalisation in the Mesh')
+    return edge_index
+
+
+CONVOLUTIONS = {
+    'ChebConv': ChebConv,
+    'GCNConv': None,
+    'TransformerConv': None,
+    'MHTransformerConv': None,
+    'GATConv': None,
+    'GATv2Conv': None,
+    'Dummy': None,
+}
+
+CONVOLUTION_KWARGS = {
+    'GCNConv': dict(add_self_loops=False),
+    'TransformerConv': dict(heads=1, edge_dim=2, dropout=0.1, concat=False),
+    'MHTransformerConv': dict(heads=3, edge_dim=2, dropout=0.1),
+    'ChebConv': dict(K=3, normalization='sym', bias=True),
+    'GATConv': dict(heads=1, edge_dim=2),
+    'GATv2Conv': dict(heads=1, edge_dim=2),
+    'Dummy': dict(),
+}
+
+
+def _conv_class(convolution_type):
+    assert convolution_type in CONVOLUTIONS, f'unknown convolution {convolution_type}'
+    cls = CONVOLUTIONS[convolution_type]
+    if cls is None:
+        raise NotImplementedError(f'{convolution_type} is not built yet on the HIP path (ChebConv is; SURVEY.md 8(f))')
+    return cls
+
+
+class GraphConv(nn.Module):
+    """n stacked convolutions with no nonlinearity in between (model/model.py:59-97)."""
+
+    def __init__(self, convolution_type, in_channels, out_channels, n_layers):
+        super().__init__()
+        self.convolution_type, self.n_layers = convolution_type, n_layers
+        cls, kw = _conv_class(convolution_type), CONVOLUTION_KWARGS[convolution_type]
+        chans = [in_channels] + [out_channels] * n_layers
+        self.convolutions = nn.ModuleList([cls(a, b, **kw) for a, b in zip(chans[:-1], chans[1:])])
+
+    def forward(self, x, edge_index, edge_attr=None, return_attention_weights=False):
+        for conv in self.convolutions:
+            x = conv(x, edge_index, edge_attr)
+        return x
+
+
+class GConvLSTM(nn.Module):
+    """Peephole graph-LSTM (model/model.py:263-463); forward returns (O, H', C') like the reference (:463).
+
+    All eight GraphConv stacks of the reference are evaluated by ONE Chebyshev pass over Z = [X | H]:
+    the stacked convolutions are pre-composed in weight space (ops.compose_chebconvs) and the four
+    gates share the recurrence T_k(L^) Z.
+    """
+
+    GATES = 'ifco'
+
+    def __init__(self, in_channels, out_channels, n_conv_layers=1, convolution_type='GCNConv', name='GConvLSTM'):
+        super().__init__()
+        assert convolution_type in CONVOLUTIONS
+        self.convolution_type, self.n_conv_layers, self.name = convolution_type, n_conv_layers, name
+        self.in_channels, self.out_channels = in_channels, out_channels
+        for g in self.GATES:        # creation order = the reference's state-dict order
+            setattr(self, f'conv_x_{g}', GraphConv(convolution_type, in_channels, out_channels, n_conv_layers))
+            setattr(self, f'conv_h_{g}', GraphConv(convolution_type, out_channels, out_channels, n_conv_layers))
+            if g != 'c':
+                setattr(self, f'w_c_{g}', nn.Parameter(torch.zeros(1, out_channels)))
+            setattr(self, f'b_{g}', nn.Parameter(torch.zeros(1, out_channels)))
+
+    # -- weight packing (tiny, differentiable torch ops) ---------------------------
+    def _branch(self, prefix):
+        convs = [getattr(self, f'{prefix}_{g}').convolutions for g in self.GATES]
+        weights, biases = [], []
+        for l in range(self.n_conv_layers):
+            weights.append(torch.stack([torch.stack([lin.weight.t() for lin in convs[g][l].lins]) for g in range(4)]))
+            biases.append(torch.stack([convs[g][l].bias for g in range(4)]))
+        return ops.compose_chebconvs(weights, biases)          # (4, K, in, h), (4, Ks, h)
+
+    def packed(self, with_h=True, in_pad=None):
+        """W ((K*C + Ks), 4h) for Z = [X (padded to in_pad) | H], peepholes (3, h), biases (4, h)."""
+        h = self.out_channels
+        Px, bx = self._branch('conv_x')
+        cin = in_pad or self.in_channels
+        if cin > self.in_channels:
+            Px = nn.functional.pad(Px, (0, 0, 0, cin - self.in_channels))
+        Ph, bh = self._branch('conv_h')
+        M = torch.cat([Px, Ph], dim=2) if with_h else Px           # (4, K, C, h)
+        K, C = M.shape[1], M.shape[2]
+        W = torch.cat([M.permute(1, 2, 0, 3).reshape(K * C, 4 * h),
+                       (bx + bh).permute(1, 0, 2).reshape(-1, 4 * h)], dim=0)
+        wc = torch.cat([self.w_c_i, self.w_c_f, self.w_c_o], dim=0)
+        b = torch.cat([self.b_i, self.b_f, self.b_c, self.b_o], dim=0)
+        return W, wc, b, K, bx.shape[1]
+
+    def step(self, X, mesh, H, C, ln, packed=None):
+        """One cell update; ln = (4, h) LayerNorm parameters fused onto H', C' or None."""
+        with_h = H is not None
+        pad = (-X.shape[1]) % 4
+        if pad:
+            X = nn.functional.pad(X, (0, pad))
+        W, wc, b, K, Ks = packed if packed is not None else self.packed(with_h, X.shape[1])
+        Z = torch.cat([X, H], dim=1) if with_h else X
+        G = ops.cheb_poly(Z, W, mesh, K, Ks)
+        return ops.lstm_cell(G, C, wc, b, ln)
+
+    def forward(self, X, edge_index, edge_weight=None, H=None, C=None):
+        return self.step(X, _need_mesh(edge_index), H, C, None)
+
+
+def _not_built(name):
+    class _Missing(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError(f'{name} is a non-default variant of the reference and is outside the '
+                                      'hot path built here (SURVEY.md section 2)')
+    _Missing.__name__ = name
+    return _Missing
+
+
+GConvGRU = _not_built('GConvGRU')
+GConvLSTM_Simple = _not_built('GConvLSTM_Simple')
+SplitGConvLSTM = _not_built('SplitGConvLSTM')
+DummyLSTM = _not_built('DummyLSTM')
+MPNNLSTM = _not_built('MPNNLSTM')
+MPNNLSTMI = _not_built('MPNNLSTMI')
+MHTransformerConv = _not_built('MHTransformerConv')

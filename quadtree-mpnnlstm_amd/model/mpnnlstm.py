@@ -1,0 +1,201 @@
+"""Trainer facade of the reference's model/mpnnlstm.py (NextFramePredictorS2S) around the HIP rollout.
+
+Same constructor / train / predict / save / load surface; the train step (mpnnlstm.py:229-257) is
+`train_step` below and additionally accepts batches of clips and a torch.distributed process group
+(one flat gradient all-reduce per step).  tensorboard is optional (absent -> no-op writer).
+"""
+import datetime
+import os
+import time
+
+import numpy as np
+import pandas as pd
+import torch
+from torch.optim.lr_scheduler import StepLR
+
+from model.graph_functions import image_to_graph, unflatten, plot_contours
+from model.seq2seq import Seq2Seq
+from model.utils import add_positional_encoding, get_n_params, int_to_datetime
+from qtmpnn import ops
+from qtmpnn.dist import allreduce_gradients
+
+try:                                        # pragma: no cover - optional dependency
+    from torch.utils.tensorboard import SummaryWriter
+except Exception:                           # tensorboard is not installed in the build image
+    class SummaryWriter:
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+        def flush(self):
+            pass
+
+
+def masked_mse(outputs, meshes, y, mask=None, binary=False):
+    """MSELoss(y_hat[:, ~mask], y[:, ~mask]) of mpnnlstm.py:243-246 without building y_hat:
+    sum over steps of the per-mesh squared error, divided by (clips x steps x unmasked pixels).
+    y: (T_out, W, H, 1) or (B, T_out, W, H, 1)."""
+    if y.dim() == 4:
+        y = y.unsqueeze(0)
+    mesh0 = meshes[0]
+    n_valid = mesh0.P if mask is None else int((~np.asarray(mask, dtype=bool)).sum())
+    if binary:
+        y_hat = torch.stack([unflatten(o, ms, (ms.n, ms.m)).reshape(ms.B, ms.n, ms.m, 1) for o, ms in zip(outputs, meshes)], 1)
+        keep = torch.ones(mesh0.n, mesh0.m, dtype=torch.bool) if mask is None else ~torch.as_tensor(np.asarray(mask, dtype=bool))
+        return torch.nn.functional.binary_cross_entropy(y_hat[:, :, keep], y.to(y_hat.device)[:, :, keep])
+    total = None
+    for t, (out, mesh) in enumerate(zip(outputs, meshes)):
+        sse = ops.step_sse(out, y[:, t].to(out.device), mesh)
+        total = sse if total is None else total + sse
+    return total / float(mesh0.B * len(outputs) * n_valid)
+
+
+class NextFramePredictorS2S:
+    def __init__(self, thresh, experiment_name='experiment', decompose=True, input_features=1, input_timesteps=3,
+                 output_timesteps=3, device=None, transform_func=None, condition='max_larger_than', remesh_input=False,
+                 binary=False, debug=False, model_kwargs={}):
+        self.input_timesteps, self.output_timesteps, self.input_features = input_timesteps, output_timesteps, input_features
+        self.binary, self.debug, self.device = binary, debug, device
+        self.thresh = thresh if decompose else -np.inf
+        self.decompose, self.transform_func, self.condition = decompose, transform_func, condition
+        self.experiment_name = experiment_name
+        model_kwargs = dict(model_kwargs)
+        model_kwargs.setdefault('transform_func', transform_func)
+        model_kwargs.setdefault('condition', condition)
+        self.model = Seq2Seq(input_features=input_features + 3,      # + positional encoding (x, y) + node size
+                             input_timesteps=input_timesteps, output_timesteps=output_timesteps, thresh=self.thresh,
+                             device=device, remesh_input=remesh_input, binary=binary, debug=debug,
+                             **model_kwargs).to(device)
+        self.training_initiated = False
+        self.process_group = None
+
+    # -- small helpers of the reference ---------------------------------------------
+    def get_n_params(self):
+        return get_n_params(self.model)
+
+    def save(self, directory):
+        torch.save(self.model.state_dict(), os.path.join(directory, f'{self.experiment_name}.pth'))
+
+    def load(self, directory):
+        path = os.path.join(directory, f'{self.experiment_name}.pth')
+        self.model.load_state_dict(torch.load(path, map_location=self.device or 'cpu', weights_only=True))
+
+    def test_threshold(self, x, thresh, mask=None, high_interest_region=None, contours=True):
+        import matplotlib.pyplot as plt
+        n_sample, w, h, _ = x.shape
+        graph = image_to_graph(add_positional_encoding(x), thresh=thresh, mask=mask, high_interest_region=high_interest_region,
+                               transform_func=self.transform_func)
+        mesh = graph['mapping']
+        rec = unflatten(graph['data'][..., [0]], mesh, (w, h)).cpu()
+        fig, axs = plt.subplots(1, n_sample, figsize=(5 * n_sample, 4), squeeze=False)
+        for i in range(n_sample):
+            axs[0, i].imshow(rec[i, ..., 0])
+            if contours:
+                plot_contours(axs[0, i], mesh.labels[0].cpu().numpy())
+        plt.suptitle(f'Threshold: {thresh} | Num. nodes: {mesh.N}')
+        return fig, axs[0]
+
+    def initiate_training(self, lr, lr_decay):
+        self.loss_func_name = 'MSE' if not self.binary else 'BCE'
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr)
+        self.scheduler = StepLR(self.optimizer, step_size=3, gamma=lr_decay)
+        self.writer = SummaryWriter('runs/' + self.experiment_name + '_' + datetime.datetime.now().strftime('%Y%m%d_%H_%M_%S'))
+        self.test_loss, self.train_loss = [], []
+        self.training_initiated = True
+
+    # -- the measured unit -----------------------------------------------------------
+    def forward_loss(self, x, y, concat_layers=None, mask=None, high_interest_region=None, graph_structure=None):
+        y_hat, meshes = self.model(x, y, concat_layers, teacher_forcing_ratio=0, mask=mask,
+                                   high_interest_region=high_interest_region, graph_structure=graph_structure)
+        return masked_mse(y_hat, meshes, y, mask, self.binary)
+
+    def train_step(self, x, y, concat_layers=None, mask=None, high_interest_region=None, graph_structure=None,
+                   max_norm=10.0):
+        """zero_grad -> forward -> masked MSE -> backward -> [all-reduce] -> clip_grad_norm_(10) -> Adam
+        (mpnnlstm.py:229-257).  x: (T_in, W, H, C) or (B, T_in, W, H, C).  Returns the loss tensor."""
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.forward_loss(x, y, concat_layers, mask, high_interest_region, graph_structure)
+        loss.backward()
+        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                               and torch.distributed.get_world_size() > 1):
+            allreduce_gradients(self.model.parameters(), self.process_group)
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=max_norm)
+        self.optimizer.step()
+        return loss.detach()
+
+    def train(self, loader_train, loader_test, climatology=None, n_epochs=200, lr=0.01, lr_decay=0.95, mask=None,
+              high_interest_region=None, truncated_backprop=45, graph_structure=None):
+        image_shape = loader_train.dataset.image_shape
+        if not self.training_initiated:
+            self.initiate_training(lr, lr_decay)
+        if mask is not None:
+            assert mask.shape == image_shape, f'Mask and image shapes do not match. Got {mask.shape} and {image_shape}'
+        if truncated_backprop not in (0, None) and truncated_backprop < self.output_timesteps:
+            raise NotImplementedError('truncated BPTT is a "next" row (SURVEY.md 8(f) row 3); pass truncated_backprop=0')
+        st = time.time()
+        batch_step = 0
+        for epoch in range(n_epochs):
+            running, steps = 0.0, 0
+            self.model.train()
+            for x, y, launch_date in loader_train:
+                x, y = self._clip(x), self._clip(y)
+                concat = self.get_climatology_array(climatology, launch_date) if climatology is not None else None
+                loss = self.train_step(x, y, concat, mask, high_interest_region, graph_structure)
+                self.writer.add_scalar('Loss/train', loss.item(), batch_step)
+                running += loss.item()
+                steps += 1
+                batch_step += 1
+            running_test, steps_test = 0.0, 0
+            for x, y, launch_date in loader_test:
+                x, y = self._clip(x), self._clip(y)
+                concat = self.get_climatology_array(climatology, launch_date) if climatology is not None else None
+                with torch.no_grad():
+                    running_test += self.forward_loss(x, y, concat, mask, high_interest_region, graph_structure).item()
+                steps_test += 1
+            running, running_test = running / (steps + 1), running_test / (steps_test + 1)   # (+1 as the reference, :360-361)
+            if np.isnan(running_test):
+                raise ValueError('NaN loss :(')
+            if running_test > 4:
+                raise ValueError('Diverged :(')
+            self.writer.add_scalar('Loss/test', running_test, epoch)
+            self.scheduler.step()
+            self.train_loss.append(running)
+            self.test_loss.append(running_test)
+            print(f'{self.experiment_name} | Epoch {epoch} train {self.loss_func_name}: {running:.4f}, '
+                  f'test {self.loss_func_name}: {running_test:.4f}, lr: {self.scheduler.get_last_lr()[0]:.4f}, '
+                  f'time_per_epoch: {(time.time() - st) / (epoch + 1):.1f}')
+        print(f'Finished in {(time.time() - st) / 60} minutes')
+        self.writer.flush()
+        self.loss = pd.DataFrame({'train_loss': self.train_loss, 'test_loss': self.test_loss})
+
+    def _clip(self, t):
+        """Loader items are (1, T, W, H, C) like the reference's batch_size=1 loaders, or (B, T, W, H, C)."""
+        t = t.to(self.device)
+        return t.squeeze(0) if t.shape[0] == 1 else t
+
+    def get_climatology_array(self, climatology, launch_date):
+        """Daily normals of the output days, (T_out, W, H, 1) (mpnnlstm.py:389-400)."""
+        doys = [int_to_datetime(launch_date.numpy()[0] + 8.640e13 * t).timetuple().tm_yday - 1
+                for t in range(self.output_timesteps)]
+        return torch.moveaxis(climatology[:, doys], 0, -1)
+
+    def predict(self, loader, climatology=None, mask=None, high_interest_region=None, graph_structure=None):
+        """Inference over a loader -> (n_clips, T_out, W, H, 1) array (mpnnlstm.py:402-440)."""
+        image_shape = loader.dataset.image_shape
+        self.model.to(self.device)
+        preds = []
+        for x, y, launch_date in loader:
+            x = self._clip(x)
+            concat = self.get_climatology_array(climatology, launch_date) if climatology is not None else None
+            with torch.no_grad():
+                y_hat, meshes = self.model(x, concat_layers=concat, teacher_forcing_ratio=0, mask=mask,
+                                           high_interest_region=high_interest_region, graph_structure=graph_structure)
+                frames = [unflatten(o, ms, image_shape, mask).cpu().numpy() for o, ms in zip(y_hat, meshes)]
+            frames = np.stack(frames, axis=0 if x.dim() == 4 else 1)
+            preds.extend([frames] if x.dim() == 4 else list(frames))
+        return np.stack(preds, 0)
+
+    def score(self, x, y, rollout=None):
+        pass

@@ -1,0 +1,256 @@
+"""Encoder / Decoder / Seq2Seq rollout of the reference's model/seq2seq.py, batched over B clips
+and running on the GPU mesh pipeline (qtmpnn).  Constructor kwargs, forward() arguments, returned
+(outputs, output_mappings) and state-dict keys follow the reference; `x` may carry a leading clip
+axis (B, T_in, W, H, C) -- the reference processes one clip per call (ice_exp.py:137-139).
+"""
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from model.graph_functions import Graph, _criterion
+from model.model import CONVOLUTION_KWARGS, GConvLSTM, _conv_class
+from qtmpnn import ops
+from qtmpnn.mesh import build_mesh
+
+
+def _ln_params(*norms):
+    return torch.stack([p for n in norms for p in (n.weight, n.bias)])
+
+
+class Encoder(nn.Module):
+    """model/seq2seq.py:21-82.  Layer 0 continues from (H, C); upper layers restart from zero state on
+    every call (:71) and one LayerNorm pair is shared by all layers (:49-50) -- reproduced as is."""
+
+    def __init__(self, input_features, hidden_size, dropout, n_layers=1, convolution_type='GCNConv', rnn_type='LSTM',
+                 n_conv_layers=3, dummy=False):
+        super().__init__()
+        assert rnn_type in ['GRU', 'LSTM', 'SplitLSTM']
+        if rnn_type != 'LSTM' or dummy:
+            raise NotImplementedError('only rnn_type="LSTM", dummy=False is on the HIP path')
+        self.rnn_type, self.hidden_size, self.n_layers, self.dummy = rnn_type, hidden_size, n_layers, dummy
+        dims = [input_features] + [hidden_size] * n_layers
+        self.rnns = nn.ModuleList([GConvLSTM(d, hidden_size, n_conv_layers, convolution_type, name='encoder')
+                                   for d in dims[:-1]])
+        self.dropout = nn.Dropout(dropout)        # constructed but never applied, like the reference (:47)
+        self.norm_h = nn.LayerNorm(hidden_size)
+        self.norm_c = nn.LayerNorm(hidden_size)
+
+    def pack(self, in_pad):
+        """Per-forward weight packing: layer 0 with and without a hidden state, upper layers without."""
+        ln = _ln_params(self.norm_h, self.norm_c)
+        return dict(ln=ln, first=self.rnns[0].packed(False, in_pad), cont=self.rnns[0].packed(True, in_pad),
+                    upper=[r.packed(False) for r in self.rnns[1:]])
+
+    def forward(self, X, edge_index, edge_weight=None, H=None, C=None, packed=None):
+        mesh = edge_index
+        X = X.squeeze(0) if X.dim() == 3 else X
+        pad = (-X.shape[1]) % 4
+        if pad:
+            X = nn.functional.pad(X, (0, pad))
+        pk = packed if packed is not None else self.pack(X.shape[1])
+        _, h, c = self.rnns[0].step(X, mesh, H, C, pk['ln'], pk['cont'] if H is not None else pk['first'])
+        hs, cs = [h], [c]
+        for rnn, w in zip(self.rnns[1:], pk['upper']):
+            _, h, c = rnn.step(hs[-1], mesh, None, None, pk['ln'], w)
+            hs.append(h)
+            cs.append(c)
+        return torch.stack(hs), torch.stack(cs)
+
+
+class Decoder(nn.Module):
+    """model/seq2seq.py:84-187: n_layers GConvLSTM (always one conv layer, :106) carrying (H[i], C[i]),
+    then norm_o + relu on the top layer's OUTPUT GATE, concat, fc_out1 -> relu -> fc_out2 -> dropout ->
+    tanh -> + X[:, [0]]."""
+
+    def __init__(self, input_features, hidden_size, dropout, n_layers=1, concat_layers_dim=3, convolution_type='GCNConv',
+                 rnn_type='LSTM', n_conv_layers=3, binary=False, dummy=False):
+        super().__init__()
+        assert rnn_type in ['GRU', 'LSTM', 'SplitLSTM']
+        if rnn_type != 'LSTM' or dummy:
+            raise NotImplementedError('only rnn_type="LSTM", dummy=False is on the HIP path')
+        self.rnn_type, self.input_features, self.hidden_size = rnn_type, input_features, hidden_size
+        self.n_layers, self.binary, self.dummy, self.concat_layers_dim = n_layers, binary, dummy, concat_layers_dim
+        dims = [input_features] + [hidden_size] * n_layers
+        self.rnns = nn.ModuleList([GConvLSTM(d, hidden_size, 1, convolution_type, name='decoder') for d in dims[:-1]])
+        cls, kw = _conv_class(convolution_type), CONVOLUTION_KWARGS[convolution_type]
+        self.fc_out1 = cls(in_channels=hidden_size + concat_layers_dim, out_channels=hidden_size, **kw)
+        self.fc_out2 = cls(in_channels=hidden_size, out_channels=1, **kw)
+        self.norm_o = nn.LayerNorm(hidden_size)
+        self.norm_h = nn.LayerNorm(hidden_size)
+        self.norm_c = nn.LayerNorm(hidden_size)
+        self.dropout = nn.Dropout(dropout)
+
+    @property
+    def head_width(self):
+        return self.hidden_size + 4          # [relu(norm_o(O)) | concat | 0 0 0] keeps rows 16-byte aligned
+
+    def pack(self, in_pad):
+        return dict(ln=_ln_params(self.norm_h, self.norm_c), ln_o=_ln_params(self.norm_o),
+                    rnns=[r.packed(True, in_pad if i == 0 else None) for i, r in enumerate(self.rnns)],
+                    fc1=self.fc_out1.packed(self.head_width, self.hidden_size), fc2=self.fc_out2.packed(self.hidden_size, 4))
+
+    def forward(self, X, edge_index, edge_weight, concat_layers, H, C, packed=None):
+        mesh = edge_index
+        assert self.concat_layers_dim == 1
+        pad = (-X.shape[1]) % 4
+        Xp = nn.functional.pad(X, (0, pad)) if pad else X
+        pk = packed if packed is not None else self.pack(Xp.shape[1])
+        hs, cs, inp = [], [], Xp
+        for i, rnn in enumerate(self.rnns):
+            out, h, c = rnn.step(inp, mesh, H[i], C[i], pk['ln'], pk['rnns'][i])
+            hs.append(h)
+            cs.append(c)
+            inp = h
+        if concat_layers is None:
+            # beyond-reference: HEAD crashes here (fc_out1 expects hidden+1 channels, seq2seq.py:115,164);
+            # the decoder's current input value is used as the 1-channel concat (what :471,484 intended)
+            concat_layers = X[:, :1]
+        z = ops.head_input(out, pk['ln_o'], concat_layers, self.head_width)
+        z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU)
+        drop = None
+        if self.training and self.dropout.p > 0:
+            keep = 1.0 - self.dropout.p
+            drop = (torch.rand(z.shape[0], device=z.device) < keep).float() / keep
+        y = ops.cheb_poly(z, pk['fc2'], mesh, self.fc_out2.K, 1, ops.ACT_TANH_RES, res=Xp, drop=drop)[:, :1]
+        if self.binary:
+            y = torch.sigmoid(y)
+        return y, torch.stack(hs), torch.stack(cs)
+
+
+class Seq2Seq(nn.Module):
+    """model/seq2seq.py:190-527 for the quadtree path (finite `thresh`)."""
+
+    def __init__(self, hidden_size, dropout, thresh, input_timesteps=3, input_features=4, output_timesteps=5, n_layers=4,
+                 n_conv_layers=2, transform_func=None, condition='max_larger_than', remesh_input=False,
+                 convolution_type='ChebConv', rnn_type='LSTM', binary=False, dummy=False, device=None, debug=False):
+        super().__init__()
+        self.encoder = Encoder(input_features, hidden_size, dropout, n_layers=n_layers, convolution_type=convolution_type,
+                               rnn_type=rnn_type, n_conv_layers=n_conv_layers, dummy=dummy)
+        self.decoder = Decoder(1 + 3, hidden_size, dropout, n_layers=n_layers, concat_layers_dim=1,
+                               convolution_type=convolution_type, rnn_type=rnn_type, n_conv_layers=n_conv_layers,
+                               binary=binary, dummy=dummy)
+        if remesh_input:
+            raise NotImplementedError('remesh_input=True is a "next" row (SURVEY.md 8(f) row 3)')
+        self.input_timesteps, self.output_timesteps, self.n_layers = input_timesteps, output_timesteps, n_layers
+        self.hidden_size, self.condition, self.remesh_input, self.debug = hidden_size, condition, remesh_input, debug
+        self.convolution_type = convolution_type
+        self.use_edge_attrs = convolution_type in ['MHTransformerConv', 'TransformerConv', 'GATConv']
+        self.thresh, self.transform_func, self.graph, self.device = thresh, transform_func, None, device
+        self.max_grid_size = 64                      # image_to_graph default, never overridden (graph_functions.py:590)
+
+    # -- mesh helpers -----------------------------------------------------------------
+    def _mesh_from_image(self, img0, mask, hir):
+        B, n, m = img0.shape
+        return build_mesh(src=_criterion(img0, n, m, self.max_grid_size, self.transform_func), n=n, m=m,
+                          thresh=self.thresh, condition=self.condition, mask=mask, high_interest_region=hir,
+                          max_size=self.max_grid_size)
+
+    def _mesh_from_nodes(self, out, mesh, mask, hir):
+        if self.transform_func is not None:
+            img0 = ops.gather_pixels(out.detach(), mesh).view(mesh.B, mesh.n, mesh.m)
+            return self._mesh_from_image(img0, mask, hir)
+        return build_mesh(prev=(out.detach()[:, 0], mesh), thresh=self.thresh, condition=self.condition, mask=mask,
+                          high_interest_region=hir, max_size=self.max_grid_size)
+
+    # -- encoder ------------------------------------------------------------------------
+    def process_inputs(self, x, mask=None, high_interest_region=None, graph_structure=None):
+        """model/seq2seq.py:254-336.  x: (T_in, W, H, C) or (B, T_in, W, H, C)."""
+        if self.thresh == -np.inf or graph_structure is not None:
+            raise NotImplementedError('pixelwise / preset static meshes are "next" rows (SURVEY.md 8(f) row 2)')
+        self._single = x.dim() == 4
+        if self._single:
+            x = x.unsqueeze(0)
+        x = x.float()
+        B, T, n, m, c = x.shape
+        self.mask = mask
+        mesh = self._mesh_from_image(x[..., 0].amax(dim=1), mask, high_interest_region)
+        means = ops.pool_image(x.reshape(B, T, n * m, c), mesh, True)                 # (T, N, c)
+        feats = torch.cat([means, mesh.posfeat.unsqueeze(0).expand(T, -1, -1)], dim=-1)
+        self.graph = Graph(None, None)
+        self.graph.mapping, self.graph.n_pixels_per_node, self.graph.image_shape = mesh, mesh.npix, (n, m)
+        self._enc_pack = self.encoder.pack(c + 3 + (-(c + 3)) % 4)
+        hidden = cell = None
+        for t in range(self.input_timesteps):
+            hidden, cell = self.encoder(feats[t], mesh, None, H=None if hidden is None else hidden[-1],
+                                        C=None if cell is None else cell[-1], packed=self._enc_pack)
+        self.graph.hidden, self.graph.cell = hidden, cell
+        self.graph.pyg.x = feats[-1][:, [0, -3, -2, -1]]                              # (:336)
+
+    # -- decoder + remesh ----------------------------------------------------------------
+    def unroll_output(self, unroll_steps, y, concat_layers=None, teacher_forcing_ratio=0.5, mask=None,
+                      high_interest_region=None, remesh_every=1):
+        """model/seq2seq.py:339-398.  concat_layers: (T_out, W, H, 1) or (B, T_out, W, H, 1)."""
+        g = self.graph
+        mesh = g.mapping
+        if concat_layers is not None:
+            concat_layers = concat_layers.to(g.pyg.x.device).float()
+            if concat_layers.dim() == 4:
+                concat_layers = concat_layers.unsqueeze(0)
+        if y is not None and y.dim() == 4:
+            y = y.unsqueeze(0)
+        dec_pack = self.decoder.pack(4)
+        outputs, output_mappings = [], []
+        steps = list(unroll_steps)
+        for t in steps:
+            concat_t = None
+            if concat_layers is not None:
+                cl = concat_layers[:, t].reshape(mesh.B, 1, mesh.P, 1)
+                concat_t = ops.pool_image(cl, mesh, True)[0]
+                g.concat_layers = concat_t
+            output, hidden, cell = self.decoder(g.pyg.x, mesh, None, concat_t, g.hidden, g.cell, packed=dec_pack)
+            outputs.append(output)
+            output_mappings.append(mesh)
+            teacher_force = random.random() < teacher_forcing_ratio
+            if t == steps[-1]:
+                # the reference re-meshes once more here (:393-394); nothing reads that mesh, so it is skipped
+                g.hidden, g.cell = hidden, cell
+                break
+            if self.thresh != -np.inf and (t + 1) % remesh_every == 0:
+                mesh = self.do_remesh(output, hidden, cell, mask, high_interest_region, teacher_force,
+                                      y[:, t] if teacher_force else None)
+            else:
+                self.update_without_remesh(output, hidden, cell, teacher_force, y[:, t] if teacher_force else None)
+        return outputs, output_mappings
+
+    def forward(self, x, y=None, concat_layers=None, teacher_forcing_ratio=0.5, mask=None, high_interest_region=None,
+                graph_structure=None, remesh_every=1):
+        self.process_inputs(x, mask=mask, high_interest_region=high_interest_region, graph_structure=graph_structure)
+        return self.unroll_output(range(self.output_timesteps), y, concat_layers=concat_layers,
+                                  teacher_forcing_ratio=teacher_forcing_ratio, mask=mask,
+                                  high_interest_region=high_interest_region, remesh_every=remesh_every)
+
+    def update_without_remesh(self, data, hidden, cell, teacher_force=False, teacher_input=None):
+        """model/seq2seq.py:420-431."""
+        g = self.graph
+        if teacher_force:
+            mesh = g.mapping
+            val = ops.pool_image(teacher_input.reshape(mesh.B, 1, mesh.P, -1)[..., :1], mesh, True)[0]
+            g.pyg.x = torch.cat([val, g.pyg.x[:, 1:]], dim=-1)
+        else:
+            g.pyg.x = torch.cat([data, g.pyg.x[:, 1:]], dim=-1)
+        g.hidden, g.cell = hidden, cell
+
+    def do_remesh(self, data, hidden, cell, mask=None, high_interest_region=None, teacher_force=False, teacher_input=None):
+        """model/seq2seq.py:434-491: the new mesh is decided by the model's own output; output, hidden and cell
+        move to it as per-cell means of their un-flattened images (one fused kernel, no image in memory)."""
+        g = self.graph
+        old = g.mapping
+        L, h = hidden.shape[0], hidden.shape[2]
+        if teacher_force:
+            img0 = teacher_input[..., 0].reshape(old.B, old.n, old.m).float()
+            new = self._mesh_from_image(img0, mask, high_interest_region)
+            val = ops.pool_image(img0.reshape(old.B, 1, old.P, 1), new, True)[0]
+            state = torch.cat([*hidden, *cell], dim=1)
+            moved = ops.remesh_transfer(state, old, new)
+        else:
+            new = self._mesh_from_nodes(data, old, mask, high_interest_region)
+            state = torch.cat([data, data.new_zeros(old.N, 3), *hidden, *cell], dim=1)
+            moved = ops.remesh_transfer(state, old, new)
+            val, moved = moved[:, :1], moved[:, 4:]
+        g.hidden = torch.stack(moved[:, :L * h].split(h, dim=1))
+        g.cell = torch.stack(moved[:, L * h:].split(h, dim=1))
+        g.pyg.x = torch.cat([val, new.posfeat], dim=-1)
+        g.mapping, g.n_pixels_per_node = new, new.npix
+        return new

@@ -1,0 +1,91 @@
+"""ctypes binding of libqtmpnn_hip.so (the C ABI declared in include/qtmpnn.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call
+fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libqtmpnn_hip.so')
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> argument types (return type is int unless listed in _RESTYPE)
+_SIGNATURES = {
+    'qt_abi_version': [],
+    'qt_quadtree_stage1': [_P, _I, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
+    'qt_quadtree_stage3': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    'qt_scan_i32': [_P, _P, _L, _P, _P],
+    'qt_node_features': [_P, _I, _I, _I, _F, _P, _P, _P],
+    'qt_edges_count': [_P, _P, _I, _I, _I, _P, _P],
+    'qt_edges_fill': [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
+    'qt_edges_norm': [_P, _P, _P, _I, _P, _P, _P],
+    'qt_gather': [_P, _I, _P, _P, _L, _P, _P],
+    'qt_pool': [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    'qt_sse': [_P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
+    'qt_spmm': [_P, _P, _P, _I, _I, _P, _F, _P, _F, _P, _F, _P, _P],
+    'qt_dense': [_P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
+    'qt_wgrad_blocks': [_I],
+    'qt_wgrad': [_P, _P, _I, _I, _P, _I, _P, _I, _I, _P, _P],
+    'qt_colsum': [_P, _I, _L, _P, _P],
+    'qt_lstm_fwd': [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
+    'qt_lstm_bwd_blocks': [_I, _I],
+    'qt_lstm_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    'qt_head_fwd': [_P, _P, _P, _I, _I, _I, _P, _P],
+    'qt_head_bwd': [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+}
+_PLAIN = {'qt_abi_version', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks'}  # return a value, not an error code
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raises if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} is missing: build it with `make -C quadtree-mpnnlstm_amd/csrc` '
+                               '(or __graft_entry__.build()); there is no CPU fallback')
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.qt_last_error.restype = ctypes.c_char_p
+        lib.qt_last_error.argtypes = []
+        for name, args in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def exported_names():
+    return ['qt_last_error'] + list(_SIGNATURES)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Call an entry point on the current torch stream; raises RuntimeError on a non-zero code."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f'{name} failed ({rc}): {lib.qt_last_error().decode()}')
+
+
+def value(name, *args):
+    return getattr(load(), name)(*args)
+
+
+def require_cuda(t, what='tensor'):
+    if not t.is_cuda:
+        raise RuntimeError(f'{what} must live on the GPU: the qtmpnn path has no CPU implementation '
+                           '(use oracle/ only as a test checker)')

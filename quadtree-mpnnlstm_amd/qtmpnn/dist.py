@@ -1,0 +1,71 @@
+"""Data-parallel glue: clips shard across ranks, one flat gradient all-reduce per step.
+
+The reference has no distributed code.  Clips are independent, the model is
+tens of thousands of parameters, so the only exchange is ONE all-reduce of a single flat fp32
+buffer (135 KiB for the Moving-MNIST model) -- latency-bound on xGMI, hence one call, never one
+per parameter tensor.  Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* when launched by torchrun.
+    Returns (rank, world_size, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of n_items clips for `rank` (equal sizes; n_items % world == 0)."""
+    assert n_items % world == 0, f'{n_items} clips do not split evenly over {world} ranks'
+    per = n_items // world
+    return rank * per, (rank + 1) * per
+
+
+def allreduce_gradients(params, group=None):
+    """Average gradients over the group with a single flat all-reduce (missing grads count as zero)."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(world)
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Make every rank start from rank `src`'s weights (one flat broadcast)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    params = list(module.parameters())
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            p.copy_(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()

@@ -1,0 +1,178 @@
+"""Device-resident quadtree mesh of a batch of B clips (block-diagonal graph).
+
+Replaces the reference's per-clip host state: quadtree labels, the dense (N, P)
+`mapping`, `n_pixels_per_node`, `edge_index`, `edge_attr` (model/graph_functions.py:590-681,
+model/seq2seq.py:297-304).  Everything is built by the HIP kernels of libqtmpnn_hip.so; the
+only host read-back is the node count N (one sync per mesh).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ptr
+
+CONDITIONS = ('max_larger_than', 'max_smaller_than', 'min_larger_than', 'min_smaller_than')
+
+
+def _as_u8(a, device, shape):
+    if a is None:
+        return None
+    t = torch.as_tensor(np.asarray(a)) if not torch.is_tensor(a) else a
+    assert tuple(t.shape) == tuple(shape), f'mask shape {tuple(t.shape)} != image shape {tuple(shape)}'
+    return t.to(device=device, dtype=torch.uint8).contiguous()
+
+
+class Mesh:
+    """labels (B,n,m) i32 | level (B,n,m) u8 | cell (N,4) i32 | npix (N) | posfeat (N,3)
+    | rowptr (N+1) / col / nrm CSR of L^ = -D^-1/2 W D^-1/2 | node_off (B+1)."""
+
+    def __init__(self):
+        self._ones = {}
+        self._E = None
+
+    # -- sizes ------------------------------------------------------------------
+    @property
+    def P(self):
+        return self.n * self.m
+
+    @property
+    def E(self):
+        """Directed non-self edges (lazy: needs a host read)."""
+        if self._E is None:
+            self._E = int(self.rowptr[-1].item()) if self.N > 0 else 0
+        return self._E
+
+    def __len__(self):
+        return self.N
+
+    # -- T_k(L^) 1 for the bias terms of stacked ChebConvs ------------------------
+    def cheb_ones(self, ks):
+        """(N, ks) matrix [1, L^1, T_2(L^)1, ...] (fp32)."""
+        if ks not in self._ones:
+            cols = [torch.ones(self.N, device=self.labels.device)]
+            for k in range(1, ks):
+                nxt = torch.empty_like(cols[0])
+                if k == 1:
+                    spmm(self, cols[0], 1.0, None, 0.0, None, 0.0, nxt, 1)
+                else:
+                    spmm(self, cols[-1], 2.0, cols[-2], -1.0, None, 0.0, nxt, 1)
+                cols.append(nxt)
+            self._ones[ks] = torch.stack(cols, dim=1).contiguous()
+        return self._ones[ks]
+
+    # -- reference-compatible views (not on the hot path) ---------------------------
+    def edge_index(self, self_loops=True):
+        """Sorted (2, E) int64 edge list; with self pairs for multi-pixel cells like get_adj (:329-333)."""
+        rp = self.rowptr.long()
+        src = torch.repeat_interleave(torch.arange(self.N, device=rp.device), rp[1:] - rp[:-1])
+        dst = self.col[: src.numel()].long()
+        if self_loops:
+            multi = torch.nonzero(self.npix > 1).flatten()
+            src, dst = torch.cat([src, multi]), torch.cat([dst, multi])
+        order = torch.argsort(src * max(self.N, 1) + dst)
+        return torch.stack([src[order], dst[order]])
+
+    def edge_attrs(self, use_edge_attrs=False, resolution=0.25):
+        """dist (E,) or [angle, dist] (E, 2) for edge_index(self_loops=True) (graph_functions.py:358-370)."""
+        ei = self.edge_index(True)
+        xx = self.posfeat[:, 0] * self.m * resolution
+        yy = self.posfeat[:, 1] * self.n * resolution
+        dx, dy = xx[ei[0]] - xx[ei[1]], yy[ei[0]] - yy[ei[1]]
+        d = torch.sqrt(dy ** 2 + dx ** 2)
+        if not use_edge_attrs:
+            return d
+        return torch.stack([torch.atan2(dx, dy) % (2 * math.pi) / (2 * math.pi), d]).T
+
+    def to_dense(self):
+        """The reference's dense (N, P) mapping (single clip only; debugging / notebooks)."""
+        assert self.B == 1, 'dense mapping is a single-clip notion'
+        lab = self.labels.reshape(-1).long()
+        mp = torch.zeros(self.N, lab.numel(), device=lab.device)
+        ok = lab >= 0
+        mp[lab[ok], torch.nonzero(ok).flatten()] = 1.0
+        return mp
+
+
+def spmm(mesh, x, alpha, p, beta, q, gamma, out, C):
+    _lib.call('qt_spmm', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), mesh.N, C, ptr(x), alpha,
+              ptr(p), beta, ptr(q), gamma, ptr(out))
+
+
+def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition='max_larger_than', mask=None,
+               high_interest_region=None, max_size=64, resolution=0.25, size_norm=None, device=None):
+    """Quadtree-decompose B criterion images and emit the block-diagonal mesh.
+
+    src  : (B, rows, cols) fp32 criterion image (edge-padded on the fly), or
+    prev : (nodeval (N_old,) fp32, old Mesh) -- the un-flattened previous output, never materialised.
+    """
+    assert condition in CONDITIONS, f'unknown condition {condition}'
+    assert max_size & (max_size - 1) == 0
+    if src is not None:
+        _lib.require_cuda(src, 'criterion image')
+        src = src.contiguous().float()
+        device = src.device
+        B = src.shape[0]
+        n = n if n is not None else src.shape[1]
+        m = m if m is not None else src.shape[2]
+    else:
+        nodeval, old = prev
+        _lib.require_cuda(nodeval, 'node values')
+        nodeval = nodeval.detach().contiguous().float()
+        device, B, n, m = nodeval.device, old.B, old.n, old.m
+    nbi, nbj = -(n // -max_size), -(m // -max_size)
+    if nbi > nbj:
+        raise IndexError('padded rows exceed padded columns: the reference split window is empty here '
+                         '(model/graph_functions.py:222-229)')
+    nbase = nbi * nbj
+    mk = _as_u8(mask, device, (n, m))
+    hr = _as_u8(high_interest_region, device, (n, m))
+    i32 = dict(dtype=torch.int32, device=device)
+    local_id = torch.empty(B, n, m, **i32)
+    level = torch.empty(B, n, m, dtype=torch.uint8, device=device)
+    cnt = torch.empty(B * nbase, **i32)
+    offs = torch.empty(B * nbase + 1, **i32)
+    tmp = torch.empty(B * nbase // 1024 + 8, **i32)
+    if src is not None:
+        _lib.call('qt_quadtree_stage1', ptr(src), src.shape[1], src.shape[2], None, None, B, n, m, max_size,
+                  float(thresh), CONDITIONS.index(condition), ptr(mk), ptr(hr), ptr(local_id), ptr(level), ptr(cnt))
+    else:
+        _lib.call('qt_quadtree_stage1', None, 0, 0, ptr(nodeval), ptr(old.labels), B, n, m, max_size,
+                  float(thresh), CONDITIONS.index(condition), ptr(mk), ptr(hr), ptr(local_id), ptr(level), ptr(cnt))
+    _lib.call('qt_scan_i32', ptr(cnt), ptr(offs), B * nbase, ptr(tmp))
+    N = int(offs[-1].item())                      # the one host sync of a mesh build
+
+    ms = Mesh()
+    ms.B, ms.n, ms.m, ms.N, ms.max_size, ms.resolution = B, n, m, N, max_size, resolution
+    ms.mask = mk
+    ms.labels = torch.empty(B, n, m, **i32)
+    ms.level = level
+    ms.cell = torch.empty(max(N, 1), 4, **i32)
+    ms.node_off = torch.empty(B + 1, **i32)
+    _lib.call('qt_quadtree_stage3', ptr(local_id), ptr(offs), B, n, m, max_size, ptr(ms.labels), ptr(level),
+              ptr(ms.cell), ptr(ms.node_off))
+    ms.posfeat = torch.empty(N, 3, device=device)
+    ms.npix = torch.empty(N, device=device)
+    ms.rowptr = torch.zeros(N + 1, **i32)
+    ms.dis = torch.empty(N, device=device)
+    if N == 0:
+        ms.col = torch.empty(0, **i32)
+        ms.w = ms.nrm = torch.empty(0, device=device)
+        return ms
+    if size_norm is None:
+        size_norm = (max_size / 2) ** 2
+    _lib.call('qt_node_features', ptr(ms.cell), N, n, m, float(size_norm), ptr(ms.posfeat), ptr(ms.npix))
+    cnt4 = torch.empty(4 * N, **i32)
+    off4 = torch.empty(4 * N + 1, **i32)
+    tmp4 = torch.empty(4 * N // 1024 + 8, **i32)
+    _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, n, m, ptr(cnt4))
+    _lib.call('qt_scan_i32', ptr(cnt4), ptr(off4), 4 * N, ptr(tmp4))
+    emax = 4 * B * n * m                          # every directed edge owns >= 1 of the 4*P pixel adjacencies
+    ms.col = torch.empty(emax, **i32)
+    ms.w = torch.empty(emax, device=device)
+    ms.nrm = torch.empty(emax, device=device)
+    _lib.call('qt_edges_fill', ptr(ms.labels), ptr(ms.cell), ptr(off4), N, n, m, float(resolution),
+              ptr(ms.rowptr), ptr(ms.col), ptr(ms.w))
+    _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), N, ptr(ms.dis), ptr(ms.nrm))
+    return ms

@@ -1,0 +1,332 @@
+"""torch.autograd.Function wrappers pairing the forward / backward HIP kernels.
+
+Every op runs on the GPU through libqtmpnn_hip.so; there is no CPU fallback.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import ptr
+from .mesh import spmm
+
+ACT_NONE, ACT_RELU, ACT_TANH_RES = 0, 1, 2
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------ ChebConv stacks
+class _ChebPoly(Function):
+    """Y = act( sum_k T_k(L^) Z M_k + S Bm ),  W = [M_0; ...; M_{K-1}; Bm]  ((K*C + Ks), Co).
+
+    One call evaluates what the reference spreads over many ChebConv modules
+    (model/model.py:59-97, :394-424): the Chebyshev recurrence runs once on Z = [X | H] for
+    all four gates, stacked ChebConv layers are pre-composed into one degree-2L polynomial
+    (compose_chebconvs below), and their inner biases become the S = T_k(L^)1 columns.
+    """
+
+    @staticmethod
+    def forward(ctx, Z, W, res, drop, mesh, K, Ks, act):
+        _lib.require_cuda(Z, 'node features')
+        Z, W = _c(Z.float()), _c(W.float())
+        N, C = Z.shape
+        Co = W.shape[1]
+        assert W.shape[0] == K * C + Ks, f'weight rows {W.shape[0]} != {K}*{C}+{Ks}'
+        TZ = Z.new_empty(max(K - 1, 1), N, C)
+        for k in range(1, K):
+            if k == 1:
+                spmm(mesh, Z, 1.0, None, 0.0, None, 0.0, TZ[0], C)
+            else:
+                spmm(mesh, TZ[k - 2], 2.0, Z if k == 2 else TZ[k - 3], -1.0, None, 0.0, TZ[k - 1], C)
+        S = mesh.cheb_ones(Ks) if Ks else None
+        Y = Z.new_empty(N, Co)
+        drop = _c(drop)
+        _lib.call('qt_dense', ptr(Z), ptr(TZ), K, C, ptr(W), ptr(S), Ks, ptr(W[K * C:]) if Ks else None, 1, Co, N,
+                  act, ptr(res), res.stride(0) if res is not None else 0, ptr(drop), ptr(Y))
+        ctx.mesh, ctx.K, ctx.Ks, ctx.act = mesh, K, Ks, act
+        ctx.save_for_backward(Z, TZ, W, Y if act != ACT_NONE else None, res, drop)
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        Z, TZ, W, Y, res, drop = ctx.saved_tensors
+        mesh, K, Ks, act = ctx.mesh, ctx.K, ctx.Ks, ctx.act
+        N, C = Z.shape
+        Co = W.shape[1]
+        G = _c(gY.float())
+        gres = None
+        if act == ACT_RELU:
+            G = G * (Y > 0)
+        elif act == ACT_TANH_RES:
+            t = Y - res[:, :1]
+            if ctx.needs_input_grad[2]:
+                gres = torch.zeros_like(res)
+                gres[:, :1] = G[:, :1]
+            G = G * (1.0 - t * t)
+            if drop is not None:
+                G = G * drop.view(-1, 1)
+        G = _c(G)
+        gZ = None
+        if ctx.needs_input_grad[0] and N > 0:
+            Wt = W[:K * C].t().contiguous()
+            gT = Z.new_empty(K, N, C)
+            _lib.call('qt_dense', ptr(G), None, 1, Co, ptr(Wt), None, 0, None, K, C, N, ACT_NONE, None, 0, None, ptr(gT))
+            # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
+            for k in range(K - 2, 0, -1):
+                spmm(mesh, gT[k + 1], 2.0, gT[k], 1.0, gT[k + 2] if k + 2 < K else None, -1.0, gT[k], C)
+            if K > 1:
+                spmm(mesh, gT[1], 1.0, gT[0], 1.0, gT[2] if K > 2 else None, -1.0, gT[0], C)
+            gZ = gT[0]
+        elif ctx.needs_input_grad[0]:
+            gZ = torch.zeros_like(Z)
+        gW = None
+        if ctx.needs_input_grad[1]:
+            gW = torch.zeros_like(W)
+            if N > 0:
+                nblk = _lib.value('qt_wgrad_blocks', N)
+                part = Z.new_empty(nblk, W.shape[0], Co)
+                S = mesh.cheb_ones(Ks) if Ks else None
+                _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), Ks, ptr(G), Co, N, ptr(part))
+                _lib.call('qt_colsum', ptr(part), nblk, W.numel(), ptr(gW))
+        return gZ, gW, gres, None, None, None, None, None
+
+
+def cheb_poly(Z, W, mesh, K, Ks, act=ACT_NONE, res=None, drop=None):
+    return _ChebPoly.apply(Z, W, res, drop, mesh, K, Ks, act)
+
+
+def compose_chebconvs(weights, biases):
+    """Collapse stacked ChebConvs (no nonlinearity in between, model/model.py:95-96) into one
+    Chebyshev series, using T_a T_b = (T_{a+b} + T_|a-b|) / 2.
+
+    weights[l]: (G, K, in_l, out) stacked lins^T of layer l for G independent stacks;
+    biases[l]: (G, out).  Returns M (G, 2L+1 .. , in_0, out) and beta (G, 2(L-1)+1, out).
+    """
+    P = weights[0]
+    beta = biases[0].unsqueeze(1)
+    for Wl, bl in zip(weights[1:], biases[1:]):
+        ka, kb = P.shape[1], Wl.shape[1]
+        comb = _comb(ka, kb, P.device)                                # (ka+kb-1, ka, kb)
+        P = torch.einsum('jab,gaio,gbop->gjip', comb, P, Wl)
+        combb = _comb(beta.shape[1], kb, P.device)
+        beta = torch.einsum('jab,gao,gbop->gjp', combb, beta, Wl)
+        beta = torch.cat([beta[:, :1] + bl.unsqueeze(1), beta[:, 1:]], dim=1)
+    return P, beta
+
+
+_COMB = {}
+
+
+def _comb(ka, kb, device):
+    key = (ka, kb, str(device))
+    if key not in _COMB:
+        c = torch.zeros(ka + kb - 1, ka, kb)
+        for a in range(ka):
+            for b in range(kb):
+                c[a + b, a, b] += 0.5
+                c[abs(a - b), a, b] += 0.5
+        _COMB[key] = c.to(device)
+    return _COMB[key]
+
+
+# ------------------------------------------------------------------------------ LSTM cell
+class _LstmCell(Function):
+    """(O, LayerNorm_h(H'), LayerNorm_c(C')) from gate pre-activations (model/model.py:394-428,
+    model/seq2seq.py:64-75)."""
+
+    @staticmethod
+    def forward(ctx, G, Cprev, wc, b, ln):
+        G = _c(G)
+        N, h4 = G.shape
+        h = h4 // 4
+        Cprev, wc, b, ln = _c(Cprev), _c(wc), _c(b), _c(ln)
+        O, Hn, Cn, Craw = (G.new_empty(N, h) for _ in range(4))
+        gates = G.new_empty(N, h4)
+        _lib.call('qt_lstm_fwd', ptr(G), ptr(Cprev), ptr(wc), ptr(b), ptr(ln), N, h, ptr(O), ptr(Hn), ptr(Cn),
+                  ptr(gates), ptr(Craw))
+        ctx.save_for_backward(gates, Craw, Cprev, wc, ln)
+        return O, Hn, Cn
+
+    @staticmethod
+    def backward(ctx, gO, gHn, gCn):
+        gates, Craw, Cprev, wc, ln = ctx.saved_tensors
+        N, h = Craw.shape
+        gHn = _c(gHn) if gHn is not None else torch.zeros_like(Craw)
+        gCn = _c(gCn) if gCn is not None else torch.zeros_like(Craw)
+        gO = _c(gO)
+        gG = torch.empty_like(gates)
+        gCp = torch.empty_like(Craw) if Cprev is not None else None
+        nblk = max(_lib.value('qt_lstm_bwd_blocks', N, h), 1)
+        part = Craw.new_zeros(nblk, 11 * h)
+        psum = Craw.new_zeros(11 * h)
+        if N > 0:
+            _lib.call('qt_lstm_bwd', ptr(gO), ptr(gHn), ptr(gCn), ptr(gates), ptr(Craw), ptr(Cprev), ptr(wc), ptr(ln),
+                      N, h, ptr(gG), ptr(gCp), ptr(part))
+            _lib.call('qt_colsum', ptr(part), nblk, 11 * h, ptr(psum))
+        psum = psum.view(11, h)
+        return gG, gCp, psum[0:3], psum[3:7], psum[7:11]
+
+
+def lstm_cell(G, Cprev, wc, b, ln):
+    return _LstmCell.apply(G, Cprev, wc, b, ln)
+
+
+# ------------------------------------------------------------------------------ decoder head input
+class _Head(Function):
+    """[relu(LayerNorm_o(O)) | concat | 0-pad] (model/seq2seq.py:160-165)."""
+
+    @staticmethod
+    def forward(ctx, O, ln_o, concat, hp):
+        O, ln_o, concat = _c(O), _c(ln_o), _c(concat)
+        N, h = O.shape
+        Z = O.new_empty(N, hp)
+        _lib.call('qt_head_fwd', ptr(O), ptr(ln_o), ptr(concat), N, h, hp, ptr(Z))
+        ctx.save_for_backward(O, ln_o)
+        ctx.hp, ctx.has_concat = hp, concat is not None
+        return Z
+
+    @staticmethod
+    def backward(ctx, gZ):
+        O, ln_o = ctx.saved_tensors
+        N, h = O.shape
+        gZ = _c(gZ)
+        gO = torch.empty_like(O)
+        gcat = O.new_empty(N, 1) if ctx.has_concat else None
+        nblk = max(_lib.value('qt_lstm_bwd_blocks', N, h), 1)
+        part = O.new_zeros(nblk, 2 * h)
+        psum = O.new_zeros(2 * h)
+        if N > 0:
+            _lib.call('qt_head_bwd', ptr(gZ), ptr(O), ptr(ln_o), N, h, ctx.hp, ptr(gO), ptr(gcat), ptr(part))
+            _lib.call('qt_colsum', ptr(part), nblk, 2 * h, ptr(psum))
+        return gO, psum.view(2, h), gcat, None
+
+
+def head_input(O, ln_o, concat, hp):
+    return _Head.apply(O, ln_o, concat, hp)
+
+
+# ------------------------------------------------------------------------------ mesh <-> image
+def _pool_raw(mesh, C, out, out_stride, out_coff, mean, img=None, S=1, src_val=None, src_mesh=None, src_inv=False):
+    _lib.call('qt_pool', ptr(img), S, ptr(src_val), ptr(src_mesh.labels) if src_mesh is not None else None,
+              ptr(src_mesh.npix) if src_mesh is not None else None, int(src_inv), C, ptr(mesh.labels), ptr(mesh.level),
+              ptr(mesh.npix), int(mean), mesh.B, mesh.n, mesh.m, mesh.N, ptr(out), out_stride, out_coff)
+
+
+def _gather_raw(mesh, val, C, inv_npix, img):
+    _lib.call('qt_gather', ptr(val), C, ptr(mesh.labels), ptr(mesh.npix) if inv_npix else None,
+              mesh.B * mesh.P, ptr(img))
+
+
+class _PoolImage(Function):
+    """flatten (model/graph_functions.py:391-419): img (B, S, n*m, C) -> node means (S, N, C)."""
+
+    @staticmethod
+    def forward(ctx, img, mesh, mean):
+        img = _c(img.float())
+        B, S, P, C = img.shape
+        out = img.new_zeros(S, mesh.N, C)
+        if mesh.N > 0:
+            _pool_raw(mesh, C, out, C, 0, mean, img=img, S=S)
+        ctx.mesh, ctx.mean, ctx.shape = mesh, mean, img.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mesh = ctx.mesh
+        B, S, P, C = ctx.shape
+        g = _c(g)
+        gi = g.new_empty(S, B, P, C)
+        for s in range(S):
+            _gather_raw(mesh, g[s], C, ctx.mean, gi[s])
+        return gi.transpose(0, 1), None, None
+
+
+def pool_image(img, mesh, mean=True):
+    return _PoolImage.apply(img, mesh, mean)
+
+
+class _Gather(Function):
+    """unflatten (model/graph_functions.py:451-458): node values (N, C) -> pixels (B, n*m, C)."""
+
+    @staticmethod
+    def forward(ctx, val, mesh):
+        val = _c(val.float())
+        C = val.shape[1]
+        img = val.new_empty(mesh.B, mesh.P, C)
+        _gather_raw(mesh, val, C, False, img)
+        ctx.mesh = mesh
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        mesh = ctx.mesh
+        g = _c(g)
+        C = g.shape[-1]
+        out = g.new_zeros(1, mesh.N, C)
+        if mesh.N > 0:
+            _pool_raw(mesh, C, out, C, 0, False, img=g.view(mesh.B, 1, mesh.P, C), S=1)
+        return out[0], None
+
+
+def gather_pixels(val, mesh):
+    return _Gather.apply(val, mesh)
+
+
+class _Remesh(Function):
+    """State transfer between meshes: new node = mean over its pixels of the old node value
+    (unflatten + flatten of model/seq2seq.py:440-442, 474-477 fused; no image is materialised)."""
+
+    @staticmethod
+    def forward(ctx, val, old, new):
+        val = _c(val.float())
+        C = val.shape[1]
+        out = val.new_zeros(new.N, C)
+        if new.N > 0:
+            _pool_raw(new, C, out, C, 0, True, src_val=val, src_mesh=old)
+        ctx.old, ctx.new = old, new
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        old, new = ctx.old, ctx.new
+        g = _c(g)
+        C = g.shape[1]
+        out = g.new_zeros(old.N, C)
+        if old.N > 0:
+            _pool_raw(old, C, out, C, 0, False, src_val=g, src_mesh=new, src_inv=True)
+        return out, None, None
+
+
+def remesh_transfer(val, old, new):
+    return _Remesh.apply(val, old, new)
+
+
+# ------------------------------------------------------------------------------ loss
+class _StepSSE(Function):
+    """Sum over clips and unmasked pixels of (out[label] - y)^2 for one output step
+    (unflatten + MSELoss numerator, model/mpnnlstm.py:243-246)."""
+
+    @staticmethod
+    def forward(ctx, out, y, mesh):
+        out = _c(out.float())
+        y = _c(y.float()).view(mesh.B, mesh.P)
+        nt = -(mesh.P // -1024)
+        part = out.new_empty(mesh.B * nt)
+        _lib.call('qt_sse', ptr(out), out.stride(0), ptr(mesh.labels), ptr(y), mesh.P, mesh.B, mesh.n, mesh.m, ptr(part))
+        sy = out.new_zeros(1, mesh.N, 1)
+        if mesh.N > 0:
+            _pool_raw(mesh, 1, sy, 1, 0, False, img=y.view(mesh.B, 1, mesh.P, 1), S=1)
+        ctx.save_for_backward(out, sy)
+        ctx.mesh = mesh
+        return part.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        out, sy = ctx.saved_tensors
+        mesh = ctx.mesh
+        return (2.0 * g) * (mesh.npix.view(-1, 1) * out[:, :1] - sy[0]), None, None
+
+
+def step_sse(out, y, mesh):
+    return _StepSSE.apply(out, y, mesh)

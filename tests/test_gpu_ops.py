@@ -1,0 +1,218 @@
+"""GPU parity of the individual HIP ops against the CPU oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import close, dev, golden, grad_close, load_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _mesh_64(seed, noise=0.0, B=1, thresh=0.1):
+    from qtmpnn import synthetic
+    from qtmpnn.mesh import build_mesh
+    img = np.stack([synthetic.make_clip(seed + i, n_frames=1, pixel_noise=noise)[0, ..., 0] for i in range(B)])
+    return build_mesh(src=torch.from_numpy(img).to(dev()), thresh=thresh), img
+
+
+def _oracle_graph(mesh):
+    ei = mesh.edge_index(True).cpu()
+    return ei, mesh.edge_attrs(False).cpu()
+
+
+def test_flatten_unflatten_golden():
+    from model.graph_functions import flatten, unflatten
+    from qtmpnn.mesh import build_mesh
+    t = golden('transfer.npz')
+    img = torch.from_numpy(t['img']).to(dev())
+    mesh = build_mesh(src=img[..., 0].amax(dim=0, keepdim=True), thresh=0.1)
+    assert np.array_equal(mesh.labels[0].cpu().numpy(), t['labels'])
+    img.requires_grad_(True)
+    flat = flatten(img, mesh, mesh.npix)
+    close(flat, t['flat'])
+    (gx,) = torch.autograd.grad(flat, img, torch.from_numpy(t['flat_gy']).to(dev()))
+    close(gx, t['flat_gx'])
+    data = torch.from_numpy(t['data']).to(dev()).requires_grad_(True)
+    im = unflatten(data, mesh, (64, 64))
+    close(im, t['unflat'])
+    (gd,) = torch.autograd.grad(im, data, torch.from_numpy(t['unflat_gi']).to(dev()))
+    close(gd, t['unflat_gd'], atol=1e-4)
+
+
+@pytest.mark.parametrize('C', [1, 4, 20])
+def test_spmm_vs_dense(C):
+    from qtmpnn.mesh import spmm
+    mesh, _ = _mesh_64(3, noise=0.02, B=2)
+    ei = mesh.edge_index(False)
+    L = torch.zeros(mesh.N, mesh.N, dtype=torch.float64, device=dev())
+    L[ei[0], ei[1]] = mesh.nrm[:mesh.E].double()
+    x = torch.randn(mesh.N, C, device=dev())
+    p, q = torch.randn_like(x), torch.randn_like(x)
+    out = torch.empty_like(x)
+    spmm(mesh, x, 2.0, p, -1.0, q, 0.5, out, C)
+    ref = 2.0 * (L @ x.double()) - p.double() + 0.5 * q.double()
+    close(out, ref.float(), atol=1e-5)
+    assert mesh.E == int((L != 0).sum())
+
+
+def test_remesh_transfer_vs_oracle():
+    from oracle import qt_oracle as O
+    from qtmpnn import ops
+    old, _ = _mesh_64(11, noise=0.0)
+    new, _ = _mesh_64(12, noise=0.03)
+    val = torch.randn(old.N, 8, device=dev(), requires_grad=True)
+    out = ops.remesh_transfer(val, old, new)
+    vc = val.detach().cpu().requires_grad_(True)
+    img = O.unflatten(vc, old.labels[0].cpu().numpy(), (64, 64))
+    ref = O.flatten(img[None], new.labels[0].cpu().numpy(), new.npix.cpu().numpy())[0]
+    close(out, ref)
+    g = torch.randn(new.N, 8)
+    (gv,) = torch.autograd.grad(out, val, g.to(dev()))
+    (gr,) = torch.autograd.grad(ref, vc, g)
+    close(gv, gr, atol=1e-4)
+
+
+@pytest.mark.parametrize('n_conv', [1, 2, 3])
+def test_graphconv_stack_vs_oracle(n_conv):
+    """Composed Chebyshev polynomial (one kernel pass) == the oracle's sequential ChebConv stack, fwd + grads."""
+    from model.model import GraphConv
+    from oracle import qt_oracle as O
+    from qtmpnn import ops
+    mesh, _ = _mesh_64(21, noise=0.0)
+    ei, ew = _oracle_graph(mesh)
+    torch.manual_seed(0)
+    ref = O.GraphConv('ChebConv', 8, 12, n_conv)
+    for p in ref.parameters():
+        p.data.normal_(0, 0.3)
+    mine = GraphConv('ChebConv', 8, 12, n_conv).to(dev())
+    mine.load_state_dict(ref.state_dict())
+    x = torch.randn(mesh.N, 8)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr, ei, ew)
+    # sequential on the GPU (module forward) and composed (one cheb_poly call)
+    xg = x.to(dev()).requires_grad_(True)
+    yg = mine(xg, mesh)
+    close(yg, yr, atol=1e-4)
+    W = [torch.stack([torch.stack([lin.weight.t() for lin in c.lins])]) for c in mine.convolutions]
+    b = [c.bias.unsqueeze(0) for c in mine.convolutions]
+    P, beta = ops.compose_chebconvs(W, b)
+    Wfull = torch.cat([P[0].reshape(-1, 12), beta[0]], dim=0)
+    xc = x.to(dev()).requires_grad_(True)
+    yc = ops.cheb_poly(xc, Wfull, mesh, P.shape[1], beta.shape[1])
+    close(yc, yr, atol=1e-4)
+    gy = torch.randn_like(yr)
+    gr = torch.autograd.grad(yr, [xr] + list(ref.parameters()), gy)
+    gg = torch.autograd.grad(yc, [xc] + list(mine.parameters()), gy.to(dev()))
+    for a, b_, name in zip(gg, gr, ['x'] + [k for k, _ in ref.named_parameters()]):
+        grad_close(a, b_, msg=name)
+
+
+@pytest.mark.parametrize('n_conv', [1, 2, 3])
+def test_gconvlstm_cell_golden(n_conv):
+    from model.model import GConvLSTM
+    from qtmpnn import synthetic
+    from qtmpnn.mesh import build_mesh
+    g = golden('cells.npz')
+    tag = f'nc{n_conv}'
+    c = synthetic.make_clip(31, canvas=(64, 64), n_digits=1, n_frames=1, pixel_noise=0.0)
+    mesh = build_mesh(src=torch.from_numpy(c[..., 0]).to(dev()), thresh=0.1)
+    assert np.array_equal(mesh.labels[0].cpu().numpy(), g['labels'])
+    cell = GConvLSTM(4, 8, n_conv, 'ChebConv')
+    load_state(cell, g, f'{tag}_w/')
+    cell.to(dev())
+    X, H, C = (torch.from_numpy(g[f'{tag}_{k}']).to(dev()).requires_grad_(True) for k in 'XHC')
+    Oo, Hn, Cn = cell(X, mesh, None, H, C)
+    for got, name in ((Oo, 'O'), (Hn, 'Hn'), (Cn, 'Cn')):
+        close(got, g[f'{tag}_{name}'], msg=name)
+    names = [k for k, _ in cell.named_parameters()]
+    grads = torch.autograd.grad([Oo, Hn, Cn], [X, H, C] + list(cell.parameters()),
+                                [torch.from_numpy(g[f'{tag}_g{k}']).to(dev()) for k in 'OHC'])
+    for got, name in zip(grads[:3], ('gX', 'gHin', 'gCin')):
+        grad_close(got, g[f'{tag}_{name}'], msg=name)
+    for got, k in zip(grads[3:], names):
+        grad_close(got, g[f'{tag}_g/{k}'], msg=k)
+
+
+def test_encoder_decoder_step_golden():
+    from model.seq2seq import Decoder, Encoder
+    from qtmpnn import synthetic
+    from qtmpnn.mesh import build_mesh
+    g = golden('cells.npz')
+    c = synthetic.make_clip(31, canvas=(64, 64), n_digits=1, n_frames=1, pixel_noise=0.0)
+    mesh = build_mesh(src=torch.from_numpy(c[..., 0]).to(dev()), thresh=0.1)
+    enc = Encoder(4, 8, 0.0, n_layers=2, convolution_type='ChebConv', rnn_type='LSTM', n_conv_layers=2)
+    load_state(enc, g, 'enc_w/')
+    enc.to(dev())
+    t = lambda k: torch.from_numpy(g[k]).to(dev())
+    hid, cel = enc(t('enc_X'), mesh, None, H=t('enc_H'), C=t('enc_C'))
+    close(hid, g['enc_hidden'])
+    close(cel, g['enc_cell'])
+    dec = Decoder(4, 8, 0.0, n_layers=2, concat_layers_dim=1, convolution_type='ChebConv', rnn_type='LSTM')
+    load_state(dec, g, 'dec_w/')
+    dec.to(dev()).eval()
+    out, hid, cel = dec(t('dec_X'), mesh, None, t('dec_concat'), t('dec_H'), t('dec_C'))
+    close(out, g['dec_out'])
+    close(hid, g['dec_hidden'])
+    close(cel, g['dec_cell'])
+
+
+@pytest.mark.parametrize('h', [8, 16, 32])
+def test_lstm_kernel_vs_torch(h):
+    """Cell + fused LayerNorm against a plain fp32 torch reference (forward and every gradient)."""
+    from qtmpnn import ops
+    torch.manual_seed(h)
+    N = 1000
+    mk = lambda *s: torch.randn(*s, device=dev(), requires_grad=True)
+    G, Cp, wc, b, ln = mk(N, 4 * h), mk(N, h), mk(3, h), mk(4, h), mk(4, h)
+
+    def ref(G, Cp, wc, b, ln):
+        gi, gf, gc, go = G.split(h, dim=1)
+        I = torch.sigmoid(gi + wc[0] * Cp + b[0])
+        F = torch.sigmoid(gf + wc[1] * Cp + b[1])
+        T = torch.tanh(gc + b[2])
+        Cr = F * Cp + I * T
+        Og = torch.sigmoid(go + wc[2] * Cr + b[3])
+        Hr = Og * torch.tanh(Cr)
+        return (Og, torch.nn.functional.layer_norm(Hr, (h,), ln[0], ln[1], 1e-5),
+                torch.nn.functional.layer_norm(Cr, (h,), ln[2], ln[3], 1e-5))
+    outs = ops.lstm_cell(G, Cp, wc, b, ln)
+    refs = ref(G, Cp, wc, b, ln)
+    for a, r in zip(outs, refs):
+        close(a, r, atol=2e-5)
+    gs = [torch.randn_like(o) for o in refs]
+    ga = torch.autograd.grad(outs, [G, Cp, wc, b, ln], gs)
+    gr = torch.autograd.grad(refs, [G, Cp, wc, b, ln], gs)
+    for a, r, name in zip(ga, gr, ['G', 'Cprev', 'wc', 'b', 'ln']):
+        grad_close(a, r, msg=name)
+
+
+def test_head_kernel_vs_torch():
+    from qtmpnn import ops
+    torch.manual_seed(1)
+    N, h = 777, 16
+    O = torch.randn(N, h, device=dev(), requires_grad=True)
+    ln = torch.randn(2, h, device=dev(), requires_grad=True)
+    cc = torch.randn(N, 1, device=dev(), requires_grad=True)
+    z = ops.head_input(O, ln, cc, h + 4)
+    ref = torch.cat([torch.relu(torch.nn.functional.layer_norm(O, (h,), ln[0], ln[1], 1e-5)), cc,
+                     torch.zeros(N, 3, device=dev())], dim=1)
+    close(z, ref, atol=2e-5)
+    g = torch.randn_like(ref)
+    ga = torch.autograd.grad(z, [O, ln, cc], g)
+    gr = torch.autograd.grad(ref, [O, ln, cc], g)
+    for a, r, name in zip(ga, gr, ['O', 'ln_o', 'concat']):
+        grad_close(a, r, msg=name)
+
+
+def test_step_sse_vs_torch():
+    from qtmpnn import ops
+    mesh, _ = _mesh_64(41, noise=0.02, B=3)
+    out = torch.randn(mesh.N, 1, device=dev(), requires_grad=True)
+    y = torch.rand(3, 64 * 64, device=dev())
+    sse = ops.step_sse(out, y, mesh)
+    img = out[mesh.labels.reshape(3, -1).long(), 0]
+    ref = ((img - y) ** 2).sum()
+    close(sse, ref, rtol=1e-5)
+    (ga,) = torch.autograd.grad(sse, out)
+    (gr,) = torch.autograd.grad(ref, out)
+    grad_close(ga, gr)

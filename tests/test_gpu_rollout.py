@@ -1,0 +1,102 @@
+"""GPU parity of the whole rollout (Seq2Seq forward + masked MSE + backward) against the golden
+traces captured from the reference, plus batching / determinism / training smoke checks."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import close, dev, dist_from_05, golden, grad_close, load_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _model_from_golden(g, x):
+    from model.seq2seq import Seq2Seq
+    model = Seq2Seq(hidden_size=int(g['hidden']), dropout=0.0, thresh=float(g['thresh']), input_timesteps=x.shape[0],
+                    input_features=x.shape[-1] + 3, output_timesteps=g['y'].shape[0], n_layers=int(g['n_layers']),
+                    n_conv_layers=int(g['n_conv']), transform_func=dist_from_05 if bool(g['has_transform']) else None,
+                    convolution_type='ChebConv')
+    load_state(model, g, 'w/')
+    return model.to(dev())
+
+
+def _run(g, batch=1):
+    from model.mpnnlstm import masked_mse
+    x, y, concat = (torch.from_numpy(g[k]).to(dev()) for k in ('x', 'y', 'concat'))
+    model = _model_from_golden(g, g['x'])
+    if batch > 1:
+        x, y, concat = (t.unsqueeze(0).repeat(batch, *[1] * t.dim()) for t in (x, y, concat))
+    hir = g['hir'] if 'hir' in g.files else None
+    outs, meshes = model(x, y, concat, teacher_forcing_ratio=0, mask=g['mask'], high_interest_region=hir)
+    loss = masked_mse(outs, meshes, y, g['mask'])
+    return model, outs, meshes, loss
+
+
+def _check_trace(g, outs, meshes, clip=0):
+    """Per-step index parity: labels must be bit-exact while the input image of the step matches; a first
+    mismatch is accepted only if explained by a value within fp tolerance of the threshold."""
+    thresh = float(g['thresh'])
+    for i, mesh in enumerate(meshes):
+        off = mesh.node_off.cpu().numpy()
+        lab = mesh.labels[clip].cpu().numpy()
+        lab = np.where(lab >= 0, lab - off[clip], -1)
+        ref = g[f'labels_{i}']
+        if not np.array_equal(lab, ref):
+            img = g[f'image_{i}']
+            near = np.abs(img - thresh).min()
+            assert near < 1e-5 * max(1.0, abs(thresh)), f'mesh {i} differs and no pixel sits on the threshold ({near})'
+            pytest.skip(f'mesh {i}: a pixel within {near:.2e} of the threshold flipped (chaotic remesh)')
+        o = outs[i][off[clip]:off[clip + 1]]
+        close(o, g[f'out_{i}'], msg=f'output step {i}')
+
+
+@pytest.mark.parametrize('name', ['mnist64_h16', 'mnist64_noise_h8', 'ice64_masked_h8'])
+def test_rollout_golden(name):
+    g = golden(f'rollout_{name}.npz')
+    model, outs, meshes, loss = _run(g)
+    _check_trace(g, outs, meshes)
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss'])), (float(loss), float(g['loss']))
+    loss.backward()
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        grad_close(p.grad, g['g/' + k], msg=k)
+
+
+def test_rollout_batched_equals_single():
+    """B identical clips: per-clip outputs equal the single-clip outputs; loss equal; grads equal (mean over clips)."""
+    g = golden('rollout_ice64_masked_h8.npz')
+    model, outs, meshes, loss = _run(g, batch=3)
+    for c in range(3):
+        _check_trace(g, outs, meshes, clip=c)
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    loss.backward()
+    for k, p in model.named_parameters():
+        grad_close(p.grad, g['g/' + k], msg=k)
+
+
+def test_rollout_deterministic():
+    g = golden('rollout_mnist64_h16.npz')
+    res = []
+    for _ in range(2):
+        model, outs, meshes, loss = _run(g)
+        loss.backward()
+        res.append((loss.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+
+
+def test_train_steps_reduce_loss():
+    from model.mpnnlstm import NextFramePredictorS2S
+    from qtmpnn import synthetic
+    torch.manual_seed(1)
+    x, y = synthetic.make_batch(1, 0, 4, 5, 5, n_digits=1, pixel_noise=0.05)
+    x, y = torch.from_numpy(x).to(dev()), torch.from_numpy(y).to(dev())
+    mask = np.zeros((64, 64), dtype=bool)
+    concat = torch.zeros(4, 5, 64, 64, 1, device=dev())
+    nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=5, output_timesteps=5, device=dev(),
+                                model_kwargs=dict(hidden_size=16, dropout=0.1, n_layers=2))
+    assert nfp.get_n_params() == 34513
+    nfp.initiate_training(lr=0.01, lr_decay=0.95)
+    losses = [float(nfp.train_step(x, y, concat, mask)) for _ in range(8)]
+    assert np.isfinite(losses).all()
+    assert losses[-1] < losses[0], losses

@@ -1,0 +1,141 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every declared symbol, the host
+logic (weight composition, packing, state-dict layout, data generator, sharding) is correct."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from qtmpnn import _lib
+    header = open(os.path.join(ROOT, 'include', 'qtmpnn.h')).read()
+    declared = set(re.findall(r'\b(qt_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} is declared in include/qtmpnn.h but not exported'
+    assert declared == set(_lib.exported_names()), declared ^ set(_lib.exported_names())
+    assert lib.qt_abi_version() == 1
+
+
+def test_bad_arguments_fail_loudly_without_gpu():
+    from qtmpnn import _lib
+    lib = _lib.load()
+    rc = lib.qt_spmm(None, None, None, 4, 4, None, 1.0, None, 0.0, None, 0.0, None, None)
+    assert rc == -1 and b'qt_spmm' in lib.qt_last_error()
+    assert lib.qt_lstm_fwd(None, None, None, None, None, 1, 16, None, None, None, None, None, None) == -1
+
+
+def test_product_path_refuses_cpu_tensors():
+    from qtmpnn.mesh import build_mesh
+    with pytest.raises(RuntimeError, match='GPU'):
+        build_mesh(src=torch.zeros(1, 8, 8), thresh=0.1)
+
+
+def test_state_dict_layout_matches_reference():
+    """KAT-6: 34 513 parameters in 238 tensors with the reference's key names (golden 'w/' keys)."""
+    from model.seq2seq import Seq2Seq
+    from oracle import qt_oracle as O
+    m = Seq2Seq(hidden_size=16, dropout=0.1, thresh=0.1, input_timesteps=10, input_features=4, output_timesteps=10, n_layers=2)
+    sd = m.state_dict()
+    assert sum(p.numel() for p in m.parameters()) == 34513
+    assert len(sd) == 238
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'rollout_mnist64_h16.npz'))
+    ref_keys = [k[2:] for k in g.files if k.startswith('w/')]
+    assert list(sd.keys()) == ref_keys                      # same names AND same order as the reference
+    for k in ref_keys:
+        assert tuple(sd[k].shape) == g['w/' + k].shape, k
+    o = O.Seq2Seq(16, 0.1, 0.1, input_timesteps=10, input_features=4, output_timesteps=10, n_layers=2)
+    assert set(o.state_dict().keys()) == set(ref_keys)
+    assert sd['encoder.rnns.0.conv_x_i.convolutions.0.lins.0.weight'].shape == (16, 4)
+    assert sd['encoder.rnns.0.w_c_i'].shape == (1, 16)
+
+
+@pytest.mark.parametrize('n_conv', [1, 2, 3])
+def test_chebconv_composition_algebra(n_conv):
+    """compose_chebconvs (host, torch): one Chebyshev series == the oracle's sequential ChebConv stack,
+    evaluated here with a dense L^ on the CPU."""
+    from oracle import qt_oracle as O
+    from qtmpnn.ops import compose_chebconvs
+    torch.manual_seed(n_conv)
+    labels = O.quadtree_decompose(np.random.default_rng(0).random((16, 16)).astype(np.float32), thresh=0.8, max_size=8)
+    ei = torch.as_tensor(O.adjacency_sorted(labels))
+    n = int(labels.max()) + 1
+    ew = torch.rand(ei.shape[1]) + 0.5
+    ew = (ew + ew[torch.argsort(torch.argsort(ei[1] * n + ei[0]))]) / 2        # symmetric weights
+    key = {(int(a), int(b)): i for i, (a, b) in enumerate(ei.T)}
+    ew = torch.stack([(ew[i] + ew[key[(int(b), int(a))]]) / 2 for i, (a, b) in enumerate(ei.T)])
+    stack = O.GraphConv('ChebConv', 5, 6, n_conv)
+    for p in stack.parameters():
+        p.data.normal_(0, 0.4)
+    x = torch.randn(n, 5)
+    ref = stack(x, ei, ew)
+    keep = ei[0] != ei[1]
+    W = torch.zeros(n, n, dtype=torch.float64)
+    W[ei[1][keep], ei[0][keep]] = ew[keep].double()
+    deg = W.sum(0)
+    dis = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
+    L = -(dis[:, None] * W * dis[None, :])
+    Ws = [torch.stack([torch.stack([lin.weight.t() for lin in c.lins])]) for c in stack.convolutions]
+    bs = [c.bias.unsqueeze(0) for c in stack.convolutions]
+    P, beta = compose_chebconvs(Ws, bs)
+    assert P.shape[1] == 2 * n_conv + 1 and beta.shape[1] == 2 * (n_conv - 1) + 1
+    T = [x.double(), L @ x.double()]
+    ones = [torch.ones(n, 1, dtype=torch.float64), L @ torch.ones(n, 1, dtype=torch.float64)]
+    for _ in range(2, P.shape[1]):
+        T.append(2 * L @ T[-1] - T[-2])
+        ones.append(2 * L @ ones[-1] - ones[-2])
+    out = sum(T[k] @ P[0, k].double() for k in range(P.shape[1])) + \
+        sum(ones[k] @ beta[0, k].double().unsqueeze(0) for k in range(beta.shape[1]))
+    np.testing.assert_allclose(out.detach().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_gconvlstm_packing_shapes():
+    from model.model import GConvLSTM
+    cell = GConvLSTM(4, 16, n_conv_layers=2, convolution_type='ChebConv')
+    W, wc, b, K, Ks = cell.packed(True, 4)
+    assert (K, Ks) == (5, 3) and W.shape == (5 * 20 + 3, 64) and wc.shape == (3, 16) and b.shape == (4, 16)
+    W, _, _, K, Ks = cell.packed(False, 8)
+    assert W.shape == (5 * 8 + 3, 64)
+    cell1 = GConvLSTM(16, 16, n_conv_layers=1, convolution_type='ChebConv')
+    W, _, _, K, Ks = cell1.packed(True)
+    assert (K, Ks) == (3, 1) and W.shape == (3 * 32 + 1, 64)
+    # gate order i, f, c, o along the output axis
+    lin = cell1.conv_x_c.convolutions[0].lins[1].weight
+    assert torch.equal(W[32:48, 32:48], lin.t())
+
+
+def test_synthetic_clips_are_deterministic_and_shaped():
+    from qtmpnn import synthetic
+    a = synthetic.make_clip(5, n_digits=2, n_frames=20)
+    b = synthetic.make_clip(5, n_digits=2, n_frames=20)
+    assert a.shape == (20, 64, 64, 1) and a.dtype == np.float32 and np.array_equal(a, b)
+    x, y = synthetic.make_batch(2, 0, 3, 10, 10, n_digits=2)
+    assert x.shape == (3, 10, 64, 64, 1) and y.shape == (3, 10, 64, 64, 1)
+    clean = synthetic.make_clip(5, n_frames=4, pixel_noise=0.0)
+    assert 0.02 < (clean > 0.1).mean() < 0.3 and clean.max() <= 1.0 and clean.min() == 0.0
+
+
+def test_positional_encoding_matches_oracle():
+    from model.utils import add_positional_encoding
+    from oracle import qt_oracle as O
+    x = torch.randn(3, 12, 20, 2)
+    assert torch.equal(add_positional_encoding(x), O.add_positional_encoding(x))
+    xn = add_positional_encoding(x.numpy())
+    np.testing.assert_array_equal(xn, O.add_positional_encoding(x).numpy())
+
+
+def test_unsupported_variants_raise_clearly():
+    from model.model import GConvGRU
+    from model.seq2seq import Seq2Seq
+    with pytest.raises(NotImplementedError):
+        GConvGRU(4, 4)
+    with pytest.raises(NotImplementedError):
+        Seq2Seq(16, 0.1, 0.1, convolution_type='TransformerConv')
+    with pytest.raises(AssertionError):
+        Seq2Seq(16, 0.1, 0.1, convolution_type='NoSuchConv')
