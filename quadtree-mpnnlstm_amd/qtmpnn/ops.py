@@ -165,7 +165,7 @@ class _LstmCell(Function):
                       N, h, ptr(gG), ptr(gCp), ptr(part))
             _lib.call('qt_colsum', ptr(part), nblk, 11 * h, ptr(psum))
         psum = psum.view(11, h)
-        return gG, gCp, psum[0:3], psum[3:7], psum[7:11]
+        return gG, gCp, psum[0:3], psum[3:7], (psum[7:11] if ln is not None else None)
 
 
 def lstm_cell(G, Cprev, wc, b, ln):

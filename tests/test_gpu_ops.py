@@ -43,9 +43,10 @@ def test_flatten_unflatten_golden():
 def test_spmm_vs_dense(C):
     from qtmpnn.mesh import spmm
     mesh, _ = _mesh_64(3, noise=0.02, B=2)
-    ei = mesh.edge_index(False)
+    rp = mesh.rowptr.long()
+    rows = torch.repeat_interleave(torch.arange(mesh.N, device=dev()), rp[1:] - rp[:-1])      # CSR order
     L = torch.zeros(mesh.N, mesh.N, dtype=torch.float64, device=dev())
-    L[ei[0], ei[1]] = mesh.nrm[:mesh.E].double()
+    L[rows, mesh.col[:mesh.E].long()] = mesh.nrm[:mesh.E].double()
     x = torch.randn(mesh.N, C, device=dev())
     p, q = torch.randn_like(x), torch.randn_like(x)
     out = torch.empty_like(x)
