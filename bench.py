@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Throughput bench of the Quadtree-MPNNLSTM training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step (forward + masked MSE + backward + [all-reduce] + clip_grad_norm_(10)
++ Adam) over one per-GPU batch of synthetic Moving-MNIST-like clips that is already resident in HBM.
+Workload at every N: BASELINE.json configs[1] per GPU (64x64, 2 digits, in=10/out=10, 32 clips per GPU,
+pixel noise 0.05, thresh 0.1, hidden 16, 2 layers, ChebConv K=3, dropout 0.1) -> weak scaling.
+Rank 0 prints ONE JSON line.  `roofline` is measured on the message-aggregate kernel (k_spmm) with HIP
+events around every launch of one extra, untimed training step; `cpu_baseline` times the CPU oracle
+(a port of the reference algorithm, one clip per optimizer step like the reference) on the host cores.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'quadtree-mpnnlstm_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+T_IN, T_OUT, CANVAS, N_DIGITS, NOISE, THRESH = 10, 10, (64, 64), 2, 0.05, 0.1
+HIDDEN, N_LAYERS, DROPOUT, LR = 16, 2, 0.1, 0.01
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
+    ap.add_argument('--noise', type=float, default=NOISE)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-clips', type=int, default=3)
+    ap.add_argument('--eager', action='store_true', help='Python-driven launches instead of hipGraph replay')
+    return ap.parse_args()
+
+
+def make_predictor(device, capturable=False):
+    import torch
+    from model.mpnnlstm import NextFramePredictorS2S
+    torch.manual_seed(1)
+    nfp = NextFramePredictorS2S(thresh=THRESH, input_features=1, input_timesteps=T_IN, output_timesteps=T_OUT,
+                                device=device, model_kwargs=dict(hidden_size=HIDDEN, dropout=DROPOUT, n_layers=N_LAYERS))
+    nfp.initiate_training(lr=LR, lr_decay=0.95, capturable=capturable)
+    return nfp
+
+
+def spmm_roofline(nfp, batch, mask):
+    """HIP events around every k_spmm launch of one extra training step on the launch stream.
+    Algorithmic bytes per launch: 4(N+1) + 8E' + 8NC."""
+    import torch
+    from qtmpnn import mesh as qmesh, ops
+    records = []
+    orig = qmesh.spmm
+
+    def timed(ms, x, alpha, p, beta, q, gamma, out, C):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        orig(ms, x, alpha, p, beta, q, gamma, out, C)
+        b.record()
+        records.append((a, b, ms, C))
+    qmesh.spmm = ops.spmm = timed
+    try:
+        nfp.train_step(*batch, mask)
+        torch.cuda.synchronize()
+    finally:
+        qmesh.spmm = ops.spmm = orig
+    tot_ms, tot_bytes = 0.0, 0.0
+    for a, b, ms, C in records:
+        tot_ms += a.elapsed_time(b)
+        nv = ms.n_valid                      # static mode: ms.N is the capacity, the count lives on the device
+        tot_bytes += 4.0 * (nv + 1) + 8.0 * ms.E + 8.0 * nv * C
+    n = len(records)
+    achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernel': 'k_spmm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'launches_per_step': n,
+            'avg_launch_us': round(tot_ms * 1e3 / n, 2), 'avg_bytes_per_launch': round(tot_bytes / n)}
+
+
+def cpu_baseline(n_clips):
+    """The CPU oracle (kind "port": a restatement of the reference algorithm, see oracle/qt_oracle.py) on a
+    bounded sample of the same workload: one clip per optimizer step, like the reference's batch_size=1 loop."""
+    import numpy as np
+    import torch
+    from oracle import qt_oracle as O
+    from qtmpnn import synthetic
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # the GPU box gives one job a 16-core share; more threads only thrash
+    torch.set_num_threads(cores)
+    torch.manual_seed(1)
+    model = O.Seq2Seq(HIDDEN, DROPOUT, THRESH, input_timesteps=T_IN, input_features=4, output_timesteps=T_OUT,
+                      n_layers=N_LAYERS, n_conv_layers=2)
+    opt = torch.optim.Adam(model.parameters(), lr=LR)
+    mask = np.zeros(CANVAS, dtype=bool)
+    x, y = synthetic.make_batch(2, 0, n_clips + 1, T_IN, T_OUT, n_digits=N_DIGITS, pixel_noise=NOISE, canvas=CANVAS)
+    concat = torch.zeros(T_OUT, *CANVAS, 1)
+    O.train_step(model, opt, torch.from_numpy(x[0]), torch.from_numpy(y[0]), concat, mask)      # warm-up clip
+    t0 = time.perf_counter()
+    for i in range(1, n_clips + 1):
+        O.train_step(model, opt, torch.from_numpy(x[i]), torch.from_numpy(y[i]), concat, mask)
+    dt = time.perf_counter() - t0
+    return {'value': round(n_clips * (T_IN + T_OUT) / dt, 3), 'unit': 'frames/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'sample': f'{n_clips} clips of the same workload, one clip per optimizer step, '
+                                      f'after 1 warm-up clip ({dt:.1f} s)'}
+
+
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started by hand: become the torchrun parent BEFORE anything touches the GPU
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', os.environ.get('MASTER_PORT', '29511'),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from qtmpnn import synthetic
+    from qtmpnn.dist import broadcast_parameters, init_from_env
+
+    rank, world, local = init_from_env('nccl')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    nfp = make_predictor(device, capturable=(world == 1 and not args.eager))
+    if world > 1:
+        broadcast_parameters(nfp.model)
+    nfp.model.train()
+
+    # synthetic batches resident in HBM before the timed region; rank r owns clips [r*B, (r+1)*B) of each batch
+    mask = np.zeros(CANVAS, dtype=bool)
+    n_pool = 4
+    pool = []
+    for i in range(n_pool):
+        x, y = synthetic.make_batch(2, (i * world + rank) * args.batch, args.batch, T_IN, T_OUT, n_digits=N_DIGITS,
+                                    pixel_noise=args.noise, canvas=CANVAS)
+        pool.append((torch.from_numpy(x).to(device), torch.from_numpy(y).to(device),
+                     torch.zeros(args.batch, T_OUT, *CANVAS, 1, device=device)))
+
+    log(f'rank {rank}: {n_pool} batches of {args.batch} clips resident on {device}')
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.eager:
+        step = lambda x, y, c: nfp.train_step(x, y, c, mask)
+    else:
+        # the whole step (forward, loss, backward, clip, Adam) as ONE hipGraph; 2 of the warm-up steps run eagerly
+        step = nfp.make_graphed_step(*pool[0], mask=mask, warmup=2)
+        log('training step captured into a hipGraph')
+    for i in range(max(args.warmup - (0 if args.eager else 2), 0)):
+        l = step(*pool[i % n_pool])
+        if rank == 0:
+            log(f'warm-up step {i}: loss {float(l):.5f}')
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(*pool[i % n_pool])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(loss).item(), 'non-finite loss in the timed region'
+
+    if rank == 0:
+        global_batch = args.batch * world
+        frames = global_batch * (T_IN + T_OUT) * args.steps
+        line = {
+            'metric': 'frames/sec (train fwd+bwd), 64x64 MovingMNIST in=10/out=10', 'value': round(frames / dt, 1),
+            'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: Moving-MNIST-like 64x64, 2 digits, in=10/out=10, '
+                                   f'{args.batch} clips per GPU, pixel noise {args.noise}, thresh {THRESH}, hidden {HIDDEN}, '
+                                   f'{N_LAYERS} layers, ChebConv K=3, dropout {DROPOUT}, Adam',
+                       'global_batch': global_batch, 'frames_per_clip': T_IN + T_OUT, 'parallelism': f'dp{world}', 'launch': 'eager' if args.eager else 'hipGraph replay',
+                       'final_loss': round(float(loss), 6)},
+        }
+        log(f'timed {args.steps} steps in {dt:.3f} s')
+        if not args.no_roofline:
+            line['roofline'] = spmm_roofline(nfp, pool[0], mask)
+            log('roofline step done')
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.cpu_clips)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

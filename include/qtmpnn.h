@@ -13,6 +13,10 @@
  *     never synchronises and keeps no global state besides the last-error text;
  *   - return value 0 = ok, negative = QT_E_* ; qt_last_error() gives the text;
  *   - fp32 data, int32 indices; node-feature matrices are row-major (N, C);
+ *   - every entry that takes a node count `int N` also takes `const int32_t* n_dev`: NULL means "N rows
+ *     are valid"; otherwise N is the CAPACITY of the buffers (row strides, grid size) and the valid row
+ *     count is read from *n_dev on the device (node_off + B of qt_quadtree_stage3), so a whole training
+ *     step can be captured in a hipGraph with no host read-back of the data-dependent mesh size;
  *   - a "mesh" is the block-diagonal quadtree graph of B clips:
  *       labels (B, n, m) int32   global node id of every pixel, -1 = masked
  *       level  (B, n, m) uint8   log2(cell size) of the pixel's leaf
@@ -74,7 +78,8 @@ int qt_scan_i32(const int32_t* in, int32_t* out, int64_t len, int32_t* tmp, void
 
 /* static node features {col centroid / m, row centroid / n, npix / size_norm} (image_to_graph :657-668,
  * utils.py:37-45) and npix; feat (N, 3), npix (N). */
-int qt_node_features(const int32_t* cell, int N, int n, int m, float size_norm, float* feat, float* npix, void* stream);
+int qt_node_features(const int32_t* cell, int N, const int32_t* n_dev, int n, int m, float size_norm,
+                     float* feat, float* npix, void* stream);
 
 /* ---------------------------------------------------------------- adjacency
  * get_adj + dist, model/graph_functions.py:261-363, and the ChebConv normalisation that PyG
@@ -82,11 +87,13 @@ int qt_node_features(const int32_t* cell, int N, int n, int m, float size_norm, 
  * stage1 counts distinct neighbours per (node, side) -> cnt4 (4N); scan; stage2 fills col and
  * w = centroid distance * resolution; stage3 computes deg, dis and nrm = -dis_i w dis_j.
  */
-int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, int n, int m, int32_t* cnt4, void* stream);
+int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, const int32_t* n_dev, int n, int m,
+                   int32_t* cnt4, void* stream);
 int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* off4 /* scan of cnt4, 4N+1 */,
-                  int N, int n, int m, float resolution,
+                  int N, const int32_t* n_dev, int n, int m, float resolution,
                   int32_t* rowptr /* N+1 */, int32_t* col, float* w, void* stream);
-int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, int N, float* dis /* N */, float* nrm, void* stream);
+int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, int N, const int32_t* n_dev,
+                  float* dis /* N */, float* nrm, void* stream);
 
 /* ---------------------------------------------------------------- mesh <-> image transfers
  * flatten / unflatten, model/graph_functions.py:391-419, 451-458, by labels instead of the dense
@@ -116,7 +123,7 @@ int qt_sse(const float* out, int out_stride, const int32_t* labels, const float*
  *   out[i,:] = alpha * sum_e nrm[e] * x[col[e],:] + beta * p[i,:] + gamma * q[i,:]      (p, q may be NULL)
  * x, out, p, q: (N, C) contiguous planes; out must not alias x (it may alias p or q).
  */
-int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, int C,
+int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, const int32_t* n_dev, int C,
             const float* x, float alpha, const float* p, float beta, const float* q, float gamma,
             float* out, void* stream);
 
@@ -127,14 +134,14 @@ int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, 
  *   act: QT_ACT_* applied to the result (only with Kb == 1); res (N) / drop (N) for QT_ACT_TANH_RES, drop may be NULL.
  */
 int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, const float* W,
-             const float* S, int Ks, const float* Ws, int Kb, int Cb, int N,
+             const float* S, int Ks, const float* Ws, int Kb, int Cb, int N, const int32_t* n_dev,
              int act, const float* res, int res_stride, const float* drop, float* out, void* stream);
 
 /* qt_wgrad: partial sums of [A planes | S]^T @ G over row blocks, then qt_colsum over the blocks.
  *   G (N, Co); part (nblk, Ka*Ca + Ks, Co) with nblk = qt_wgrad_blocks(N).  */
 int qt_wgrad_blocks(int N);
 int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, const float* S, int Ks,
-             const float* G, int Co, int N, float* part, void* stream);
+             const float* G, int Co, int N, const int32_t* n_dev, float* part, void* stream);
 /* out[j] = sum_i part[i*len + j], i < nblk */
 int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream);
 
@@ -148,18 +155,19 @@ int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream
  *   gates (N, 4h) activated I, F, T, O and Craw (N, h) saved for the backward.
  */
 int qt_lstm_fwd(const float* G, const float* Cprev, const float* wc, const float* b, const float* ln,
-                int N, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw, void* stream);
+                int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw,
+                void* stream);
 /* gO may be NULL.  part: (nblk, 11*h) partial sums [g_wc(3h) | g_b(4h) | g_ln(4h)], nblk = qt_lstm_bwd_blocks(N, h) */
 int qt_lstm_bwd_blocks(int N, int h);
 int qt_lstm_bwd(const float* gO, const float* gHn, const float* gCn,
                 const float* gates, const float* Craw, const float* Cprev, const float* wc, const float* ln,
-                int N, int h, float* gG, float* gCprev, float* part, void* stream);
+                int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, void* stream);
 
 /* decoder head input, model/seq2seq.py:160-165: Z (N, hp) = [relu(LayerNorm_o(O)) | concat | 0...], hp >= h+1 */
 int qt_head_fwd(const float* O, const float* ln_o /* (2,h) */, const float* concat /* (N) or NULL */,
-                int N, int h, int hp, float* Z, void* stream);
+                int N, const int32_t* n_dev, int h, int hp, float* Z, void* stream);
 /* gO (N,h), gconcat (N) or NULL; part (nblk, 2h) partial sums of g_ln_o, nblk = qt_lstm_bwd_blocks(N, h) */
-int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, int h, int hp,
+int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, const int32_t* n_dev, int h, int hp,
                 float* gO, float* gconcat, float* part, void* stream);
 
 #ifdef __cplusplus

@@ -1,7 +1,7 @@
 // Chebyshev graph convolution pieces (PyG ChebConv as used by model/model.py:53,96):
 //   k_spmm  -- the CSR message-aggregate  out = alpha * L^ x + beta * p + gamma * q
-//   k_gemm  -- tiled fp32 GEMM used for the gate GEMM  Y = [T_0 .. T_{K-1} | S] W, its
-//              data gradient and (split over row blocks) its weight gradient
+//   k_gemm_fwd / k_gemm_wgrad -- fp32 MFMA (32x32x2) GEMMs: the gate GEMM Y = [T_0 .. T_{K-1} | S] W and its
+//              data gradient; the weight gradient split over row blocks
 //   k_colsum -- fixed-order reduction of per-block partial sums
 #include "qt_common.h"
 
@@ -10,13 +10,14 @@ namespace {
 // ------------------------------------------------------------------ message aggregate
 template <int VEC>
 __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                              const float* __restrict__ nrm, int N, int C, const float* __restrict__ x,
-                                              float alpha, const float* p, float beta, const float* q, float gamma,
+                                              const float* __restrict__ nrm, int Ncap, const int32_t* __restrict__ n_dev,
+                                              int C, const float* __restrict__ x, float alpha, const float* p, float beta,
+                                              const float* q, float gamma,
                                               float* out) {  // out may alias p or q (in-place Clenshaw step)
     const int nch = C / VEC;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = idx / nch;
-    if (row >= N) return;
+    if (row >= qt_rows(n_dev, Ncap)) return;
     const int ch = (int)(idx % nch) * VEC;
     float acc[VEC];
 #pragma unroll
@@ -77,95 +78,141 @@ struct GemmArgs {
     const float* drop;
     float* out;
     int64_t row0_step;  // wgrad: rows per block
+    const int32_t* n_dev;  // valid node rows on the device (NULL: A.N)
 };
 
-constexpr int TM = 64, TN = 64, TK = 16;
+// ---- fp32 MFMA tiles (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 64 FLOP/clk/SIMD).
+// Operand maps (cdna_hip_programming.md section 3): lane l holds A[i = l & 31][k = l >> 5] and
+// B[k = l >> 5][j = l & 31]; accumulator register r of lane l is C[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int KC = 32;        // reduction depth staged in LDS per pass
+constexpr int BM = 128;       // block rows (4 waves x 32)
+constexpr int BN = 64;        // block columns (2 MFMA tiles per wave)
 
-// MODE 0: out planes = act(A @ W);  MODE 1: part[blockIdx.z] = A[rows]^T @ G[rows]
-template <int MODE>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
-    __shared__ float As[TK][TM + 4];
-    __shared__ float Bs[TK][TN + 4];
-    const int t = threadIdx.x;
-    const int tx = t & 15, ty = t >> 4;
-    const int i0 = blockIdx.x * TM, j0 = blockIdx.y * TN;
-    int64_t kbeg = 0, kend = g.K;
-    if (MODE == 1) {
-        kbeg = (int64_t)blockIdx.z * g.row0_step;
-        kend = min((int64_t)g.A.N, kbeg + g.row0_step);
-    }
-    float acc[4][4];
+// MODE 0: out planes = act(A @ W).  Block = 128 node rows x 64 output columns, wave w owns rows [32w, 32w+32).
+__global__ __launch_bounds__(256) void k_gemm_fwd(GemmArgs g) {
+    __shared__ float As[BM][KC + 1];
+    __shared__ float Bs[KC][BN];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l32 = lane & 31, half = lane >> 5;
+    const int64_t i0 = (int64_t)blockIdx.x * BM;
+    const int j0 = blockIdx.y * BN;
+    const int64_t rows = qt_rows(g.n_dev, g.M);      // g.M stays the plane stride (capacity)
+    if (i0 >= rows) return;
+    f32x16 acc0 = {0}, acc1 = {0};
+    for (int k0 = 0; k0 < g.K; k0 += KC) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
-
-    for (int64_t k0 = kbeg; k0 < kend; k0 += TK) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < BM * KC / 256; ++u) {
             const int e = t + 256 * u;
-            if (MODE == 0) {
-                const int i = e >> 4, k = e & 15;
-                const int64_t row = i0 + i;
-                As[k][i] = (row < g.M && k0 + k < kend) ? g.A.at(row, (int)(k0 + k)) : 0.0f;
-            } else {
-                const int i = e & 63, k = e >> 6;
-                const int feat = i0 + i;
-                As[k][i] = (feat < g.M && k0 + k < kend) ? g.A.at(k0 + k, feat) : 0.0f;
-            }
+            const int r = e >> 5, k = e & 31;
+            const int64_t row = i0 + r;
+            As[r][k] = (row < rows && k0 + k < g.K) ? g.A.at(row, k0 + k) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < KC * BN / 256; ++u) {
+            const int e = t + 256 * u;
             const int kb = e >> 6, j = e & 63;
-            Bs[kb][j] = (j0 + j < g.NB && k0 + kb < kend) ? g.B[(k0 + kb) * g.NB + j0 + j] : 0.0f;
+            Bs[kb][j] = (j0 + j < g.NB && k0 + kb < g.K) ? g.B[(int64_t)(k0 + kb) * g.NB + j0 + j] : 0.0f;
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < TK; ++k) {
-            const float4 av = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
-            const float4 bv = *reinterpret_cast<const float4*>(&Bs[k][tx * 4]);
-            const float a_[4] = {av.x, av.y, av.z, av.w};
-            const float b_[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(a_[a], b_[b], acc[a][b]);
+        for (int ks = 0; ks < KC / 2; ++ks) {
+            const float a = As[wave * 32 + l32][2 * ks + half];
+            const float b0 = Bs[2 * ks + half][l32];
+            const float b1 = Bs[2 * ks + half][32 + l32];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
         }
         __syncthreads();
     }
-
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int64_t i = i0 + ty * 4 + a;
-        if (i >= g.M) continue;
+    for (int jt = 0; jt < 2; ++jt) {
+        const int j = j0 + jt * 32 + l32;
+        if (j >= g.NB) continue;
+        const int pl = j / g.Cb, ch = j - pl * g.Cb;
+        float* obase = g.out + (int64_t)pl * g.M * g.Cb + ch;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int j = j0 + tx * 4 + b;
-            if (j >= g.NB) continue;
-            float r = acc[a][b];
-            if (MODE == 0) {
-                if (g.act == QT_ACT_RELU) r = fmaxf(r, 0.0f);
-                if (g.act == QT_ACT_TANH_RES) r = tanhf((g.drop ? g.drop[i] : 1.0f) * r) + g.res[i * g.res_stride];
-                const int pl = j / g.Cb, ch = j - pl * g.Cb;
-                g.out[(int64_t)pl * g.M * g.Cb + i * g.Cb + ch] = r;
-            } else {
-                g.out[((int64_t)blockIdx.z * g.M + i) * g.NB + j] = r;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int64_t i = i0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (i >= rows) continue;
+            float v = jt == 0 ? acc0[r] : acc1[r];
+            if (g.act == QT_ACT_RELU) v = fmaxf(v, 0.0f);
+            if (g.act == QT_ACT_TANH_RES) v = tanhf((g.drop ? g.drop[i] : 1.0f) * v) + g.res[i * g.res_stride];
+            obase[i * g.Cb] = v;
         }
     }
 }
 
-__global__ void k_colsum(const float* __restrict__ part, int nblk, int64_t len, float* __restrict__ out) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= len) return;
+// MODE 1: part[blockIdx.z] = A[rows]^T @ G[rows] over this block's row chunk.  Block = 128 features x 64
+// columns of the weight gradient, wave w owns features [32w, 32w+32); the reduction runs over node rows.
+__global__ __launch_bounds__(256) void k_gemm_wgrad(GemmArgs g) {
+    __shared__ float As[KC][BM];
+    __shared__ float Gs[KC][BN];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l32 = lane & 31, half = lane >> 5;
+    const int f0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    const int64_t rbeg = (int64_t)blockIdx.z * g.row0_step;
+    const int64_t rend = min((int64_t)qt_rows(g.n_dev, g.A.N), rbeg + g.row0_step);
+    f32x16 acc0 = {0}, acc1 = {0};
+    for (int64_t r0 = rbeg; r0 < rend; r0 += KC) {
+#pragma unroll
+        for (int u = 0; u < KC * BM / 256; ++u) {
+            const int e = t + 256 * u;
+            const int k = e >> 7, f = e & 127;
+            As[k][f] = (f0 + f < g.M && r0 + k < rend) ? g.A.at(r0 + k, f0 + f) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < KC * BN / 256; ++u) {
+            const int e = t + 256 * u;
+            const int k = e >> 6, j = e & 63;
+            Gs[k][j] = (j0 + j < g.NB && r0 + k < rend) ? g.B[(r0 + k) * g.NB + j0 + j] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KC / 2; ++ks) {
+            const float a = As[2 * ks + half][wave * 32 + l32];
+            const float b0 = Gs[2 * ks + half][l32];
+            const float b1 = Gs[2 * ks + half][32 + l32];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* obase = g.out + (int64_t)blockIdx.z * g.M * g.NB;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const int j = j0 + jt * 32 + l32;
+        if (j >= g.NB) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = f0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (i >= g.M) continue;
+            obase[(int64_t)i * g.NB + j] = jt == 0 ? acc0[r] : acc1[r];
+        }
+    }
+}
+
+// 32 columns x 8 row groups per workgroup; fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ part, int nblk, int64_t len, float* __restrict__ out) {
+    __shared__ float sm[8][33];
+    const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int64_t c = (int64_t)blockIdx.x * 32 + cl;
     float acc = 0.0f;
-    for (int i = 0; i < nblk; ++i) acc += part[(int64_t)i * len + j];
-    out[j] = acc;
+    if (c < len)
+        for (int i = r; i < nblk; i += 8) acc += part[(int64_t)i * len + c];
+    sm[r][cl] = acc;
+    __syncthreads();
+    if (r == 0 && c < len)
+        out[c] = ((sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl])) + ((sm[4][cl] + sm[5][cl]) + (sm[6][cl] + sm[7][cl]));
 }
 
 constexpr int WGRAD_ROWS = 512;
 
 }  // namespace
 
-extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, int C, const float* x,
-                       float alpha, const float* p, float beta, const float* q, float gamma, float* out, void* stream) {
+extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, const int32_t* n_dev, int C,
+                       const float* x, float alpha, const float* p, float beta, const float* q, float gamma, float* out,
+                       void* stream) {
     QT_ARG(rowptr && col && nrm && x && out && C > 0, "bad arguments");
     QT_ARG(x != out, "out must not alias x");
     if (N <= 0) return QT_OK;
@@ -173,16 +220,16 @@ extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* n
     const int nch = v4 ? C / 4 : C;
     const int grid = qt_cdiv((int64_t)N * nch, 256);
     if (v4)
-        hipLaunchKernelGGL(k_spmm<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, C, x, alpha, p, beta, q, gamma, out);
+        hipLaunchKernelGGL(k_spmm<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, C, x, alpha, p, beta, q, gamma, out);
     else
-        hipLaunchKernelGGL(k_spmm<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, C, x, alpha, p, beta, q, gamma, out);
+        hipLaunchKernelGGL(k_spmm<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, C, x, alpha, p, beta, q, gamma, out);
     QT_LAUNCHED();
     return QT_OK;
 }
 
 extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, const float* W, const float* S, int Ks,
-                        const float* Ws, int Kb, int Cb, int N, int act, const float* res, int res_stride,
-                        const float* drop, float* out, void* stream) {
+                        const float* Ws, int Kb, int Cb, int N, const int32_t* n_dev, int act, const float* res,
+                        int res_stride, const float* drop, float* out, void* stream) {
     QT_ARG(a0 && W && out && Ka >= 1 && Ca >= 1 && Kb >= 1 && Cb >= 1, "bad arguments");
     QT_ARG(Ka == 1 || a_rest, "a_rest missing");
     QT_ARG((Ks == 0) || (S && Ws), "S / Ws missing");
@@ -193,8 +240,8 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
     GemmArgs g;
     g.A.a0 = a0; g.A.a_rest = a_rest; g.A.S = S; g.A.Ka = Ka; g.A.Ca = Ca; g.A.Ks = Ks; g.A.N = N;
     g.B = W; g.M = N; g.K = Ka * Ca + Ks; g.NB = Kb * Cb;
-    g.Kb = Kb; g.Cb = Cb; g.act = act; g.res = res; g.res_stride = res_stride; g.drop = drop; g.out = out; g.row0_step = 0;
-    hipLaunchKernelGGL(k_gemm<0>, dim3(qt_cdiv(N, TM), qt_cdiv(g.NB, TN), 1), dim3(256), 0, (hipStream_t)stream, g);
+    g.Kb = Kb; g.Cb = Cb; g.act = act; g.res = res; g.res_stride = res_stride; g.drop = drop; g.out = out; g.row0_step = 0; g.n_dev = n_dev;
+    hipLaunchKernelGGL(k_gemm_fwd, dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, BN), 1), dim3(256), 0, (hipStream_t)stream, g);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -202,7 +249,7 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
 extern "C" int qt_wgrad_blocks(int N) { return N > 0 ? qt_cdiv(N, WGRAD_ROWS) : 0; }
 
 extern "C" int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, const float* S, int Ks, const float* G,
-                        int Co, int N, float* part, void* stream) {
+                        int Co, int N, const int32_t* n_dev, float* part, void* stream) {
     QT_ARG(a0 && G && part && Ka >= 1 && Ca >= 1 && Co >= 1, "bad arguments");
     QT_ARG(Ka == 1 || a_rest, "a_rest missing");
     QT_ARG(Ks == 0 || S, "S missing");
@@ -212,7 +259,8 @@ extern "C" int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, co
     g.B = G; g.M = Ka * Ca + Ks; g.K = N; g.NB = Co;
     g.Kb = 1; g.Cb = Co; g.act = QT_ACT_NONE; g.res = nullptr; g.res_stride = 0; g.drop = nullptr; g.out = part;
     g.row0_step = WGRAD_ROWS;
-    hipLaunchKernelGGL(k_gemm<1>, dim3(qt_cdiv(g.M, TM), qt_cdiv(Co, TN), qt_cdiv(N, WGRAD_ROWS)), dim3(256), 0,
+    g.n_dev = n_dev;
+    hipLaunchKernelGGL(k_gemm_wgrad, dim3(qt_cdiv(g.M, BM), qt_cdiv(Co, BN), qt_cdiv(N, WGRAD_ROWS)), dim3(256), 0,
                        (hipStream_t)stream, g);
     QT_LAUNCHED();
     return QT_OK;
@@ -220,7 +268,7 @@ extern "C" int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, co
 
 extern "C" int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream) {
     QT_ARG(part && out && len > 0 && nblk >= 0, "bad arguments");
-    hipLaunchKernelGGL(k_colsum, dim3(qt_cdiv(len, 256)), dim3(256), 0, (hipStream_t)stream, part, nblk, len, out);
+    hipLaunchKernelGGL(k_colsum, dim3(qt_cdiv(len, 32)), dim3(256), 0, (hipStream_t)stream, part, nblk, len, out);
     QT_LAUNCHED();
     return QT_OK;
 }

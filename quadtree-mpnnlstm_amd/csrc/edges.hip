@@ -40,10 +40,14 @@ __device__ __forceinline__ void centroid(int4 cl, int n, int m, float res, float
     *yy = ((float)cl.x + 0.5f * (float)(hh - 1)) * res;
 }
 
-__global__ void k_edges_count(const int32_t* __restrict__ labels, const int32_t* __restrict__ cell, int N, int n, int m,
-                              int32_t* __restrict__ cnt4) {
+__global__ void k_edges_count(const int32_t* __restrict__ labels, const int32_t* __restrict__ cell, int Ncap,
+                              const int32_t* __restrict__ n_dev, int n, int m, int32_t* __restrict__ cnt4) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 4 * N) return;
+    if (idx >= 4 * Ncap) return;
+    if (idx >= 4 * qt_rows(n_dev, Ncap)) {
+        cnt4[idx] = 0;      // capacity rows beyond N: keep the prefix sum flat
+        return;
+    }
     const int4 cl = reinterpret_cast<const int4*>(cell)[idx >> 2];
     const SideWalk w = side_walk(cl, idx & 3, n, m);
     const int32_t* L = labels + (int64_t)w.b * n * m;
@@ -57,11 +61,16 @@ __global__ void k_edges_count(const int32_t* __restrict__ labels, const int32_t*
 }
 
 __global__ void k_edges_fill(const int32_t* __restrict__ labels, const int32_t* __restrict__ cell,
-                             const int32_t* __restrict__ off4, int N, int n, int m, float res,
-                             int32_t* __restrict__ rowptr, int32_t* __restrict__ col, float* __restrict__ wgt) {
+                             const int32_t* __restrict__ off4, int Ncap, const int32_t* __restrict__ n_dev, int n, int m,
+                             float res, int32_t* __restrict__ rowptr, int32_t* __restrict__ col, float* __restrict__ wgt) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = qt_rows(n_dev, Ncap);
+    if (idx >= 4 * Ncap) return;
     if (idx == 0) rowptr[N] = off4[4 * N];
-    if (idx >= 4 * N) return;
+    if (idx >= 4 * N) {     // rows N .. Ncap of rowptr all point at the end (empty rows)
+        if ((idx & 3) == 0) rowptr[(idx >> 2) + 1] = off4[4 * N];
+        return;
+    }
     const int node = idx >> 2;
     const int4 cl = reinterpret_cast<const int4*>(cell)[node];
     if ((idx & 3) == 0) rowptr[node] = off4[idx];
@@ -83,49 +92,52 @@ __global__ void k_edges_fill(const int32_t* __restrict__ labels, const int32_t* 
     }
 }
 
-__global__ void k_edges_deg(const int32_t* __restrict__ rowptr, const float* __restrict__ w, int N, float* __restrict__ dis) {
+__global__ void k_edges_deg(const int32_t* __restrict__ rowptr, const float* __restrict__ w, int Ncap,
+                            const int32_t* __restrict__ n_dev, float* __restrict__ dis) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    if (i >= qt_rows(n_dev, Ncap)) return;
     float deg = 0.0f;
     for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) deg += w[e];
     dis[i] = deg > 0.0f ? 1.0f / sqrtf(deg) : 0.0f;
 }
 
 __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
-                            const float* __restrict__ dis, int N, float* __restrict__ nrm) {
+                            const float* __restrict__ dis, int Ncap, const int32_t* __restrict__ n_dev,
+                            float* __restrict__ nrm) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    if (i >= qt_rows(n_dev, Ncap)) return;
     const float di = dis[i];
     for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) nrm[e] = -(di * w[e] * dis[col[e]]);
 }
 
 }  // namespace
 
-extern "C" int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, int n, int m, int32_t* cnt4, void* stream) {
+extern "C" int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, const int32_t* n_dev, int n, int m,
+                              int32_t* cnt4, void* stream) {
     QT_ARG(labels && cell && cnt4, "null pointer");
     if (N <= 0) return QT_OK;
     hipLaunchKernelGGL(k_edges_count, dim3(qt_cdiv(4 * (int64_t)N, 256)), dim3(256), 0, (hipStream_t)stream, labels, cell,
-                       N, n, m, cnt4);
+                       N, n_dev, n, m, cnt4);
     QT_LAUNCHED();
     return QT_OK;
 }
 
-extern "C" int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* off4, int N, int n, int m,
-                             float resolution, int32_t* rowptr, int32_t* col, float* w, void* stream) {
+extern "C" int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* off4, int N, const int32_t* n_dev,
+                             int n, int m, float resolution, int32_t* rowptr, int32_t* col, float* w, void* stream) {
     QT_ARG(labels && cell && off4 && rowptr && col && w, "null pointer");
     if (N <= 0) return QT_OK;
     hipLaunchKernelGGL(k_edges_fill, dim3(qt_cdiv(4 * (int64_t)N, 256)), dim3(256), 0, (hipStream_t)stream, labels, cell,
-                       off4, N, n, m, resolution, rowptr, col, w);
+                       off4, N, n_dev, n, m, resolution, rowptr, col, w);
     QT_LAUNCHED();
     return QT_OK;
 }
 
-extern "C" int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, int N, float* dis, float* nrm,
-                             void* stream) {
+extern "C" int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, int N, const int32_t* n_dev,
+                             float* dis, float* nrm, void* stream) {
     QT_ARG(rowptr && col && w && dis && nrm, "null pointer");
     if (N <= 0) return QT_OK;
-    hipLaunchKernelGGL(k_edges_deg, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, w, N, dis);
-    hipLaunchKernelGGL(k_edges_nrm, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, w, dis, N, nrm);
+    hipLaunchKernelGGL(k_edges_deg, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, w, N, n_dev, dis);
+    hipLaunchKernelGGL(k_edges_nrm, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, w, dis, N, n_dev, nrm);
     QT_LAUNCHED();
     return QT_OK;
 }

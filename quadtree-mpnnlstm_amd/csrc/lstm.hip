@@ -70,12 +70,13 @@ __device__ __forceinline__ F4 layer_norm_bwd(const F4& gy, const F4& gamma, cons
 template <int LPN>
 __global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, const float* __restrict__ Cprev,
                                                   const float* __restrict__ wc, const float* __restrict__ b,
-                                                  const float* __restrict__ ln, int N, int h, float* __restrict__ O,
-                                                  float* __restrict__ Hn, float* __restrict__ Cn,
-                                                  float* __restrict__ gates, float* __restrict__ Craw) {
+                                                  const float* __restrict__ ln, int Ncap, const int32_t* __restrict__ n_dev,
+                                                  int h, float* __restrict__ O, float* __restrict__ Hn,
+                                                  float* __restrict__ Cn, float* __restrict__ gates,
+                                                  float* __restrict__ Craw) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t node = gid / LPN;
-    if (node >= N) return;
+    if (node >= qt_rows(n_dev, Ncap)) return;
     const int j0 = (int)(gid % LPN) * 4;
     const float* g = G + node * 4 * h + j0;
     const F4 gi = ld4(g), gf = ld4(g + h), gc = ld4(g + 2 * h), go = ld4(g + 3 * h);
@@ -151,10 +152,11 @@ template <int LPN>
 __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, const float* __restrict__ gHn,
                                                   const float* __restrict__ gCn, const float* __restrict__ gates,
                                                   const float* __restrict__ Craw, const float* __restrict__ Cprev,
-                                                  const float* __restrict__ wc, const float* __restrict__ ln, int N, int h,
-                                                  float* __restrict__ gG, float* __restrict__ gCprev,
-                                                  float* __restrict__ part) {
+                                                  const float* __restrict__ wc, const float* __restrict__ ln, int Ncap,
+                                                  const int32_t* __restrict__ n_dev, int h, float* __restrict__ gG,
+                                                  float* __restrict__ gCprev, float* __restrict__ part) {
     __shared__ float sm[4 * LPN * 11 * 4];
+    const int N = qt_rows(n_dev, Ncap);
     const int j0 = (threadIdx.x % LPN) * 4;
     const F4 wci = ld4(wc + j0), wcf = ld4(wc + h + j0), wco = ld4(wc + 2 * h + j0);
     F4 gam_h = {{1, 1, 1, 1}}, gam_c = {{1, 1, 1, 1}};
@@ -228,11 +230,11 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, 
 
 template <int LPN>
 __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ O, const float* __restrict__ ln_o,
-                                                  const float* __restrict__ concat, int N, int h, int hp,
-                                                  float* __restrict__ Z) {
+                                                  const float* __restrict__ concat, int Ncap,
+                                                  const int32_t* __restrict__ n_dev, int h, int hp, float* __restrict__ Z) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t node = gid / LPN;
-    if (node >= N) return;
+    if (node >= qt_rows(n_dev, Ncap)) return;
     const int li = (int)(gid % LPN), j0 = li * 4;
     const F4 x = ld4(O + node * h + j0);
     F4 xh;
@@ -249,10 +251,11 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ O, c
 
 template <int LPN>
 __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ gZ, const float* __restrict__ O,
-                                                  const float* __restrict__ ln_o, int N, int h, int hp,
-                                                  float* __restrict__ gO, float* __restrict__ gconcat,
-                                                  float* __restrict__ part) {
+                                                  const float* __restrict__ ln_o, int Ncap,
+                                                  const int32_t* __restrict__ n_dev, int h, int hp, float* __restrict__ gO,
+                                                  float* __restrict__ gconcat, float* __restrict__ part) {
     __shared__ float sm[4 * LPN * 2 * 4];
+    const int N = qt_rows(n_dev, Ncap);
     const int li = threadIdx.x % LPN, j0 = li * 4;
     const F4 gm = ld4(ln_o + j0), bt = ld4(ln_o + h + j0);
     float acc[2][4];
@@ -292,12 +295,13 @@ inline bool h_ok(int h) { return h == 8 || h == 16 || h == 32 || h == 64 || h ==
     }
 
 extern "C" int qt_lstm_fwd(const float* G, const float* Cprev, const float* wc, const float* b, const float* ln, int N,
-                           int h, float* O, float* Hn, float* Cn, float* gates, float* Craw, void* stream) {
+                           const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw,
+                           void* stream) {
     QT_ARG(G && wc && b && O && Hn && Cn && gates && Craw, "null pointer");
     QT_ARG(h_ok(h), "hidden size must be 8, 16, 32, 64 or 128");
     if (N <= 0) return QT_OK;
     const int grid = qt_cdiv((int64_t)N * lanes_per_node(h), 256);
-    QT_DISPATCH_LPN(h, k_lstm_fwd, grid, stream, G, Cprev, wc, b, ln, N, h, O, Hn, Cn, gates, Craw);
+    QT_DISPATCH_LPN(h, k_lstm_fwd, grid, stream, G, Cprev, wc, b, ln, N, n_dev, h, O, Hn, Cn, gates, Craw);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -309,35 +313,35 @@ extern "C" int qt_lstm_bwd_blocks(int N, int h) {
 }
 
 extern "C" int qt_lstm_bwd(const float* gO, const float* gHn, const float* gCn, const float* gates, const float* Craw,
-                           const float* Cprev, const float* wc, const float* ln, int N, int h, float* gG, float* gCprev,
-                           float* part, void* stream) {
+                           const float* Cprev, const float* wc, const float* ln, int N, const int32_t* n_dev, int h,
+                           float* gG, float* gCprev, float* part, void* stream) {
     QT_ARG(gHn && gCn && gates && Craw && wc && gG && part, "null pointer");
     QT_ARG(h_ok(h), "hidden size must be 8, 16, 32, 64 or 128");
     if (N <= 0) return QT_OK;
     const int grid = qt_lstm_bwd_blocks(N, h);
-    QT_DISPATCH_LPN(h, k_lstm_bwd, grid, stream, gO, gHn, gCn, gates, Craw, Cprev, wc, ln, N, h, gG, gCprev, part);
+    QT_DISPATCH_LPN(h, k_lstm_bwd, grid, stream, gO, gHn, gCn, gates, Craw, Cprev, wc, ln, N, n_dev, h, gG, gCprev, part);
     QT_LAUNCHED();
     return QT_OK;
 }
 
-extern "C" int qt_head_fwd(const float* O, const float* ln_o, const float* concat, int N, int h, int hp, float* Z,
-                           void* stream) {
+extern "C" int qt_head_fwd(const float* O, const float* ln_o, const float* concat, int N, const int32_t* n_dev, int h,
+                           int hp, float* Z, void* stream) {
     QT_ARG(O && ln_o && Z, "null pointer");
     QT_ARG(h_ok(h) && hp >= h && hp % 4 == 0, "bad h / hp");
     if (N <= 0) return QT_OK;
     const int grid = qt_cdiv((int64_t)N * lanes_per_node(h), 256);
-    QT_DISPATCH_LPN(h, k_head_fwd, grid, stream, O, ln_o, concat, N, h, hp, Z);
+    QT_DISPATCH_LPN(h, k_head_fwd, grid, stream, O, ln_o, concat, N, n_dev, h, hp, Z);
     QT_LAUNCHED();
     return QT_OK;
 }
 
-extern "C" int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, int h, int hp, float* gO,
-                           float* gconcat, float* part, void* stream) {
+extern "C" int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, const int32_t* n_dev, int h, int hp,
+                           float* gO, float* gconcat, float* part, void* stream) {
     QT_ARG(gZ && O && ln_o && gO && part, "null pointer");
     QT_ARG(h_ok(h) && hp >= h && hp % 4 == 0, "bad h / hp");
     if (N <= 0) return QT_OK;
     const int grid = qt_lstm_bwd_blocks(N, h);
-    QT_DISPATCH_LPN(h, k_head_bwd, grid, stream, gZ, O, ln_o, N, h, hp, gO, gconcat, part);
+    QT_DISPATCH_LPN(h, k_head_bwd, grid, stream, gZ, O, ln_o, N, n_dev, h, hp, gO, gconcat, part);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -23,6 +23,9 @@ void qt_set_error(const char* fmt, ...);
         }                                                               \
     } while (0)
 
+// Valid row count: read on the device when n_dev != NULL (hipGraph-capturable, no host sync), else `cap`.
+__device__ __forceinline__ int qt_rows(const int32_t* n_dev, int cap) { return n_dev ? min(*n_dev, cap) : cap; }
+
 static inline int qt_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Exclusive scan of one int per thread over a 256-thread workgroup (4 waves of 64).

@@ -265,10 +265,10 @@ __global__ __launch_bounds__(256) void k_scan_apply(const int32_t* __restrict__ 
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[len] = sums[gridDim.x];
 }
 
-__global__ void k_node_features(const int32_t* __restrict__ cell, int N, int n, int m, float size_norm,
-                                float* __restrict__ feat, float* __restrict__ npix) {
+__global__ void k_node_features(const int32_t* __restrict__ cell, int Ncap, const int32_t* __restrict__ n_dev, int n,
+                                int m, float size_norm, float* __restrict__ feat, float* __restrict__ npix) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    if (i >= qt_rows(n_dev, Ncap)) return;
     const int4 cl = reinterpret_cast<const int4*>(cell)[i];
     const int hh = min(cl.x + cl.z, n) - cl.x, ww = min(cl.y + cl.z, m) - cl.y;
     const float np_ = (float)(hh * ww);
@@ -339,12 +339,12 @@ extern "C" int qt_scan_i32(const int32_t* in, int32_t* out, int64_t len, int32_t
     return QT_OK;
 }
 
-extern "C" int qt_node_features(const int32_t* cell, int N, int n, int m, float size_norm, float* feat, float* npix,
-                                void* stream) {
+extern "C" int qt_node_features(const int32_t* cell, int N, const int32_t* n_dev, int n, int m, float size_norm,
+                                float* feat, float* npix, void* stream) {
     QT_ARG(cell && feat && npix, "null pointer");
     if (N <= 0) return QT_OK;
-    hipLaunchKernelGGL(k_node_features, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, cell, N, n, m,
-                       size_norm, feat, npix);
+    hipLaunchKernelGGL(k_node_features, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, cell, N, n_dev,
+                       n, m, size_norm, feat, npix);
     QT_LAUNCHED();
     return QT_OK;
 }

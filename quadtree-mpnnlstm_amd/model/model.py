@@ -153,7 +153,7 @@ class GConvLSTM(nn.Module):
         W, wc, b, K, Ks = packed if packed is not None else self.packed(with_h, X.shape[1])
         Z = torch.cat([X, H], dim=1) if with_h else X
         G = ops.cheb_poly(Z, W, mesh, K, Ks)
-        return ops.lstm_cell(G, C, wc, b, ln)
+        return ops.lstm_cell(G, C, wc, b, ln, mesh)
 
     def forward(self, X, edge_index, edge_weight=None, H=None, C=None):
         return self.step(X, _need_mesh(edge_index), H, C, None)

@@ -97,9 +97,11 @@ class NextFramePredictorS2S:
         plt.suptitle(f'Threshold: {thresh} | Num. nodes: {mesh.N}')
         return fig, axs[0]
 
-    def initiate_training(self, lr, lr_decay):
+    def initiate_training(self, lr, lr_decay, capturable=False):
         self.loss_func_name = 'MSE' if not self.binary else 'BCE'
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr)
+        if capturable:      # optimizer.step() inside a hipGraph needs device-side step counters and lr
+            lr = torch.tensor(float(lr), device=self.device)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, capturable=capturable)
         self.scheduler = StepLR(self.optimizer, step_size=3, gamma=lr_decay)
         self.writer = SummaryWriter('runs/' + self.experiment_name + '_' + datetime.datetime.now().strftime('%Y%m%d_%H_%M_%S'))
         self.test_loss, self.train_loss = [], []
@@ -124,6 +126,66 @@ class NextFramePredictorS2S:
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=max_norm)
         self.optimizer.step()
         return loss.detach()
+
+    def make_graphed_step(self, x, y, concat_layers=None, mask=None, high_interest_region=None, max_norm=10.0,
+                          warmup=2):
+        """Capture one whole training step in a hipGraph and return `step(x, y, concat) -> loss`.
+
+        The rollout is data dependent (every decoder step re-meshes on its own output), so the capture
+        runs in static mode: all node buffers have the worst-case capacity B*W*H and every kernel reads
+        the actual node count from device memory -- no host sync, no shape change, ~2.7k launches replayed
+        by one hipGraphLaunch.  Single process: forward + loss + backward + clip + Adam are all in the
+        graph.  Under torch.distributed the graph ends after backward; the flat gradient all-reduce, clip
+        and Adam run eagerly after each replay.  The `warmup` eager steps are real training steps.
+        """
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.model.static_shapes = True
+        if not multi and not self.optimizer.defaults.get('capturable', False):
+            lr = self.optimizer.param_groups[0]['lr']
+            assert not self.optimizer.state, 'make_graphed_step must be called before the first optimizer step'
+            self.initiate_training(float(lr), self.scheduler.gamma, capturable=True)
+        params = [p for p in self.model.parameters()]
+        sx, sy = x.clone(), y.clone()
+        sc = concat_layers.clone() if concat_layers is not None else None
+
+        def body():
+            self.optimizer.zero_grad(set_to_none=True)
+            loss = self.forward_loss(sx, sy, sc, mask, high_interest_region)
+            loss.backward()
+            if not multi:
+                torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+                self.optimizer.step()
+            return loss.detach()
+
+        def finish():
+            if multi:
+                allreduce_gradients(params, self.process_group)
+                torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+                self.optimizer.step()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                body()
+                finish()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph, stream=side):      # capture on the warm-up stream
+            static_loss = body()
+        self._graph = graph
+
+        def step(x, y, concat_layers=None):
+            sx.copy_(x)
+            sy.copy_(y)
+            if sc is not None:
+                sc.copy_(concat_layers)
+            graph.replay()
+            finish()
+            return static_loss
+        return step
 
     def train(self, loader_train, loader_test, climatology=None, n_epochs=200, lr=0.01, lr_decay=0.95, mask=None,
               high_interest_region=None, truncated_backprop=45, graph_structure=None):

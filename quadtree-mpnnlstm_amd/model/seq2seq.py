@@ -107,7 +107,7 @@ class Decoder(nn.Module):
             # beyond-reference: HEAD crashes here (fc_out1 expects hidden+1 channels, seq2seq.py:115,164);
             # the decoder's current input value is used as the 1-channel concat (what :471,484 intended)
             concat_layers = X[:, :1]
-        z = ops.head_input(out, pk['ln_o'], concat_layers, self.head_width)
+        z = ops.head_input(out, pk['ln_o'], concat_layers, self.head_width, mesh)
         z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU)
         drop = None
         if self.training and self.dropout.p > 0:
@@ -139,20 +139,21 @@ class Seq2Seq(nn.Module):
         self.use_edge_attrs = convolution_type in ['MHTransformerConv', 'TransformerConv', 'GATConv']
         self.thresh, self.transform_func, self.graph, self.device = thresh, transform_func, None, device
         self.max_grid_size = 64                      # image_to_graph default, never overridden (graph_functions.py:590)
+        self.static_shapes = False                   # True: worst-case capacities + device-side node counts (hipGraph)
 
     # -- mesh helpers -----------------------------------------------------------------
     def _mesh_from_image(self, img0, mask, hir):
         B, n, m = img0.shape
         return build_mesh(src=_criterion(img0, n, m, self.max_grid_size, self.transform_func), n=n, m=m,
                           thresh=self.thresh, condition=self.condition, mask=mask, high_interest_region=hir,
-                          max_size=self.max_grid_size)
+                          max_size=self.max_grid_size, static=self.static_shapes)
 
     def _mesh_from_nodes(self, out, mesh, mask, hir):
         if self.transform_func is not None:
             img0 = ops.gather_pixels(out.detach(), mesh).view(mesh.B, mesh.n, mesh.m)
             return self._mesh_from_image(img0, mask, hir)
         return build_mesh(prev=(out.detach()[:, 0], mesh), thresh=self.thresh, condition=self.condition, mask=mask,
-                          high_interest_region=hir, max_size=self.max_grid_size)
+                          high_interest_region=hir, max_size=self.max_grid_size, static=self.static_shapes)
 
     # -- encoder ------------------------------------------------------------------------
     def process_inputs(self, x, mask=None, high_interest_region=None, graph_structure=None):
@@ -170,13 +171,13 @@ class Seq2Seq(nn.Module):
         feats = torch.cat([means, mesh.posfeat.unsqueeze(0).expand(T, -1, -1)], dim=-1)
         self.graph = Graph(None, None)
         self.graph.mapping, self.graph.n_pixels_per_node, self.graph.image_shape = mesh, mesh.npix, (n, m)
-        self._enc_pack = self.encoder.pack(c + 3 + (-(c + 3)) % 4)
+        enc_pack = self.encoder.pack(c + 3 + (-(c + 3)) % 4)     # local: nothing on `self` may keep the autograd graph alive
         hidden = cell = None
         for t in range(self.input_timesteps):
             hidden, cell = self.encoder(feats[t], mesh, None, H=None if hidden is None else hidden[-1],
-                                        C=None if cell is None else cell[-1], packed=self._enc_pack)
+                                        C=None if cell is None else cell[-1], packed=enc_pack)
         self.graph.hidden, self.graph.cell = hidden, cell
-        self.graph.pyg.x = feats[-1][:, [0, -3, -2, -1]]                              # (:336)
+        self.graph.pyg.x = torch.cat([feats[-1][:, :1], feats[-1][:, -3:]], dim=1)     # x[-1, :, [0,-3,-2,-1]] (:336)
 
     # -- decoder + remesh ----------------------------------------------------------------
     def unroll_output(self, unroll_steps, y, concat_layers=None, teacher_forcing_ratio=0.5, mask=None,
@@ -204,8 +205,12 @@ class Seq2Seq(nn.Module):
             output_mappings.append(mesh)
             teacher_force = random.random() < teacher_forcing_ratio
             if t == steps[-1]:
-                # the reference re-meshes once more here (:393-394); nothing reads that mesh, so it is skipped
-                g.hidden, g.cell = hidden, cell
+                # the reference re-meshes once more here (:393-394); nothing reads that mesh, so it is skipped.
+                # The kept state is detached: a live reference into the autograd graph would pin its AccumulateGrad
+                # nodes (and their stream) across iterations, which breaks hipGraph capture of the next step.
+                g.hidden, g.cell, g.pyg.x = hidden.detach(), cell.detach(), g.pyg.x.detach()
+                if concat_layers is not None:
+                    g.concat_layers = g.concat_layers.detach()
                 break
             if self.thresh != -np.inf and (t + 1) % remesh_every == 0:
                 mesh = self.do_remesh(output, hidden, cell, mask, high_interest_region, teacher_force,

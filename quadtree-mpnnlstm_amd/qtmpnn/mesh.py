@@ -16,12 +16,27 @@ from ._lib import ptr
 CONDITIONS = ('max_larger_than', 'max_smaller_than', 'min_larger_than', 'min_smaller_than')
 
 
+_MASKS = {}
+
+
 def _as_u8(a, device, shape):
+    """Device uint8 copy of a host mask, cached per (object, device): the upload happens once, outside any
+    hipGraph capture (a warm-up step always precedes capture)."""
     if a is None:
         return None
+    if torch.is_tensor(a) and a.is_cuda and a.dtype == torch.uint8:
+        return a.contiguous()
+    key = (id(a), str(device))
+    hit = _MASKS.get(key)
+    if hit is not None and hit[0] is a:
+        return hit[1]
     t = torch.as_tensor(np.asarray(a)) if not torch.is_tensor(a) else a
     assert tuple(t.shape) == tuple(shape), f'mask shape {tuple(t.shape)} != image shape {tuple(shape)}'
-    return t.to(device=device, dtype=torch.uint8).contiguous()
+    d = t.to(device=device, dtype=torch.uint8).contiguous()
+    if len(_MASKS) > 64:
+        _MASKS.clear()
+    _MASKS[key] = (a, d)
+    return d
 
 
 class Mesh:
@@ -31,6 +46,7 @@ class Mesh:
     def __init__(self):
         self._ones = {}
         self._E = None
+        self.n_dev = None        # device int32[1] with the valid node count when N is a capacity (static mode)
 
     # -- sizes ------------------------------------------------------------------
     @property
@@ -40,9 +56,14 @@ class Mesh:
     @property
     def E(self):
         """Directed non-self edges (lazy: needs a host read)."""
-        if self._E is None:
+        if self._E is None or self.n_dev is not None:
             self._E = int(self.rowptr[-1].item()) if self.N > 0 else 0
         return self._E
+
+    @property
+    def n_valid(self):
+        """Valid node count (a host read in static mode)."""
+        return self.N if self.n_dev is None else int(self.n_dev.item())
 
     def __len__(self):
         return self.N
@@ -96,16 +117,18 @@ class Mesh:
 
 
 def spmm(mesh, x, alpha, p, beta, q, gamma, out, C):
-    _lib.call('qt_spmm', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), mesh.N, C, ptr(x), alpha,
+    _lib.call('qt_spmm', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), mesh.N, ptr(mesh.n_dev), C, ptr(x), alpha,
               ptr(p), beta, ptr(q), gamma, ptr(out))
 
 
 def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition='max_larger_than', mask=None,
-               high_interest_region=None, max_size=64, resolution=0.25, size_norm=None, device=None):
+               high_interest_region=None, max_size=64, resolution=0.25, size_norm=None, device=None, static=False):
     """Quadtree-decompose B criterion images and emit the block-diagonal mesh.
 
     src  : (B, rows, cols) fp32 criterion image (edge-padded on the fly), or
     prev : (nodeval (N_old,) fp32, old Mesh) -- the un-flattened previous output, never materialised.
+    static: size every buffer for the worst case N = B*n*m and keep the node count on the device
+            (mesh.n_dev): no host sync, fixed shapes -> the whole step can be captured in a hipGraph.
     """
     assert condition in CONDITIONS, f'unknown condition {condition}'
     assert max_size & (max_size - 1) == 0
@@ -141,7 +164,7 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
         _lib.call('qt_quadtree_stage1', None, 0, 0, ptr(nodeval), ptr(old.labels), B, n, m, max_size,
                   float(thresh), CONDITIONS.index(condition), ptr(mk), ptr(hr), ptr(local_id), ptr(level), ptr(cnt))
     _lib.call('qt_scan_i32', ptr(cnt), ptr(offs), B * nbase, ptr(tmp))
-    N = int(offs[-1].item())                      # the one host sync of a mesh build
+    N = B * n * m if static else int(offs[-1].item())     # dynamic mode: the one host sync of a mesh build
 
     ms = Mesh()
     ms.B, ms.n, ms.m, ms.N, ms.max_size, ms.resolution = B, n, m, N, max_size, resolution
@@ -152,8 +175,13 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     ms.node_off = torch.empty(B + 1, **i32)
     _lib.call('qt_quadtree_stage3', ptr(local_id), ptr(offs), B, n, m, max_size, ptr(ms.labels), ptr(level),
               ptr(ms.cell), ptr(ms.node_off))
-    ms.posfeat = torch.empty(N, 3, device=device)
-    ms.npix = torch.empty(N, device=device)
+    nd = None
+    if static:
+        ms.n_dev = ms.node_off[B:]                # view of the last entry = N
+        nd = ptr(ms.n_dev)
+    alloc = torch.zeros if static else torch.empty      # capacity rows beyond N stay finite
+    ms.posfeat = alloc(N, 3, device=device)
+    ms.npix = alloc(N, device=device)
     ms.rowptr = torch.zeros(N + 1, **i32)
     ms.dis = torch.empty(N, device=device)
     if N == 0:
@@ -162,17 +190,17 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
         return ms
     if size_norm is None:
         size_norm = (max_size / 2) ** 2
-    _lib.call('qt_node_features', ptr(ms.cell), N, n, m, float(size_norm), ptr(ms.posfeat), ptr(ms.npix))
+    _lib.call('qt_node_features', ptr(ms.cell), N, nd, n, m, float(size_norm), ptr(ms.posfeat), ptr(ms.npix))
     cnt4 = torch.empty(4 * N, **i32)
     off4 = torch.empty(4 * N + 1, **i32)
     tmp4 = torch.empty(4 * N // 1024 + 8, **i32)
-    _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, n, m, ptr(cnt4))
+    _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4))
     _lib.call('qt_scan_i32', ptr(cnt4), ptr(off4), 4 * N, ptr(tmp4))
     emax = 4 * B * n * m                          # every directed edge owns >= 1 of the 4*P pixel adjacencies
     ms.col = torch.empty(emax, **i32)
     ms.w = torch.empty(emax, device=device)
     ms.nrm = torch.empty(emax, device=device)
-    _lib.call('qt_edges_fill', ptr(ms.labels), ptr(ms.cell), ptr(off4), N, n, m, float(resolution),
+    _lib.call('qt_edges_fill', ptr(ms.labels), ptr(ms.cell), ptr(off4), N, nd, n, m, float(resolution),
               ptr(ms.rowptr), ptr(ms.col), ptr(ms.w))
-    _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), N, ptr(ms.dis), ptr(ms.nrm))
+    _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), N, nd, ptr(ms.dis), ptr(ms.nrm))
     return ms

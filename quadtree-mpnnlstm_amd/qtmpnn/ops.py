@@ -43,7 +43,7 @@ class _ChebPoly(Function):
         Y = Z.new_empty(N, Co)
         drop = _c(drop)
         _lib.call('qt_dense', ptr(Z), ptr(TZ), K, C, ptr(W), ptr(S), Ks, ptr(W[K * C:]) if Ks else None, 1, Co, N,
-                  act, ptr(res), res.stride(0) if res is not None else 0, ptr(drop), ptr(Y))
+                  ptr(mesh.n_dev), act, ptr(res), res.stride(0) if res is not None else 0, ptr(drop), ptr(Y))
         ctx.mesh, ctx.K, ctx.Ks, ctx.act = mesh, K, Ks, act
         ctx.save_for_backward(Z, TZ, W, Y if act != ACT_NONE else None, res, drop)
         return Y
@@ -71,7 +71,8 @@ class _ChebPoly(Function):
         if ctx.needs_input_grad[0] and N > 0:
             Wt = W[:K * C].t().contiguous()
             gT = Z.new_empty(K, N, C)
-            _lib.call('qt_dense', ptr(G), None, 1, Co, ptr(Wt), None, 0, None, K, C, N, ACT_NONE, None, 0, None, ptr(gT))
+            _lib.call('qt_dense', ptr(G), None, 1, Co, ptr(Wt), None, 0, None, K, C, N, ptr(mesh.n_dev), ACT_NONE, None, 0,
+                      None, ptr(gT))
             # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
             for k in range(K - 2, 0, -1):
                 spmm(mesh, gT[k + 1], 2.0, gT[k], 1.0, gT[k + 2] if k + 2 < K else None, -1.0, gT[k], C)
@@ -82,12 +83,12 @@ class _ChebPoly(Function):
             gZ = torch.zeros_like(Z)
         gW = None
         if ctx.needs_input_grad[1]:
-            gW = torch.zeros_like(W)
+            gW = torch.empty_like(W) if N > 0 else torch.zeros_like(W)
             if N > 0:
                 nblk = _lib.value('qt_wgrad_blocks', N)
                 part = Z.new_empty(nblk, W.shape[0], Co)
                 S = mesh.cheb_ones(Ks) if Ks else None
-                _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), Ks, ptr(G), Co, N, ptr(part))
+                _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), Ks, ptr(G), Co, N, ptr(mesh.n_dev), ptr(part))
                 _lib.call('qt_colsum', ptr(part), nblk, W.numel(), ptr(gW))
         return gZ, gW, gres, None, None, None, None, None
 
@@ -136,16 +137,17 @@ class _LstmCell(Function):
     model/seq2seq.py:64-75)."""
 
     @staticmethod
-    def forward(ctx, G, Cprev, wc, b, ln):
+    def forward(ctx, G, Cprev, wc, b, ln, mesh):
         G = _c(G)
         N, h4 = G.shape
         h = h4 // 4
         Cprev, wc, b, ln = _c(Cprev), _c(wc), _c(b), _c(ln)
         O, Hn, Cn, Craw = (G.new_empty(N, h) for _ in range(4))
         gates = G.new_empty(N, h4)
-        _lib.call('qt_lstm_fwd', ptr(G), ptr(Cprev), ptr(wc), ptr(b), ptr(ln), N, h, ptr(O), ptr(Hn), ptr(Cn),
-                  ptr(gates), ptr(Craw))
+        _lib.call('qt_lstm_fwd', ptr(G), ptr(Cprev), ptr(wc), ptr(b), ptr(ln), N, ptr(mesh.n_dev), h, ptr(O), ptr(Hn),
+                  ptr(Cn), ptr(gates), ptr(Craw))
         ctx.save_for_backward(gates, Craw, Cprev, wc, ln)
+        ctx.mesh = mesh
         return O, Hn, Cn
 
     @staticmethod
@@ -158,18 +160,18 @@ class _LstmCell(Function):
         gG = torch.empty_like(gates)
         gCp = torch.empty_like(Craw) if Cprev is not None else None
         nblk = max(_lib.value('qt_lstm_bwd_blocks', N, h), 1)
-        part = Craw.new_zeros(nblk, 11 * h)
-        psum = Craw.new_zeros(11 * h)
+        part = Craw.new_empty(nblk, 11 * h)
+        psum = Craw.new_empty(11 * h) if N > 0 else Craw.new_zeros(11 * h)
         if N > 0:
             _lib.call('qt_lstm_bwd', ptr(gO), ptr(gHn), ptr(gCn), ptr(gates), ptr(Craw), ptr(Cprev), ptr(wc), ptr(ln),
-                      N, h, ptr(gG), ptr(gCp), ptr(part))
+                      N, ptr(ctx.mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part))
             _lib.call('qt_colsum', ptr(part), nblk, 11 * h, ptr(psum))
         psum = psum.view(11, h)
-        return gG, gCp, psum[0:3], psum[3:7], (psum[7:11] if ln is not None else None)
+        return gG, gCp, psum[0:3], psum[3:7], (psum[7:11] if ln is not None else None), None
 
 
-def lstm_cell(G, Cprev, wc, b, ln):
-    return _LstmCell.apply(G, Cprev, wc, b, ln)
+def lstm_cell(G, Cprev, wc, b, ln, mesh):
+    return _LstmCell.apply(G, Cprev, wc, b, ln, mesh)
 
 
 # ------------------------------------------------------------------------------ decoder head input
@@ -177,13 +179,13 @@ class _Head(Function):
     """[relu(LayerNorm_o(O)) | concat | 0-pad] (model/seq2seq.py:160-165)."""
 
     @staticmethod
-    def forward(ctx, O, ln_o, concat, hp):
+    def forward(ctx, O, ln_o, concat, hp, mesh):
         O, ln_o, concat = _c(O), _c(ln_o), _c(concat)
         N, h = O.shape
         Z = O.new_empty(N, hp)
-        _lib.call('qt_head_fwd', ptr(O), ptr(ln_o), ptr(concat), N, h, hp, ptr(Z))
+        _lib.call('qt_head_fwd', ptr(O), ptr(ln_o), ptr(concat), N, ptr(mesh.n_dev), h, hp, ptr(Z))
         ctx.save_for_backward(O, ln_o)
-        ctx.hp, ctx.has_concat = hp, concat is not None
+        ctx.hp, ctx.has_concat, ctx.mesh = hp, concat is not None, mesh
         return Z
 
     @staticmethod
@@ -194,16 +196,17 @@ class _Head(Function):
         gO = torch.empty_like(O)
         gcat = O.new_empty(N, 1) if ctx.has_concat else None
         nblk = max(_lib.value('qt_lstm_bwd_blocks', N, h), 1)
-        part = O.new_zeros(nblk, 2 * h)
-        psum = O.new_zeros(2 * h)
+        part = O.new_empty(nblk, 2 * h)
+        psum = O.new_empty(2 * h) if N > 0 else O.new_zeros(2 * h)
         if N > 0:
-            _lib.call('qt_head_bwd', ptr(gZ), ptr(O), ptr(ln_o), N, h, ctx.hp, ptr(gO), ptr(gcat), ptr(part))
+            _lib.call('qt_head_bwd', ptr(gZ), ptr(O), ptr(ln_o), N, ptr(ctx.mesh.n_dev), h, ctx.hp, ptr(gO), ptr(gcat),
+                      ptr(part))
             _lib.call('qt_colsum', ptr(part), nblk, 2 * h, ptr(psum))
-        return gO, psum.view(2, h), gcat, None
+        return gO, psum.view(2, h), gcat, None, None
 
 
-def head_input(O, ln_o, concat, hp):
-    return _Head.apply(O, ln_o, concat, hp)
+def head_input(O, ln_o, concat, hp, mesh):
+    return _Head.apply(O, ln_o, concat, hp, mesh)
 
 
 # ------------------------------------------------------------------------------ mesh <-> image
@@ -225,7 +228,7 @@ class _PoolImage(Function):
     def forward(ctx, img, mesh, mean):
         img = _c(img.float())
         B, S, P, C = img.shape
-        out = img.new_zeros(S, mesh.N, C)
+        out = img.new_empty(S, mesh.N, C)
         if mesh.N > 0:
             _pool_raw(mesh, C, out, C, 0, mean, img=img, S=S)
         ctx.mesh, ctx.mean, ctx.shape = mesh, mean, img.shape
@@ -263,7 +266,7 @@ class _Gather(Function):
         mesh = ctx.mesh
         g = _c(g)
         C = g.shape[-1]
-        out = g.new_zeros(1, mesh.N, C)
+        out = g.new_empty(1, mesh.N, C)
         if mesh.N > 0:
             _pool_raw(mesh, C, out, C, 0, False, img=g.view(mesh.B, 1, mesh.P, C), S=1)
         return out[0], None
@@ -281,7 +284,7 @@ class _Remesh(Function):
     def forward(ctx, val, old, new):
         val = _c(val.float())
         C = val.shape[1]
-        out = val.new_zeros(new.N, C)
+        out = val.new_empty(new.N, C)
         if new.N > 0:
             _pool_raw(new, C, out, C, 0, True, src_val=val, src_mesh=old)
         ctx.old, ctx.new = old, new
@@ -292,7 +295,7 @@ class _Remesh(Function):
         old, new = ctx.old, ctx.new
         g = _c(g)
         C = g.shape[1]
-        out = g.new_zeros(old.N, C)
+        out = g.new_empty(old.N, C)
         if old.N > 0:
             _pool_raw(old, C, out, C, 0, False, src_val=g, src_mesh=new, src_inv=True)
         return out, None, None
@@ -314,7 +317,7 @@ class _StepSSE(Function):
         nt = -(mesh.P // -1024)
         part = out.new_empty(mesh.B * nt)
         _lib.call('qt_sse', ptr(out), out.stride(0), ptr(mesh.labels), ptr(y), mesh.P, mesh.B, mesh.n, mesh.m, ptr(part))
-        sy = out.new_zeros(1, mesh.N, 1)
+        sy = out.new_empty(1, mesh.N, 1)
         if mesh.N > 0:
             _pool_raw(mesh, 1, sy, 1, 0, False, img=y.view(mesh.B, 1, mesh.P, 1), S=1)
         ctx.save_for_backward(out, sy)

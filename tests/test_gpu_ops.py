@@ -176,7 +176,8 @@ def test_lstm_kernel_vs_torch(h):
         Hr = Og * torch.tanh(Cr)
         return (Og, torch.nn.functional.layer_norm(Hr, (h,), ln[0], ln[1], 1e-5),
                 torch.nn.functional.layer_norm(Cr, (h,), ln[2], ln[3], 1e-5))
-    outs = ops.lstm_cell(G, Cp, wc, b, ln)
+    from qtmpnn.mesh import Mesh
+    outs = ops.lstm_cell(G, Cp, wc, b, ln, Mesh())
     refs = ref(G, Cp, wc, b, ln)
     for a, r in zip(outs, refs):
         close(a, r, atol=2e-5)
@@ -194,7 +195,8 @@ def test_head_kernel_vs_torch():
     O = torch.randn(N, h, device=dev(), requires_grad=True)
     ln = torch.randn(2, h, device=dev(), requires_grad=True)
     cc = torch.randn(N, 1, device=dev(), requires_grad=True)
-    z = ops.head_input(O, ln, cc, h + 4)
+    from qtmpnn.mesh import Mesh
+    z = ops.head_input(O, ln, cc, h + 4, Mesh())
     ref = torch.cat([torch.relu(torch.nn.functional.layer_norm(O, (h,), ln[0], ln[1], 1e-5)), cc,
                      torch.zeros(N, 3, device=dev())], dim=1)
     close(z, ref, atol=2e-5)

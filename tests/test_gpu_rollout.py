@@ -108,3 +108,53 @@ def test_train_steps_reduce_loss():
     losses = [float(nfp.train_step(x, y, concat, mask)) for _ in range(8)]
     assert np.isfinite(losses).all()
     assert losses[-1] < losses[0], losses
+
+
+def test_rollout_static_capacity_mode_equals_golden():
+    """Static mode (worst-case buffers, node counts read on the device, no host sync): same results."""
+    g = golden('rollout_ice64_masked_h8.npz')
+    from model.mpnnlstm import masked_mse
+    x, y, concat = (torch.from_numpy(g[k]).to(dev()) for k in ('x', 'y', 'concat'))
+    model = _model_from_golden(g, g['x'])
+    model.static_shapes = True
+    outs, meshes = model(x, y, concat, teacher_forcing_ratio=0, mask=g['mask'], high_interest_region=g['hir'] if 'hir' in g.files else None)
+    assert all(ms.n_dev is not None and ms.N == 64 * 64 for ms in meshes)
+    for i, ms in enumerate(meshes):
+        nv = ms.n_valid
+        assert nv == len(g[f'out_{i}'])
+        assert np.array_equal(ms.labels[0].cpu().numpy(), g[f'labels_{i}'])
+        close(outs[i][:nv], g[f'out_{i}'], msg=f'output step {i}')
+    loss = masked_mse(outs, meshes, y, g['mask'])
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    loss.backward()
+    _check_grads(model, g)
+
+
+def test_graphed_step_matches_eager_steps():
+    """A hipGraph-captured training step (fwd + loss + bwd + clip + Adam in ONE graph launch) replays to the same
+    losses and weights as eager steps from the same state."""
+    from model.mpnnlstm import NextFramePredictorS2S
+    from qtmpnn import synthetic
+    x, y = synthetic.make_batch(1, 0, 3, 4, 4, n_digits=1, pixel_noise=0.05)
+    x2, y2 = synthetic.make_batch(1, 50, 3, 4, 4, n_digits=1, pixel_noise=0.05)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    mask = np.zeros((64, 64), dtype=bool)
+    concat = torch.zeros(3, 4, 64, 64, 1, device=dev())
+
+    def fresh():
+        torch.manual_seed(3)
+        nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=4, output_timesteps=4, device=dev(),
+                                    model_kwargs=dict(hidden_size=16, dropout=0.0, n_layers=2))
+        nfp.initiate_training(lr=1e-3, lr_decay=0.95, capturable=True)
+        nfp.model.static_shapes = True
+        return nfp
+    eager, graphed = fresh(), fresh()
+    for _ in range(2):
+        eager.train_step(t(x), t(y), concat, mask)
+    step = graphed.make_graphed_step(t(x), t(y), concat, mask, warmup=2)     # two eager warm-up steps on (x, y)
+    for a, b in ((x2, y2), (x, y), (x2, y2)):
+        le, lg = float(eager.train_step(t(a), t(b), concat, mask)), float(step(t(a), t(b), concat))
+        assert abs(le - lg) <= 1e-4 * abs(le), (le, lg)
+    for (k, p), (_, q) in zip(eager.model.named_parameters(), graphed.model.named_parameters()):
+        # Adam moves a weight by ~lr even for a gradient at rounding-noise level, hence the absolute tolerance
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=1e-3, atol=5e-3, err_msg=k)
