@@ -84,46 +84,80 @@ struct GemmArgs {
 // ---- fp32 MFMA tiles (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 64 FLOP/clk/SIMD).
 // Operand maps (cdna_hip_programming.md section 3): lane l holds A[i = l & 31][k = l >> 5] and
 // B[k = l >> 5][j = l & 31]; accumulator register r of lane l is C[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
+// The two k slots of one MFMA may be ANY two reduction indices as long as A and B agree, which is what lets a
+// lane fetch its A operand as one float4 (4 consecutive k of its own row): in step (j, i) lane half h feeds
+// k = 8 j + 4 h + i.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int KC = 32;        // reduction depth staged in LDS per pass
 constexpr int BM = 128;       // block rows (4 waves x 32)
 constexpr int BN = 64;        // block columns (2 MFMA tiles per wave)
+constexpr int KW = 128;       // reduction depth per pass of the forward GEMM (W chunk in LDS)
+constexpr int MAXQ = 128;     // quads (4 consecutive k) in the reduction dimension
+
+// Quad table: quad Q of a node row lives at qptr[Q] + row * qstr[Q] (plane Q*4/Ca of the operand, or S).
+__device__ __forceinline__ void build_quad_table(const PlaneSrc& A, const float** qptr, int* qstr, int nquad) {
+    for (int Q = threadIdx.x; Q < nquad; Q += 256) {
+        const int k = 4 * Q, kc = A.Ka * A.Ca;
+        if (k < kc) {
+            const int pl = k / A.Ca, c = k - pl * A.Ca;
+            qptr[Q] = (pl == 0 ? A.a0 : A.a_rest + (int64_t)(pl - 1) * A.N * A.Ca) + c;
+            qstr[Q] = A.Ca;
+        } else {
+            qptr[Q] = A.S + (k - kc);
+            qstr[Q] = A.Ks;
+        }
+    }
+}
 
 // MODE 0: out planes = act(A @ W).  Block = 128 node rows x 64 output columns, wave w owns rows [32w, 32w+32).
+// A fragments go global -> VGPR directly (float4 per lane and k-quad); only W is staged in LDS.
 __global__ __launch_bounds__(256) void k_gemm_fwd(GemmArgs g) {
-    __shared__ float As[BM][KC + 1];
-    __shared__ float Bs[KC][BN];
+    __shared__ float Bs[KW][BN];
+    __shared__ const float* qptr[MAXQ];
+    __shared__ int qstr[MAXQ];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l32 = lane & 31, half = lane >> 5;
     const int64_t i0 = (int64_t)blockIdx.x * BM;
     const int j0 = blockIdx.y * BN;
     const int64_t rows = qt_rows(g.n_dev, g.M);      // g.M stays the plane stride (capacity)
     if (i0 >= rows) return;
+    const int nquad = g.K >> 2;
+    build_quad_table(g.A, qptr, qstr, nquad);
+    const int64_t my_row = i0 + wave * 32 + l32;
+    const bool row_ok = my_row < rows;
     f32x16 acc0 = {0}, acc1 = {0};
-    for (int k0 = 0; k0 < g.K; k0 += KC) {
-#pragma unroll
-        for (int u = 0; u < BM * KC / 256; ++u) {
-            const int e = t + 256 * u;
-            const int r = e >> 5, k = e & 31;
-            const int64_t row = i0 + r;
-            As[r][k] = (row < rows && k0 + k < g.K) ? g.A.at(row, k0 + k) : 0.0f;
+    for (int k0 = 0; k0 < g.K; k0 += KW) {
+        const int kn = min(KW, g.K - k0);            // multiple of 4
+        __syncthreads();                              // table ready / previous pass done with Bs
+        for (int e = t; e < kn * (BN / 4); e += 256) {
+            const int kb = e >> 4, jq = (e & 15) * 4;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j0 + jq < g.NB) w = *reinterpret_cast<const float4*>(g.B + (int64_t)(k0 + kb) * g.NB + j0 + jq);
+            *reinterpret_cast<float4*>(&Bs[kb][jq]) = w;
         }
+        // this lane's A quads of the pass: quad 2 j + half
+        float4 areg[KW / 8];
+        const int q0 = k0 >> 2, qn = kn >> 2;
 #pragma unroll
-        for (int u = 0; u < KC * BN / 256; ++u) {
-            const int e = t + 256 * u;
-            const int kb = e >> 6, j = e & 63;
-            Bs[kb][j] = (j0 + j < g.NB && k0 + kb < g.K) ? g.B[(int64_t)(k0 + kb) * g.NB + j0 + j] : 0.0f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < KC / 2; ++ks) {
-            const float a = As[wave * 32 + l32][2 * ks + half];
-            const float b0 = Bs[2 * ks + half][l32];
-            const float b1 = Bs[2 * ks + half][32 + l32];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        for (int j = 0; j < KW / 8; ++j) {
+            const int q = 2 * j + half;
+            areg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_ok && q < qn) areg[j] = *reinterpret_cast<const float4*>(qptr[q0 + q] + my_row * qstr[q0 + q]);
         }
         __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KW / 8; ++j) {
+            if (8 * j < kn) {
+                const float av[4] = {areg[j].x, areg[j].y, areg[j].z, areg[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int kk = 8 * j + 4 * half + i;      // rows >= kn of Bs are only met with a zero A quad
+                    const float b0 = kk < kn ? Bs[kk][l32] : 0.0f;
+                    const float b1 = kk < kn ? Bs[kk][32 + l32] : 0.0f;
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1, acc1, 0, 0, 0);
+                }
+            }
+        }
     }
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
@@ -144,39 +178,69 @@ __global__ __launch_bounds__(256) void k_gemm_fwd(GemmArgs g) {
 }
 
 // MODE 1: part[blockIdx.z] = A[rows]^T @ G[rows] over this block's row chunk.  Block = 128 features x 64
-// columns of the weight gradient, wave w owns features [32w, 32w+32); the reduction runs over node rows.
+// columns of the weight gradient, wave w owns features [32w, 32w+32); the reduction runs over node rows in
+// passes of 32 rows: float4 global loads -> registers (prefetch of the next pass) -> double-buffered LDS.
+constexpr int WR = 32;
 __global__ __launch_bounds__(256) void k_gemm_wgrad(GemmArgs g) {
-    __shared__ float As[KC][BM];
-    __shared__ float Gs[KC][BN];
+    __shared__ float As[2][WR][BM];
+    __shared__ float Gs[2][WR][BN];
+    __shared__ const float* qptr[MAXQ];
+    __shared__ int qstr[MAXQ];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l32 = lane & 31, half = lane >> 5;
     const int f0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
     const int64_t rbeg = (int64_t)blockIdx.z * g.row0_step;
     const int64_t rend = min((int64_t)qt_rows(g.n_dev, g.A.N), rbeg + g.row0_step);
+    const int nquad = g.M >> 2;
+    build_quad_table(g.A, qptr, qstr, nquad);
+    __syncthreads();
+    // staging roles: A tile = 32 rows x 32 quads -> 4 float4 per thread; G tile = 32 rows x 16 quads -> 2 per thread
+    const int a_row = t >> 3, a_q = (t & 7) * 4;           // 4 consecutive quads of one row
+    const int g_row = t >> 3, g_q = (t & 7) * 2;
+    float4 pa[4], pg[2];
+    auto fetch = [&](int64_t r0) {
+        const int64_t ra = r0 + a_row;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int Q = (f0 >> 2) + a_q + u;
+            pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ra < rend && Q < nquad) pa[u] = *reinterpret_cast<const float4*>(qptr[Q] + ra * qstr[Q]);
+        }
+        const int64_t rg = r0 + g_row;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int jq = (g_q + u) * 4;
+            pg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rg < rend && j0 + jq < g.NB) pg[u] = *reinterpret_cast<const float4*>(g.B + rg * g.NB + j0 + jq);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(&As[buf][a_row][(a_q + u) * 4]) = pa[u];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Gs[buf][g_row][(g_q + u) * 4]) = pg[u];
+    };
     f32x16 acc0 = {0}, acc1 = {0};
-    for (int64_t r0 = rbeg; r0 < rend; r0 += KC) {
-#pragma unroll
-        for (int u = 0; u < KC * BM / 256; ++u) {
-            const int e = t + 256 * u;
-            const int k = e >> 7, f = e & 127;
-            As[k][f] = (f0 + f < g.M && r0 + k < rend) ? g.A.at(r0 + k, f0 + f) : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < KC * BN / 256; ++u) {
-            const int e = t + 256 * u;
-            const int k = e >> 6, j = e & 63;
-            Gs[k][j] = (j0 + j < g.NB && r0 + k < rend) ? g.B[(r0 + k) * g.NB + j0 + j] : 0.0f;
-        }
+    if (rbeg < rend) {
+        fetch(rbeg);
+        stash(0);
         __syncthreads();
+        int buf = 0;
+        for (int64_t r0 = rbeg; r0 < rend; r0 += WR) {
+            const bool more = r0 + WR < rend;
+            if (more) fetch(r0 + WR);
 #pragma unroll
-        for (int ks = 0; ks < KC / 2; ++ks) {
-            const float a = As[2 * ks + half][wave * 32 + l32];
-            const float b0 = Gs[2 * ks + half][l32];
-            const float b1 = Gs[2 * ks + half][32 + l32];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            for (int ks = 0; ks < WR / 2; ++ks) {
+                const float a = As[buf][2 * ks + half][wave * 32 + l32];
+                const float b0 = Gs[buf][2 * ks + half][l32];
+                const float b1 = Gs[buf][2 * ks + half][32 + l32];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            }
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
         }
-        __syncthreads();
     }
     float* obase = g.out + (int64_t)blockIdx.z * g.M * g.NB;
 #pragma unroll
@@ -235,6 +299,9 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
     QT_ARG((Ks == 0) || (S && Ws), "S / Ws missing");
     QT_ARG(Ks == 0 || Ws == W + (int64_t)Ka * Ca * Kb * Cb, "Ws must follow W contiguously ([W ; Ws] is one matrix)");
     QT_ARG(act == QT_ACT_NONE || Kb == 1, "activation needs Kb == 1");
+    QT_ARG(Ca % 4 == 0 && Ks % 4 == 0 && (Kb * Cb) % 4 == 0, "Ca, Ks and Kb*Cb must be multiples of 4 (float4 operands)");
+    QT_ARG((Ka * Ca + Ks) / 4 <= MAXQ, "reduction dimension too large (max 512)");
+    QT_ARG((((uintptr_t)a0 | (uintptr_t)a_rest | (uintptr_t)S | (uintptr_t)W) & 15) == 0, "operands must be 16-byte aligned");
     QT_ARG(act != QT_ACT_TANH_RES || res, "QT_ACT_TANH_RES needs res");
     if (N <= 0) return QT_OK;
     GemmArgs g;
@@ -253,6 +320,9 @@ extern "C" int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, co
     QT_ARG(a0 && G && part && Ka >= 1 && Ca >= 1 && Co >= 1, "bad arguments");
     QT_ARG(Ka == 1 || a_rest, "a_rest missing");
     QT_ARG(Ks == 0 || S, "S missing");
+    QT_ARG(Ca % 4 == 0 && Ks % 4 == 0 && Co % 4 == 0, "Ca, Ks and Co must be multiples of 4 (float4 operands)");
+    QT_ARG((Ka * Ca + Ks) / 4 <= MAXQ, "reduction dimension too large (max 512)");
+    QT_ARG((((uintptr_t)a0 | (uintptr_t)a_rest | (uintptr_t)S | (uintptr_t)G) & 15) == 0, "operands must be 16-byte aligned");
     if (N <= 0) return QT_OK;
     GemmArgs g;
     g.A.a0 = a0; g.A.a_rest = a_rest; g.A.S = S; g.A.Ka = Ka; g.A.Ca = Ca; g.A.Ks = Ks; g.A.N = N;

@@ -70,7 +70,7 @@ class Mesh:
 
     # -- T_k(L^) 1 for the bias terms of stacked ChebConvs ------------------------
     def cheb_ones(self, ks):
-        """(N, ks) matrix [1, L^1, T_2(L^)1, ...] (fp32)."""
+        """(N, 4*ceil(ks/4)) matrix [1, L^1, T_2(L^)1, ... | 0-pad] (fp32; padded so rows are float4 operands)."""
         if ks not in self._ones:
             cols = [torch.ones(self.N, device=self.labels.device)]
             for k in range(1, ks):
@@ -80,6 +80,7 @@ class Mesh:
                 else:
                     spmm(self, cols[-1], 2.0, cols[-2], -1.0, None, 0.0, nxt, 1)
                 cols.append(nxt)
+            cols += [torch.zeros_like(cols[0])] * ((-ks) % 4)
             self._ones[ks] = torch.stack(cols, dim=1).contiguous()
         return self._ones[ks]
 

@@ -32,7 +32,8 @@ class _ChebPoly(Function):
         Z, W = _c(Z.float()), _c(W.float())
         N, C = Z.shape
         Co = W.shape[1]
-        assert W.shape[0] == K * C + Ks, f'weight rows {W.shape[0]} != {K}*{C}+{Ks}'
+        ksp = (Ks + 3) // 4 * 4
+        assert W.shape[0] == K * C + ksp, f'weight rows {W.shape[0]} != {K}*{C}+{ksp}'
         TZ = Z.new_empty(max(K - 1, 1), N, C)
         for k in range(1, K):
             if k == 1:
@@ -42,7 +43,7 @@ class _ChebPoly(Function):
         S = mesh.cheb_ones(Ks) if Ks else None
         Y = Z.new_empty(N, Co)
         drop = _c(drop)
-        _lib.call('qt_dense', ptr(Z), ptr(TZ), K, C, ptr(W), ptr(S), Ks, ptr(W[K * C:]) if Ks else None, 1, Co, N,
+        _lib.call('qt_dense', ptr(Z), ptr(TZ), K, C, ptr(W), ptr(S), ksp, ptr(W[K * C:]) if Ks else None, 1, Co, N,
                   ptr(mesh.n_dev), act, ptr(res), res.stride(0) if res is not None else 0, ptr(drop), ptr(Y))
         ctx.mesh, ctx.K, ctx.Ks, ctx.act = mesh, K, Ks, act
         ctx.save_for_backward(Z, TZ, W, Y if act != ACT_NONE else None, res, drop)
@@ -88,12 +89,17 @@ class _ChebPoly(Function):
                 nblk = _lib.value('qt_wgrad_blocks', N)
                 part = Z.new_empty(nblk, W.shape[0], Co)
                 S = mesh.cheb_ones(Ks) if Ks else None
-                _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), Ks, ptr(G), Co, N, ptr(mesh.n_dev), ptr(part))
+                _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), (Ks + 3) // 4 * 4, ptr(G), Co, N, ptr(mesh.n_dev),
+                          ptr(part))
                 _lib.call('qt_colsum', ptr(part), nblk, W.numel(), ptr(gW))
         return gZ, gW, gres, None, None, None, None, None
 
 
 def cheb_poly(Z, W, mesh, K, Ks, act=ACT_NONE, res=None, drop=None):
+    """W: ((K*C + Ks), Co).  The Ks bias rows are zero-padded to a multiple of 4 to match mesh.cheb_ones."""
+    pad = (-Ks) % 4
+    if pad:
+        W = torch.nn.functional.pad(W, (0, 0, 0, pad))
     return _ChebPoly.apply(Z, W, res, drop, mesh, K, Ks, act)
 
 

@@ -219,3 +219,43 @@ def test_step_sse_vs_torch():
     (ga,) = torch.autograd.grad(sse, out)
     (gr,) = torch.autograd.grad(ref, out)
     grad_close(ga, gr)
+
+
+def test_static_mode_ignores_capacity_rows():
+    """Static (hipGraph) mode: rows >= N of every node buffer are garbage by contract.  Poison them with NaN and
+    check that cheb_poly / lstm / head / remesh results for the valid rows and every parameter gradient are
+    bit-identical to the dynamic-mode results."""
+    from qtmpnn import ops, synthetic
+    from qtmpnn.mesh import build_mesh
+    img = torch.from_numpy(np.stack([synthetic.make_clip(60 + i, n_frames=1, pixel_noise=0.02)[0, ..., 0] for i in range(2)])).to(dev())
+    dyn = build_mesh(src=img, thresh=0.1)
+    sta = build_mesh(src=img, thresh=0.1, static=True)
+    N, cap = dyn.N, sta.N
+    assert sta.n_valid == N and cap == 2 * 64 * 64 and torch.equal(dyn.labels, sta.labels)
+    torch.manual_seed(0)
+    C, Co, K, Ks = 20, 64, 5, 3
+    Zd = torch.randn(N, C, device=dev())
+    W0 = torch.randn(K * C + Ks, Co, device=dev()) * 0.2
+    wc, b, ln = torch.randn(3, 16, device=dev()), torch.randn(4, 16, device=dev()), torch.randn(4, 16, device=dev())
+    Cp = torch.randn(N, 16, device=dev())
+    gO, gH, gC = (torch.randn(N, 16, device=dev()) for _ in range(3))
+
+    def run(mesh, rows):
+        def padn(t):
+            out = torch.full((rows, *t.shape[1:]), float('nan'), device=dev())
+            out[:N] = t
+            return out
+        Z = padn(Zd).requires_grad_(True)
+        W = W0.clone().requires_grad_(True)
+        params = [p.clone().requires_grad_(True) for p in (wc, b, ln)]
+        cp = padn(Cp).requires_grad_(True)
+        G = ops.cheb_poly(Z, W, mesh, K, Ks)
+        O, Hn, Cn = ops.lstm_cell(G, cp, *params, mesh)
+        loss_terms = [O, Hn, Cn]
+        grads = torch.autograd.grad(loss_terms, [Z, W, cp] + params, [padn(gO), padn(gH), padn(gC)])
+        return [O[:N], Hn[:N], Cn[:N], grads[0][:N], grads[1], grads[2][:N]] + list(grads[3:])
+    a, s = run(dyn, N), run(sta, cap)
+    names = ['O', 'Hn', 'Cn', 'gZ', 'gW', 'gCprev', 'g_wc', 'g_b', 'g_ln']
+    for x, y, nm in zip(a, s, names):
+        assert not torch.isnan(y).any(), f'{nm}: NaN leaked from the capacity rows'
+        assert torch.equal(x, y) or torch.allclose(x, y, rtol=1e-5, atol=1e-6), nm
