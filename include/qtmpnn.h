@@ -138,10 +138,11 @@ int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, const float* 
              int act, const float* res, int res_stride, const float* drop, float* out, void* stream);
 
 /* qt_wgrad: partial sums of [A planes | S]^T @ G over row blocks, then qt_colsum over the blocks.
- *   G (N, Co); part (nblk, Ka*Ca + Ks, Co) with nblk = qt_wgrad_blocks(N).  */
+ *   G (N, Co); part (nblk, Ka*Ca + Ks, Co) with nblk = qt_wgrad_blocks(N).  accumulate != 0 adds into part
+ *   (each block owns its slab, so the sum over several uses of one weight keeps a fixed order).  */
 int qt_wgrad_blocks(int N);
 int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, const float* S, int Ks,
-             const float* G, int Co, int N, const int32_t* n_dev, float* part, void* stream);
+             const float* G, int Co, int N, const int32_t* n_dev, int accumulate, float* part, void* stream);
 /* out[j] = sum_i part[i*len + j], i < nblk */
 int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream);
 
@@ -161,14 +162,15 @@ int qt_lstm_fwd(const float* G, const float* Cprev, const float* wc, const float
 int qt_lstm_bwd_blocks(int N, int h);
 int qt_lstm_bwd(const float* gO, const float* gHn, const float* gCn,
                 const float* gates, const float* Craw, const float* Cprev, const float* wc, const float* ln,
-                int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, void* stream);
+                int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
+                void* stream);
 
 /* decoder head input, model/seq2seq.py:160-165: Z (N, hp) = [relu(LayerNorm_o(O)) | concat | 0...], hp >= h+1 */
 int qt_head_fwd(const float* O, const float* ln_o /* (2,h) */, const float* concat /* (N) or NULL */,
                 int N, const int32_t* n_dev, int h, int hp, float* Z, void* stream);
 /* gO (N,h), gconcat (N) or NULL; part (nblk, 2h) partial sums of g_ln_o, nblk = qt_lstm_bwd_blocks(N, h) */
 int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, const int32_t* n_dev, int h, int hp,
-                float* gO, float* gconcat, float* part, void* stream);
+                float* gO, float* gconcat, float* part, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

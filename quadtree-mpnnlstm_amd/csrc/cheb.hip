@@ -23,14 +23,31 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
     const int e1 = rowptr[row + 1];
-    for (int e = rowptr[row]; e < e1; ++e) {
-        const float w = nrm[e];
-        const float* xp = x + (int64_t)col[e] * C + ch;
+    // 4 edges per trip: the index/weight loads, then the 4 neighbour gathers, are independent and stay in flight
+    // together (quadtree rows have ~4 neighbours, so most rows finish in one trip)
+    for (int e = rowptr[row]; e < e1; e += 4) {
+        int cj[4];
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = e + u < e1;
+            cj[u] = ok ? col[e + u] : (int)row;
+            w[u] = ok ? nrm[e + u] : 0.0f;
+        }
         if constexpr (VEC == 4) {
-            const float4 f = *reinterpret_cast<const float4*>(xp);
-            acc[0] += w * f.x; acc[1] += w * f.y; acc[2] += w * f.z; acc[3] += w * f.w;
+            float4 f[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f[u] = *reinterpret_cast<const float4*>(x + (int64_t)cj[u] * C + ch);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] += w[u] * f[u].x; acc[1] += w[u] * f[u].y; acc[2] += w[u] * f[u].z; acc[3] += w[u] * f[u].w;
+            }
         } else {
-            acc[0] += w * xp[0];
+            float f[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f[u] = x[(int64_t)cj[u] * C + ch];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[0] += w[u] * f[u];
         }
     }
     const int64_t o = row * C + ch;
@@ -79,6 +96,7 @@ struct GemmArgs {
     float* out;
     int64_t row0_step;  // wgrad: rows per block
     const int32_t* n_dev;  // valid node rows on the device (NULL: A.N)
+    int accumulate;        // wgrad: add into part instead of overwriting (sums several uses of one weight)
 };
 
 // ---- fp32 MFMA tiles (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 64 FLOP/clk/SIMD).
@@ -251,7 +269,9 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(GemmArgs g) {
         for (int r = 0; r < 16; ++r) {
             const int i = f0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (i >= g.M) continue;
-            obase[(int64_t)i * g.NB + j] = jt == 0 ? acc0[r] : acc1[r];
+            float* o = obase + (int64_t)i * g.NB + j;
+            const float v = jt == 0 ? acc0[r] : acc1[r];
+            *o = g.accumulate ? *o + v : v;
         }
     }
 }
@@ -307,7 +327,7 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
     GemmArgs g;
     g.A.a0 = a0; g.A.a_rest = a_rest; g.A.S = S; g.A.Ka = Ka; g.A.Ca = Ca; g.A.Ks = Ks; g.A.N = N;
     g.B = W; g.M = N; g.K = Ka * Ca + Ks; g.NB = Kb * Cb;
-    g.Kb = Kb; g.Cb = Cb; g.act = act; g.res = res; g.res_stride = res_stride; g.drop = drop; g.out = out; g.row0_step = 0; g.n_dev = n_dev;
+    g.Kb = Kb; g.Cb = Cb; g.act = act; g.res = res; g.res_stride = res_stride; g.drop = drop; g.out = out; g.row0_step = 0; g.n_dev = n_dev; g.accumulate = 0;
     hipLaunchKernelGGL(k_gemm_fwd, dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, BN), 1), dim3(256), 0, (hipStream_t)stream, g);
     QT_LAUNCHED();
     return QT_OK;
@@ -316,7 +336,7 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
 extern "C" int qt_wgrad_blocks(int N) { return N > 0 ? qt_cdiv(N, WGRAD_ROWS) : 0; }
 
 extern "C" int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, const float* S, int Ks, const float* G,
-                        int Co, int N, const int32_t* n_dev, float* part, void* stream) {
+                        int Co, int N, const int32_t* n_dev, int accumulate, float* part, void* stream) {
     QT_ARG(a0 && G && part && Ka >= 1 && Ca >= 1 && Co >= 1, "bad arguments");
     QT_ARG(Ka == 1 || a_rest, "a_rest missing");
     QT_ARG(Ks == 0 || S, "S missing");
@@ -330,6 +350,7 @@ extern "C" int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, co
     g.Kb = 1; g.Cb = Co; g.act = QT_ACT_NONE; g.res = nullptr; g.res_stride = 0; g.drop = nullptr; g.out = part;
     g.row0_step = WGRAD_ROWS;
     g.n_dev = n_dev;
+    g.accumulate = accumulate;
     hipLaunchKernelGGL(k_gemm_wgrad, dim3(qt_cdiv(g.M, BM), qt_cdiv(Co, BN), qt_cdiv(N, WGRAD_ROWS)), dim3(256), 0,
                        (hipStream_t)stream, g);
     QT_LAUNCHED();

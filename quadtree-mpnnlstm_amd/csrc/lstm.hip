@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, c
 
 // reduce NACC*4 per-thread accumulators over the workgroup; lane group layout as above
 template <int LPN, int NACC>
-__device__ __forceinline__ void block_param_reduce(float (&acc)[NACC][4], int h, float* sm, float* part_row) {
+__device__ __forceinline__ void block_param_reduce(float (&acc)[NACC][4], int h, float* sm, float* part_row, int accumulate) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
@@ -144,7 +144,7 @@ __device__ __forceinline__ void block_param_reduce(float (&acc)[NACC][4], int h,
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += sm[(w * LPN + li) * NACC * 4 + a * 4 + k];
-        part_row[idx] = s;
+        part_row[idx] = accumulate ? part_row[idx] + s : s;
     }
 }
 
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, 
                                                   const float* __restrict__ Craw, const float* __restrict__ Cprev,
                                                   const float* __restrict__ wc, const float* __restrict__ ln, int Ncap,
                                                   const int32_t* __restrict__ n_dev, int h, float* __restrict__ gG,
-                                                  float* __restrict__ gCprev, float* __restrict__ part) {
+                                                  float* __restrict__ gCprev, float* __restrict__ part, int accumulate) {
     __shared__ float sm[4 * LPN * 11 * 4];
     const int N = qt_rows(n_dev, Ncap);
     const int j0 = (threadIdx.x % LPN) * 4;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, 
         st4(gg + 3 * h, ggo);
         if (gCprev) st4(gCprev + node * h + j0, gcp);
     }
-    block_param_reduce<LPN, 11>(acc, h, sm, part + (int64_t)blockIdx.x * 11 * h);
+    block_param_reduce<LPN, 11>(acc, h, sm, part + (int64_t)blockIdx.x * 11 * h, accumulate);
 }
 
 template <int LPN>
@@ -253,7 +253,7 @@ template <int LPN>
 __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ gZ, const float* __restrict__ O,
                                                   const float* __restrict__ ln_o, int Ncap,
                                                   const int32_t* __restrict__ n_dev, int h, int hp, float* __restrict__ gO,
-                                                  float* __restrict__ gconcat, float* __restrict__ part) {
+                                                  float* __restrict__ gconcat, float* __restrict__ part, int accumulate) {
     __shared__ float sm[4 * LPN * 2 * 4];
     const int N = qt_rows(n_dev, Ncap);
     const int li = threadIdx.x % LPN, j0 = li * 4;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ gZ, 
         st4(gO + node * h + j0, layer_norm_bwd<LPN>(gy, gm, xh, r, h));
         if (li == 0 && gconcat) gconcat[node] = gZ[node * hp + h];
     }
-    block_param_reduce<LPN, 2>(acc, h, sm, part + (int64_t)blockIdx.x * 2 * h);
+    block_param_reduce<LPN, 2>(acc, h, sm, part + (int64_t)blockIdx.x * 2 * h, accumulate);
 }
 
 inline int lanes_per_node(int h) { return h / 4; }
@@ -314,12 +314,13 @@ extern "C" int qt_lstm_bwd_blocks(int N, int h) {
 
 extern "C" int qt_lstm_bwd(const float* gO, const float* gHn, const float* gCn, const float* gates, const float* Craw,
                            const float* Cprev, const float* wc, const float* ln, int N, const int32_t* n_dev, int h,
-                           float* gG, float* gCprev, float* part, void* stream) {
+                           float* gG, float* gCprev, float* part, int accumulate, void* stream) {
     QT_ARG(gHn && gCn && gates && Craw && wc && gG && part, "null pointer");
     QT_ARG(h_ok(h), "hidden size must be 8, 16, 32, 64 or 128");
     if (N <= 0) return QT_OK;
     const int grid = qt_lstm_bwd_blocks(N, h);
-    QT_DISPATCH_LPN(h, k_lstm_bwd, grid, stream, gO, gHn, gCn, gates, Craw, Cprev, wc, ln, N, n_dev, h, gG, gCprev, part);
+    QT_DISPATCH_LPN(h, k_lstm_bwd, grid, stream, gO, gHn, gCn, gates, Craw, Cprev, wc, ln, N, n_dev, h, gG, gCprev, part,
+                    accumulate);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -336,12 +337,12 @@ extern "C" int qt_head_fwd(const float* O, const float* ln_o, const float* conca
 }
 
 extern "C" int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, const int32_t* n_dev, int h, int hp,
-                           float* gO, float* gconcat, float* part, void* stream) {
+                           float* gO, float* gconcat, float* part, int accumulate, void* stream) {
     QT_ARG(gZ && O && ln_o && gO && part, "null pointer");
     QT_ARG(h_ok(h) && hp >= h && hp % 4 == 0, "bad h / hp");
     if (N <= 0) return QT_OK;
     const int grid = qt_lstm_bwd_blocks(N, h);
-    QT_DISPATCH_LPN(h, k_head_bwd, grid, stream, gZ, O, ln_o, N, n_dev, h, hp, gO, gconcat, part);
+    QT_DISPATCH_LPN(h, k_head_bwd, grid, stream, gZ, O, ln_o, N, n_dev, h, hp, gO, gconcat, part, accumulate);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -26,15 +26,13 @@ class ChebConv(nn.Module):
             nn.init.xavier_uniform_(lin.weight)
 
     def packed(self, in_pad=None, out_pad=None):
-        """[W_0^T; ...; W_{K-1}^T; bias] as one ((K*in_pad)+1, out_pad) matrix, zero padded."""
+        """[W_0^T; ...; W_{K-1}^T; bias; 0 0 0] as one ((K*in_pad)+4, out_pad) matrix, zero padded."""
         cin, cout = in_pad or self.in_channels, out_pad or self.out_channels
-        rows = []
-        for lin in self.lins:
-            w = lin.weight.t()
-            rows.append(nn.functional.pad(w, (0, cout - w.shape[1], 0, cin - w.shape[0])))
-        b = self.bias if self.bias is not None else torch.zeros(self.out_channels, device=rows[0].device)
-        rows.append(nn.functional.pad(b, (0, cout - self.out_channels)).unsqueeze(0))
-        return torch.cat(rows, dim=0)
+        w = torch.stack([lin.weight for lin in self.lins]).transpose(1, 2)                 # (K, in, out)
+        w = nn.functional.pad(w, (0, cout - self.out_channels, 0, cin - self.in_channels))
+        b = self.bias if self.bias is not None else w.new_zeros(self.out_channels)
+        tail = nn.functional.pad(b.unsqueeze(0), (0, cout - self.out_channels, 0, 3))        # bias row + 3 zero rows
+        return torch.cat([w.reshape(self.K * cin, cout), tail], dim=0)
 
     def forward(self, x, edge_index, edge_weight=None):
         mesh = _need_mesh(edge_index)
@@ -119,44 +117,56 @@ class GConvLSTM(nn.Module):
                 setattr(self, f'w_c_{g}', nn.Parameter(torch.zeros(1, out_channels)))
             setattr(self, f'b_{g}', nn.Parameter(torch.zeros(1, out_channels)))
 
-    # -- weight packing (tiny, differentiable torch ops) ---------------------------
+    # -- weight packing (tiny, differentiable torch ops; once per forward pass) ----------
     def _branch(self, prefix):
-        convs = [getattr(self, f'{prefix}_{g}').convolutions for g in self.GATES]
         weights, biases = [], []
         for l in range(self.n_conv_layers):
-            weights.append(torch.stack([torch.stack([lin.weight.t() for lin in convs[g][l].lins]) for g in range(4)]))
-            biases.append(torch.stack([convs[g][l].bias for g in range(4)]))
+            convs = [getattr(self, f'{prefix}_{g}').convolutions[l] for g in self.GATES]
+            w = torch.stack([lin.weight for c in convs for lin in c.lins])             # one copy: (4*K, h, in)
+            weights.append(w.view(4, len(convs[0].lins), *w.shape[1:]).transpose(-1, -2))
+            biases.append(torch.stack([c.bias for c in convs]))
         return ops.compose_chebconvs(weights, biases)          # (4, K, in, h), (4, Ks, h)
 
-    def packed(self, with_h=True, in_pad=None):
-        """W ((K*C + Ks), 4h) for Z = [X (padded to in_pad) | H], peepholes (3, h), biases (4, h)."""
+    def pack(self, in_pad=None, ln=None, variants=(True,)):
+        """One PackedCell per requested variant (with_h True / False); the variants share the peephole / bias
+        tensors and their gradient accumulator.  W: ((K*C + Ks_padded), 4h) for Z = [X (padded to in_pad) | H]."""
         h = self.out_channels
         Px, bx = self._branch('conv_x')
         cin = in_pad or self.in_channels
         if cin > self.in_channels:
             Px = nn.functional.pad(Px, (0, 0, 0, cin - self.in_channels))
         Ph, bh = self._branch('conv_h')
-        M = torch.cat([Px, Ph], dim=2) if with_h else Px           # (4, K, C, h)
-        K, C = M.shape[1], M.shape[2]
-        W = torch.cat([M.permute(1, 2, 0, 3).reshape(K * C, 4 * h),
-                       (bx + bh).permute(1, 0, 2).reshape(-1, 4 * h)], dim=0)
+        K, Ks = Px.shape[1], bx.shape[1]
+        bias_rows = nn.functional.pad((bx + ops.unalias(bh)).permute(1, 0, 2).reshape(Ks, 4 * h), (0, 0, 0, (-Ks) % 4))
         wc = torch.cat([self.w_c_i, self.w_c_f, self.w_c_o], dim=0)
         b = torch.cat([self.b_i, self.b_f, self.b_c, self.b_o], dim=0)
-        return W, wc, b, K, bx.shape[1]
+        acc_p = ops.GradAcc()
+        out = []
+        for with_h in variants:
+            M = torch.cat([Px, Ph], dim=2) if with_h else Px           # (4, K, C, h)
+            W = torch.cat([M.permute(1, 2, 0, 3).reshape(K * M.shape[2], 4 * h), bias_rows], dim=0)
+            out.append(PackedCell(W, K, Ks, wc, b, ln, ops.GradAcc(), acc_p))
+        return out
 
-    def step(self, X, mesh, H, C, ln, packed=None):
-        """One cell update; ln = (4, h) LayerNorm parameters fused onto H', C' or None."""
-        with_h = H is not None
+    def step(self, X, mesh, H, C, pk):
+        """One cell update with packed weights `pk`; pk.ln = (4, h) LayerNorm parameters fused onto H', C' or None."""
+        Z = torch.cat([X, H], dim=1) if H is not None else X
+        G = ops.cheb_poly(Z, pk.W, mesh, pk.K, pk.Ks, acc=pk.acc_w)
+        return ops.lstm_cell(G, C, pk.wc, pk.b, pk.ln, mesh, pk.acc_p)
+
+    def forward(self, X, edge_index, edge_weight=None, H=None, C=None):
         pad = (-X.shape[1]) % 4
         if pad:
             X = nn.functional.pad(X, (0, pad))
-        W, wc, b, K, Ks = packed if packed is not None else self.packed(with_h, X.shape[1])
-        Z = torch.cat([X, H], dim=1) if with_h else X
-        G = ops.cheb_poly(Z, W, mesh, K, Ks)
-        return ops.lstm_cell(G, C, wc, b, ln, mesh)
+        return self.step(X, _need_mesh(edge_index), H, C, self.pack(X.shape[1], None, (H is not None,))[0])
 
-    def forward(self, X, edge_index, edge_weight=None, H=None, C=None):
-        return self.step(X, _need_mesh(edge_index), H, C, None)
+
+class PackedCell:
+    """Packed weights of one GConvLSTM for one forward pass (+ the gradient accumulators of that pass)."""
+    __slots__ = ('W', 'K', 'Ks', 'wc', 'b', 'ln', 'acc_w', 'acc_p')
+
+    def __init__(self, W, K, Ks, wc, b, ln, acc_w, acc_p):
+        self.W, self.K, self.Ks, self.wc, self.b, self.ln, self.acc_w, self.acc_p = W, K, Ks, wc, b, ln, acc_w, acc_p
 
 
 def _not_built(name):

@@ -40,22 +40,25 @@ class Encoder(nn.Module):
     def pack(self, in_pad):
         """Per-forward weight packing: layer 0 with and without a hidden state, upper layers without."""
         ln = _ln_params(self.norm_h, self.norm_c)
-        return dict(ln=ln, first=self.rnns[0].packed(False, in_pad), cont=self.rnns[0].packed(True, in_pad),
-                    upper=[r.packed(False) for r in self.rnns[1:]])
+        first, cont = self.rnns[0].pack(in_pad, ln, (False, True))
+        return dict(first=first, cont=cont, upper=[r.pack(None, ln, (False,))[0] for r in self.rnns[1:]])
+
+    def run(self, X, mesh, H, C, pk):
+        """One encoder step on packed weights; returns per-layer lists (no stacking on the hot path)."""
+        _, h, c = self.rnns[0].step(X, mesh, H, C, pk['cont'] if H is not None else pk['first'])
+        hs, cs = [h], [c]
+        for rnn, w in zip(self.rnns[1:], pk['upper']):
+            _, h, c = rnn.step(hs[-1], mesh, None, None, w)
+            hs.append(h)
+            cs.append(c)
+        return hs, cs
 
     def forward(self, X, edge_index, edge_weight=None, H=None, C=None, packed=None):
-        mesh = edge_index
         X = X.squeeze(0) if X.dim() == 3 else X
         pad = (-X.shape[1]) % 4
         if pad:
             X = nn.functional.pad(X, (0, pad))
-        pk = packed if packed is not None else self.pack(X.shape[1])
-        _, h, c = self.rnns[0].step(X, mesh, H, C, pk['ln'], pk['cont'] if H is not None else pk['first'])
-        hs, cs = [h], [c]
-        for rnn, w in zip(self.rnns[1:], pk['upper']):
-            _, h, c = rnn.step(hs[-1], mesh, None, None, pk['ln'], w)
-            hs.append(h)
-            cs.append(c)
+        hs, cs = self.run(X, edge_index, H, C, packed if packed is not None else self.pack(X.shape[1]))
         return torch.stack(hs), torch.stack(cs)
 
 
@@ -87,19 +90,18 @@ class Decoder(nn.Module):
         return self.hidden_size + 4          # [relu(norm_o(O)) | concat | 0 0 0] keeps rows 16-byte aligned
 
     def pack(self, in_pad):
-        return dict(ln=_ln_params(self.norm_h, self.norm_c), ln_o=_ln_params(self.norm_o),
-                    rnns=[r.packed(True, in_pad if i == 0 else None) for i, r in enumerate(self.rnns)],
-                    fc1=self.fc_out1.packed(self.head_width, self.hidden_size), fc2=self.fc_out2.packed(self.hidden_size, 4))
+        ln = _ln_params(self.norm_h, self.norm_c)
+        return dict(ln_o=_ln_params(self.norm_o), acc_o=ops.GradAcc(),
+                    rnns=[r.pack(in_pad if i == 0 else None, ln, (True,))[0] for i, r in enumerate(self.rnns)],
+                    fc1=self.fc_out1.packed(self.head_width, self.hidden_size), acc1=ops.GradAcc(),
+                    fc2=self.fc_out2.packed(self.hidden_size, 4), acc2=ops.GradAcc())
 
-    def forward(self, X, edge_index, edge_weight, concat_layers, H, C, packed=None):
-        mesh = edge_index
+    def run(self, X, mesh, concat_layers, H, C, pk):
+        """One decoder step on packed weights; X (N, 4k) padded input, H / C per-layer lists."""
         assert self.concat_layers_dim == 1
-        pad = (-X.shape[1]) % 4
-        Xp = nn.functional.pad(X, (0, pad)) if pad else X
-        pk = packed if packed is not None else self.pack(Xp.shape[1])
-        hs, cs, inp = [], [], Xp
+        hs, cs, inp = [], [], X
         for i, rnn in enumerate(self.rnns):
-            out, h, c = rnn.step(inp, mesh, H[i], C[i], pk['ln'], pk['rnns'][i])
+            out, h, c = rnn.step(inp, mesh, H[i], C[i], pk['rnns'][i])
             hs.append(h)
             cs.append(c)
             inp = h
@@ -107,15 +109,21 @@ class Decoder(nn.Module):
             # beyond-reference: HEAD crashes here (fc_out1 expects hidden+1 channels, seq2seq.py:115,164);
             # the decoder's current input value is used as the 1-channel concat (what :471,484 intended)
             concat_layers = X[:, :1]
-        z = ops.head_input(out, pk['ln_o'], concat_layers, self.head_width, mesh)
-        z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU)
+        z = ops.head_input(out, pk['ln_o'], concat_layers, self.head_width, mesh, pk['acc_o'])
+        z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'])
         drop = None
         if self.training and self.dropout.p > 0:
             keep = 1.0 - self.dropout.p
             drop = (torch.rand(z.shape[0], device=z.device) < keep).float() / keep
-        y = ops.cheb_poly(z, pk['fc2'], mesh, self.fc_out2.K, 1, ops.ACT_TANH_RES, res=Xp, drop=drop)[:, :1]
+        y = ops.cheb_poly(z, pk['fc2'], mesh, self.fc_out2.K, 1, ops.ACT_TANH_RES, res=X, drop=drop, acc=pk['acc2'])[:, :1]
         if self.binary:
             y = torch.sigmoid(y)
+        return y, hs, cs
+
+    def forward(self, X, edge_index, edge_weight, concat_layers, H, C, packed=None):
+        pad = (-X.shape[1]) % 4
+        Xp = nn.functional.pad(X, (0, pad)) if pad else X
+        y, hs, cs = self.run(Xp, edge_index, concat_layers, H, C, packed if packed is not None else self.pack(Xp.shape[1]))
         return y, torch.stack(hs), torch.stack(cs)
 
 
@@ -171,12 +179,14 @@ class Seq2Seq(nn.Module):
         feats = torch.cat([means, mesh.posfeat.unsqueeze(0).expand(T, -1, -1)], dim=-1)
         self.graph = Graph(None, None)
         self.graph.mapping, self.graph.n_pixels_per_node, self.graph.image_shape = mesh, mesh.npix, (n, m)
-        enc_pack = self.encoder.pack(c + 3 + (-(c + 3)) % 4)     # local: nothing on `self` may keep the autograd graph alive
+        fpad = (-(c + 3)) % 4
+        enc_pack = self.encoder.pack(c + 3 + fpad)     # local: nothing on `self` may keep the autograd graph alive
+        feats_in = nn.functional.pad(feats, (0, fpad)) if fpad else feats
         hidden = cell = None
         for t in range(self.input_timesteps):
-            hidden, cell = self.encoder(feats[t], mesh, None, H=None if hidden is None else hidden[-1],
-                                        C=None if cell is None else cell[-1], packed=enc_pack)
-        self.graph.hidden, self.graph.cell = hidden, cell
+            hidden, cell = self.encoder.run(feats_in[t], mesh, None if hidden is None else hidden[-1],
+                                            None if cell is None else cell[-1], enc_pack)
+        self.graph.hidden, self.graph.cell = hidden, cell            # per-layer lists while the rollout runs
         self.graph.pyg.x = torch.cat([feats[-1][:, :1], feats[-1][:, -3:]], dim=1)     # x[-1, :, [0,-3,-2,-1]] (:336)
 
     # -- decoder + remesh ----------------------------------------------------------------
@@ -200,7 +210,7 @@ class Seq2Seq(nn.Module):
                 cl = concat_layers[:, t].reshape(mesh.B, 1, mesh.P, 1)
                 concat_t = ops.pool_image(cl, mesh, True)[0]
                 g.concat_layers = concat_t
-            output, hidden, cell = self.decoder(g.pyg.x, mesh, None, concat_t, g.hidden, g.cell, packed=dec_pack)
+            output, hidden, cell = self.decoder.run(g.pyg.x, mesh, concat_t, g.hidden, g.cell, dec_pack)
             outputs.append(output)
             output_mappings.append(mesh)
             teacher_force = random.random() < teacher_forcing_ratio
@@ -208,7 +218,9 @@ class Seq2Seq(nn.Module):
                 # the reference re-meshes once more here (:393-394); nothing reads that mesh, so it is skipped.
                 # The kept state is detached: a live reference into the autograd graph would pin its AccumulateGrad
                 # nodes (and their stream) across iterations, which breaks hipGraph capture of the next step.
-                g.hidden, g.cell, g.pyg.x = hidden.detach(), cell.detach(), g.pyg.x.detach()
+                g.hidden = torch.stack([h.detach() for h in hidden])
+                g.cell = torch.stack([c.detach() for c in cell])
+                g.pyg.x = g.pyg.x.detach()
                 if concat_layers is not None:
                     g.concat_layers = g.concat_layers.detach()
                 break
@@ -242,7 +254,7 @@ class Seq2Seq(nn.Module):
         move to it as per-cell means of their un-flattened images (one fused kernel, no image in memory)."""
         g = self.graph
         old = g.mapping
-        L, h = hidden.shape[0], hidden.shape[2]
+        L, h = len(hidden), hidden[0].shape[1]
         if teacher_force:
             img0 = teacher_input[..., 0].reshape(old.B, old.n, old.m).float()
             new = self._mesh_from_image(img0, mask, high_interest_region)
@@ -251,11 +263,11 @@ class Seq2Seq(nn.Module):
             moved = ops.remesh_transfer(state, old, new)
         else:
             new = self._mesh_from_nodes(data, old, mask, high_interest_region)
-            state = torch.cat([data, data.new_zeros(old.N, 3), *hidden, *cell], dim=1)
+            state = torch.cat([data.expand(-1, 4), *hidden, *cell], dim=1)   # 4 copies of the output keep rows float4-sized
             moved = ops.remesh_transfer(state, old, new)
             val, moved = moved[:, :1], moved[:, 4:]
-        g.hidden = torch.stack(moved[:, :L * h].split(h, dim=1))
-        g.cell = torch.stack(moved[:, L * h:].split(h, dim=1))
+        g.hidden = list(moved[:, :L * h].split(h, dim=1))
+        g.cell = list(moved[:, L * h:].split(h, dim=1))
         g.pyg.x = torch.cat([val, new.posfeat], dim=-1)
         g.mapping, g.n_pixels_per_node = new, new.npix
         return new

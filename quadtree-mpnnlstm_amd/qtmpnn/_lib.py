@@ -29,13 +29,13 @@ _SIGNATURES = {
     'qt_spmm': [_P, _P, _P, _I, _P, _I, _P, _F, _P, _F, _P, _F, _P, _P],
     'qt_dense': [_P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P],
     'qt_wgrad_blocks': [_I],
-    'qt_wgrad': [_P, _P, _I, _I, _P, _I, _P, _I, _I, _P, _P, _P],
+    'qt_wgrad': [_P, _P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P],
     'qt_colsum': [_P, _I, _L, _P, _P],
     'qt_lstm_fwd': [_P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     'qt_lstm_bwd_blocks': [_I, _I],
-    'qt_lstm_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P],
+    'qt_lstm_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P],
     'qt_head_fwd': [_P, _P, _P, _I, _P, _I, _I, _P, _P],
-    'qt_head_bwd': [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P],
+    'qt_head_bwd': [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
 }
 _PLAIN = {'qt_abi_version', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks'}  # return a value, not an error code
 

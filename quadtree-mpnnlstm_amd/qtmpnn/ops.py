@@ -16,6 +16,58 @@ def _c(t):
     return t if t is None or t.is_contiguous() else t.contiguous()
 
 
+class _Unalias(Function):
+    """Identity whose backward hands out a private copy of the gradient.
+
+    `a + b` gives both operands the SAME gradient tensor; when both are (views of) leaf parameters autograd may
+    let two .grad fields alias one buffer, and the in-place clip_grad_norm_ then scales that buffer twice."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.clone()
+
+
+def unalias(x):
+    return _Unalias.apply(x)
+
+
+class GradAcc:
+    """Sums the parameter-gradient partials of every use of one packed weight inside ONE forward pass.
+
+    A weight is used once per rollout step; instead of one reduction + one autograd add per use, every use adds its
+    per-block partial sums into a shared slab buffer (fixed order: each block owns its slab) and only the FIRST
+    forward use -- the last one to run in the backward pass, because the recurrent state chains the uses --
+    reduces the slabs and hands the gradient to autograd.
+    """
+    __slots__ = ('uses', 'done', 'part')
+
+    def __init__(self):
+        self.uses, self.done, self.part = 0, 0, None
+
+    def enter(self):
+        self.uses += 1
+        return self.uses - 1
+
+    def slab(self, like, nblk, width):
+        if self.part is None:
+            self.part = like.new_zeros(nblk, width)
+        return self.part
+
+    def leave(self, use_idx):
+        """True when this use must emit the summed gradient."""
+        self.done += 1
+        if use_idx != 0:
+            return False
+        if self.done != self.uses:
+            raise RuntimeError('GradAcc: the first use of a packed weight ran its backward before a later use; '
+                               'the uses are not chained by the recurrent state')
+        return True
+
+
 # ------------------------------------------------------------------------------ ChebConv stacks
 class _ChebPoly(Function):
     """Y = act( sum_k T_k(L^) Z M_k + S Bm ),  W = [M_0; ...; M_{K-1}; Bm]  ((K*C + Ks), Co).
@@ -27,7 +79,7 @@ class _ChebPoly(Function):
     """
 
     @staticmethod
-    def forward(ctx, Z, W, res, drop, mesh, K, Ks, act):
+    def forward(ctx, Z, W, res, drop, mesh, K, Ks, act, acc):
         _lib.require_cuda(Z, 'node features')
         Z, W = _c(Z.float()), _c(W.float())
         N, C = Z.shape
@@ -45,7 +97,8 @@ class _ChebPoly(Function):
         drop = _c(drop)
         _lib.call('qt_dense', ptr(Z), ptr(TZ), K, C, ptr(W), ptr(S), ksp, ptr(W[K * C:]) if Ks else None, 1, Co, N,
                   ptr(mesh.n_dev), act, ptr(res), res.stride(0) if res is not None else 0, ptr(drop), ptr(Y))
-        ctx.mesh, ctx.K, ctx.Ks, ctx.act = mesh, K, Ks, act
+        ctx.mesh, ctx.K, ctx.Ks, ctx.act, ctx.acc = mesh, K, Ks, act, acc
+        ctx.use_idx = acc.enter() if acc is not None else 0
         ctx.save_for_backward(Z, TZ, W, Y if act != ACT_NONE else None, res, drop)
         return Y
 
@@ -84,23 +137,38 @@ class _ChebPoly(Function):
             gZ = torch.zeros_like(Z)
         gW = None
         if ctx.needs_input_grad[1]:
-            gW = torch.empty_like(W) if N > 0 else torch.zeros_like(W)
-            if N > 0:
-                nblk = _lib.value('qt_wgrad_blocks', N)
-                part = Z.new_empty(nblk, W.shape[0], Co)
-                S = mesh.cheb_ones(Ks) if Ks else None
-                _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), (Ks + 3) // 4 * 4, ptr(G), Co, N, ptr(mesh.n_dev),
-                          ptr(part))
-                _lib.call('qt_colsum', ptr(part), nblk, W.numel(), ptr(gW))
-        return gZ, gW, gres, None, None, None, None, None
+            acc = ctx.acc
+            ksp = (Ks + 3) // 4 * 4
+            S = mesh.cheb_ones(Ks) if Ks else None
+            if acc is None:
+                gW = torch.empty_like(W) if N > 0 else torch.zeros_like(W)
+                if N > 0:
+                    nblk = _lib.value('qt_wgrad_blocks', N)
+                    part = Z.new_empty(nblk, W.shape[0], Co)
+                    _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), ksp, ptr(G), Co, N, ptr(mesh.n_dev), 0, ptr(part))
+                    _lib.call('qt_colsum', ptr(part), nblk, W.numel(), ptr(gW))
+            else:
+                nblk = _lib.value('qt_wgrad_blocks', mesh.B * mesh.P)         # capacity: the same slab count for every mesh
+                part = acc.slab(Z, nblk, W.numel())
+                if N > 0:
+                    _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), ksp, ptr(G), Co, N, ptr(mesh.n_dev), 1, ptr(part))
+                if acc.leave(ctx.use_idx):
+                    gW = torch.empty_like(W)
+                    _lib.call('qt_colsum', ptr(part), nblk, W.numel(), ptr(gW))
+        return gZ, gW, gres, None, None, None, None, None, None
 
 
-def cheb_poly(Z, W, mesh, K, Ks, act=ACT_NONE, res=None, drop=None):
-    """W: ((K*C + Ks), Co).  The Ks bias rows are zero-padded to a multiple of 4 to match mesh.cheb_ones."""
+def pad_bias_rows(W, Ks):
+    """Zero-pad the Ks bias rows of a packed weight to a multiple of 4 (they pair with mesh.cheb_ones columns)."""
     pad = (-Ks) % 4
-    if pad:
-        W = torch.nn.functional.pad(W, (0, 0, 0, pad))
-    return _ChebPoly.apply(Z, W, res, drop, mesh, K, Ks, act)
+    return torch.nn.functional.pad(W, (0, 0, 0, pad)) if pad else W
+
+
+def cheb_poly(Z, W, mesh, K, Ks, act=ACT_NONE, res=None, drop=None, acc=None):
+    """W: ((K*C + Ks [padded to a multiple of 4]), Co).  acc: GradAcc shared by all uses of W in this pass."""
+    if W.shape[0] == K * Z.shape[1] + Ks and Ks % 4:
+        W = pad_bias_rows(W, Ks)
+    return _ChebPoly.apply(Z, W, res, drop, mesh, K, Ks, act, acc)
 
 
 def compose_chebconvs(weights, biases):
@@ -143,7 +211,7 @@ class _LstmCell(Function):
     model/seq2seq.py:64-75)."""
 
     @staticmethod
-    def forward(ctx, G, Cprev, wc, b, ln, mesh):
+    def forward(ctx, G, Cprev, wc, b, ln, mesh, acc):
         G = _c(G)
         N, h4 = G.shape
         h = h4 // 4
@@ -153,7 +221,8 @@ class _LstmCell(Function):
         _lib.call('qt_lstm_fwd', ptr(G), ptr(Cprev), ptr(wc), ptr(b), ptr(ln), N, ptr(mesh.n_dev), h, ptr(O), ptr(Hn),
                   ptr(Cn), ptr(gates), ptr(Craw))
         ctx.save_for_backward(gates, Craw, Cprev, wc, ln)
-        ctx.mesh = mesh
+        ctx.mesh, ctx.acc = mesh, acc
+        ctx.use_idx = acc.enter() if acc is not None else 0
         return O, Hn, Cn
 
     @staticmethod
@@ -165,19 +234,29 @@ class _LstmCell(Function):
         gO = _c(gO)
         gG = torch.empty_like(gates)
         gCp = torch.empty_like(Craw) if Cprev is not None else None
-        nblk = max(_lib.value('qt_lstm_bwd_blocks', N, h), 1)
-        part = Craw.new_empty(nblk, 11 * h)
-        psum = Craw.new_empty(11 * h) if N > 0 else Craw.new_zeros(11 * h)
+        acc, mesh = ctx.acc, ctx.mesh
+        if acc is None:
+            nblk = max(_lib.value('qt_lstm_bwd_blocks', N, h), 1)
+            part = Craw.new_empty(nblk, 11 * h)
+        else:
+            nblk = max(_lib.value('qt_lstm_bwd_blocks', mesh.B * mesh.P, h), 1)
+            part = acc.slab(Craw, nblk, 11 * h)
         if N > 0:
             _lib.call('qt_lstm_bwd', ptr(gO), ptr(gHn), ptr(gCn), ptr(gates), ptr(Craw), ptr(Cprev), ptr(wc), ptr(ln),
-                      N, ptr(ctx.mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part))
+                      N, ptr(mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part), 0 if acc is None else 1)
+        if acc is not None and not acc.leave(ctx.use_idx):
+            return gG, gCp, None, None, None, None, None
+        psum = Craw.new_empty(11 * h)
+        if N > 0 or acc is not None:
             _lib.call('qt_colsum', ptr(part), nblk, 11 * h, ptr(psum))
+        else:
+            psum.zero_()
         psum = psum.view(11, h)
-        return gG, gCp, psum[0:3], psum[3:7], (psum[7:11] if ln is not None else None), None
+        return gG, gCp, psum[0:3], psum[3:7], (psum[7:11] if ln is not None else None), None, None
 
 
-def lstm_cell(G, Cprev, wc, b, ln, mesh):
-    return _LstmCell.apply(G, Cprev, wc, b, ln, mesh)
+def lstm_cell(G, Cprev, wc, b, ln, mesh, acc=None):
+    return _LstmCell.apply(G, Cprev, wc, b, ln, mesh, acc)
 
 
 # ------------------------------------------------------------------------------ decoder head input
@@ -185,13 +264,14 @@ class _Head(Function):
     """[relu(LayerNorm_o(O)) | concat | 0-pad] (model/seq2seq.py:160-165)."""
 
     @staticmethod
-    def forward(ctx, O, ln_o, concat, hp, mesh):
+    def forward(ctx, O, ln_o, concat, hp, mesh, acc):
         O, ln_o, concat = _c(O), _c(ln_o), _c(concat)
         N, h = O.shape
         Z = O.new_empty(N, hp)
         _lib.call('qt_head_fwd', ptr(O), ptr(ln_o), ptr(concat), N, ptr(mesh.n_dev), h, hp, ptr(Z))
         ctx.save_for_backward(O, ln_o)
-        ctx.hp, ctx.has_concat, ctx.mesh = hp, concat is not None, mesh
+        ctx.hp, ctx.has_concat, ctx.mesh, ctx.acc = hp, concat is not None, mesh, acc
+        ctx.use_idx = acc.enter() if acc is not None else 0
         return Z
 
     @staticmethod
@@ -201,18 +281,28 @@ class _Head(Function):
         gZ = _c(gZ)
         gO = torch.empty_like(O)
         gcat = O.new_empty(N, 1) if ctx.has_concat else None
-        nblk = max(_lib.value('qt_lstm_bwd_blocks', N, h), 1)
-        part = O.new_empty(nblk, 2 * h)
-        psum = O.new_empty(2 * h) if N > 0 else O.new_zeros(2 * h)
+        acc, mesh = ctx.acc, ctx.mesh
+        if acc is None:
+            nblk = max(_lib.value('qt_lstm_bwd_blocks', N, h), 1)
+            part = O.new_empty(nblk, 2 * h)
+        else:
+            nblk = max(_lib.value('qt_lstm_bwd_blocks', mesh.B * mesh.P, h), 1)
+            part = acc.slab(O, nblk, 2 * h)
         if N > 0:
-            _lib.call('qt_head_bwd', ptr(gZ), ptr(O), ptr(ln_o), N, ptr(ctx.mesh.n_dev), h, ctx.hp, ptr(gO), ptr(gcat),
-                      ptr(part))
+            _lib.call('qt_head_bwd', ptr(gZ), ptr(O), ptr(ln_o), N, ptr(mesh.n_dev), h, ctx.hp, ptr(gO), ptr(gcat),
+                      ptr(part), 0 if acc is None else 1)
+        if acc is not None and not acc.leave(ctx.use_idx):
+            return gO, None, gcat, None, None, None
+        psum = O.new_empty(2 * h)
+        if N > 0 or acc is not None:
             _lib.call('qt_colsum', ptr(part), nblk, 2 * h, ptr(psum))
-        return gO, psum.view(2, h), gcat, None, None
+        else:
+            psum.zero_()
+        return gO, psum.view(2, h), gcat, None, None, None
 
 
-def head_input(O, ln_o, concat, hp, mesh):
-    return _Head.apply(O, ln_o, concat, hp, mesh)
+def head_input(O, ln_o, concat, hp, mesh, acc=None):
+    return _Head.apply(O, ln_o, concat, hp, mesh, acc)
 
 
 # ------------------------------------------------------------------------------ mesh <-> image

@@ -98,16 +98,19 @@ def test_chebconv_composition_algebra(n_conv):
 def test_gconvlstm_packing_shapes():
     from model.model import GConvLSTM
     cell = GConvLSTM(4, 16, n_conv_layers=2, convolution_type='ChebConv')
-    W, wc, b, K, Ks = cell.packed(True, 4)
-    assert (K, Ks) == (5, 3) and W.shape == (5 * 20 + 3, 64) and wc.shape == (3, 16) and b.shape == (4, 16)
-    W, _, _, K, Ks = cell.packed(False, 8)
-    assert W.shape == (5 * 8 + 3, 64)
+    no_h, with_h = cell.pack(4, None, (False, True))
+    assert (with_h.K, with_h.Ks) == (5, 3) and with_h.W.shape == (5 * 20 + 4, 64)          # 3 bias rows padded to 4
+    assert no_h.W.shape == (5 * 4 + 4, 64) and no_h.wc is with_h.wc and no_h.acc_p is with_h.acc_p
+    assert with_h.wc.shape == (3, 16) and with_h.b.shape == (4, 16)
+    assert not with_h.W[-1].any()                                                           # the pad row is zero
+    assert cell.pack(8, None, (False,))[0].W.shape == (5 * 8 + 4, 64)
     cell1 = GConvLSTM(16, 16, n_conv_layers=1, convolution_type='ChebConv')
-    W, _, _, K, Ks = cell1.packed(True)
-    assert (K, Ks) == (3, 1) and W.shape == (3 * 32 + 1, 64)
-    # gate order i, f, c, o along the output axis
+    pk = cell1.pack(None, None, (True,))[0]
+    assert (pk.K, pk.Ks) == (3, 1) and pk.W.shape == (3 * 32 + 4, 64)
+    # gate order i, f, c, o along the output axis; rows = [k][x channels | h channels]
     lin = cell1.conv_x_c.convolutions[0].lins[1].weight
-    assert torch.equal(W[32:48, 32:48], lin.t())
+    assert torch.equal(pk.W[32:48, 32:48], lin.t())
+    assert torch.equal(pk.W[96, :16], cell1.conv_x_i.convolutions[0].bias + cell1.conv_h_i.convolutions[0].bias)
 
 
 def test_synthetic_clips_are_deterministic_and_shaped():
