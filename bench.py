@@ -148,9 +148,10 @@ def main():
     from qtmpnn import synthetic
     from qtmpnn.dist import broadcast_parameters, init_from_env
 
-    rank, world, local = init_from_env('nccl')
+    # QT_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box); the real runs use RCCL
+    rank, world, local = init_from_env(os.environ.get('QT_DIST_BACKEND', 'nccl'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    device = torch.device('cuda', local)
+    device = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     nfp = make_predictor(device, capturable=(world == 1 and not args.eager))
     if world > 1:

@@ -108,7 +108,6 @@ struct GemmArgs {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128;       // block rows (4 waves x 32)
 constexpr int BN = 64;        // block columns (2 MFMA tiles per wave)
-constexpr int KW = 128;       // reduction depth per pass of the forward GEMM (W chunk in LDS)
 constexpr int MAXQ = 128;     // quads (4 consecutive k) in the reduction dimension
 
 // Quad table: quad Q of a node row lives at qptr[Q] + row * qstr[Q] (plane Q*4/Ca of the operand, or S).
@@ -126,60 +125,68 @@ __device__ __forceinline__ void build_quad_table(const PlaneSrc& A, const float*
     }
 }
 
-// MODE 0: out planes = act(A @ W).  Block = 128 node rows x 64 output columns, wave w owns rows [32w, 32w+32).
-// A fragments go global -> VGPR directly (float4 per lane and k-quad); only W is staged in LDS.
+// MODE 0: out planes = act(A @ W).  Block = 128 node rows x (32 NT) output columns, wave w owns rows [32w, 32w+32).
+// A fragments go global -> VGPR directly (float4 per lane and k-quad); only W is staged in LDS (KWT x 32 NT floats).
+// NT = 2 for NB <= 64 (gate GEMM), NT = 4 for wide outputs (the data gradient, NB = K*C) so A is read only once.
+template <int NT, int KWT>
 __global__ __launch_bounds__(256) void k_gemm_fwd(GemmArgs g) {
-    __shared__ float Bs[KW][BN];
+    constexpr int BNT = 32 * NT;
+    __shared__ float Bs[KWT][BNT];
     __shared__ const float* qptr[MAXQ];
     __shared__ int qstr[MAXQ];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l32 = lane & 31, half = lane >> 5;
     const int64_t i0 = (int64_t)blockIdx.x * BM;
-    const int j0 = blockIdx.y * BN;
+    const int j0 = blockIdx.y * BNT;
     const int64_t rows = qt_rows(g.n_dev, g.M);      // g.M stays the plane stride (capacity)
     if (i0 >= rows) return;
     const int nquad = g.K >> 2;
     build_quad_table(g.A, qptr, qstr, nquad);
     const int64_t my_row = i0 + wave * 32 + l32;
     const bool row_ok = my_row < rows;
-    f32x16 acc0 = {0}, acc1 = {0};
-    for (int k0 = 0; k0 < g.K; k0 += KW) {
-        const int kn = min(KW, g.K - k0);            // multiple of 4
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    for (int k0 = 0; k0 < g.K; k0 += KWT) {
+        const int kn = min(KWT, g.K - k0);           // multiple of 4
         __syncthreads();                              // table ready / previous pass done with Bs
-        for (int e = t; e < kn * (BN / 4); e += 256) {
-            const int kb = e >> 4, jq = (e & 15) * 4;
+        for (int e = t; e < kn * (BNT / 4); e += 256) {
+            const int kb = e / (BNT / 4), jq = (e % (BNT / 4)) * 4;
             float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j0 + jq < g.NB) w = *reinterpret_cast<const float4*>(g.B + (int64_t)(k0 + kb) * g.NB + j0 + jq);
             *reinterpret_cast<float4*>(&Bs[kb][jq]) = w;
         }
         // this lane's A quads of the pass: quad 2 j + half
-        float4 areg[KW / 8];
+        float4 areg[KWT / 8];
         const int q0 = k0 >> 2, qn = kn >> 2;
 #pragma unroll
-        for (int j = 0; j < KW / 8; ++j) {
+        for (int j = 0; j < KWT / 8; ++j) {
             const int q = 2 * j + half;
             areg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row_ok && q < qn) areg[j] = *reinterpret_cast<const float4*>(qptr[q0 + q] + my_row * qstr[q0 + q]);
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < KW / 8; ++j) {
+        for (int j = 0; j < KWT / 8; ++j) {
             if (8 * j < kn) {
                 const float av[4] = {areg[j].x, areg[j].y, areg[j].z, areg[j].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int kk = 8 * j + 4 * half + i;      // rows >= kn of Bs are only met with a zero A quad
-                    const float b0 = kk < kn ? Bs[kk][l32] : 0.0f;
-                    const float b1 = kk < kn ? Bs[kk][32 + l32] : 0.0f;
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1, acc1, 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float b = kk < kn ? Bs[kk][nt * 32 + l32] : 0.0f;
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b, acc[nt], 0, 0, 0);
+                    }
                 }
             }
         }
     }
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-        const int j = j0 + jt * 32 + l32;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int j = j0 + nt * 32 + l32;
         if (j >= g.NB) continue;
         const int pl = j / g.Cb, ch = j - pl * g.Cb;
         float* obase = g.out + (int64_t)pl * g.M * g.Cb + ch;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256) void k_gemm_fwd(GemmArgs g) {
         for (int r = 0; r < 16; ++r) {
             const int64_t i = i0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (i >= rows) continue;
-            float v = jt == 0 ? acc0[r] : acc1[r];
+            float v = acc[nt][r];
             if (g.act == QT_ACT_RELU) v = fmaxf(v, 0.0f);
             if (g.act == QT_ACT_TANH_RES) v = tanhf((g.drop ? g.drop[i] : 1.0f) * v) + g.res[i * g.res_stride];
             obase[i * g.Cb] = v;
@@ -265,13 +272,16 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(GemmArgs g) {
     for (int jt = 0; jt < 2; ++jt) {
         const int j = j0 + jt * 32 + l32;
         if (j >= g.NB) continue;
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {      // all slab reads first: 16 independent loads in flight
+            const int i = f0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            old[r] = (g.accumulate && i < g.M) ? obase[(int64_t)i * g.NB + j] : 0.0f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = f0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (i >= g.M) continue;
-            float* o = obase + (int64_t)i * g.NB + j;
-            const float v = jt == 0 ? acc0[r] : acc1[r];
-            *o = g.accumulate ? *o + v : v;
+            if (i < g.M) obase[(int64_t)i * g.NB + j] = old[r] + (jt == 0 ? acc0[r] : acc1[r]);
         }
     }
 }
@@ -328,7 +338,10 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
     g.A.a0 = a0; g.A.a_rest = a_rest; g.A.S = S; g.A.Ka = Ka; g.A.Ca = Ca; g.A.Ks = Ks; g.A.N = N;
     g.B = W; g.M = N; g.K = Ka * Ca + Ks; g.NB = Kb * Cb;
     g.Kb = Kb; g.Cb = Cb; g.act = act; g.res = res; g.res_stride = res_stride; g.drop = drop; g.out = out; g.row0_step = 0; g.n_dev = n_dev; g.accumulate = 0;
-    hipLaunchKernelGGL(k_gemm_fwd, dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, BN), 1), dim3(256), 0, (hipStream_t)stream, g);
+    if (g.NB > 64)
+        hipLaunchKernelGGL((k_gemm_fwd<4, 64>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128), 1), dim3(256), 0, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL((k_gemm_fwd<2, 128>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 64), 1), dim3(256), 0, (hipStream_t)stream, g);
     QT_LAUNCHED();
     return QT_OK;
 }

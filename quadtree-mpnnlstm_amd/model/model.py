@@ -25,10 +25,14 @@ class ChebConv(nn.Module):
         for lin in self.lins:
             nn.init.xavier_uniform_(lin.weight)
 
+    def cheb_coeffs(self):
+        """Coefficient matrices (K, in, out) of the Chebyshev series this layer applies, and its bias."""
+        return torch.stack([lin.weight for lin in self.lins]).transpose(1, 2), self.bias
+
     def packed(self, in_pad=None, out_pad=None):
         """[W_0^T; ...; W_{K-1}^T; bias; 0 0 0] as one ((K*in_pad)+4, out_pad) matrix, zero padded."""
         cin, cout = in_pad or self.in_channels, out_pad or self.out_channels
-        w = torch.stack([lin.weight for lin in self.lins]).transpose(1, 2)                 # (K, in, out)
+        w, _ = self.cheb_coeffs()                                                           # (K, in, out)
         w = nn.functional.pad(w, (0, cout - self.out_channels, 0, cin - self.in_channels))
         b = self.bias if self.bias is not None else w.new_zeros(self.out_channels)
         tail = nn.functional.pad(b.unsqueeze(0), (0, cout - self.out_channels, 0, 3))        # bias row + 3 zero rows
@@ -43,6 +47,25 @@ class ChebConv(nn.Module):
         return y[:, :self.out_channels] if opad else y
 
 
+class GCNConv(ChebConv):
+    """torch_geometric GCNConv(add_self_loops=False) (model/model.py:50; parameters lin.weight (out, in), bias):
+    out = A^ (x W^T) + b with A^_ij = d_i^-1/2 w_ij d_j^-1/2.  The mesh weights are symmetric and its self pairs have
+    weight 0, so A^ = -L^ off the diagonal: a GCNConv IS the Chebyshev series [0, -W^T] and reuses the ChebConv
+    kernels, including the weight-space composition of stacked layers."""
+
+    def __init__(self, in_channels, out_channels, add_self_loops=False):
+        nn.Module.__init__(self)
+        assert not add_self_loops, 'the reference uses add_self_loops=False'
+        self.in_channels, self.out_channels, self.K = in_channels, out_channels, 2
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        nn.init.xavier_uniform_(self.lin.weight)
+
+    def cheb_coeffs(self):
+        wt = self.lin.weight.t()
+        return torch.stack([torch.zeros_like(wt), -wt]), self.bias
+
+
 def _need_mesh(edge_index):
     if not isinstance(edge_index, Mesh):
         raise TypeError('pass the Mesh (graph_structure["mapping"]) where the reference passes edge_index: '
@@ -52,7 +75,7 @@ def _need_mesh(edge_index):
 
 CONVOLUTIONS = {
     'ChebConv': ChebConv,
-    'GCNConv': None,
+    'GCNConv': GCNConv,
     'TransformerConv': None,
     'MHTransformerConv': None,
     'GATConv': None,
@@ -122,8 +145,11 @@ class GConvLSTM(nn.Module):
         weights, biases = [], []
         for l in range(self.n_conv_layers):
             convs = [getattr(self, f'{prefix}_{g}').convolutions[l] for g in self.GATES]
-            w = torch.stack([lin.weight for c in convs for lin in c.lins])             # one copy: (4*K, h, in)
-            weights.append(w.view(4, len(convs[0].lins), *w.shape[1:]).transpose(-1, -2))
+            if isinstance(convs[0], GCNConv):
+                weights.append(torch.stack([c.cheb_coeffs()[0] for c in convs]))
+            else:
+                w = torch.stack([lin.weight for c in convs for lin in c.lins])             # one copy: (4*K, h, in)
+                weights.append(w.view(4, len(convs[0].lins), *w.shape[1:]).transpose(-1, -2))
             biases.append(torch.stack([c.bias for c in convs]))
         return ops.compose_chebconvs(weights, biases)          # (4, K, in, h), (4, Ks, h)
 

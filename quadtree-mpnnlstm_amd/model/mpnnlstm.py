@@ -176,7 +176,8 @@ class NextFramePredictorS2S:
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph, stream=side):      # capture on the warm-up stream
+        # thread_local: other threads (the RCCL watchdog under torch.distributed) may issue HIP calls meanwhile
+        with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):      # capture on the warm-up stream
             static_loss = body()
         self._graph = graph
 

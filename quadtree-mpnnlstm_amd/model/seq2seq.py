@@ -260,14 +260,14 @@ class Seq2Seq(nn.Module):
             new = self._mesh_from_image(img0, mask, high_interest_region)
             val = ops.pool_image(img0.reshape(old.B, 1, old.P, 1), new, True)[0]
             state = torch.cat([*hidden, *cell], dim=1)
-            moved = ops.remesh_transfer(state, old, new)
+            parts = ops.remesh_transfer(state, old, new).split([h] * (2 * L), dim=1)
         else:
             new = self._mesh_from_nodes(data, old, mask, high_interest_region)
             state = torch.cat([data.expand(-1, 4), *hidden, *cell], dim=1)   # 4 copies of the output keep rows float4-sized
-            moved = ops.remesh_transfer(state, old, new)
-            val, moved = moved[:, :1], moved[:, 4:]
-        g.hidden = list(moved[:, :L * h].split(h, dim=1))
-        g.cell = list(moved[:, L * h:].split(h, dim=1))
+            # ONE split (its backward is one concat; separate slices would each zero-fill a full (N, 4+2Lh) gradient)
+            val4, *parts = ops.remesh_transfer(state, old, new).split([4] + [h] * (2 * L), dim=1)
+            val = val4[:, :1]
+        g.hidden, g.cell = list(parts[:L]), list(parts[L:])
         g.pyg.x = torch.cat([val, new.posfeat], dim=-1)
         g.mapping, g.n_pixels_per_node = new, new.npix
         return new

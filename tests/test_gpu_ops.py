@@ -259,3 +259,30 @@ def test_static_mode_ignores_capacity_rows():
     for x, y, nm in zip(a, s, names):
         assert not torch.isnan(y).any(), f'{nm}: NaN leaked from the capacity rows'
         assert torch.equal(x, y) or torch.allclose(x, y, rtol=1e-5, atol=1e-6), nm
+
+
+def test_gcnconv_cell_vs_oracle():
+    """R11: GConvLSTM with GCNConv(add_self_loops=False) against the oracle's restatement (fwd + grads)."""
+    from model.model import GConvLSTM
+    from oracle import qt_oracle as O
+    mesh, _ = _mesh_64(71, noise=0.0)
+    ei, ew = _oracle_graph(mesh)
+    torch.manual_seed(5)
+    ref = O.GConvLSTM(4, 8, 2, 'GCNConv')
+    for p in ref.parameters():
+        p.data.normal_(0, 0.4)
+    mine = GConvLSTM(4, 8, 2, 'GCNConv')
+    mine.load_state_dict(ref.state_dict())
+    mine.to(dev())
+    X, H, C = torch.randn(mesh.N, 4), torch.randn(mesh.N, 8), torch.randn(mesh.N, 8)
+    xr, hr, cr = (t.clone().requires_grad_(True) for t in (X, H, C))
+    outs_r = ref(xr, ei, ew, hr, cr)
+    xg, hg, cg = (t.to(dev()).requires_grad_(True) for t in (X, H, C))
+    outs_g = mine(xg, mesh, None, hg, cg)
+    for a, b in zip(outs_g, outs_r):
+        close(a, b, atol=1e-4)
+    gs = [torch.randn_like(o) for o in outs_r]
+    gr = torch.autograd.grad(outs_r, [xr, hr, cr] + list(ref.parameters()), gs)
+    gg = torch.autograd.grad(outs_g, [xg, hg, cg] + list(mine.parameters()), [g.to(dev()) for g in gs])
+    for a, b, name in zip(gg, gr, ['X', 'H', 'C'] + [k for k, _ in ref.named_parameters()]):
+        grad_close(a, b, msg=name)
