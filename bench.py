@@ -153,7 +153,7 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     device = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(device)
-    nfp = make_predictor(device, capturable=(world == 1 and not args.eager))
+    nfp = make_predictor(device, capturable=not args.eager)
     if world > 1:
         broadcast_parameters(nfp.model)
     nfp.model.train()

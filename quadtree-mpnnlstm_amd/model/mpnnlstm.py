@@ -132,19 +132,21 @@ class NextFramePredictorS2S:
 
     def make_graphed_step(self, x, y, concat_layers=None, mask=None, high_interest_region=None, max_norm=10.0,
                           warmup=2):
-        """Capture one whole training step in a hipGraph and return `step(x, y, concat) -> loss`.
+        """Capture one whole training step in hipGraphs and return `step(x, y, concat) -> loss`.
 
-        The rollout is data dependent (every decoder step re-meshes on its own output), so the capture
-        runs in static mode: all node buffers have the worst-case capacity B*W*H and every kernel reads
-        the actual node count from device memory -- no host sync, no shape change, ~2.7k launches replayed
-        by one hipGraphLaunch.  Single process: forward + loss + backward + clip + Adam are all in the
-        graph.  Under torch.distributed the graph ends after backward; the flat gradient all-reduce, clip
-        and Adam run eagerly after each replay.  The `warmup` eager steps are real training steps.
+        The rollout is data dependent (every decoder step re-meshes on its own output), so the capture runs in
+        static mode: all node buffers have the worst-case capacity B*W*H and every kernel reads the actual node
+        count from device memory -- no host sync, no shape change, ~1.8k launches replayed by one hipGraphLaunch.
+        Single process: forward + loss + backward + clip + fused Adam are ONE graph.  Under torch.distributed the
+        first graph ends with the gradients packed into one flat buffer; the step is then
+        `graph1.replay(); all_reduce(flat); graph2.replay()` with graph2 = average + clip + fused Adam on views of
+        that buffer: one collective and three host calls per step.  The `warmup` eager steps are real training steps.
         """
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        world = dist.get_world_size() if multi else 1
         self.model.static_shapes = True
-        if not multi and not self.optimizer.defaults.get('capturable', False):
+        if not self.optimizer.defaults.get('capturable', False):
             lr = self.optimizer.param_groups[0]['lr']
             assert not self.optimizer.state, 'make_graphed_step must be called before the first optimizer step'
             self.initiate_training(float(lr), self.scheduler.gamma, capturable=True)
@@ -152,34 +154,45 @@ class NextFramePredictorS2S:
         sx, sy = x.clone(), y.clone()
         sc = concat_layers.clone() if concat_layers is not None else None
 
-        def body():
+        def fwd_bwd():
             self.optimizer.zero_grad(set_to_none=True)
             loss = self.forward_loss(sx, sy, sc, mask, high_interest_region)
             loss.backward()
-            if not multi:
-                torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
-                self.optimizer.step()
             return loss.detach()
 
-        def finish():
-            if multi:
-                allreduce_gradients(params, self.process_group)
-                torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
-                self.optimizer.step()
+        def update():
+            torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+            self.optimizer.step()
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                body()
-                finish()
+                fwd_bwd()
+                if multi:
+                    allreduce_gradients(params, self.process_group)
+                update()
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
         # thread_local: other threads (the RCCL watchdog under torch.distributed) may issue HIP calls meanwhile
-        with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):      # capture on the warm-up stream
-            static_loss = body()
+        with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
+            static_loss = fwd_bwd()
+            if multi:
+                flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+            else:
+                update()
         self._graph = graph
+        graph2 = None
+        if multi:
+            off = 0
+            for p in params:                              # gradients become views of the flat buffer: no unpack copies
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph2, stream=side, capture_error_mode='thread_local'):
+                flat.mul_(1.0 / world)
+                update()
 
         def step(x, y, concat_layers=None):
             sx.copy_(x)
@@ -187,7 +200,9 @@ class NextFramePredictorS2S:
             if sc is not None:
                 sc.copy_(concat_layers)
             graph.replay()
-            finish()
+            if multi:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+                graph2.replay()
             return static_loss
         return step
 

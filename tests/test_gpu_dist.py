@@ -1,0 +1,77 @@
+"""Data-parallel equivalence on the GPU: two ranks (gloo transport, both on cuda:0 -- RCCL needs one GPU per rank, the
+driver's multi-GPU bench covers that) training on half the clips each must reproduce the single-process step on all
+clips: same loss (mean of the rank losses) and the same weights after the update."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+T, B = 3, 4
+
+
+def _setup():
+    from model.mpnnlstm import NextFramePredictorS2S
+    torch.manual_seed(11)
+    dev = torch.device('cuda', 0)
+    nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=T, output_timesteps=T, device=dev,
+                                model_kwargs=dict(hidden_size=8, dropout=0.0, n_layers=1))
+    nfp.initiate_training(lr=1e-3, lr_decay=0.95, capturable=True)
+    return nfp, dev
+
+
+def _data(dev, lo, hi):
+    from qtmpnn import synthetic
+    x, y = synthetic.make_batch(3, 0, B, T, T, n_digits=1, pixel_noise=0.02)
+    t = lambda a: torch.from_numpy(a[lo:hi]).to(dev)
+    return t(x), t(y), torch.zeros(hi - lo, T, 64, 64, 1, device=dev)
+
+
+def _rank(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from qtmpnn.dist import init_from_env, shard_range
+    init_from_env('gloo')
+    nfp, dev = _setup()
+    lo, hi = shard_range(B, rank, world)
+    x, y, c = _data(dev, lo, hi)
+    mask = np.zeros((64, 64), dtype=bool)
+    step = nfp.make_graphed_step(x, y, c, mask, warmup=1)          # 1 eager DP step, then graph1 + all-reduce + graph2
+    losses = [float(step(x, y, c)) for _ in range(2)]
+    out.put((rank, losses, {k: v.detach().cpu().numpy() for k, v in nfp.model.state_dict().items()}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process():
+    nfp, dev = _setup()
+    x, y, c = _data(dev, 0, B)
+    mask = np.zeros((64, 64), dtype=bool)
+    ref_losses = [float(nfp.train_step(x, y, c, mask)) for _ in range(3)]
+    ref = {k: v.detach().cpu() for k, v in nfp.model.state_dict().items()}
+
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.environ['PYTHONPATH'] = os.pathsep.join([os.path.join(root, 'quadtree-mpnnlstm_amd'), root, os.path.join(root, 'tests'),
+                                                os.environ.get('PYTHONPATH', '')])
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((out.get(timeout=240) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # steps 2 and 3 of the reference correspond to the two graphed steps; global loss = mean over ranks
+    for i in range(2):
+        glob = 0.5 * (res[0][1][i] + res[1][1][i])
+        assert abs(glob - ref_losses[i + 1]) <= 1e-4 * abs(ref_losses[i + 1]), (i, glob, ref_losses)
+    for k in ref:
+        np.testing.assert_allclose(res[0][2][k], res[1][2][k], rtol=0, atol=0, err_msg=f'ranks diverged: {k}')
+        np.testing.assert_allclose(res[0][2][k], ref[k].numpy(), rtol=2e-3, atol=2e-4, err_msg=k)
