@@ -155,13 +155,14 @@ int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream
  * Outputs: O (N, h) raw output gate, Hn / Cn (N, h) LayerNorm'ed states,
  *   gates (N, 4h) activated I, F, T, O and Craw (N, h) saved for the backward.
  */
-int qt_lstm_fwd(const float* G, const float* Cprev, const float* wc, const float* b, const float* ln,
+int qt_lstm_fwd(const float* G, const float* Cprev, int ld_c /* row stride of Cprev, floats */, const float* wc,
+                const float* b, const float* ln,
                 int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw,
                 void* stream);
 /* gO may be NULL.  part: (nblk, 11*h) partial sums [g_wc(3h) | g_b(4h) | g_ln(4h)], nblk = qt_lstm_bwd_blocks(N, h) */
 int qt_lstm_bwd_blocks(int N, int h);
-int qt_lstm_bwd(const float* gO, const float* gHn, const float* gCn,
-                const float* gates, const float* Craw, const float* Cprev, const float* wc, const float* ln,
+int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,   /* row strides */
+                const float* gates, const float* Craw, const float* Cprev, int ld_c, const float* wc, const float* ln,
                 int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
                 void* stream);
 

@@ -71,7 +71,7 @@ template <int LPN>
 __global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, const float* __restrict__ Cprev,
                                                   const float* __restrict__ wc, const float* __restrict__ b,
                                                   const float* __restrict__ ln, int Ncap, const int32_t* __restrict__ n_dev,
-                                                  int h, float* __restrict__ O, float* __restrict__ Hn,
+                                                  int h, int ld_c, float* __restrict__ O, float* __restrict__ Hn,
                                                   float* __restrict__ Cn, float* __restrict__ gates,
                                                   float* __restrict__ Craw) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, c
     const float* g = G + node * 4 * h + j0;
     const F4 gi = ld4(g), gf = ld4(g + h), gc = ld4(g + 2 * h), go = ld4(g + 3 * h);
     F4 cp = {{0, 0, 0, 0}};
-    if (Cprev) cp = ld4(Cprev + node * h + j0);
+    if (Cprev) cp = ld4(Cprev + node * ld_c + j0);
     const F4 wci = ld4(wc + j0), wcf = ld4(wc + h + j0), wco = ld4(wc + 2 * h + j0);
     const F4 bi = ld4(b + j0), bf = ld4(b + h + j0), bc = ld4(b + 2 * h + j0), bo = ld4(b + 3 * h + j0);
     F4 I, F, T, Og, Cr, Hr;
@@ -153,8 +153,9 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, 
                                                   const float* __restrict__ gCn, const float* __restrict__ gates,
                                                   const float* __restrict__ Craw, const float* __restrict__ Cprev,
                                                   const float* __restrict__ wc, const float* __restrict__ ln, int Ncap,
-                                                  const int32_t* __restrict__ n_dev, int h, float* __restrict__ gG,
-                                                  float* __restrict__ gCprev, float* __restrict__ part, int accumulate) {
+                                                  const int32_t* __restrict__ n_dev, int h, int ld_go, int ld_gh, int ld_gc,
+                                                  int ld_c, float* __restrict__ gG, float* __restrict__ gCprev,
+                                                  float* __restrict__ part, int accumulate) {
     __shared__ float sm[4 * LPN * 11 * 4];
     const int N = qt_rows(n_dev, Ncap);
     const int j0 = (threadIdx.x % LPN) * 4;
@@ -176,14 +177,14 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, 
         const F4 I = ld4(gs), F = ld4(gs + h), T = ld4(gs + 2 * h), Og = ld4(gs + 3 * h);
         const F4 Cr = ld4(Craw + node * h + j0);
         F4 cp = {{0, 0, 0, 0}};
-        if (Cprev) cp = ld4(Cprev + node * h + j0);
+        if (Cprev) cp = ld4(Cprev + node * ld_c + j0);
         F4 Hr, tc;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             tc.v[k] = tanhf(Cr.v[k]);
             Hr.v[k] = Og.v[k] * tc.v[k];
         }
-        const F4 gyh = ld4(gHn + node * h + j0), gyc = ld4(gCn + node * h + j0);
+        const F4 gyh = ld4(gHn + node * ld_gh + j0), gyc = ld4(gCn + node * ld_gc + j0);
         F4 xh = {{0, 0, 0, 0}}, xc = {{0, 0, 0, 0}};
         F4 gHr = gyh, gCr = gyc;
         if (ln) {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, 
             gCr = layer_norm_bwd<LPN>(gyc, gam_c, xc, rc, h);
         }
         F4 go_in = {{0, 0, 0, 0}};
-        if (gO) go_in = ld4(gO + node * h + j0);
+        if (gO) go_in = ld4(gO + node * ld_go + j0);
         F4 ggi, ggf, ggc, ggo, gcp;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -294,14 +295,15 @@ inline bool h_ok(int h) { return h == 8 || h == 16 || h == 32 || h == 64 || h ==
         default: hipLaunchKernelGGL(KERNEL<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
     }
 
-extern "C" int qt_lstm_fwd(const float* G, const float* Cprev, const float* wc, const float* b, const float* ln, int N,
-                           const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw,
+extern "C" int qt_lstm_fwd(const float* G, const float* Cprev, int ld_c, const float* wc, const float* b, const float* ln,
+                           int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw,
                            void* stream) {
     QT_ARG(G && wc && b && O && Hn && Cn && gates && Craw, "null pointer");
     QT_ARG(h_ok(h), "hidden size must be 8, 16, 32, 64 or 128");
     if (N <= 0) return QT_OK;
     const int grid = qt_cdiv((int64_t)N * lanes_per_node(h), 256);
-    QT_DISPATCH_LPN(h, k_lstm_fwd, grid, stream, G, Cprev, wc, b, ln, N, n_dev, h, O, Hn, Cn, gates, Craw);
+    QT_ARG(!Cprev || (ld_c >= h && ld_c % 4 == 0), "bad Cprev row stride");
+    QT_DISPATCH_LPN(h, k_lstm_fwd, grid, stream, G, Cprev, wc, b, ln, N, n_dev, h, ld_c, O, Hn, Cn, gates, Craw);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -312,15 +314,17 @@ extern "C" int qt_lstm_bwd_blocks(int N, int h) {
     return need < 512 ? need : 512;
 }
 
-extern "C" int qt_lstm_bwd(const float* gO, const float* gHn, const float* gCn, const float* gates, const float* Craw,
-                           const float* Cprev, const float* wc, const float* ln, int N, const int32_t* n_dev, int h,
-                           float* gG, float* gCprev, float* part, int accumulate, void* stream) {
+extern "C" int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,
+                           const float* gates, const float* Craw, const float* Cprev, int ld_c, const float* wc,
+                           const float* ln, int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part,
+                           int accumulate, void* stream) {
     QT_ARG(gHn && gCn && gates && Craw && wc && gG && part, "null pointer");
     QT_ARG(h_ok(h), "hidden size must be 8, 16, 32, 64 or 128");
     if (N <= 0) return QT_OK;
     const int grid = qt_lstm_bwd_blocks(N, h);
-    QT_DISPATCH_LPN(h, k_lstm_bwd, grid, stream, gO, gHn, gCn, gates, Craw, Cprev, wc, ln, N, n_dev, h, gG, gCprev, part,
-                    accumulate);
+    QT_ARG(ld_gh >= h && ld_gc >= h && ld_gh % 4 == 0 && ld_gc % 4 == 0 && ld_go % 4 == 0 && ld_c % 4 == 0, "bad row stride");
+    QT_DISPATCH_LPN(h, k_lstm_bwd, grid, stream, gO, gHn, gCn, gates, Craw, Cprev, wc, ln, N, n_dev, h, ld_go, ld_gh, ld_gc,
+                    ld_c, gG, gCprev, part, accumulate);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -16,6 +16,17 @@ def _c(t):
     return t if t is None or t.is_contiguous() else t.contiguous()
 
 
+def _rows(t):
+    """(tensor, row stride) for a 2-D fp32 operand whose rows are dense and 16-byte aligned -- column slices of a
+    wider matrix (views produced by split / cat backward) are passed to the kernels as they are, without a copy."""
+    if t is None:
+        return None, 0
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0:
+        return t, t.stride(0)
+    t = t.contiguous()
+    return t, t.shape[1]
+
+
 class _Unalias(Function):
     """Identity whose backward hands out a private copy of the gradient.
 
@@ -43,10 +54,10 @@ class GradAcc:
     forward use -- the last one to run in the backward pass, because the recurrent state chains the uses --
     reduces the slabs and hands the gradient to autograd.
     """
-    __slots__ = ('uses', 'done', 'part')
+    __slots__ = ('uses', 'done', 'part', 'wt')
 
     def __init__(self):
-        self.uses, self.done, self.part = 0, 0, None
+        self.uses, self.done, self.part, self.wt = 0, 0, None, None
 
     def enter(self):
         self.uses += 1
@@ -123,7 +134,12 @@ class _ChebPoly(Function):
         G = _c(G)
         gZ = None
         if ctx.needs_input_grad[0] and N > 0:
-            Wt = W[:K * C].t().contiguous()
+            if ctx.acc is None:
+                Wt = W[:K * C].t().contiguous()
+            else:                                    # the transposed weight is shared by every use of W in this pass
+                if ctx.acc.wt is None:
+                    ctx.acc.wt = W[:K * C].t().contiguous()
+                Wt = ctx.acc.wt
             gT = Z.new_empty(K, N, C)
             _lib.call('qt_dense', ptr(G), None, 1, Co, ptr(Wt), None, 0, None, K, C, N, ptr(mesh.n_dev), ACT_NONE, None, 0,
                       None, ptr(gT))
@@ -215,11 +231,12 @@ class _LstmCell(Function):
         G = _c(G)
         N, h4 = G.shape
         h = h4 // 4
-        Cprev, wc, b, ln = _c(Cprev), _c(wc), _c(b), _c(ln)
+        wc, b, ln = _c(wc), _c(b), _c(ln)
+        Cprev, ld_c = _rows(Cprev)
         O, Hn, Cn, Craw = (G.new_empty(N, h) for _ in range(4))
         gates = G.new_empty(N, h4)
-        _lib.call('qt_lstm_fwd', ptr(G), ptr(Cprev), ptr(wc), ptr(b), ptr(ln), N, ptr(mesh.n_dev), h, ptr(O), ptr(Hn),
-                  ptr(Cn), ptr(gates), ptr(Craw))
+        _lib.call('qt_lstm_fwd', ptr(G), ptr(Cprev), ld_c, ptr(wc), ptr(b), ptr(ln), N, ptr(mesh.n_dev), h, ptr(O),
+                  ptr(Hn), ptr(Cn), ptr(gates), ptr(Craw))
         ctx.save_for_backward(gates, Craw, Cprev, wc, ln)
         ctx.mesh, ctx.acc = mesh, acc
         ctx.use_idx = acc.enter() if acc is not None else 0
@@ -229,9 +246,9 @@ class _LstmCell(Function):
     def backward(ctx, gO, gHn, gCn):
         gates, Craw, Cprev, wc, ln = ctx.saved_tensors
         N, h = Craw.shape
-        gHn = _c(gHn) if gHn is not None else torch.zeros_like(Craw)
-        gCn = _c(gCn) if gCn is not None else torch.zeros_like(Craw)
-        gO = _c(gO)
+        (gHn, ld_gh), (gCn, ld_gc) = _rows(gHn if gHn is not None else torch.zeros_like(Craw)), \
+            _rows(gCn if gCn is not None else torch.zeros_like(Craw))
+        (gO, ld_go), (Cprev, ld_c) = _rows(gO), _rows(Cprev)
         gG = torch.empty_like(gates)
         gCp = torch.empty_like(Craw) if Cprev is not None else None
         acc, mesh = ctx.acc, ctx.mesh
@@ -242,8 +259,8 @@ class _LstmCell(Function):
             nblk = max(_lib.value('qt_lstm_bwd_blocks', mesh.B * mesh.P, h), 1)
             part = acc.slab(Craw, nblk, 11 * h)
         if N > 0:
-            _lib.call('qt_lstm_bwd', ptr(gO), ptr(gHn), ptr(gCn), ptr(gates), ptr(Craw), ptr(Cprev), ptr(wc), ptr(ln),
-                      N, ptr(mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part), 0 if acc is None else 1)
+            _lib.call('qt_lstm_bwd', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Craw), ptr(Cprev),
+                      ld_c, ptr(wc), ptr(ln), N, ptr(mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part), 0 if acc is None else 1)
         if acc is not None and not acc.leave(ctx.use_idx):
             return gG, gCp, None, None, None, None, None
         psum = Craw.new_empty(11 * h)
