@@ -94,8 +94,12 @@ def spmm_roofline(nfp, batch, mask, reps=10):
         tot_bytes += 4.0 * (nv + 1) + 8.0 * ms.E + 8.0 * nv * C
     n = len(records)
     achieved = tot_bytes / (tot_us * 1e-6) / 1e9
+    traffic = None           # HBM-side bytes per launch from the committed PMC passes (cannot be collected in-process)
+    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_spmm.json')
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc))['traffic_bytes_per_launch']
     return {'bound': 'hbm', 'kernel': 'k_spmm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'launches_per_step': n,
+            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'launches_per_step': n,
             'avg_launch_us': round(tot_us / n, 2), 'avg_bytes_per_launch': round(tot_bytes / n)}
 
 

@@ -216,6 +216,8 @@ def cheb_norm(edge_index, edge_weight, n_nodes):
     add self loops with fill -1.  Returns the full (index, weight) propagate list in PyG order:
     off-diagonal entries, the +1 diagonal, then the -1 diagonal.  PARITY UNPINNED (module header)."""
     row, col = edge_index
+    if edge_weight is None:                       # PyG: unweighted graph -> unit weights
+        edge_weight = torch.ones(row.numel())
     keep = row != col
     row, col, w = row[keep], col[keep], edge_weight[keep]
     deg = torch.zeros(n_nodes, dtype=w.dtype).index_add_(0, row, w)

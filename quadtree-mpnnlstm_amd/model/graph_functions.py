@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from qtmpnn import ops
-from qtmpnn.mesh import CONDITIONS as _CONDITIONS, Mesh, build_mesh
+from qtmpnn.mesh import CONDITIONS as _CONDITIONS, Mesh, build_mesh, build_pixel_mesh
 
 CONDITIONS = list(_CONDITIONS)
 
@@ -167,6 +167,8 @@ def unflatten(data, mapping, image_shape, mask=None):
     else:
         packed = flat.permute(1, 0, 2).reshape(N, -1)
     img = ops.gather_pixels(packed, mesh)                                     # (B, P, L*c)
+    if mesh.pixelwise and mesh.mask is not None:                              # unflatten_pixelwise: NaN under the mask (:460-468)
+        img = img.masked_fill((mesh.labels < 0).view(mesh.B, mesh.P, 1), float('nan'))
     img = img.reshape(mesh.B, mesh.n, mesh.m, flat.shape[0], c).permute(0, 3, 1, 2, 4)
     img = img.reshape(mesh.B, *lead, mesh.n, mesh.m, c)
     return img[0] if mesh.B == 1 else img
@@ -183,16 +185,27 @@ def image_to_graph(img, thresh=0.05, max_grid_size=64, mask=None, high_interest_
     assert len(img.shape) in (4, 5), f'array should be 4-dimensional (n_samples, w, h, c); got {img.shape}'
     if torch.any(torch.isnan(img)):
         raise ValueError(f'Found NaNs in image data {torch.sum(torch.isnan(img))} / {np.prod(img.shape)}')
-    if thresh == -np.inf:
-        raise NotImplementedError('pixelwise graphs (thresh=-inf) are not built yet (SURVEY.md 8(f) row 2)')
     single = img.dim() == 4
     x = img.unsqueeze(0) if single else img
     x = x.to(_device_of(x)).float()
     B, ns, n, m, c = x.shape
+    if thresh == -np.inf:
+        # image_to_graph_pixelwise (:506-539): one node per unmasked pixel, size feature = resolution^2, no self
+        # pairs; `mapping` is the pixelwise Mesh where the reference returns None
+        mesh = build_pixel_mesh(B, n, m, mask, x.device, resolution)
+        data = ops.pool_image(x.reshape(B, ns, n * m, c), mesh, True)
+        data = torch.cat([data, mesh.posfeat[:, 2:3].unsqueeze(0).expand(ns, -1, 1)], dim=-1)
+        return dict(edge_index=mesh.edge_index(False), edge_attrs=mesh.edge_attrs(True, resolution) if use_edge_attrs else None,
+                    data=data, graph_nodes=torch.arange(mesh.N), mapping=mesh, n_pixels_per_node=mesh.npix)
     img0 = x[..., 0].amax(dim=1).detach()
     mesh = build_mesh(src=_criterion(img0, n, m, max_grid_size, transform_func), n=n, m=m, thresh=thresh,
                       condition=condition, mask=mask, high_interest_region=high_interest_region,
                       max_size=max_grid_size, resolution=resolution)
+    if thresh in (np.inf, -np.inf) or np.isinf(thresh):
+        # data independent (create_static_heterogeneous_graph): can be rebuilt for any batch size
+        mesh.recipe = lambda b: build_mesh(src=torch.zeros(b, n, m, device=x.device), thresh=thresh, condition=condition,
+                                           mask=mask, high_interest_region=high_interest_region, max_size=max_grid_size,
+                                           resolution=resolution)
     data = ops.pool_image(x.reshape(B, ns, n * m, c), mesh, True)
     if torch.any(torch.isnan(data)):
         raise ValueError(f'Found NaNs in graph data {torch.sum(torch.isnan(data))} / {np.prod(data.shape)}')
@@ -210,6 +223,12 @@ def create_static_heterogeneous_graph(image_shape, max_grid_size, mask, high_int
                        high_interest_region=high_interest_region, use_edge_attrs=use_edge_attrs, resolution=resolution)
     del g['data']
     return g
+
+
+def create_static_homogeneous_graph(image_shape, max_grid_size, mask, use_edge_attrs=True, resolution=0.25, device=None):
+    """Uniform preset mesh with fully masked cells removed (graph_functions.py:707-737)."""
+    raise NotImplementedError('create_static_homogeneous_graph is not built yet (SURVEY.md 8(f) row 2); the '
+                              'heterogeneous preset mesh and the pixelwise mesh are')
 
 
 def plot_contours(ax, labels):

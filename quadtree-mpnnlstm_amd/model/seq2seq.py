@@ -12,7 +12,7 @@ import torch.nn as nn
 from model.graph_functions import Graph, _criterion
 from model.model import CONVOLUTION_KWARGS, GConvLSTM, _conv_class
 from qtmpnn import ops
-from qtmpnn.mesh import build_mesh
+from qtmpnn.mesh import build_mesh, build_pixel_mesh
 
 
 def _ln_params(*norms):
@@ -166,17 +166,25 @@ class Seq2Seq(nn.Module):
     # -- encoder ------------------------------------------------------------------------
     def process_inputs(self, x, mask=None, high_interest_region=None, graph_structure=None):
         """model/seq2seq.py:254-336.  x: (T_in, W, H, C) or (B, T_in, W, H, C)."""
-        if self.thresh == -np.inf or graph_structure is not None:
-            raise NotImplementedError('pixelwise / preset static meshes are "next" rows (SURVEY.md 8(f) row 2)')
         self._single = x.dim() == 4
         if self._single:
             x = x.unsqueeze(0)
         x = x.float()
         B, T, n, m, c = x.shape
         self.mask = mask
-        mesh = self._mesh_from_image(x[..., 0].amax(dim=1), mask, high_interest_region)
+        if graph_structure is not None:
+            # preset static mesh (:288-294): node size feature = n_pixels_per_node / 4 ("Don't assume 4 !!" in the reference)
+            mesh = graph_structure['mapping'].for_batch(B)
+            size = (mesh.npix / 4.0).unsqueeze(1)
+        elif self.thresh == -np.inf:
+            mesh = build_pixel_mesh(B, n, m, mask, x.device)            # every unmasked pixel a node (:629-630)
+            size = mesh.posfeat[:, 2:3]
+        else:
+            mesh = self._mesh_from_image(x[..., 0].amax(dim=1), mask, high_interest_region)
+            size = mesh.posfeat[:, 2:3]
         means = ops.pool_image(x.reshape(B, T, n * m, c), mesh, True)                 # (T, N, c)
-        feats = torch.cat([means, mesh.posfeat.unsqueeze(0).expand(T, -1, -1)], dim=-1)
+        nodefeat = torch.cat([mesh.posfeat[:, :2], size], dim=1)
+        feats = torch.cat([means, nodefeat.unsqueeze(0).expand(T, -1, -1)], dim=-1)
         self.graph = Graph(None, None)
         self.graph.mapping, self.graph.n_pixels_per_node, self.graph.image_shape = mesh, mesh.npix, (n, m)
         fpad = (-(c + 3)) % 4

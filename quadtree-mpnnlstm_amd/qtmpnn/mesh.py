@@ -47,6 +47,8 @@ class Mesh:
         self._ones = {}
         self._E = None
         self.n_dev = None        # device int32[1] with the valid node count when N is a capacity (static mode)
+        self.pixelwise = False   # every unmasked pixel is a node (thresh = -inf); unflatten then NaN-fills the mask
+        self.recipe = None       # arguments that rebuild a data-independent mesh for another batch size
 
     # -- sizes ------------------------------------------------------------------
     @property
@@ -67,6 +69,16 @@ class Mesh:
 
     def __len__(self):
         return self.N
+
+    def for_batch(self, B):
+        """The same data-independent mesh (pixelwise / preset static) replicated block-diagonally for B clips."""
+        if B == self.B:
+            return self
+        assert self.recipe is not None, 'only pixelwise and preset static meshes can be re-batched'
+        key = ('batch', B)
+        if key not in self._ones:
+            self._ones[key] = self.recipe(B)
+        return self._ones[key]
 
     # -- T_k(L^) 1 for the bias terms of stacked ChebConvs ------------------------
     def cheb_ones(self, ks):
@@ -180,7 +192,15 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     if static:
         ms.n_dev = ms.node_off[B:]                # view of the last entry = N
         nd = ptr(ms.n_dev)
-    alloc = torch.zeros if static else torch.empty      # capacity rows beyond N stay finite
+    _finish_mesh(ms, device, size_norm if size_norm is not None else (max_size / 2) ** 2, resolution, nd)
+    return ms
+
+
+def _finish_mesh(ms, device, size_norm, resolution, nd):
+    """Node features and CSR adjacency of a mesh whose labels / level / cell / node_off are in place."""
+    N, n, m, B = ms.N, ms.n, ms.m, ms.B
+    i32 = dict(dtype=torch.int32, device=device)
+    alloc = torch.zeros if nd is not None else torch.empty      # static mode: capacity rows beyond N stay finite
     ms.posfeat = alloc(N, 3, device=device)
     ms.npix = alloc(N, device=device)
     ms.rowptr = torch.zeros(N + 1, **i32)
@@ -188,9 +208,7 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     if N == 0:
         ms.col = torch.empty(0, **i32)
         ms.w = ms.nrm = torch.empty(0, device=device)
-        return ms
-    if size_norm is None:
-        size_norm = (max_size / 2) ** 2
+        return
     _lib.call('qt_node_features', ptr(ms.cell), N, nd, n, m, float(size_norm), ptr(ms.posfeat), ptr(ms.npix))
     cnt4 = torch.empty(4 * N, **i32)
     off4 = torch.empty(4 * N + 1, **i32)
@@ -204,4 +222,38 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     _lib.call('qt_edges_fill', ptr(ms.labels), ptr(ms.cell), ptr(off4), N, nd, n, m, float(resolution),
               ptr(ms.rowptr), ptr(ms.col), ptr(ms.w))
     _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), N, nd, ptr(ms.dis), ptr(ms.nrm))
+
+_PIXEL_MESHES = {}
+
+
+def build_pixel_mesh(B, n, m, mask=None, device=None, resolution=0.25):
+    """Every unmasked pixel is a node, raster order, 4-neighbour edges (image_to_graph_pixelwise / get_adj_pixelwise,
+    model/graph_functions.py:471-539).  Data independent: built once per (mask, B, shape) and cached.
+    The reference passes edge_weight=None (unit weights) here; the CSR carries the uniform pixel distance instead,
+    which gives the same L^ because the symmetric normalisation is scale invariant."""
+    key = (id(mask), B, n, m, str(device))
+    hit = _PIXEL_MESHES.get(key)
+    if hit is not None and hit[0] is mask:
+        return hit[1]
+    mk = _as_u8(mask, device, (n, m))
+    valid = torch.ones(n, m, dtype=torch.bool, device=device) if mk is None else mk == 0
+    flat = valid.reshape(-1)
+    idx = torch.cumsum(flat.int(), 0, dtype=torch.int32) - 1
+    nv = int(flat.sum().item())
+    i32 = dict(dtype=torch.int32, device=device)
+    offs = torch.arange(B, **i32).view(B, 1) * nv
+    ms = Mesh()
+    ms.B, ms.n, ms.m, ms.N, ms.max_size, ms.resolution, ms.mask, ms.pixelwise = B, n, m, B * nv, 1, resolution, mk, True
+    ms.labels = torch.where(flat, idx, torch.full_like(idx, -1)).view(1, -1).repeat(B, 1)
+    ms.labels = torch.where(ms.labels >= 0, ms.labels + offs, ms.labels).view(B, n, m).contiguous()
+    ms.level = torch.zeros(B, n, m, dtype=torch.uint8, device=device)
+    rc = torch.nonzero(valid).to(torch.int32)                                    # raster order
+    cell = torch.cat([rc, torch.ones(nv, 1, **i32), torch.zeros(nv, 1, **i32)], dim=1)
+    ms.cell = torch.cat([cell + torch.tensor([0, 0, 0, b], **i32) for b in range(B)]).contiguous()
+    ms.node_off = (torch.arange(B + 1, **i32) * nv).contiguous()
+    ms.recipe = lambda b: build_pixel_mesh(b, n, m, mask, device, resolution)
+    _finish_mesh(ms, device, 1.0 / (resolution ** 2), resolution, None)          # size feature = resolution^2 (:521)
+    if len(_PIXEL_MESHES) > 16:
+        _PIXEL_MESHES.clear()
+    _PIXEL_MESHES[key] = (mask, ms)
     return ms

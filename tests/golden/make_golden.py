@@ -27,9 +27,13 @@ import torch.nn as nn
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'quadtree-mpnnlstm_amd'))
 from oracle import qt_oracle as O          # noqa: E402
-from qtmpnn import synthetic               # noqa: E402
+import importlib.util                      # noqa: E402
+# the build's own package dir must NOT be on sys.path here: it holds a regular package called `model`, which would
+# shadow the reference's `model/` (a namespace package: no __init__.py) whatever the path order
+_spec = importlib.util.spec_from_file_location('qt_synthetic', os.path.join(ROOT, 'quadtree-mpnnlstm_amd', 'qtmpnn', 'synthetic.py'))
+synthetic = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synthetic)
 
 
 def install_standins():
@@ -86,6 +90,7 @@ def install_standins():
 install_standins()
 sys.path.insert(0, '/root/reference')
 from model import graph_functions as RG    # noqa: E402  (the reference)
+assert RG.__file__.startswith('/root/reference/'), RG.__file__
 from model import utils as RU              # noqa: E402
 from model import model as RM              # noqa: E402
 from model import seq2seq as RS            # noqa: E402
@@ -311,12 +316,59 @@ def rollouts():
             t_in=2, t_out=3, transform=dist_from_05, seed=62, scale=0.1)
 
 
+# ------------------------------------------------------------------ pixelwise and preset static meshes
+def rollout_fixed_mesh(name, x, y, concat, mask, hidden, n_layers, n_conv, t_in, t_out, static=None, seed=70, scale=0.1):
+    """thresh = -inf: no quadtree, no re-mesh.  static=None -> every unmasked pixel is a node (image_to_graph_pixelwise);
+    static=(max_grid_size, hir) -> preset mesh from create_static_heterogeneous_graph."""
+    model = RS.Seq2Seq(hidden_size=hidden, dropout=0.0, thresh=-np.inf, input_timesteps=t_in, input_features=x.shape[-1] + 3,
+                       output_timesteps=t_out, n_layers=n_layers, n_conv_layers=n_conv, convolution_type='ChebConv')
+    randomize(model, seed, scale=scale, bscale=0.05)
+    model.train()
+    xt, yt, ct = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(concat)
+    gs, extra = None, {}
+    if static is not None:
+        gs = RG.create_static_heterogeneous_graph(x.shape[1:3], static[0], mask, high_interest_region=static[1], use_edge_attrs=False)
+        mp = gs['mapping'].numpy()
+        extra = dict(static_labels=np.where(mp.sum(0) > 0, mp.argmax(0), -1).reshape(x.shape[1:3]).astype(np.int32),
+                     static_npix=gs['n_pixels_per_node'].numpy(), max_grid_size=np.int64(static[0]))
+        ei, at = sort_edges(gs['edge_index'], gs['edge_attrs'])
+        extra.update(static_edges=ei, static_dist=at)
+        if static[1] is not None:
+            extra['hir'] = static[1]
+    outs, maps = model(xt, yt, ct, teacher_forcing_ratio=0, mask=mask, graph_structure=gs)
+    shape = x.shape[1:3]
+    y_hat = torch.stack([RG.unflatten(outs[i], maps[i], shape, mask) for i in range(t_out)])
+    mk = torch.from_numpy(mask)
+    loss = torch.nn.MSELoss()(y_hat[:, ~mk], yt[:, ~mk])
+    loss.backward()
+    out = dict(x=x, y=y, concat=concat, mask=mask, loss=np.float64(loss.item()), y_hat=y_hat.detach().numpy(),
+               hidden=np.int64(hidden), n_layers=np.int64(n_layers), n_conv=np.int64(n_conv), **extra)
+    for i, o in enumerate(outs):
+        out[f'out_{i}'] = o.detach().numpy()
+    out.update(state_arrays(model, 'w/'))
+    for k, p in model.named_parameters():
+        out['g/' + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f'fixed_{name}.npz'), **out)
+    print(name, 'loss', loss.item(), 'N', len(outs[0]))
+
+
+def fixed_meshes():
+    f, m = synthetic.make_ice_like(19, shape=(48, 64), channels=3, n_frames=5)
+    concat = f[2:5, ..., :1].copy() * 0.5
+    rollout_fixed_mesh('pixelwise48x64', f[:2], f[2:5, ..., :1].copy(), concat, m, hidden=8, n_layers=1, n_conv=3, t_in=2, t_out=3)
+    hir = np.zeros_like(m); hir[10:20, 30:44] = True
+    rollout_fixed_mesh('static48x64', f[:2], f[2:5, ..., :1].copy(), concat, m, hidden=8, n_layers=2, n_conv=1, t_in=2, t_out=3,
+                       static=(8, hir), seed=71)
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(4)
-    kats()
-    graphs()
-    transfers()
-    cells()
-    rollouts()
+    if os.environ.get('GOLDEN_ONLY', '') != 'fixed':
+        kats()
+        graphs()
+        transfers()
+        cells()
+        rollouts()
+    fixed_meshes()
     print('golden vectors written to', HERE)

@@ -212,3 +212,62 @@ def test_graph_replay_gradients_bit_identical_to_eager():
             assert (p.grad is None) == (r is None)
             if r is not None:
                 assert torch.equal(p.grad, r)
+
+
+def _run_fixed(g, gs_builder=None, batch=1):
+    from model.mpnnlstm import masked_mse
+    from model.seq2seq import Seq2Seq
+    x, y, concat = (torch.from_numpy(g[k]).to(dev()) for k in ('x', 'y', 'concat'))
+    model = Seq2Seq(hidden_size=int(g['hidden']), dropout=0.0, thresh=-np.inf, input_timesteps=g['x'].shape[0],
+                    input_features=g['x'].shape[-1] + 3, output_timesteps=g['y'].shape[0], n_layers=int(g['n_layers']),
+                    n_conv_layers=int(g['n_conv']), convolution_type='ChebConv')
+    load_state(model, g, 'w/')
+    model.to(dev())
+    if batch > 1:
+        x, y, concat = (t.unsqueeze(0).repeat(batch, *[1] * t.dim()) for t in (x, y, concat))
+    gs = gs_builder() if gs_builder else None
+    outs, meshes = model(x, y, concat, teacher_forcing_ratio=0, mask=g['mask'], graph_structure=gs)
+    return model, outs, meshes, masked_mse(outs, meshes, y, g['mask']), gs
+
+
+@pytest.mark.parametrize('batch', [1, 2])
+def test_pixelwise_rollout_golden(batch):
+    """thresh = -inf (one node per unmasked pixel, no re-mesh) against the reference trace."""
+    from model.graph_functions import unflatten
+    g = golden('fixed_pixelwise48x64.npz')
+    model, outs, meshes, loss, _ = _run_fixed(g, batch=batch)
+    n1 = meshes[0].N // batch
+    for b in range(batch):
+        for i, o in enumerate(outs):
+            close(o[b * n1:(b + 1) * n1], g[f'out_{i}'], msg=f'clip {b} step {i}')
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    if batch == 1:
+        img = unflatten(outs[0], meshes[0], (48, 64), g['mask'])             # NaN under the mask like unflatten_pixelwise
+        ref = g['y_hat'][0]
+        assert np.array_equal(np.isnan(img.detach().cpu().numpy()), np.isnan(ref))
+        close(torch.nan_to_num(img), np.nan_to_num(ref))
+    loss.backward()
+    _check_grads(model, g)
+
+
+def test_static_mesh_rollout_golden():
+    """preset heterogeneous mesh (create_static_heterogeneous_graph) + thresh = -inf."""
+    from model.graph_functions import create_static_heterogeneous_graph
+    g = golden('fixed_static48x64.npz')
+    build = lambda: create_static_heterogeneous_graph((48, 64), int(g['max_grid_size']), g['mask'], high_interest_region=g['hir'],
+                                                      use_edge_attrs=False, device=dev())
+    model, outs, meshes, loss, gs = _run_fixed(g, build)
+    mesh = gs['mapping']
+    assert np.array_equal(mesh.labels[0].cpu().numpy(), g['static_labels'])
+    assert np.array_equal(gs['n_pixels_per_node'].cpu().numpy(), g['static_npix'])
+    assert np.array_equal(gs['edge_index'].cpu().numpy(), g['static_edges'])
+    close(gs['edge_attrs'], g['static_dist'], atol=2e-5)
+    for i, o in enumerate(outs):
+        close(o, g[f'out_{i}'], msg=f'step {i}')
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    loss.backward()
+    _check_grads(model, g)
+    # the same preset mesh drives a 3-clip batch
+    model2, outs2, meshes2, loss2, _ = _run_fixed(g, build, batch=3)
+    assert meshes2[0].B == 3 and meshes2[0].N == 3 * mesh.N
+    assert abs(float(loss2) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
