@@ -109,7 +109,7 @@ int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, int
  */
 int qt_gather(const float* val, int C, const int32_t* labels, const float* inv_npix,
               int64_t npixels_total, float* img, void* stream);
-int qt_pool(const float* img, int S, const float* src_val, const int32_t* src_labels, const float* src_npix, int src_inv,
+int qt_pool(const float* img, int S, int64_t img_clip_stride /* floats between clips, 0 = dense */, const float* src_val, const int32_t* src_labels, const float* src_npix, int src_inv,
             int C, const int32_t* labels, const uint8_t* level, const float* npix, int mean,
             int B, int n, int m, int N, float* out, int out_stride, int out_coff, void* stream);
 

@@ -14,6 +14,7 @@ namespace {
 struct PoolArgs {
     const float* img;
     int S;
+    int64_t img_clip_stride;   // floats between clips of img (S*P*C when dense)
     const float* src_val;
     const int32_t* src_labels;
     const float* src_npix;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
                         for (int k = 0; k < VEC; ++k) x.v[k] *= sscale[q];
                     }
                 } else if (lab[q] >= 0) {
-                    x = vload<VEC>(a.img + (((int64_t)b * a.S + s) * P + (int64_t)r * a.m + c) * a.C + ch * VEC);
+                    x = vload<VEC>(a.img + (int64_t)b * a.img_clip_stride + ((int64_t)s * P + (int64_t)r * a.m + c) * a.C + ch * VEC);
                 }
                 val[q] = x;
             }
@@ -240,7 +241,7 @@ extern "C" int qt_gather(const float* val, int C, const int32_t* labels, const f
     return QT_OK;
 }
 
-extern "C" int qt_pool(const float* img, int S, const float* src_val, const int32_t* src_labels, const float* src_npix,
+extern "C" int qt_pool(const float* img, int S, int64_t img_clip_stride, const float* src_val, const int32_t* src_labels, const float* src_npix,
                        int src_inv, int C, const int32_t* labels, const uint8_t* level, const float* npix, int mean,
                        int B, int n, int m, int N, float* out, int out_stride, int out_coff, void* stream) {
     QT_ARG(labels && level && out && C > 0 && B > 0, "bad arguments");
@@ -250,12 +251,12 @@ extern "C" int qt_pool(const float* img, int S, const float* src_val, const int3
     QT_ARG(out_stride >= out_coff + C, "output row too short");
     if (N <= 0) return QT_OK;
     PoolArgs a;
-    a.img = img; a.S = img ? S : 1; a.src_val = src_val; a.src_labels = src_labels; a.src_npix = src_npix;
+    a.img = img; a.S = img ? S : 1; a.img_clip_stride = img_clip_stride > 0 ? img_clip_stride : (int64_t)a.S * n * m * C; a.src_val = src_val; a.src_labels = src_labels; a.src_npix = src_npix;
     a.src_inv = src_inv; a.C = C; a.labels = labels; a.level = level; a.npix = npix; a.mean = mean;
     a.B = B; a.n = n; a.m = m; a.N = N; a.out = out; a.out_stride = out_stride; a.out_coff = out_coff;
     a.tiles_r = qt_cdiv(n, 64); a.tiles_c = qt_cdiv(m, 64);
     const float* srcp = img ? img : src_val;
-    const bool v4 = (C % 4 == 0) && ((uintptr_t)srcp % 16 == 0);
+    const bool v4 = (C % 4 == 0) && ((uintptr_t)srcp % 16 == 0) && (img_clip_stride % 4 == 0);
     const int total = a.S * (v4 ? C / 4 : C);
     const int blocks = B * a.tiles_r * a.tiles_c;
     int gy = total;

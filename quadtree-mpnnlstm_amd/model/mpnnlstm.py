@@ -45,11 +45,9 @@ def masked_mse(outputs, meshes, y, mask=None, binary=False):
         y_hat = torch.stack([unflatten(o, ms, (ms.n, ms.m)).reshape(ms.B, ms.n, ms.m, 1) for o, ms in zip(outputs, meshes)], 1)
         keep = torch.ones(mesh0.n, mesh0.m, dtype=torch.bool) if mask is None else ~torch.as_tensor(np.asarray(mask, dtype=bool))
         return torch.nn.functional.binary_cross_entropy(y_hat[:, :, keep], y.to(y_hat.device)[:, :, keep])
-    total = None
-    for t, (out, mesh) in enumerate(zip(outputs, meshes)):
-        sse = ops.step_sse(out, y[:, t].to(out.device), mesh)
-        total = sse if total is None else total + sse
-    return total / float(mesh0.B * len(outputs) * n_valid)
+    y = y.to(outputs[0].device)
+    parts = [ops.step_sse_partials(out, y[:, t], mesh) for t, (out, mesh) in enumerate(zip(outputs, meshes))]
+    return torch.cat(parts).sum() / float(mesh0.B * len(outputs) * n_valid)        # one reduction for all steps
 
 
 class NextFramePredictorS2S:

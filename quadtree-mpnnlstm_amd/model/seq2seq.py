@@ -96,7 +96,15 @@ class Decoder(nn.Module):
                     fc1=self.fc_out1.packed(self.head_width, self.hidden_size), acc1=ops.GradAcc(),
                     fc2=self.fc_out2.packed(self.hidden_size, 4), acc2=ops.GradAcc())
 
-    def run(self, X, mesh, concat_layers, H, C, pk):
+    def dropout_masks(self, steps, rows, device):
+        """Inverted-dropout multipliers for `steps` decoder steps at once (one RNG launch instead of one per step);
+        None in eval mode.  rows = an upper bound of the node count (B*W*H); a step uses the first N of its row."""
+        if not (self.training and self.dropout.p > 0):
+            return None
+        keep = 1.0 - self.dropout.p
+        return (torch.rand(steps, rows, device=device) < keep).float() / keep
+
+    def run(self, X, mesh, concat_layers, H, C, pk, drop=None):
         """One decoder step on packed weights; X (N, 4k) padded input, H / C per-layer lists."""
         assert self.concat_layers_dim == 1
         hs, cs, inp = [], [], X
@@ -111,10 +119,8 @@ class Decoder(nn.Module):
             concat_layers = X[:, :1]
         z = ops.head_input(out, pk['ln_o'], concat_layers, self.head_width, mesh, pk['acc_o'])
         z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'])
-        drop = None
-        if self.training and self.dropout.p > 0:
-            keep = 1.0 - self.dropout.p
-            drop = (torch.rand(z.shape[0], device=z.device) < keep).float() / keep
+        if drop is None and self.training and self.dropout.p > 0:
+            drop = self.dropout_masks(1, z.shape[0], z.device)[0]
         y = ops.cheb_poly(z, pk['fc2'], mesh, self.fc_out2.K, 1, ops.ACT_TANH_RES, res=X, drop=drop, acc=pk['acc2'])[:, :1]
         if self.binary:
             y = torch.sigmoid(y)
@@ -212,13 +218,15 @@ class Seq2Seq(nn.Module):
         dec_pack = self.decoder.pack(4)
         outputs, output_mappings = [], []
         steps = list(unroll_steps)
-        for t in steps:
+        drops = self.decoder.dropout_masks(len(steps), mesh.B * mesh.P, g.pyg.x.device)
+        for si, t in enumerate(steps):
             concat_t = None
             if concat_layers is not None:
                 cl = concat_layers[:, t].reshape(mesh.B, 1, mesh.P, 1)
                 concat_t = ops.pool_image(cl, mesh, True)[0]
                 g.concat_layers = concat_t
-            output, hidden, cell = self.decoder.run(g.pyg.x, mesh, concat_t, g.hidden, g.cell, dec_pack)
+            output, hidden, cell = self.decoder.run(g.pyg.x, mesh, concat_t, g.hidden, g.cell, dec_pack,
+                                                    None if drops is None else drops[si, :mesh.N])
             outputs.append(output)
             output_mappings.append(mesh)
             teacher_force = random.random() < teacher_forcing_ratio

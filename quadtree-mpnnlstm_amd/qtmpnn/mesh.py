@@ -203,7 +203,7 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
     alloc = torch.zeros if nd is not None else torch.empty      # static mode: capacity rows beyond N stay finite
     ms.posfeat = alloc(N, 3, device=device)
     ms.npix = alloc(N, device=device)
-    ms.rowptr = torch.zeros(N + 1, **i32)
+    ms.rowptr = torch.zeros(N + 1, **i32) if N == 0 else torch.empty(N + 1, **i32)   # k_edges_fill writes every entry
     ms.dis = torch.empty(N, device=device)
     if N == 0:
         ms.col = torch.empty(0, **i32)

@@ -323,8 +323,9 @@ def head_input(O, ln_o, concat, hp, mesh, acc=None):
 
 
 # ------------------------------------------------------------------------------ mesh <-> image
-def _pool_raw(mesh, C, out, out_stride, out_coff, mean, img=None, S=1, src_val=None, src_mesh=None, src_inv=False):
-    _lib.call('qt_pool', ptr(img), S, ptr(src_val), ptr(src_mesh.labels) if src_mesh is not None else None,
+def _pool_raw(mesh, C, out, out_stride, out_coff, mean, img=None, S=1, src_val=None, src_mesh=None, src_inv=False,
+              img_clip_stride=0):
+    _lib.call('qt_pool', ptr(img), S, img_clip_stride, ptr(src_val), ptr(src_mesh.labels) if src_mesh is not None else None,
               ptr(src_mesh.npix) if src_mesh is not None else None, int(src_inv), C, ptr(mesh.labels), ptr(mesh.level),
               ptr(mesh.npix), int(mean), mesh.B, mesh.n, mesh.m, mesh.N, ptr(out), out_stride, out_coff)
 
@@ -420,29 +421,37 @@ def remesh_transfer(val, old, new):
 
 # ------------------------------------------------------------------------------ loss
 class _StepSSE(Function):
-    """Sum over clips and unmasked pixels of (out[label] - y)^2 for one output step
-    (unflatten + MSELoss numerator, model/mpnnlstm.py:243-246)."""
+    """Per-block partial sums over clips and unmasked pixels of (out[label] - y)^2 for one output step
+    (unflatten + MSELoss numerator, model/mpnnlstm.py:243-246).  The caller sums the partials of all steps once."""
 
     @staticmethod
     def forward(ctx, out, y, mesh):
-        out = _c(out.float())
-        y = _c(y.float()).view(mesh.B, mesh.P)
+        assert out.dtype == torch.float32 and out.stride(1) == 1, 'out must be fp32 with unit column stride'
+        # y: one output step of a (B, T, W, H, 1) tensor -- a strided view is fine (clip stride passed to the kernel)
+        yv = y.reshape(mesh.B, mesh.P) if y.is_contiguous() else y
+        if not (yv.dim() >= 2 and yv[0].is_contiguous() and yv.dtype == torch.float32):
+            yv = y.float().contiguous().view(mesh.B, mesh.P)
         nt = -(mesh.P // -1024)
         part = out.new_empty(mesh.B * nt)
-        _lib.call('qt_sse', ptr(out), out.stride(0), ptr(mesh.labels), ptr(y), mesh.P, mesh.B, mesh.n, mesh.m, ptr(part))
+        _lib.call('qt_sse', ptr(out), out.stride(0), ptr(mesh.labels), ptr(yv), yv.stride(0), mesh.B, mesh.n, mesh.m, ptr(part))
         sy = out.new_empty(1, mesh.N, 1)
         if mesh.N > 0:
-            _pool_raw(mesh, 1, sy, 1, 0, False, img=y.view(mesh.B, 1, mesh.P, 1), S=1)
+            _pool_raw(mesh, 1, sy, 1, 0, False, img=yv, S=1, img_clip_stride=yv.stride(0))
         ctx.save_for_backward(out, sy)
         ctx.mesh = mesh
-        return part.sum()
+        return part
 
     @staticmethod
     def backward(ctx, g):
         out, sy = ctx.saved_tensors
         mesh = ctx.mesh
-        return (2.0 * g) * (mesh.npix.view(-1, 1) * out[:, :1] - sy[0]), None, None
+        # every partial has the same upstream gradient (they are only ever summed)
+        return (2.0 * g[:1]) * (mesh.npix.view(-1, 1) * out[:, :1] - sy[0]), None, None
+
+
+def step_sse_partials(out, y, mesh):
+    return _StepSSE.apply(out, y, mesh)
 
 
 def step_sse(out, y, mesh):
-    return _StepSSE.apply(out, y, mesh)
+    return _StepSSE.apply(out, y, mesh).sum()
