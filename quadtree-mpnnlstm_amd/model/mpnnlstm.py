@@ -128,6 +128,26 @@ class NextFramePredictorS2S:
         self.optimizer.step()
         return loss.detach()
 
+    def truncated_backward(self, x, y, concat_layers, mask, high_interest_region=None, graph_structure=None,
+                           truncated_backprop=45):
+        """The reference's truncated-BPTT loop (mpnnlstm.py:281-315), quirks included: every chunk re-runs the encoder
+        and unrolls ITS steps from the encoder state, `zero_grad` runs per chunk (so only the last chunk's gradient
+        survives to optimizer.step()), and the chunk bound is min(start + tb, T_out + 1).  Returns the chunk losses."""
+        losses, step = [], 0
+        if y.dim() == 4:
+            y = y.unsqueeze(0)
+        while step < self.output_timesteps:
+            step = min(step + truncated_backprop, self.output_timesteps + 1)
+            steps = range(step - truncated_backprop, step)
+            self.optimizer.zero_grad(set_to_none=True)
+            self.model.process_inputs(x, mask=mask, high_interest_region=high_interest_region, graph_structure=graph_structure)
+            y_hat, meshes = self.model.unroll_output(steps, y, concat_layers=concat_layers, teacher_forcing_ratio=0, mask=mask,
+                                                     high_interest_region=high_interest_region, remesh_every=1)
+            loss = masked_mse(y_hat, meshes, y[:, steps.start:steps.stop], mask, self.binary)
+            loss.backward()
+            losses.append(loss.detach())
+        return losses
+
     def make_graphed_step(self, x, y, concat_layers=None, mask=None, high_interest_region=None, max_norm=10.0,
                           warmup=2):
         """Capture one whole training step in hipGraphs and return `step(x, y, concat) -> loss`.
@@ -211,8 +231,7 @@ class NextFramePredictorS2S:
             self.initiate_training(lr, lr_decay)
         if mask is not None:
             assert mask.shape == image_shape, f'Mask and image shapes do not match. Got {mask.shape} and {image_shape}'
-        if truncated_backprop not in (0, None) and truncated_backprop < self.output_timesteps:
-            raise NotImplementedError('truncated BPTT is a "next" row (SURVEY.md 8(f) row 3); pass truncated_backprop=0')
+        truncate = truncated_backprop not in (0, None)
         st = time.time()
         batch_step = 0
         for epoch in range(n_epochs):
@@ -221,7 +240,12 @@ class NextFramePredictorS2S:
             for x, y, launch_date in loader_train:
                 x, y = self._clip(x), self._clip(y)
                 concat = self.get_climatology_array(climatology, launch_date) if climatology is not None else None
-                loss = self.train_step(x, y, concat, mask, high_interest_region, graph_structure)
+                if truncate:
+                    loss = self.truncated_backward(x, y, concat, mask, high_interest_region, graph_structure,
+                                                   truncated_backprop)[-1]
+                    self.optimizer.step()                 # no gradient clipping in this branch (:311 is commented out)
+                else:
+                    loss = self.train_step(x, y, concat, mask, high_interest_region, graph_structure)
                 self.writer.add_scalar('Loss/train', loss.item(), batch_step)
                 running += loss.item()
                 steps += 1

@@ -361,14 +361,79 @@ def fixed_meshes():
                        static=(8, hir), seed=71)
 
 
+# ------------------------------------------------------------------ trainer parity features
+def rollout_variants():
+    """teacher forcing (ratio 1 -> deterministic), binary head (sigmoid + BCE), truncated BPTT chunk loop."""
+    x, y = synthetic.make_batch(9, 20, 1, 3, 4, n_digits=1, pixel_noise=0.0)
+    x, y = x[0], np.clip(y[0], 0.0, 1.0)
+    mask = np.zeros((64, 64), dtype=bool)
+    concat = (0.05 * np.random.default_rng(5).random((4, 64, 64, 1))).astype(np.float32)
+    xt, yt, ct, mk = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(concat), torch.from_numpy(mask)
+
+    def build(binary=False, seed=80):
+        model = RS.Seq2Seq(hidden_size=8, dropout=0.0, thresh=0.1, input_timesteps=3, input_features=4, output_timesteps=4,
+                           n_layers=1, n_conv_layers=2, convolution_type='ChebConv', binary=binary)
+        randomize(model, seed, scale=0.08, bscale=0.02)
+        model.train()
+        return model
+
+    def dump(name, model, outs, loss, extra=None):
+        out = dict(x=x, y=y, concat=concat, mask=mask, loss=np.float64(loss.item()))
+        for i, o in enumerate(outs):
+            out[f'out_{i}'] = o.detach().numpy()
+        out.update(state_arrays(model, 'w/'))
+        for k, p in model.named_parameters():
+            out['g/' + k] = p.grad.numpy() if p.grad is not None else np.zeros(p.shape, np.float32)
+        out.update(extra or {})
+        np.savez_compressed(os.path.join(HERE, f'variant_{name}.npz'), **out)
+        print(name, 'loss', loss.item(), 'N', [len(o) for o in outs])
+
+    # teacher forcing on every step: the next mesh / input come from the ground truth (seq2seq.py:448-458)
+    model = build()
+    outs, maps = model(xt, yt, ct, teacher_forcing_ratio=1.0, mask=mask)
+    y_hat = torch.stack([RG.unflatten(outs[i], maps[i], (64, 64), mask) for i in range(4)])
+    loss = torch.nn.MSELoss()(y_hat[:, ~mk], yt[:, ~mk])
+    loss.backward()
+    dump('teacher', model, outs, loss)
+
+    # binary head: sigmoid output (seq2seq.py:177-178) + BCELoss (mpnnlstm.py:171)
+    model = build(binary=True, seed=81)
+    outs, maps = model(xt, yt, ct, teacher_forcing_ratio=0, mask=mask)
+    y_hat = torch.stack([RG.unflatten(outs[i], maps[i], (64, 64), mask) for i in range(4)])
+    loss = torch.nn.BCELoss()(y_hat[:, ~mk], yt[:, ~mk])
+    loss.backward()
+    dump('binary', model, outs, loss)
+
+    # truncated BPTT with truncated_backprop = 2 (mpnnlstm.py:281-315): every chunk re-encodes, zeroes the gradients
+    # and unrolls its own steps from the encoder state; only the last chunk's gradient reaches optimizer.step()
+    model = build(seed=82)
+    tb, t_out, step, losses, last_outs = 2, 4, 0, [], None
+    while step < t_out:
+        step = min(step + tb, t_out + 1)
+        steps = range(step - tb, step)
+        model.zero_grad()
+        model.process_inputs(xt, mask=mask)
+        outs, maps = model.unroll_output(steps, yt, concat_layers=ct, teacher_forcing_ratio=0, mask=mask, remesh_every=1)
+        y_hat = torch.stack([RG.unflatten(outs[i], maps[i], (64, 64), mask) for i in range(len(outs))])
+        loss = torch.nn.MSELoss()(y_hat[:, ~mk], yt[steps][:, ~mk])
+        loss.backward(retain_graph=True)
+        losses.append(loss.item())
+        last_outs = outs
+    dump('tbptt', model, last_outs, loss, dict(chunk_losses=np.array(losses)))
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(4)
-    if os.environ.get('GOLDEN_ONLY', '') != 'fixed':
+    only = os.environ.get('GOLDEN_ONLY', '')
+    if not only:
         kats()
         graphs()
         transfers()
         cells()
         rollouts()
-    fixed_meshes()
+    if only in ('', 'fixed'):
+        fixed_meshes()
+    if only in ('', 'variants'):
+        rollout_variants()
     print('golden vectors written to', HERE)

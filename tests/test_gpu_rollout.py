@@ -271,3 +271,94 @@ def test_static_mesh_rollout_golden():
     model2, outs2, meshes2, loss2, _ = _run_fixed(g, build, batch=3)
     assert meshes2[0].B == 3 and meshes2[0].N == 3 * mesh.N
     assert abs(float(loss2) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+
+
+@pytest.mark.parametrize('cfg', ['cfg3_mnist128', 'cfg4_ice128', 'cfg5_ice256'])
+def test_baseline_config_shapes_train(cfg):
+    """BASELINE.json configs[2..4] at their full image sizes (reduced batch): one eager training step must run, give a
+    finite loss and gradients for every used parameter, and the meshes must satisfy the size-independent invariants."""
+    from model.mpnnlstm import NextFramePredictorS2S
+    from qtmpnn import synthetic
+    torch.manual_seed(0)
+    if cfg == 'cfg3_mnist128':
+        B, t_in, t_out, shape, kw = 4, 10, 20, (128, 128), dict(hidden_size=16, dropout=0.1, n_layers=2)
+        x, y = synthetic.make_batch(3, 0, B, t_in, t_out, n_digits=2, pixel_noise=0.05, canvas=shape)
+        mask, thresh, tf, feat = np.zeros(shape, dtype=bool), 0.1, None, 1
+    else:
+        n = 128 if cfg == 'cfg4_ice128' else 256
+        B, t_in, t_out, shape = (2, 12, 6, (n, n)) if n == 128 else (1, 12, 12, (n, n))
+        kw = dict(hidden_size=32, dropout=0.1, n_layers=1, n_conv_layers=3)
+        clips = [synthetic.make_ice_like(40 + i, shape=shape, channels=5, n_frames=t_in + t_out) for i in range(B)]
+        x = np.stack([c[0][:t_in] for c in clips])
+        y = np.stack([c[0][t_in:, ..., :1] for c in clips])
+        mask, thresh, feat = clips[0][1], 0.15, 5
+        tf = lambda a: abs(abs(a - 0.5) - 0.5)
+    nfp = NextFramePredictorS2S(thresh=thresh, input_features=feat, input_timesteps=t_in, output_timesteps=t_out, device=dev(),
+                                transform_func=tf, model_kwargs=kw)
+    nfp.initiate_training(lr=1e-3, lr_decay=0.95)
+    xt, yt = torch.from_numpy(x).to(dev()), torch.from_numpy(y).to(dev())
+    concat = torch.zeros(B, t_out, *shape, 1, device=dev())
+    outs, meshes = nfp.model(xt, yt, concat, teacher_forcing_ratio=0, mask=mask)
+    P_valid = int((~mask).sum())
+    for ms in meshes:
+        assert float(ms.npix.sum()) == B * P_valid
+        lab = ms.labels
+        assert int(lab.max()) == ms.N - 1 and bool(((lab < 0) == torch.from_numpy(mask).to(dev())).all())
+    loss = float(nfp.train_step(xt, yt, concat, mask))
+    assert np.isfinite(loss)
+    missing = [k for k, p in nfp.model.named_parameters() if p.grad is None and 'rnns.1.conv_h' not in k]
+    assert not missing, missing[:5]
+    assert all(torch.isfinite(p.grad).all() for p in nfp.model.parameters() if p.grad is not None)
+
+
+def _variant_model(g, binary=False):
+    from model.seq2seq import Seq2Seq
+    model = Seq2Seq(hidden_size=8, dropout=0.0, thresh=0.1, input_timesteps=3, input_features=4, output_timesteps=4,
+                    n_layers=1, n_conv_layers=2, convolution_type='ChebConv', binary=binary)
+    load_state(model, g, 'w/')
+    return model.to(dev())
+
+
+def test_teacher_forcing_golden():
+    """teacher_forcing_ratio = 1 -- next mesh and input come from the ground-truth frame."""
+    from model.mpnnlstm import masked_mse
+    g = golden('variant_teacher.npz')
+    model = _variant_model(g)
+    x, y, concat = (torch.from_numpy(g[k]).to(dev()) for k in ('x', 'y', 'concat'))
+    outs, meshes = model(x, y, concat, teacher_forcing_ratio=1.0, mask=g['mask'])
+    for i, o in enumerate(outs):
+        assert o.shape[0] == g[f'out_{i}'].shape[0], f'mesh size of step {i}'
+        close(o, g[f'out_{i}'], msg=f'step {i}')
+    loss = masked_mse(outs, meshes, y, g['mask'])
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    loss.backward()
+    _check_grads(model, g)
+
+
+def test_binary_head_golden():
+    """binary=True -- sigmoid on the decoder output, BCE loss."""
+    from model.mpnnlstm import masked_mse
+    g = golden('variant_binary.npz')
+    model = _variant_model(g, binary=True)
+    x, y, concat = (torch.from_numpy(g[k]).to(dev()) for k in ('x', 'y', 'concat'))
+    outs, meshes = model(x, y, concat, teacher_forcing_ratio=0, mask=g['mask'])
+    for i, o in enumerate(outs):
+        close(o, g[f'out_{i}'], msg=f'step {i}')
+    loss = masked_mse(outs, meshes, y, g['mask'], binary=True)
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    loss.backward()
+    _check_grads(model, g)
+
+
+def test_truncated_bptt_golden():
+    """the reference's truncated-BPTT chunk loop with truncated_backprop = 2."""
+    from model.mpnnlstm import NextFramePredictorS2S
+    g = golden('variant_tbptt.npz')
+    nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=3, output_timesteps=4, device=dev(),
+                                model_kwargs=dict(hidden_size=8, dropout=0.0, n_layers=1, n_conv_layers=2))
+    load_state(nfp.model, g, 'w/')
+    nfp.initiate_training(lr=1e-3, lr_decay=0.95)
+    x, y, concat = (torch.from_numpy(g[k]).to(dev()) for k in ('x', 'y', 'concat'))
+    losses = nfp.truncated_backward(x, y, concat, g['mask'], truncated_backprop=2)
+    np.testing.assert_allclose([float(l) for l in losses], g['chunk_losses'], rtol=1e-4)
+    _check_grads(nfp.model, g)          # the surviving gradient is the LAST chunk's
