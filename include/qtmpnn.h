@@ -173,6 +173,25 @@ int qt_head_fwd(const float* O, const float* ln_o /* (2,h) */, const float* conc
 int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, const int32_t* n_dev, int h, int hp,
                 float* gO, float* gconcat, float* part, int accumulate, void* stream);
 
+/* ---------------------------------------------------------------- edge-softmax attention (TransformerConv)
+ * torch_geometric TransformerConv(heads=1, concat=False, beta=False, edge_dim=2, root_weight=True) as configured by
+ * model/model.py:51 (third-party arithmetic, restated in oracle/): SURVEY.md 8(f) row 1.
+ *   out_i = sum_{j->i} d_ij alpha_ij (v_j + e_ij) + skip_i,  alpha = softmax_j(q_i.(k_j + e_ij) / sqrt(c_real)),
+ *   e_ij = We [angle(j->i), dist(j,i)]  (graph_functions.py:358-370), d_ij = inverted-dropout multiplier (keep, seed).
+ * proj (N, ld): q | k | v | skip column blocks of C (multiple of 4, zero padded above c_real) columns each;
+ * xy (N, 2) node centroids in edge-attribute units; selfloop (N) > 0 where get_adj emits the pair (i, i), or NULL;
+ * incoming edges of i = CSR row i (symmetric adjacency).  stats (N, 2) = running max / sum of the softmax.
+ * qt_attn_bwd: g (N, C) -> gproj (N, ld) [dq | dk | dv | g], Dn (N) scratch, part (qt_attn_blocks, 2*C) partials of dWe^T.
+ */
+int qt_attn_blocks(int N, int C);
+int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
+                const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
+                float keep, uint32_t seed, float* out, float* stats, void* stream);
+int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
+                const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
+                float keep, uint32_t seed, const float* g, const float* stats, float* gproj, float* Dn,
+                float* part, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -286,6 +286,45 @@ def gcn_conv(x, edge_index, edge_weight, weight, bias):
     return out + bias if bias is not None else out
 
 
+def transformer_conv(x, edge_index, edge_attr, p, dropout=0.0, training=False):
+    """torch_geometric 2.2.0 TransformerConv(heads=1, concat=False, beta=False, edge_dim=2, root_weight=True), restated
+    from the library's published definition: q = Wq x_i + bq, k = Wk x_j + bk, v = Wv x_j + bv,
+    e = We edge_attr (no bias), alpha = softmax_j(q_i . (k_j + e) / sqrt(C)) over the incoming edges of i (PyG softmax:
+    exp(a - max) / (sum + 1e-16)), dropout on alpha, out_i = sum_j alpha (v_j + e) + Wskip x_i + bskip.
+    PARITY UNPINNED (module header).  p: dict of the nine parameter tensors."""
+    src, dst = edge_index
+    n, c = x.shape[0], p['lin_query.weight'].shape[0]
+    q = F.linear(x, p['lin_query.weight'], p['lin_query.bias'])
+    k = F.linear(x, p['lin_key.weight'], p['lin_key.bias'])
+    v = F.linear(x, p['lin_value.weight'], p['lin_value.bias'])
+    e = F.linear(edge_attr, p['lin_edge.weight'])
+    a = (q[dst] * (k[src] + e)).sum(-1) / np.sqrt(c)
+    amax = torch.full((n,), -float('inf'), dtype=a.dtype).scatter_reduce(0, dst, a.detach(), 'amax', include_self=True)
+    ex = torch.exp(a - amax[dst])
+    alpha = ex / (torch.zeros(n, dtype=a.dtype).index_add(0, dst, ex)[dst] + 1e-16)
+    alpha = F.dropout(alpha, dropout, training)
+    out = torch.zeros(n, c, dtype=x.dtype).index_add(0, dst, alpha.unsqueeze(-1) * (v[src] + e))
+    return out + F.linear(x, p['lin_skip.weight'], p['lin_skip.bias'])
+
+
+class TransformerConv(nn.Module):
+    """State-dict layout of PyG TransformerConv: lin_key / lin_query / lin_value (.weight, .bias), lin_edge.weight,
+    lin_skip (.weight, .bias), created in that order."""
+
+    def __init__(self, in_channels, out_channels, heads=1, edge_dim=2, dropout=0.0, concat=False):
+        super().__init__()
+        assert heads == 1 and not concat and edge_dim == 2
+        self.dropout = dropout
+        self.lin_key = nn.Linear(in_channels, out_channels)
+        self.lin_query = nn.Linear(in_channels, out_channels)
+        self.lin_value = nn.Linear(in_channels, out_channels)
+        self.lin_edge = nn.Linear(edge_dim, out_channels, bias=False)
+        self.lin_skip = nn.Linear(in_channels, out_channels)
+
+    def forward(self, x, edge_index, edge_attr=None):
+        return transformer_conv(x, edge_index, edge_attr, dict(self.named_parameters()), self.dropout, self.training)
+
+
 class ChebConv(nn.Module):
     """State-dict layout of PyG ChebConv: lins.{k}.weight (out, in), bias (out,)."""
 
@@ -316,7 +355,8 @@ class GCNConv(nn.Module):
 
 
 CONVS = {'ChebConv': (ChebConv, dict(K=3, normalization='sym', bias=True)),
-         'GCNConv': (GCNConv, dict(add_self_loops=False))}
+         'GCNConv': (GCNConv, dict(add_self_loops=False)),
+         'TransformerConv': (TransformerConv, dict(heads=1, edge_dim=2, dropout=0.1, concat=False))}
 
 
 # --------------------------------------------------------------------------- R9
@@ -435,11 +475,12 @@ class Seq2Seq(nn.Module):
         self.decoder = Decoder(4, hidden_size, dropout, n_layers, 1, convolution_type)
         self.thresh, self.transform_func, self.condition = thresh, transform_func, condition
         self.input_timesteps, self.output_timesteps = input_timesteps, output_timesteps
+        self.use_edge_attrs = convolution_type in ('TransformerConv',)          # seq2seq.py:244-247
 
     def _graph(self, img, mask, hir):
         return image_to_graph(img, thresh=self.thresh, mask=mask, high_interest_region=hir,
                               transform_func=self.transform_func, condition=self.condition,
-                              use_edge_attrs=False)
+                              use_edge_attrs=self.use_edge_attrs)
 
     def forward(self, x, concat_layers, mask=None, high_interest_region=None, remesh_every=1,
                 skip_last_remesh=True):

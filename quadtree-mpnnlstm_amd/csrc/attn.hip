@@ -1,0 +1,300 @@
+// Edge-softmax attention of TransformerConv(heads=1, concat=False, beta=False, edge_dim=2, root_weight=True), the
+// convolution the reference's sea-ice scripts hard-code (model/model.py:51, ice_exp.py:48; PyG 2.2.0, restated in
+// oracle/qt_oracle.py:transformer_conv).  SURVEY.md 8(f) row 1.
+//
+//   out_i = sum_{j -> i} d_ij alpha_ij (v_j + e_ij) + skip_i,   alpha_i. = softmax_j( q_i . (k_j + e_ij) / sqrt(C) )
+//   e_ij  = We [angle(j -> i), dist(j, i)]          (lin_edge has no bias)
+//
+// q | k | v | skip are the four column blocks of ONE projection GEMM (proj, row stride ld).  Incoming edges of i are
+// row i of the mesh CSR (the quadtree adjacency is symmetric) plus the self pair (i, i) that get_adj emits for
+// multi-pixel cells (attrs (0, 0)); edge attributes are recomputed from the node centroids instead of being stored.
+// One node per group of C/4 lanes (float4 each), online softmax, dot products reduced with xor shuffles.
+// Backward in gather form, no atomics: pass A per target (D_i, dq_i), pass B per source (dk_j, dv_j, dWe partials).
+#include "qt_common.h"
+#include <math.h>
+
+namespace {
+
+struct F4 {
+    float v[4];
+};
+__device__ __forceinline__ F4 ld4(const float* p) {
+    const float4 f = *reinterpret_cast<const float4*>(p);
+    return F4{{f.x, f.y, f.z, f.w}};
+}
+__device__ __forceinline__ void st4(float* p, const F4& a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+template <int LPN>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int d = 1; d < LPN; d <<= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ float dot4(const F4& a, const F4& b) {
+    return (a.v[0] * b.v[0] + a.v[1] * b.v[1]) + (a.v[2] * b.v[2] + a.v[3] * b.v[3]);
+}
+
+struct AttnArgs {
+    const int32_t* rowptr;
+    const int32_t* col;
+    const float* xy;        // (N, 2): centroid x, y in edge-attribute units
+    const float* selfloop;  // (N) > 0 where the node carries a self pair, or NULL
+    const float* proj;      // (N, ld): q | k | v | skip, C columns each
+    const float* We;        // (C, 2)
+    int ld, C, Ncap;
+    const int32_t* n_dev;
+    float scale;            // 1 / sqrt(real channel count)
+    float keep;             // 1 - dropout p (1 = no dropout)
+    uint32_t seed;
+};
+
+// [angle, dist] of the message j -> i (graph_functions.py:358-370): atan2(xx_j - xx_i, yy_j - yy_i) mod 2pi / 2pi
+__device__ __forceinline__ void edge_attr(const float* xy, int j, int i, float* ang, float* dst) {
+    const float dx = xy[2 * j] - xy[2 * i], dy = xy[2 * j + 1] - xy[2 * i + 1];
+    float a = atan2f(dx, dy);
+    if (a < 0.0f) a += 6.283185307179586f;
+    *ang = a / 6.283185307179586f;
+    *dst = sqrtf(dy * dy + dx * dx);
+}
+
+// inverted-dropout multiplier of the attention coefficient of edge (j -> i): the same in forward and both backward passes
+__device__ __forceinline__ float drop_mult(uint32_t seed, int i, int j, float keep) {
+    if (keep >= 1.0f) return 1.0f;
+    uint32_t h = seed ^ ((uint32_t)i * 0x9E3779B1u) ^ ((uint32_t)j * 0x85EBCA77u);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return ((h >> 8) * (1.0f / 16777216.0f)) < keep ? 1.0f / keep : 0.0f;
+}
+
+template <int LPN>
+__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a, float* __restrict__ out, float* __restrict__ stats) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(gid / LPN);
+    if (i >= qt_rows(a.n_dev, a.Ncap)) return;
+    const int j0 = (int)(gid % LPN) * 4;
+    const float* pi = a.proj + (int64_t)i * a.ld;
+    const F4 q = ld4(pi + j0);
+    const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
+    const F4 w1 = {{a.We[2 * j0 + 1], a.We[2 * j0 + 3], a.We[2 * j0 + 5], a.We[2 * j0 + 7]}};
+    float m = -INFINITY, l = 0.0f;
+    F4 acc = {{0, 0, 0, 0}};
+    const int e0 = a.rowptr[i], e1 = a.rowptr[i + 1];
+    const int extra = (a.selfloop && a.selfloop[i] > 0.0f) ? 1 : 0;
+    for (int e = e0; e < e1 + extra; ++e) {
+        const int j = e < e1 ? a.col[e] : i;
+        float ang = 0.0f, dst = 0.0f;
+        if (j != i) edge_attr(a.xy, j, i, &ang, &dst);
+        const float* pj = a.proj + (int64_t)j * a.ld;
+        F4 kj = ld4(pj + a.C + j0), vj = ld4(pj + 2 * a.C + j0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float ee = w0.v[c] * ang + w1.v[c] * dst;
+            kj.v[c] += ee;
+            vj.v[c] += ee;
+        }
+        const float s = group_sum<LPN>(dot4(q, kj)) * a.scale;
+        const float mn = fmaxf(m, s);
+        const float r = __expf(m - mn), p = __expf(s - mn);       // m = -inf on the first edge: r = 0
+        const float pd = p * drop_mult(a.seed, i, j, a.keep);
+        l = l * r + p;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc.v[c] = acc.v[c] * r + pd * vj.v[c];
+        m = mn;
+    }
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+    const F4 sk = ld4(pi + 3 * a.C + j0);
+    F4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o.v[c] = acc.v[c] * inv + sk.v[c];
+    st4(out + (int64_t)i * a.C + j0, o);
+    if (j0 == 0) {
+        stats[2 * i] = m;
+        stats[2 * i + 1] = l;
+    }
+}
+
+// pass A: per target i -- D_i = sum_e alpha_e t_e (t_e = d_e g_i.(v_j + e)), dq_i = scale * sum_e alpha_e (t_e - D_i)(k_j + e)
+template <int LPN>
+__global__ __launch_bounds__(256) void k_attn_bwd_target(AttnArgs a, const float* __restrict__ g, const float* __restrict__ stats,
+                                                         float* __restrict__ gproj, float* __restrict__ Dn) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(gid / LPN);
+    if (i >= qt_rows(a.n_dev, a.Ncap)) return;
+    const int j0 = (int)(gid % LPN) * 4;
+    const float* pi = a.proj + (int64_t)i * a.ld;
+    const F4 q = ld4(pi + j0), gi = ld4(g + (int64_t)i * a.C + j0);
+    const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
+    const F4 w1 = {{a.We[2 * j0 + 1], a.We[2 * j0 + 3], a.We[2 * j0 + 5], a.We[2 * j0 + 7]}};
+    const float m = stats[2 * i], l = stats[2 * i + 1];
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+    const int e0 = a.rowptr[i], e1 = a.rowptr[i + 1];
+    const int extra = (a.selfloop && a.selfloop[i] > 0.0f) ? 1 : 0;
+    float D = 0.0f;
+    F4 dq = {{0, 0, 0, 0}}, dqk = {{0, 0, 0, 0}};      // dq = sum alpha t (k+e) ; dqk = sum alpha (k+e)
+    for (int e = e0; e < e1 + extra; ++e) {
+        const int j = e < e1 ? a.col[e] : i;
+        float ang = 0.0f, dst = 0.0f;
+        if (j != i) edge_attr(a.xy, j, i, &ang, &dst);
+        const float* pj = a.proj + (int64_t)j * a.ld;
+        F4 kj = ld4(pj + a.C + j0), vj = ld4(pj + 2 * a.C + j0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float ee = w0.v[c] * ang + w1.v[c] * dst;
+            kj.v[c] += ee;
+            vj.v[c] += ee;
+        }
+        const float s = group_sum<LPN>(dot4(q, kj)) * a.scale;
+        const float alpha = __expf(s - m) * inv;
+        const float t = drop_mult(a.seed, i, j, a.keep) * group_sum<LPN>(dot4(gi, vj));
+        D += alpha * t;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            dq.v[c] += alpha * t * kj.v[c];
+            dqk.v[c] += alpha * kj.v[c];
+        }
+    }
+    F4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o.v[c] = a.scale * (dq.v[c] - D * dqk.v[c]);
+    float* gp = gproj + (int64_t)i * a.ld;
+    st4(gp + j0, o);
+    st4(gp + 3 * a.C + j0, gi);          // skip branch: identity
+    if (j0 == 0) Dn[i] = D;
+}
+
+// pass B: per source j over its outgoing messages j -> i (i runs over row j: the adjacency is symmetric)
+template <int LPN>
+__global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float* __restrict__ g, const float* __restrict__ stats,
+                                                         const float* __restrict__ Dn, float* __restrict__ gproj,
+                                                         float* __restrict__ part) {
+    __shared__ float sm[4 * LPN * 2 * 4];
+    const int lj = threadIdx.x % LPN, j0 = lj * 4;
+    const int N = qt_rows(a.n_dev, a.Ncap);
+    const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
+    const F4 w1 = {{a.We[2 * j0 + 1], a.We[2 * j0 + 3], a.We[2 * j0 + 5], a.We[2 * j0 + 7]}};
+    float acc[2][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[0][c] = acc[1][c] = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * (256 / LPN);
+    for (int64_t j = (int64_t)blockIdx.x * (256 / LPN) + threadIdx.x / LPN; j < N; j += stride) {
+        const float* pj = a.proj + j * a.ld;
+        const F4 kj0 = ld4(pj + a.C + j0), vj0 = ld4(pj + 2 * a.C + j0);
+        F4 dk = {{0, 0, 0, 0}}, dv = {{0, 0, 0, 0}};
+        const int e0 = a.rowptr[j], e1 = a.rowptr[j + 1];
+        const int extra = (a.selfloop && a.selfloop[j] > 0.0f) ? 1 : 0;
+        for (int e = e0; e < e1 + extra; ++e) {
+            const int i = e < e1 ? a.col[e] : (int)j;
+            float ang = 0.0f, dst = 0.0f;
+            if (i != j) edge_attr(a.xy, (int)j, i, &ang, &dst);
+            const float* pi = a.proj + (int64_t)i * a.ld;
+            const F4 qi = ld4(pi + j0), gi = ld4(g + (int64_t)i * a.C + j0);
+            F4 kj = kj0, vj = vj0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float ee = w0.v[c] * ang + w1.v[c] * dst;
+                kj.v[c] += ee;
+                vj.v[c] += ee;
+            }
+            const float m = stats[2 * i], l = stats[2 * i + 1];
+            const float s = group_sum<LPN>(dot4(qi, kj)) * a.scale;
+            const float alpha = l > 0.0f ? __expf(s - m) / l : 0.0f;
+            const float d = drop_mult(a.seed, i, (int)j, a.keep);
+            const float t = d * group_sum<LPN>(dot4(gi, vj));
+            const float ds = alpha * (t - Dn[i]) * a.scale;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float dkc = ds * qi.v[c], dvc = alpha * d * gi.v[c];
+                dk.v[c] += dkc;
+                dv.v[c] += dvc;
+                acc[0][c] += (dkc + dvc) * ang;      // d We[:, 0]
+                acc[1][c] += (dkc + dvc) * dst;      // d We[:, 1]
+            }
+        }
+        float* gp = gproj + j * a.ld;
+        st4(gp + a.C + j0, dk);
+        st4(gp + 2 * a.C + j0, dv);
+    }
+    // block reduction of the We partials (same scheme as the LSTM parameter gradients): [2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = acc[k][c];
+#pragma unroll
+            for (int dd = LPN; dd < 64; dd <<= 1) v += __shfl_xor(v, dd, 64);
+            acc[k][c] = v;
+        }
+    if (lane < LPN)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sm[(wave * LPN + lane) * 8 + k * 4 + c] = acc[k][c];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * a.C; idx += 256) {
+        const int k = idx / a.C, ch = idx % a.C;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += sm[(w * LPN + (ch >> 2)) * 8 + k * 4 + (ch & 3)];
+        part[(int64_t)blockIdx.x * 2 * a.C + idx] = s;     // layout [k][channel]; the host transposes to (C, 2)
+    }
+}
+
+inline bool c_ok(int C) { return C == 4 || C == 8 || C == 16 || C == 32 || C == 64 || C == 128; }
+
+}  // namespace
+
+#define QT_ATTN_DISPATCH(C, KERNEL, grid, stream, ...)                                                               \
+    switch ((C) / 4) {                                                                                               \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;    \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;    \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;    \
+        case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;    \
+        case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL(KERNEL<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;  \
+    }
+
+static int fill_args(AttnArgs* a, const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
+                     const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
+                     float keep, uint32_t seed) {
+    a->rowptr = rowptr; a->col = col; a->xy = xy; a->selfloop = selfloop; a->proj = proj; a->We = We;
+    a->ld = ld; a->C = C; a->Ncap = N; a->n_dev = n_dev; a->scale = 1.0f / sqrtf((float)c_real); a->keep = keep; a->seed = seed;
+    return 0;
+}
+
+extern "C" int qt_attn_blocks(int N, int C) {
+    if (N <= 0 || !c_ok(C)) return 0;
+    const int need = qt_cdiv((int64_t)N * (C / 4), 256);
+    return need < 512 ? need : 512;
+}
+
+extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
+                           const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
+                           float keep, uint32_t seed, float* out, float* stats, void* stream) {
+    QT_ARG(rowptr && col && xy && proj && We && out && stats, "null pointer");
+    QT_ARG(c_ok(C) && ld >= 4 * C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
+    if (N <= 0) return QT_OK;
+    AttnArgs a;
+    fill_args(&a, rowptr, col, xy, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed);
+    const int grid = qt_cdiv((int64_t)N * (C / 4), 256);
+    QT_ATTN_DISPATCH(C, k_attn_fwd, grid, stream, a, out, stats);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
+                           const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
+                           float keep, uint32_t seed, const float* g, const float* stats, float* gproj, float* Dn,
+                           float* part, void* stream) {
+    QT_ARG(rowptr && col && xy && proj && We && g && stats && gproj && Dn && part, "null pointer");
+    QT_ARG(c_ok(C) && ld >= 4 * C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
+    if (N <= 0) return QT_OK;
+    AttnArgs a;
+    fill_args(&a, rowptr, col, xy, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed);
+    const int grid = qt_cdiv((int64_t)N * (C / 4), 256);
+    QT_ATTN_DISPATCH(C, k_attn_bwd_target, grid, stream, a, g, stats, gproj, Dn);
+    const int gridB = qt_attn_blocks(N, C);
+    QT_ATTN_DISPATCH(C, k_attn_bwd_source, gridB, stream, a, g, stats, Dn, gproj, part);
+    QT_LAUNCHED();
+    return QT_OK;
+}

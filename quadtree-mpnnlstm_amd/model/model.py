@@ -66,6 +66,43 @@ class GCNConv(ChebConv):
         return torch.stack([torch.zeros_like(wt), -wt]), self.bias
 
 
+class TransformerConv(nn.Module):
+    """torch_geometric TransformerConv(heads=1, edge_dim=2, dropout=0.1, concat=False) (model/model.py:51): parameters
+    lin_key / lin_query / lin_value (.weight (out, in), .bias), lin_edge.weight (out, 2), lin_skip (.weight, .bias).
+    One projection GEMM produces [q | k | v | skip]; the edge softmax runs in the fused attention kernel, which
+    recomputes the [angle, dist] edge attributes from the node centroids."""
+
+    def __init__(self, in_channels, out_channels, heads=1, edge_dim=2, dropout=0.0, concat=False):
+        super().__init__()
+        assert heads == 1 and not concat and edge_dim == 2, 'the reference uses heads=1, concat=False, edge_dim=2'
+        self.in_channels, self.out_channels, self.dropout = in_channels, out_channels, dropout
+        self.lin_key = nn.Linear(in_channels, out_channels)
+        self.lin_query = nn.Linear(in_channels, out_channels)
+        self.lin_value = nn.Linear(in_channels, out_channels)
+        self.lin_edge = nn.Linear(edge_dim, out_channels, bias=False)
+        self.lin_skip = nn.Linear(in_channels, out_channels)
+        for lin in (self.lin_key, self.lin_query, self.lin_value, self.lin_edge, self.lin_skip):
+            nn.init.xavier_uniform_(lin.weight)
+            if lin.bias is not None:
+                nn.init.zeros_(lin.bias)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        mesh = _need_mesh(edge_index)
+        cin, cout = self.in_channels, self.out_channels
+        cin_p, cp = cin + (-cin) % 4, cout + (-cout) % 4
+        x = x[:, :cin] if x.shape[1] > cin_p else x
+        if x.shape[1] < cin_p:
+            x = nn.functional.pad(x, (0, cin_p - x.shape[1]))
+        blocks = [self.lin_query, self.lin_key, self.lin_value, self.lin_skip]
+        w = torch.cat([nn.functional.pad(l.weight.t(), (0, cp - cout, 0, cin_p - cin)) for l in blocks], dim=1)   # (cin_p, 4 cp)
+        b = torch.cat([nn.functional.pad(l.bias, (0, cp - cout)) for l in blocks]).unsqueeze(0)
+        W = torch.cat([w, nn.functional.pad(b, (0, 0, 0, 3))], dim=0)                   # bias row + 3 zero rows
+        proj = ops.cheb_poly(x, W, mesh, 1, 1)                                          # one GEMM: [q | k | v | skip]
+        We = nn.functional.pad(self.lin_edge.weight, (0, 0, 0, cp - cout))
+        out = ops.attention(proj, We, mesh, cout, self.dropout, self.training)
+        return out[:, :cout] if cp != cout else out
+
+
 def _need_mesh(edge_index):
     if not isinstance(edge_index, Mesh):
         raise TypeError('pass the Mesh (graph_structure["mapping"]) where the reference passes edge_index: '
@@ -76,7 +113,7 @@ def _need_mesh(edge_index):
 CONVOLUTIONS = {
     'ChebConv': ChebConv,
     'GCNConv': GCNConv,
-    'TransformerConv': None,
+    'TransformerConv': TransformerConv,
     'MHTransformerConv': None,
     'GATConv': None,
     'GATv2Conv': None,
@@ -153,10 +190,20 @@ class GConvLSTM(nn.Module):
             biases.append(torch.stack([c.bias for c in convs]))
         return ops.compose_chebconvs(weights, biases)          # (4, K, in, h), (4, Ks, h)
 
+    @property
+    def is_series(self):
+        """True when every convolution is a Chebyshev series (ChebConv, GCNConv): the stacks compose in weight space."""
+        return hasattr(self.conv_x_i.convolutions[0], 'cheb_coeffs')
+
     def pack(self, in_pad=None, ln=None, variants=(True,)):
         """One PackedCell per requested variant (with_h True / False); the variants share the peephole / bias
         tensors and their gradient accumulator.  W: ((K*C + Ks_padded), 4h) for Z = [X (padded to in_pad) | H]."""
         h = self.out_channels
+        if not self.is_series:          # attention convolutions are nonlinear: the eight stacks run one after another
+            wc = torch.cat([self.w_c_i, self.w_c_f, self.w_c_o], dim=0)
+            b = torch.cat([self.b_i, self.b_f, self.b_c, self.b_o], dim=0)
+            acc_p = ops.GradAcc()
+            return [PackedCell(None, 0, 0, wc, b, ln, None, acc_p) for _ in variants]
         Px, bx = self._branch('conv_x')
         cin = in_pad or self.in_channels
         if cin > self.in_channels:
@@ -176,6 +223,11 @@ class GConvLSTM(nn.Module):
 
     def step(self, X, mesh, H, C, pk):
         """One cell update with packed weights `pk`; pk.ln = (4, h) LayerNorm parameters fused onto H', C' or None."""
+        if pk.W is None:
+            Hz = H if H is not None else X.new_zeros(X.shape[0], self.out_channels)     # conv_h(0) is not 0 (biases)
+            G = torch.cat([getattr(self, f'conv_x_{g}')(X, mesh) + getattr(self, f'conv_h_{g}')(Hz, mesh)
+                           for g in self.GATES], dim=1)
+            return ops.lstm_cell(G, C, pk.wc, pk.b, pk.ln, mesh, pk.acc_p)
         Z = torch.cat([X, H], dim=1) if H is not None else X
         G = ops.cheb_poly(Z, pk.W, mesh, pk.K, pk.Ks, acc=pk.acc_w)
         return ops.lstm_cell(G, C, pk.wc, pk.b, pk.ln, mesh, pk.acc_p)

@@ -91,10 +91,11 @@ class Decoder(nn.Module):
 
     def pack(self, in_pad):
         ln = _ln_params(self.norm_h, self.norm_c)
+        series = hasattr(self.fc_out1, 'packed')
         return dict(ln_o=_ln_params(self.norm_o), acc_o=ops.GradAcc(),
                     rnns=[r.pack(in_pad if i == 0 else None, ln, (True,))[0] for i, r in enumerate(self.rnns)],
-                    fc1=self.fc_out1.packed(self.head_width, self.hidden_size), acc1=ops.GradAcc(),
-                    fc2=self.fc_out2.packed(self.hidden_size, 4), acc2=ops.GradAcc())
+                    fc1=self.fc_out1.packed(self.head_width, self.hidden_size) if series else None, acc1=ops.GradAcc(),
+                    fc2=self.fc_out2.packed(self.hidden_size, 4) if series else None, acc2=ops.GradAcc())
 
     def dropout_masks(self, steps, rows, device):
         """Inverted-dropout multipliers for `steps` decoder steps at once (one RNG launch instead of one per step);
@@ -118,9 +119,13 @@ class Decoder(nn.Module):
             # the decoder's current input value is used as the 1-channel concat (what :471,484 intended)
             concat_layers = X[:, :1]
         z = ops.head_input(out, pk['ln_o'], concat_layers, self.head_width, mesh, pk['acc_o'])
-        z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'])
         if drop is None and self.training and self.dropout.p > 0:
             drop = self.dropout_masks(1, z.shape[0], z.device)[0]
+        if pk['fc1'] is None:           # attention head (TransformerConv): activations as plain tensor ops
+            y = self.fc_out2(torch.relu(self.fc_out1(z, mesh)), mesh)
+            y = torch.tanh(y if drop is None else y * drop.unsqueeze(1)) + X[:, :1]
+            return (torch.sigmoid(y) if self.binary else y), hs, cs
+        z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'])
         y = ops.cheb_poly(z, pk['fc2'], mesh, self.fc_out2.K, 1, ops.ACT_TANH_RES, res=X, drop=drop, acc=pk['acc2'])[:, :1]
         if self.binary:
             y = torch.sigmoid(y)

@@ -34,10 +34,13 @@ _SIGNATURES = {
     'qt_lstm_fwd': [_P, _P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     'qt_lstm_bwd_blocks': [_I, _I],
     'qt_lstm_bwd': [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P],
+    'qt_attn_blocks': [_I, _I],
+    'qt_attn_fwd': [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _P],
+    'qt_attn_bwd': [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _P, _P, _P, _P],
     'qt_head_fwd': [_P, _P, _P, _I, _P, _I, _I, _P, _P],
     'qt_head_bwd': [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
 }
-_PLAIN = {'qt_abi_version', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks'}  # return a value, not an error code
+_PLAIN = {'qt_abi_version', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_attn_blocks'}  # return a value, not an error code
 
 _lib = None
 

@@ -80,6 +80,17 @@ class Mesh:
             self._ones[key] = self.recipe(B)
         return self._ones[key]
 
+    # -- per-node data of the attention convolutions --------------------------------
+    def attn_geometry(self):
+        """(xy (N, 2) centroids in edge-attribute units (graph_functions.py:657), selfpair (N) or None): the inputs from
+        which the attention kernels recompute [angle, dist] and know which nodes carry a self pair (multi-pixel cells of
+        quadtree meshes, get_adj :329-333; pixelwise meshes have none, get_adj_pixelwise)."""
+        if 'geom' not in self._ones:
+            scale = torch.tensor([self.m * self.resolution, self.n * self.resolution], device=self.posfeat.device)
+            xy = (self.posfeat[:, :2] * scale).contiguous()
+            self._ones['geom'] = (xy, None if self.pixelwise else (self.npix > 1).float())
+        return self._ones['geom']
+
     # -- T_k(L^) 1 for the bias terms of stacked ChebConvs ------------------------
     def cheb_ones(self, ks):
         """(N, 4*ceil(ks/4)) matrix [1, L^1, T_2(L^)1, ... | 0-pad] (fp32; padded so rows are float4 operands)."""

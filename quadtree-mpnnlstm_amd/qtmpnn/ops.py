@@ -221,6 +221,54 @@ def _comb(ka, kb, device):
     return _COMB[key]
 
 
+# ------------------------------------------------------------------------------ TransformerConv attention
+_ATTN_CALLS = [0]
+
+
+class _Attention(Function):
+    """out = edge-softmax attention over the mesh adjacency + skip, from the fused projection proj = [q | k | v | skip]
+    (N, 4C) and the edge-feature weight We (C, 2)  (PyG TransformerConv as configured by model/model.py:51)."""
+
+    @staticmethod
+    def forward(ctx, proj, We, mesh, c_real, keep, seed):
+        proj, We = _c(proj.float()), _c(We.float())
+        N, C = proj.shape[0], proj.shape[1] // 4
+        xy, selfpair = mesh.attn_geometry()
+        out = proj.new_empty(N, C)
+        stats = proj.new_empty(N, 2)
+        _lib.call('qt_attn_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(selfpair), ptr(proj), 4 * C, ptr(We), C, c_real,
+                  N, ptr(mesh.n_dev), keep, seed, ptr(out), ptr(stats))
+        ctx.save_for_backward(proj, We, stats)
+        ctx.mesh, ctx.c_real, ctx.keep, ctx.seed = mesh, c_real, keep, seed
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        proj, We, stats = ctx.saved_tensors
+        mesh = ctx.mesh
+        N, C = proj.shape[0], proj.shape[1] // 4
+        xy, selfpair = mesh.attn_geometry()
+        g = _c(g.float())
+        gproj = torch.empty_like(proj)
+        Dn = proj.new_empty(N)
+        nblk = max(_lib.value('qt_attn_blocks', N, C), 1)
+        part = proj.new_zeros(nblk, 2 * C)
+        if N > 0:
+            _lib.call('qt_attn_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(selfpair), ptr(proj), 4 * C, ptr(We), C,
+                      ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(g), ptr(stats), ptr(gproj), ptr(Dn), ptr(part))
+        else:
+            gproj.zero_()
+        gWe = part.sum(0).view(2, C).t().contiguous()
+        return gproj, gWe, None, None, None, None
+
+
+def attention(proj, We, mesh, c_real, dropout_p=0.0, training=False):
+    keep = 1.0 - dropout_p if (training and dropout_p > 0) else 1.0
+    _ATTN_CALLS[0] += 1
+    seed = (_ATTN_CALLS[0] * 2654435761 + int(torch.initial_seed())) & 0xFFFFFFFF       # host-side counter: no device sync
+    return _Attention.apply(proj, We, mesh, c_real, keep, seed)
+
+
 # ------------------------------------------------------------------------------ LSTM cell
 class _LstmCell(Function):
     """(O, LayerNorm_h(H'), LayerNorm_c(C')) from gate pre-activations (model/model.py:394-428,

@@ -70,7 +70,7 @@ def install_standins():
 
     pyg = mod('torch_geometric')
     pyg.data = mod('torch_geometric.data', Data=Data)
-    pyg.nn = mod('torch_geometric.nn', ChebConv=O.ChebConv, GCNConv=O.GCNConv, TransformerConv=_Absent,
+    pyg.nn = mod('torch_geometric.nn', ChebConv=O.ChebConv, GCNConv=O.GCNConv, TransformerConv=O.TransformerConv,
                  GATConv=_Absent, GATv2Conv=_Absent, GraphConv=_Absent, MessagePassing=MessagePassing)
     pyg.nn.conv = mod('torch_geometric.nn.conv', MessagePassing=MessagePassing)
     pyg.nn.dense = mod('torch_geometric.nn.dense')
@@ -422,6 +422,59 @@ def rollout_variants():
     dump('tbptt', model, last_outs, loss, dict(chunk_losses=np.array(losses)))
 
 
+# ------------------------------------------------------------------ TransformerConv
+def transformer_cases():
+    """GConvLSTM cell with TransformerConv stacks (edge attrs [angle, dist], self pairs of multi-pixel cells are real
+    attention keys) and a masked rollout.  The conv arithmetic is the oracle's restatement (parity unpinned); the cell,
+    encoder / decoder wiring and re-mesh control flow are the reference's own code."""
+    c = synthetic.make_clip(33, canvas=(64, 64), n_digits=1, n_frames=1, pixel_noise=0.0)
+    g = RG.image_to_graph(RU.add_positional_encoding(torch.from_numpy(c)), thresh=0.1, use_edge_attrs=True)
+    ei, ea = g['edge_index'], g['edge_attrs']
+    n = g['data'].shape[1]
+    labels = g['mapping'].numpy().argmax(0).reshape(64, 64).astype(np.int32)
+    sei, sea = sort_edges(ei, ea)
+    gen = torch.Generator().manual_seed(6)
+    out = dict(labels=labels, edges=sei, attrs=sea)
+    cell = RM.GConvLSTM(4, 8, n_conv_layers=2, convolution_type='TransformerConv')
+    randomize(cell, 90)
+    cell.eval()                                   # attention dropout off (cannot be RNG matched)
+    X = torch.randn(n, 4, generator=gen).requires_grad_(True)
+    H = torch.randn(n, 8, generator=gen).requires_grad_(True)
+    C = torch.randn(n, 8, generator=gen).requires_grad_(True)
+    Oo, Hn, Cn = cell(X, ei, ea, H, C)
+    gO, gH, gC = (torch.randn(n, 8, generator=gen) for _ in range(3))
+    grads = torch.autograd.grad([Oo, Hn, Cn], [X, H, C] + list(cell.parameters()), [gO, gH, gC])
+    out.update(X=X.detach().numpy(), H=H.detach().numpy(), C=C.detach().numpy(), O=Oo.detach().numpy(),
+               Hn=Hn.detach().numpy(), Cn=Cn.detach().numpy(), gO=gO.numpy(), gH=gH.numpy(), gC=gC.numpy(),
+               gX=grads[0].numpy(), gHin=grads[1].numpy(), gCin=grads[2].numpy())
+    out.update(state_arrays(cell, 'w/'))
+    for (k, _), gr in zip(cell.named_parameters(), grads[3:]):
+        out['g/' + k] = gr.numpy()
+    np.savez_compressed(os.path.join(HERE, 'transformer_cell.npz'), **out)
+    print('transformer cell N =', n, 'E =', sei.shape[1])
+
+    f, m = synthetic.make_ice_like(23, shape=(64, 64), channels=3, n_frames=5)
+    x, y = f[:2], f[2:5, ..., :1].copy()
+    concat = y * 0.5
+    model = RS.Seq2Seq(hidden_size=8, dropout=0.0, thresh=0.15, input_timesteps=2, input_features=6, output_timesteps=3,
+                       n_layers=1, n_conv_layers=2, transform_func=dist_from_05, convolution_type='TransformerConv')
+    randomize(model, 91, scale=0.1, bscale=0.05)
+    model.eval()
+    xt, yt, ct, mk = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(concat), torch.from_numpy(m)
+    outs, maps = model(xt, yt, ct, teacher_forcing_ratio=0, mask=m)
+    y_hat = torch.stack([RG.unflatten(outs[i], maps[i], (64, 64), m) for i in range(3)])
+    loss = torch.nn.MSELoss()(y_hat[:, ~mk], yt[:, ~mk])
+    loss.backward()
+    out = dict(x=x, y=y, concat=concat, mask=m, loss=np.float64(loss.item()))
+    for i, o in enumerate(outs):
+        out[f'out_{i}'] = o.detach().numpy()
+    out.update(state_arrays(model, 'w/'))
+    for k, p in model.named_parameters():
+        out['g/' + k] = p.grad.numpy() if p.grad is not None else np.zeros(p.shape, np.float32)
+    np.savez_compressed(os.path.join(HERE, 'transformer_rollout.npz'), **out)
+    print('transformer rollout loss', loss.item(), 'N', [len(o) for o in outs])
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -436,4 +489,6 @@ if __name__ == '__main__':
         fixed_meshes()
     if only in ('', 'variants'):
         rollout_variants()
+    if only in ('', 'transformer'):
+        transformer_cases()
     print('golden vectors written to', HERE)

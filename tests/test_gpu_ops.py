@@ -286,3 +286,63 @@ def test_gcnconv_cell_vs_oracle():
     gg = torch.autograd.grad(outs_g, [xg, hg, cg] + list(mine.parameters()), [g.to(dev()) for g in gs])
     for a, b, name in zip(gg, gr, ['X', 'H', 'C'] + [k for k, _ in ref.named_parameters()]):
         grad_close(a, b, msg=name)
+
+
+def test_transformerconv_vs_oracle_dense():
+    """Attention kernel (forward and every gradient) against the oracle's scatter formulation of TransformerConv on the
+    mesh's own edge list (self pairs of multi-pixel cells included, edge attributes [angle, dist])."""
+    from model.model import TransformerConv
+    from oracle import qt_oracle as O
+    mesh, _ = _mesh_64(81, noise=0.0, B=2)
+    ei = mesh.edge_index(True).cpu()
+    ea = mesh.edge_attrs(True).cpu()
+    torch.manual_seed(7)
+    for cin, cout in ((6, 8), (9, 1), (16, 16)):
+        ref = O.TransformerConv(cin, cout)
+        for p in ref.parameters():
+            p.data.normal_(0, 0.5)
+        mine = TransformerConv(cin, cout)
+        mine.load_state_dict(ref.state_dict())
+        mine.to(dev())
+        x = torch.randn(mesh.N, cin)
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr, ei, ea)
+        xg = x.to(dev()).requires_grad_(True)
+        yg = mine(xg, mesh)
+        close(yg, yr, atol=1e-4, msg=f'{cin}->{cout}')
+        gy = torch.randn_like(yr)
+        gr = torch.autograd.grad(yr, [xr] + list(ref.parameters()), gy)
+        gg = torch.autograd.grad(yg, [xg] + list(mine.parameters()), gy.to(dev()))
+        names = ['x'] + [k for k, _ in ref.named_parameters()]
+        wscale = float(gr[names.index('lin_key.weight')].abs().max())
+        for a, b, name in zip(gg, gr, names):
+            if name == 'lin_key.bias':       # exactly zero in exact arithmetic (softmax shift invariance): rounding noise only
+                assert float(a.abs().max()) <= 1e-4 * wscale and float(b.abs().max()) <= 1e-4 * wscale
+                continue
+            grad_close(a, b, msg=f'{cin}->{cout} {name}')
+
+
+def test_transformer_gconvlstm_cell_golden():
+    """GConvLSTM with TransformerConv stacks against the trace of the reference's cell code."""
+    from model.model import GConvLSTM
+    from qtmpnn import synthetic
+    from qtmpnn.mesh import build_mesh
+    g = golden('transformer_cell.npz')
+    c = synthetic.make_clip(33, canvas=(64, 64), n_digits=1, n_frames=1, pixel_noise=0.0)
+    mesh = build_mesh(src=torch.from_numpy(c[..., 0]).to(dev()), thresh=0.1)
+    assert np.array_equal(mesh.labels[0].cpu().numpy(), g['labels'])
+    assert np.array_equal(mesh.edge_index(True).cpu().numpy(), g['edges'])
+    close(mesh.edge_attrs(True), g['attrs'], atol=2e-5)
+    cell = GConvLSTM(4, 8, 2, 'TransformerConv')
+    load_state(cell, g, 'w/')
+    cell.to(dev()).eval()
+    X, H, C = (torch.from_numpy(g[k]).to(dev()).requires_grad_(True) for k in 'XHC')
+    Oo, Hn, Cn = cell(X, mesh, None, H, C)
+    for got, name in ((Oo, 'O'), (Hn, 'Hn'), (Cn, 'Cn')):
+        close(got, g[name], msg=name)
+    grads = torch.autograd.grad([Oo, Hn, Cn], [X, H, C] + list(cell.parameters()),
+                                [torch.from_numpy(g[k]).to(dev()) for k in ('gO', 'gH', 'gC')])
+    for got, name in zip(grads[:3], ('gX', 'gHin', 'gCin')):
+        grad_close(got, g[name], msg=name)
+    for got, (k, _) in zip(grads[3:], cell.named_parameters()):
+        grad_close(got, g['g/' + k], msg=k, floor=0.05 if k.endswith('lin_key.bias') else 1e-3)

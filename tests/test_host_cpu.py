@@ -139,6 +139,6 @@ def test_unsupported_variants_raise_clearly():
     with pytest.raises(NotImplementedError):
         GConvGRU(4, 4)
     with pytest.raises(NotImplementedError):
-        Seq2Seq(16, 0.1, 0.1, convolution_type='TransformerConv')
+        Seq2Seq(16, 0.1, 0.1, convolution_type='GATConv')
     with pytest.raises(AssertionError):
         Seq2Seq(16, 0.1, 0.1, convolution_type='NoSuchConv')

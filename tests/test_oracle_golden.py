@@ -159,3 +159,19 @@ def test_cheb_conv_self_consistency(golden_dir):
     a = O.cheb_conv(x, ei, ew, ws, b)
     d = O.cheb_conv_dense(x, ei, ew, ws, b)
     np.testing.assert_allclose(a.numpy(), d.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_rollout_transformerconv(golden_dir):
+    """Oracle control flow with attention convolutions (edge attributes [angle, dist], self pairs) vs the reference trace.
+    The conv arithmetic itself is the shared restatement (parity unpinned, see the oracle header)."""
+    g = load(golden_dir, 'transformer_rollout.npz')
+    x, y, concat = (torch.from_numpy(g[k]) for k in ('x', 'y', 'concat'))
+    model = O.Seq2Seq(8, 0.0, 0.15, input_timesteps=2, input_features=6, output_timesteps=3, n_layers=1, n_conv_layers=2,
+                      transform_func=dist_from_05, convolution_type='TransformerConv')
+    _load_state(model, g, 'w/')
+    model.eval()
+    outs, maps, _ = model(x, concat, mask=g['mask'])
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().numpy(), g[f'out_{i}'], rtol=RTOL, atol=ATOL)
+    loss = O.clip_loss(outs, maps, y, (64, 64), g['mask'])
+    assert abs(float(loss.detach()) - float(g['loss'])) <= RTOL * abs(float(g['loss']))
