@@ -112,6 +112,15 @@ constexpr int BM = 128;       // block rows (4 waves x 32)
 constexpr int BN = 64;        // block columns (2 MFMA tiles per wave)
 constexpr int MAXQ = 128;     // quads (4 consecutive k) in the reduction dimension
 
+// Pointers that went through the LDS quad table lose their address space: hipcc then emits flat_load, and flat loads
+// force `s_waitcnt vmcnt(0) lgkmcnt(0)` at every use (they may return out of order), which serialised the whole
+// operand stream.  Loading through an explicit global (address space 1) pointer restores counted vmcnt waits.
+typedef float qt_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gload4(const float* p) {
+    const qt_v4f v = *(const __attribute__((address_space(1))) qt_v4f*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // Quad table: quad Q of a node row lives at qptr[Q] + row * qstr[Q] (plane Q*4/Ca of the operand, or S).
 __device__ __forceinline__ void build_quad_table(const PlaneSrc& A, const float** qptr, int* qstr, int nquad) {
     for (int Q = threadIdx.x; Q < nquad; Q += 256) {
@@ -131,9 +140,13 @@ __device__ __forceinline__ void build_quad_table(const PlaneSrc& A, const float*
 // A fragments go global -> VGPR directly (float4 per lane and k-quad); only W is staged in LDS (KWT x 32 NT floats).
 // NT = 2 for NB <= 64 (gate GEMM), NT = 4 for wide outputs (the data gradient, NB = K*C) so A is read only once.
 template <int NT, int KWT>
-__global__ __launch_bounds__(256) void k_gemm_fwd(GemmArgs g) {
+__global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgroups per CU: all N/128 blocks of the
+                                                                      // bench shape are resident at once (<= 128 registers)
     constexpr int BNT = 32 * NT;
-    __shared__ float Bs[KWT][BNT];
+    constexpr int PITCH = KWT + 4;      // == 4 (mod 64) floats: the 16 lanes of a ds_read_b128 group hit distinct banks
+    // W chunk TRANSPOSED in LDS, Bt[column][k]: a lane's four B operands of one k-quad are one ds_read_b128
+    // (measured: with one ds_read_b32 per MFMA the kernel ran at half the MFMA rate)
+    __shared__ __attribute__((aligned(16))) float Bt[BNT * PITCH];
     __shared__ const float* qptr[MAXQ];
     __shared__ int qstr[MAXQ];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -154,52 +167,82 @@ __global__ __launch_bounds__(256) void k_gemm_fwd(GemmArgs g) {
     for (int k0 = 0; k0 < g.K; k0 += KWT) {
         const int kn = min(KWT, g.K - k0);           // multiple of 4
         __syncthreads();                              // table ready / previous pass done with Bs
+        // W chunk -> LDS first (small, L2 resident) ...
         for (int e = t; e < kn * (BNT / 4); e += 256) {
             const int kb = e / (BNT / 4), jq = (e % (BNT / 4)) * 4;
             float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j0 + jq < g.NB) w = *reinterpret_cast<const float4*>(g.B + (int64_t)(k0 + kb) * g.NB + j0 + jq);
-            *reinterpret_cast<float4*>(&Bs[kb][jq]) = w;
+            Bt[(jq + 0) * PITCH + kb] = w.x;
+            Bt[(jq + 1) * PITCH + kb] = w.y;
+            Bt[(jq + 2) * PITCH + kb] = w.z;
+            Bt[(jq + 3) * PITCH + kb] = w.w;
         }
-        // this lane's A quads of the pass: quad 2 j + half
-        float4 areg[KWT / 8];
-        const int q0 = k0 >> 2, qn = kn >> 2;
-#pragma unroll
-        for (int j = 0; j < KWT / 8; ++j) {
-            const int q = 2 * j + half;
-            areg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row_ok && q < qn) areg[j] = *reinterpret_cast<const float4*>(qptr[q0 + q] + my_row * qstr[q0 + q]);
+        for (int e = t; e < BNT * ((KWT - kn) / 4); e += 256) {          // zero the k tail of a short last pass
+            const int c = e / ((KWT - kn) / 4), kq = kn + (e % ((KWT - kn) / 4)) * 4;
+            *reinterpret_cast<float4*>(&Bt[c * PITCH + kq]) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
+        // ... then the MFMA stream.  The A quads (quad 2 j + half of this lane's row) come straight from global memory
+        // through a 4-deep register ring loaded four k-groups ahead; the loop is a plain runtime loop with NO branch
+        // around the MFMAs (conditionals there made hipcc shuttle the accumulators between VGPRs and AGPRs: 1088
+        // v_accvgpr moves and a vmcnt(0) per group, 2.75x slower than the MFMA rate).
+        const int q0 = k0 >> 2, qn = kn >> 2, nj = (kn + 7) >> 3;
+        auto ldq = [&](int j) {
+            const int q = 2 * j + half;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_ok && q < qn) r = gload4(qptr[q0 + q] + my_row * qstr[q0 + q]);
+            return r;
+        };
+        float4 a0 = ldq(0), a1 = ldq(1), a2 = ldq(2), a3 = ldq(3);
+        for (int j = 0; j < nj; ++j) {
+            const float4 a = a0;
+            a0 = a1; a1 = a2; a2 = a3;
+            a3 = ldq(j + 4);
+            float4 bq[NT];
 #pragma unroll
-        for (int j = 0; j < KWT / 8; ++j) {
-            if (8 * j < kn) {
-                const float av[4] = {areg[j].x, areg[j].y, areg[j].z, areg[j].w};
+            for (int nt = 0; nt < NT; ++nt)
+                bq[nt] = *reinterpret_cast<const float4*>(&Bt[(nt * 32 + l32) * PITCH + 8 * j + 4 * half]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int kk = 8 * j + 4 * half + i;      // rows >= kn of Bs are only met with a zero A quad
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const float b = kk < kn ? Bs[kk][nt * 32 + l32] : 0.0f;
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b, acc[nt], 0, 0, 0);
-                    }
-                }
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[nt].x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[nt].y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[nt].z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[nt].w, acc[nt], 0, 0, 0);
             }
         }
     }
+    // Epilogue: an MFMA accumulator holds one COLUMN per lane; staging the tile in LDS (the W buffer is free now) lets
+    // every thread write float4 pieces of output ROWS instead (4x fewer, 16-byte wide, row-contiguous stores).
+    float* Cs = Bt;                              // 128 rows x 64 columns per pass
+    static_assert(BNT * PITCH >= BM * 64, "LDS staging tile does not fit in the W buffer");
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int j = j0 + nt * 32 + l32;
-        if (j >= g.NB) continue;
-        const int pl = j / g.Cb, ch = j - pl * g.Cb;
-        float* obase = g.out + (int64_t)pl * g.M * g.Cb + ch;
+    for (int h2 = 0; h2 < NT / 2; ++h2) {        // two 32-column MFMA tiles per pass
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t i = i0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (i >= rows) continue;
-            float v = acc[nt][r];
-            if (g.act == QT_ACT_RELU) v = fmaxf(v, 0.0f);
-            if (g.act == QT_ACT_TANH_RES) v = tanhf((g.drop ? g.drop[i] : 1.0f) * v) + g.res[i * g.res_stride];
-            obase[i * g.Cb] = v;
+        for (int u = 0; u < 2; ++u) {
+            const int nt = 2 * h2 + u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + u * 32 + l32] = acc[nt][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < BM * 16 / 256; ++u) {
+            const int e = t + 256 * u;
+            const int row = e >> 4, c4 = (e & 15) * 4;
+            const int64_t i = i0 + row;
+            const int j = j0 + h2 * 64 + c4;
+            if (i >= rows || j >= g.NB) continue;
+            float4 v = *reinterpret_cast<const float4*>(&Cs[row * 64 + c4]);
+            if (g.act == QT_ACT_RELU) {
+                v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            }
+            if (g.act == QT_ACT_TANH_RES) {
+                const float d = g.drop ? g.drop[i] : 1.0f, rs = g.res[i * g.res_stride];
+                v.x = tanhf(d * v.x) + rs; v.y = tanhf(d * v.y) + rs; v.z = tanhf(d * v.z) + rs; v.w = tanhf(d * v.w) + rs;
+            }
+            const int pl = j / g.Cb, ch = j - pl * g.Cb;          // Cb % 4 == 0: a float4 never straddles two planes
+            *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
         }
     }
 }
@@ -231,7 +274,7 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(GemmArgs g) {
         for (int u = 0; u < 4; ++u) {
             const int Q = (f0 >> 2) + a_q + u;
             pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ra < rend && Q < nquad) pa[u] = *reinterpret_cast<const float4*>(qptr[Q] + ra * qstr[Q]);
+            if (ra < rend && Q < nquad) pa[u] = gload4(qptr[Q] + ra * qstr[Q]);
         }
         const int64_t rg = r0 + g_row;
 #pragma unroll
@@ -331,7 +374,7 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
     QT_ARG((Ks == 0) || (S && Ws), "S / Ws missing");
     QT_ARG(Ks == 0 || Ws == W + (int64_t)Ka * Ca * Kb * Cb, "Ws must follow W contiguously ([W ; Ws] is one matrix)");
     QT_ARG(act == QT_ACT_NONE || Kb == 1, "activation needs Kb == 1");
-    QT_ARG(Ca % 4 == 0 && Ks % 4 == 0 && (Kb * Cb) % 4 == 0, "Ca, Ks and Kb*Cb must be multiples of 4 (float4 operands)");
+    QT_ARG(Ca % 4 == 0 && Ks % 4 == 0 && Cb % 4 == 0, "Ca, Ks and Cb must be multiples of 4 (float4 operands)");
     QT_ARG((Ka * Ca + Ks) / 4 <= MAXQ, "reduction dimension too large (max 512)");
     QT_ARG((((uintptr_t)a0 | (uintptr_t)a_rest | (uintptr_t)S | (uintptr_t)W) & 15) == 0, "operands must be 16-byte aligned");
     QT_ARG(act != QT_ACT_TANH_RES || res, "QT_ACT_TANH_RES needs res");
