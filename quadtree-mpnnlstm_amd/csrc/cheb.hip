@@ -4,6 +4,7 @@
 //              data gradient; the weight gradient split over row blocks
 //   k_colsum -- fixed-order reduction of per-block partial sums
 #include "qt_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -247,6 +248,142 @@ __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgr
     }
 }
 
+// ---- bf16x3 variant of the forward / data-gradient GEMM -------------------------------------------------------------
+// fp32 MFMA runs at the VALU FLOP rate on gfx950 and bounds k_gemm_fwd.  Here every fp32 operand
+// is split into three bf16 terms (x = hi + mid + lo, each rounded to nearest) and a product group is six bf16 MFMAs
+// (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) accumulated in fp32: the dropped terms are O(2^-24) of the product,
+// i.e. fp32-level error, at 16 k per 32-cycle instruction instead of 2 k per 64-cycle instruction.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float x, __bf16* h, __bf16* m, __bf16* l) {
+    const __bf16 hh = (__bf16)x;
+    const float r = x - (float)hh;
+    const __bf16 mm = (__bf16)r;
+    const float r2 = r - (float)mm;
+    *h = hh; *m = mm; *l = (__bf16)r2;
+}
+
+template <int NT, int KWT>
+__global__ __launch_bounds__(256) void k_gemm_fwd3(GemmArgs g) {
+    constexpr int BNT = 32 * NT;
+    constexpr int PITCH = KWT + 8;          // bf16 elements; row pitch in bytes = 16 (mod 32): conflict-free ds_read_b128
+    constexpr int PLANE = BNT * PITCH;      // one of the three split planes of W^T: Bt[x][column][k]
+    static_assert(3 * PLANE * 2 >= BM * 64 * 4, "LDS staging tile does not fit in the W buffer");
+    __shared__ __attribute__((aligned(16))) __bf16 Bt[3 * PLANE];
+    __shared__ const float* qptr[MAXQ];
+    __shared__ int qstr[MAXQ];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l32 = lane & 31, half = lane >> 5;
+    const int64_t i0 = (int64_t)blockIdx.x * BM;
+    const int j0 = blockIdx.y * BNT;
+    const int64_t rows = qt_rows(g.n_dev, g.M);
+    if (i0 >= rows) return;
+    const int nquad = g.K >> 2;
+    build_quad_table(g.A, qptr, qstr, nquad);
+    const int64_t my_row = i0 + wave * 32 + l32;
+    const bool row_ok = my_row < rows;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    for (int k0 = 0; k0 < g.K; k0 += KWT) {
+        const int kn = min(KWT, g.K - k0);           // multiple of 4
+        const int kn16 = (kn + 15) & ~15;
+        __syncthreads();
+        // W chunk -> LDS, transposed and split: pairs of k rows so that every LDS store is a packed 32-bit word
+        for (int e = t; e < (kn16 / 2) * (BNT / 4); e += 256) {
+            const int kp = e / (BNT / 4), jq = (e % (BNT / 4)) * 4;
+            float w[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kb = 2 * kp + u;
+                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kb < kn && j0 + jq < g.NB) f = *reinterpret_cast<const float4*>(g.B + (int64_t)(k0 + kb) * g.NB + j0 + jq);
+                w[u][0] = f.x; w[u][1] = f.y; w[u][2] = f.z; w[u][3] = f.w;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                __bf16 h0, m0, l0, h1, m1, l1;
+                split3(w[0][c], &h0, &m0, &l0);
+                split3(w[1][c], &h1, &m1, &l1);
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                const int o = (jq + c) * PITCH + 2 * kp;
+                *reinterpret_cast<bf16x2*>(&Bt[o]) = bf16x2{h0, h1};
+                *reinterpret_cast<bf16x2*>(&Bt[PLANE + o]) = bf16x2{m0, m1};
+                *reinterpret_cast<bf16x2*>(&Bt[2 * PLANE + o]) = bf16x2{l0, l1};
+            }
+        }
+        __syncthreads();
+        // MFMA stream: step J covers k = 16 J .. 16 J + 15; this lane feeds k = 16 J + 8 half .. + 7 (two quads of its row)
+        const int q0 = k0 >> 2, qn = kn >> 2, nJ = kn16 >> 4;
+        auto ldq = [&](int q) {
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_ok && q < qn) r = gload4(qptr[q0 + q] + my_row * qstr[q0 + q]);
+            return r;
+        };
+        float4 c0 = ldq(2 * half), c1 = ldq(2 * half + 1);                 // J = 0
+        float4 n0 = ldq(4 + 2 * half), n1 = ldq(4 + 2 * half + 1);         // J = 1
+        for (int J = 0; J < nJ; ++J) {
+            const float av[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            c0 = n0; c1 = n1;
+            n0 = ldq(4 * (J + 2) + 2 * half);
+            n1 = ldq(4 * (J + 2) + 2 * half + 1);
+            bf16x8 ah, am, al;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __bf16 h, m, l;
+                split3(av[i], &h, &m, &l);
+                ah[i] = h; am[i] = m; al[i] = l;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int o = (nt * 32 + l32) * PITCH + 16 * J + 8 * half;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bt[o]);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&Bt[PLANE + o]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bt[2 * PLANE + o]);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);     // small terms first
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    float* Cs = reinterpret_cast<float*>(Bt);    // 128 rows x 64 columns per pass
+#pragma unroll
+    for (int h2 = 0; h2 < NT / 2; ++h2) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int nt = 2 * h2 + u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + u * 32 + l32] = acc[nt][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < BM * 16 / 256; ++u) {
+            const int e = t + 256 * u;
+            const int row = e >> 4, c4 = (e & 15) * 4;
+            const int64_t i = i0 + row;
+            const int j = j0 + h2 * 64 + c4;
+            if (i >= rows || j >= g.NB) continue;
+            float4 v = *reinterpret_cast<const float4*>(&Cs[row * 64 + c4]);
+            if (g.act == QT_ACT_RELU) {
+                v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            }
+            if (g.act == QT_ACT_TANH_RES) {
+                const float d = g.drop ? g.drop[i] : 1.0f, rs = g.res[i * g.res_stride];
+                v.x = tanhf(d * v.x) + rs; v.y = tanhf(d * v.y) + rs; v.z = tanhf(d * v.z) + rs; v.w = tanhf(d * v.w) + rs;
+            }
+            const int pl = j / g.Cb, ch = j - pl * g.Cb;
+            *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+        }
+    }
+}
+
 // MODE 1: part[blockIdx.z] = A[rows]^T @ G[rows] over this block's row chunk.  Block = 128 features x 64
 // columns of the weight gradient, wave w owns features [32w, 32w+32); the reduction runs over node rows in
 // passes of 32 rows: float4 global loads -> registers (prefetch of the next pass) -> double-buffered LDS.
@@ -383,10 +520,20 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
     g.A.a0 = a0; g.A.a_rest = a_rest; g.A.S = S; g.A.Ka = Ka; g.A.Ca = Ca; g.A.Ks = Ks; g.A.N = N;
     g.B = W; g.M = N; g.K = Ka * Ca + Ks; g.NB = Kb * Cb;
     g.Kb = Kb; g.Cb = Cb; g.act = act; g.res = res; g.res_stride = res_stride; g.drop = drop; g.out = out; g.row0_step = 0; g.n_dev = n_dev; g.accumulate = 0;
-    if (g.NB > 64)
-        hipLaunchKernelGGL((k_gemm_fwd<4, 64>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128), 1), dim3(256), 0, (hipStream_t)stream, g);
-    else
-        hipLaunchKernelGGL((k_gemm_fwd<2, 128>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 64), 1), dim3(256), 0, (hipStream_t)stream, g);
+    // default: exact fp32 MFMA (bit-for-bit a k-ordered fmaf chain).  QT_GEMM_BF16X3=1 opts into the bf16x3 split
+    // kernels (fp32-level error, ~8 % faster on these memory/latency-shaped GEMMs: measured 27.7 vs 30.1 us).
+    static const bool exact_fp32 = getenv("QT_GEMM_BF16X3") == nullptr;
+    if (exact_fp32) {
+        if (g.NB > 64)
+            hipLaunchKernelGGL((k_gemm_fwd<4, 64>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128), 1), dim3(256), 0, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL((k_gemm_fwd<2, 128>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 64), 1), dim3(256), 0, (hipStream_t)stream, g);
+    } else {
+        if (g.NB > 64)
+            hipLaunchKernelGGL((k_gemm_fwd3<4, 64>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128), 1), dim3(256), 0, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL((k_gemm_fwd3<2, 128>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 64), 1), dim3(256), 0, (hipStream_t)stream, g);
+    }
     QT_LAUNCHED();
     return QT_OK;
 }

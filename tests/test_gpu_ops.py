@@ -346,3 +346,36 @@ def test_transformer_gconvlstm_cell_golden():
         grad_close(got, g[name], msg=name)
     for got, (k, _) in zip(grads[3:], cell.named_parameters()):
         grad_close(got, g['g/' + k], msg=k, floor=0.05 if k.endswith('lin_key.bias') else 1e-3)
+
+
+def test_bf16x3_gemm_matches_fp32_gemm():
+    """Opt-in bf16x3 GEMM (QT_GEMM_BF16X3=1; three bf16 terms per operand, six MFMAs per product group) must agree with
+    the default exact-fp32 MFMA GEMM to fp32 rounding level.  Run in a child process: the switch is read once per process."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import sys, os, torch
+        sys.path.insert(0, os.path.join(os.getcwd(), 'quadtree-mpnnlstm_amd'))
+        from qtmpnn import _lib
+        from qtmpnn._lib import ptr
+        torch.manual_seed(0)
+        dev = torch.device('cuda', 0)
+        N, K, C, Co = 5000, 5, 20, 64
+        Z = torch.randn(N, C, device=dev); TZ = torch.randn(K - 1, N, C, device=dev)
+        S = torch.randn(N, 4, device=dev); W = torch.randn(K * C + 4, Co, device=dev); Y = torch.empty(N, Co, device=dev)
+        _lib.call('qt_dense', ptr(Z), ptr(TZ), K, C, ptr(W), ptr(S), 4, ptr(W[K * C:]), 1, Co, N, None, 0, None, 0, None, ptr(Y))
+        A = torch.cat([Z] + list(TZ) + [S], dim=1).double()
+        ref = (A @ W.double())
+        err = ((Y.double() - ref).abs().max() / ref.abs().max()).item()
+        print('RELERR', err)
+    ''')
+    errs = {}
+    for mode in ('0', '1'):
+        env = dict(os.environ)
+        env.pop('QT_GEMM_BF16X3', None)
+        if mode == '1':
+            env['QT_GEMM_BF16X3'] = '1'
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert out.returncode == 0, out.stderr[-2000:]
+        errs[mode] = float(out.stdout.split('RELERR')[1])
+    assert errs['0'] < 2e-6 and errs['1'] < 2e-6, errs

@@ -34,3 +34,12 @@ print('spmm C=20 us', round(timeit(lambda: spmm(mesh, Z, 2.0, p_, -1.0, None, 0.
 print('spmm C=20 no addend us', round(timeit(lambda: spmm(mesh, Z, 1.0, None, 0.0, None, 0.0, out, C)), 2))
 cp = torch.empty(N * 164, device=dev); src = torch.randn(N * 164, device=dev)
 print('copy of the same bytes (N x 164 floats) us', round(timeit(lambda: cp.copy_(src)), 2))
+# interleaved operand: one (N, K*C) matrix instead of K planes (N, C)
+Zi = torch.randn(N, K * C, device=dev)
+densei = lambda: _lib.call('qt_dense', ptr(Zi), None, 1, K * C, ptr(W), ptr(S), 4, ptr(W[K * C:]), 1, Co, N, None, 0, None, 0, None, ptr(Y))
+print('gemm fwd interleaved A (N x 100 rows contiguous) us', round(timeit(densei), 2))
+gTi = torch.empty(N, K * C, device=dev)
+bwdi = lambda: _lib.call('qt_dense', ptr(G), None, 1, Co, ptr(Wt), None, 0, None, 1, K * C, N, None, 0, None, 0, None, ptr(gTi))
+print('gemm bwd-data interleaved out us', round(timeit(bwdi), 2))
+wgi = lambda: _lib.call('qt_wgrad', ptr(Zi), None, 1, K * C, ptr(S), 4, ptr(G), Co, N, None, 1, ptr(part))
+print('wgrad interleaved A us', round(timeit(wgi), 2))
