@@ -173,6 +173,11 @@ int qt_head_fwd(const float* O, const float* ln_o /* (2,h) */, const float* conc
 int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, const int32_t* n_dev, int h, int hp,
                 float* gO, float* gconcat, float* part, int accumulate, void* stream);
 
+/* backward of the qt_dense epilogue activations: G = gY * act'(Y) (QT_ACT_RELU, QT_ACT_TANH_RES with res / drop as in
+ * qt_dense); gres (N, res_stride) or NULL receives the gradient of the residual operand (column 0 = gY[:, 0], rest 0). */
+int qt_act_bwd(const float* gY, const float* Y, const float* res, int res_stride, const float* drop, int act, int N,
+               const int32_t* n_dev, int Co, float* G, float* gres, void* stream);
+
 /* ---------------------------------------------------------------- edge-softmax attention (TransformerConv)
  * torch_geometric TransformerConv(heads=1, concat=False, beta=False, edge_dim=2, root_weight=True) as configured by
  * model/model.py:51 (third-party arithmetic, restated in oracle/): SURVEY.md 8(f) row 1.

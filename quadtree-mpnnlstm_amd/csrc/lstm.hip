@@ -281,6 +281,27 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ gZ, 
     block_param_reduce<LPN, 2>(acc, h, sm, part + (int64_t)blockIdx.x * 2 * h, accumulate);
 }
 
+// G = gY * act'(Y) for the GEMM epilogue activations (QT_ACT_RELU / QT_ACT_TANH_RES); for TANH_RES also the gradient of
+// the residual operand, gres (N, rs): column 0 = gY[:, 0], the rest 0.  One launch instead of ~8 elementwise tensor ops.
+__global__ void k_act_bwd(const float* __restrict__ gY, const float* __restrict__ Y, const float* __restrict__ res, int rs,
+                          const float* __restrict__ drop, int act, int Ncap, const int32_t* __restrict__ n_dev, int Co,
+                          float* __restrict__ G, float* __restrict__ gres) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = idx / Co;
+    if (row >= qt_rows(n_dev, Ncap)) return;
+    const int c = (int)(idx - row * Co);
+    const float g = gY[idx], y = Y[idx];
+    float o;
+    if (act == QT_ACT_RELU) {
+        o = y > 0.0f ? g : 0.0f;
+    } else {
+        const float t = y - res[row * rs];
+        o = g * (1.0f - t * t) * (drop ? drop[row] : 1.0f);
+        if (gres && c < rs) gres[row * rs + c] = c == 0 ? g : 0.0f;
+    }
+    G[idx] = o;
+}
+
 inline int lanes_per_node(int h) { return h / 4; }
 inline bool h_ok(int h) { return h == 8 || h == 16 || h == 32 || h == 64 || h == 128; }
 
@@ -347,6 +368,17 @@ extern "C" int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, i
     if (N <= 0) return QT_OK;
     const int grid = qt_lstm_bwd_blocks(N, h);
     QT_DISPATCH_LPN(h, k_head_bwd, grid, stream, gZ, O, ln_o, N, n_dev, h, hp, gO, gconcat, part, accumulate);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_act_bwd(const float* gY, const float* Y, const float* res, int res_stride, const float* drop, int act, int N,
+                          const int32_t* n_dev, int Co, float* G, float* gres, void* stream) {
+    QT_ARG(gY && Y && G && Co >= 1, "null pointer");
+    QT_ARG(act == QT_ACT_RELU || (act == QT_ACT_TANH_RES && res && res_stride >= 1 && res_stride <= Co), "bad activation arguments");
+    if (N <= 0) return QT_OK;
+    hipLaunchKernelGGL(k_act_bwd, dim3(qt_cdiv((int64_t)N * Co, 256)), dim3(256), 0, (hipStream_t)stream, gY, Y, res, res_stride,
+                       drop, act, N, n_dev, Co, G, gres);
     QT_LAUNCHED();
     return QT_OK;
 }

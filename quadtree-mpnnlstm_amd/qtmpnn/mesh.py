@@ -17,6 +17,7 @@ CONDITIONS = ('max_larger_than', 'max_smaller_than', 'min_larger_than', 'min_sma
 
 
 _MASKS = {}
+_ONES1 = {}
 
 
 def _as_u8(a, device, shape):
@@ -94,6 +95,15 @@ class Mesh:
     # -- T_k(L^) 1 for the bias terms of stacked ChebConvs ------------------------
     def cheb_ones(self, ks):
         """(N, 4*ceil(ks/4)) matrix [1, L^1, T_2(L^)1, ... | 0-pad] (fp32; padded so rows are float4 operands)."""
+        if ks == 1:                      # [1 0 0 0] does not depend on the mesh: one constant per (rows, device)
+            key = (self.N, str(self.labels.device))
+            if key not in _ONES1:
+                if len(_ONES1) > 8:
+                    _ONES1.clear()
+                c = torch.zeros(self.N, 4, device=self.labels.device)
+                c[:, 0] = 1.0
+                _ONES1[key] = c
+            return _ONES1[key]
         if ks not in self._ones:
             cols = [torch.ones(self.N, device=self.labels.device)]
             for k in range(1, ks):
@@ -211,9 +221,10 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
     """Node features and CSR adjacency of a mesh whose labels / level / cell / node_off are in place."""
     N, n, m, B = ms.N, ms.n, ms.m, ms.B
     i32 = dict(dtype=torch.int32, device=device)
-    alloc = torch.zeros if nd is not None else torch.empty      # static mode: capacity rows beyond N stay finite
-    ms.posfeat = alloc(N, 3, device=device)
-    ms.npix = alloc(N, device=device)
+    # static mode: rows beyond the valid count stay uninitialised -- every consumer is row local (pinned by
+    # tests/test_gpu_ops.py::test_static_mode_ignores_capacity_rows)
+    ms.posfeat = torch.empty(N, 3, device=device)
+    ms.npix = torch.empty(N, device=device)
     ms.rowptr = torch.zeros(N + 1, **i32) if N == 0 else torch.empty(N + 1, **i32)   # k_edges_fill writes every entry
     ms.dis = torch.empty(N, device=device)
     if N == 0:

@@ -121,17 +121,15 @@ class _ChebPoly(Function):
         Co = W.shape[1]
         G = _c(gY.float())
         gres = None
-        if act == ACT_RELU:
-            G = G * (Y > 0)
-        elif act == ACT_TANH_RES:
-            t = Y - res[:, :1]
-            if ctx.needs_input_grad[2]:
-                gres = torch.zeros_like(res)
-                gres[:, :1] = G[:, :1]
-            G = G * (1.0 - t * t)
-            if drop is not None:
-                G = G * drop.view(-1, 1)
-        G = _c(G)
+        if act != ACT_NONE:
+            gin = G
+            G = torch.empty_like(gin)
+            if act == ACT_TANH_RES and ctx.needs_input_grad[2]:
+                assert res.is_contiguous() and res.shape[1] <= Co
+                gres = torch.empty_like(res)
+            if N > 0:
+                _lib.call('qt_act_bwd', ptr(gin), ptr(Y), ptr(res), res.stride(0) if res is not None else 0, ptr(drop), act, N,
+                          ptr(mesh.n_dev), Co, ptr(G), ptr(gres))
         gZ = None
         if ctx.needs_input_grad[0] and N > 0:
             if ctx.acc is None:
