@@ -173,6 +173,12 @@ int qt_head_fwd(const float* O, const float* ln_o /* (2,h) */, const float* conc
 int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, const int32_t* n_dev, int h, int hp,
                 float* gO, float* gconcat, float* part, int accumulate, void* stream);
 
+/* out (N, sum widths) = [src_0 | src_1 | ...] for up to 8 row-strided fp32 sources (host arrays of nsrc device pointers,
+ * widths and row strides, all multiples of 4): Z = [X | H] of GConvLSTM (model/model.py:394-424 feed X and H to separate
+ * convolutions; here they share one Chebyshev pass) and the re-mesh state matrix. */
+int qt_concat(const float* const* srcs, const int* widths, const int* lds, int nsrc, int N, const int32_t* n_dev,
+              float* out, void* stream);
+
 /* backward of the qt_dense epilogue activations: G = gY * act'(Y) (QT_ACT_RELU, QT_ACT_TANH_RES with res / drop as in
  * qt_dense); gres (N, res_stride) or NULL receives the gradient of the residual operand (column 0 = gY[:, 0], rest 0). */
 int qt_act_bwd(const float* gY, const float* Y, const float* res, int res_stride, const float* drop, int act, int N,

@@ -228,7 +228,7 @@ class GConvLSTM(nn.Module):
             G = torch.cat([getattr(self, f'conv_x_{g}')(X, mesh) + getattr(self, f'conv_h_{g}')(Hz, mesh)
                            for g in self.GATES], dim=1)
             return ops.lstm_cell(G, C, pk.wc, pk.b, pk.ln, mesh, pk.acc_p)
-        Z = torch.cat([X, H], dim=1) if H is not None else X
+        Z = ops.concat_cols([X, H], mesh) if H is not None else X
         G = ops.cheb_poly(Z, pk.W, mesh, pk.K, pk.Ks, acc=pk.acc_w)
         return ops.lstm_cell(G, C, pk.wc, pk.b, pk.ln, mesh, pk.acc_p)
 

@@ -280,11 +280,11 @@ class Seq2Seq(nn.Module):
             img0 = teacher_input[..., 0].reshape(old.B, old.n, old.m).float()
             new = self._mesh_from_image(img0, mask, high_interest_region)
             val = ops.pool_image(img0.reshape(old.B, 1, old.P, 1), new, True)[0]
-            state = torch.cat([*hidden, *cell], dim=1)
+            state = ops.concat_cols([*hidden, *cell], old)
             parts = ops.remesh_transfer(state, old, new).split([h] * (2 * L), dim=1)
         else:
             new = self._mesh_from_nodes(data, old, mask, high_interest_region)
-            state = torch.cat([data.expand(-1, 4), *hidden, *cell], dim=1)   # 4 copies of the output keep rows float4-sized
+            state = ops.concat_cols([data.expand(-1, 4).contiguous(), *hidden, *cell], old)   # 4 copies of the output keep rows float4-sized
             # ONE split (its backward is one concat; separate slices would each zero-fill a full (N, 4+2Lh) gradient)
             val4, *parts = ops.remesh_transfer(state, old, new).split([4] + [h] * (2 * L), dim=1)
             val = val4[:, :1]

@@ -79,6 +79,41 @@ class GradAcc:
         return True
 
 
+# ------------------------------------------------------------------------------ column concatenation
+class _ConcatCols(Function):
+    """[t_0 | t_1 | ...] for 2-D fp32 node matrices (row-strided views welcome); backward = column views, no copy."""
+
+    @staticmethod
+    def forward(ctx, mesh, *ts):
+        import ctypes
+        ops_ = [_rows(t.float()) for t in ts]
+        N = ts[0].shape[0]
+        widths = [t.shape[1] for t in ts]
+        out = ts[0].new_empty(N, sum(widths))
+        n = len(ts)
+        srcs = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in ops_])
+        w = (ctypes.c_int * n)(*widths)
+        lds = (ctypes.c_int * n)(*[ld for _, ld in ops_])
+        _lib.call('qt_concat', srcs, w, lds, n, N, ptr(mesh.n_dev) if mesh is not None else None, ptr(out))
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for w in ctx.widths:
+            outs.append(g[:, o:o + w])
+            o += w
+        return (None, *outs)
+
+
+def concat_cols(tensors, mesh=None):
+    """Column concatenation on the custom kernel when every width is a multiple of 4 (else torch.cat)."""
+    if len(tensors) <= 8 and all(t.dim() == 2 and t.shape[1] % 4 == 0 and t.is_cuda for t in tensors):
+        return _ConcatCols.apply(mesh, *tensors)
+    return torch.cat(tensors, dim=1)
+
+
 # ------------------------------------------------------------------------------ ChebConv stacks
 class _ChebPoly(Function):
     """Y = act( sum_k T_k(L^) Z M_k + S Bm ),  W = [M_0; ...; M_{K-1}; Bm]  ((K*C + Ks), Co).
