@@ -118,6 +118,11 @@ int qt_pool(const float* img, int S, int64_t img_clip_stride /* floats between c
 int qt_sse(const float* out, int out_stride, const int32_t* labels, const float* y, int64_t y_clip_stride,
            int B, int n, int m, float* partial /* B*ceil(P/1024) */, void* stream);
 
+/* gradient of the qt_sse partial sums with respect to the node values, written as full rows of width W (column 0 carries
+ * the value, the rest zeros): gout[i, 0] = 2 * g[0] * (npix[i] * out[i * out_stride] - sy[i]), sy = per-node sum of y. */
+int qt_sse_bwd(const float* out, int out_stride, const float* npix, const float* sy, const float* g, int N,
+               const int32_t* n_dev, int W, float* gout, void* stream);
+
 /* ---------------------------------------------------------------- message passing (ChebConv)
  * qt_spmm (the message-aggregate kernel; PyG MessagePassing.propagate of ChebConv, model/model.py:53,96):
  *   out[i,:] = alpha * sum_e nrm[e] * x[col[e],:] + beta * p[i,:] + gamma * q[i,:]      (p, q may be NULL)
@@ -159,7 +164,7 @@ int qt_lstm_fwd(const float* G, const float* Cprev, int ld_c /* row stride of Cp
                 const float* b, const float* ln,
                 int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw,
                 void* stream);
-/* gO may be NULL.  part: (nblk, 11*h) partial sums [g_wc(3h) | g_b(4h) | g_ln(4h)], nblk = qt_lstm_bwd_blocks(N, h) */
+/* gO, gHn, gCn may each be NULL (that output was not used: zero gradient).  part: (nblk, 11*h) partial sums [g_wc(3h) | g_b(4h) | g_ln(4h)], nblk = qt_lstm_bwd_blocks(N, h) */
 int qt_lstm_bwd_blocks(int N, int h);
 int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,   /* row strides */
                 const float* gates, const float* Craw, const float* Cprev, int ld_c, const float* wc, const float* ln,

@@ -14,9 +14,13 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
                                               const float* __restrict__ nrm, int Ncap, const int32_t* __restrict__ n_dev,
                                               int C, const float* __restrict__ x, float alpha, const float* p, float beta,
                                               const float* q, float gamma,
-                                              float* out) {  // out may alias p or q (in-place Clenshaw step)
+                                              float* out,    // out may alias p or q (in-place Clenshaw step)
+                                              int xcd_chunk) {
     const int nch = C / VEC;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with a private L2.  Giving XCD x the contiguous node range
+    // [x * chunk, (x+1) * chunk) keeps a node's neighbours (close in the reversed-Morton order) in the L2 that reads them.
+    const int blk = xcd_chunk ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int64_t idx = (int64_t)blk * 256 + threadIdx.x;
     const int64_t row = idx / nch;
     if (row >= qt_rows(n_dev, Ncap)) return;
     const int ch = (int)(idx % nch) * VEC;
@@ -494,11 +498,17 @@ extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* n
     if (N <= 0) return QT_OK;
     const bool v4 = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)p | (uintptr_t)q) % 16) == 0);
     const int nch = v4 ? C / 4 : C;
-    const int grid = qt_cdiv((int64_t)N * nch, 256);
+    int grid = qt_cdiv((int64_t)N * nch, 256);
+    static const bool xcd = getenv("QT_SPMM_FLAT") == nullptr;
+    int chunk = 0;
+    if (xcd && grid >= 64) {
+        chunk = qt_cdiv(grid, 8);
+        grid = chunk * 8;           // surplus workgroups fall past the row count and exit
+    }
     if (v4)
-        hipLaunchKernelGGL(k_spmm<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, C, x, alpha, p, beta, q, gamma, out);
+        hipLaunchKernelGGL(k_spmm<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, C, x, alpha, p, beta, q, gamma, out, chunk);
     else
-        hipLaunchKernelGGL(k_spmm<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, C, x, alpha, p, beta, q, gamma, out);
+        hipLaunchKernelGGL(k_spmm<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, C, x, alpha, p, beta, q, gamma, out, chunk);
     QT_LAUNCHED();
     return QT_OK;
 }

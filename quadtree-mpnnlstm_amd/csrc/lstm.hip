@@ -184,7 +184,9 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, 
             tc.v[k] = tanhf(Cr.v[k]);
             Hr.v[k] = Og.v[k] * tc.v[k];
         }
-        const F4 gyh = ld4(gHn + node * ld_gh + j0), gyc = ld4(gCn + node * ld_gc + j0);
+        F4 gyh = {{0, 0, 0, 0}}, gyc = {{0, 0, 0, 0}};      // an output nobody used has no gradient
+        if (gHn) gyh = ld4(gHn + node * ld_gh + j0);
+        if (gCn) gyc = ld4(gCn + node * ld_gc + j0);
         F4 xh = {{0, 0, 0, 0}}, xc = {{0, 0, 0, 0}};
         F4 gHr = gyh, gCr = gyc;
         if (ln) {
@@ -358,11 +360,11 @@ extern "C" int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_
                            const float* gates, const float* Craw, const float* Cprev, int ld_c, const float* wc,
                            const float* ln, int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part,
                            int accumulate, void* stream) {
-    QT_ARG(gHn && gCn && gates && Craw && wc && gG && part, "null pointer");
+    QT_ARG(gates && Craw && wc && gG && part, "null pointer");
     QT_ARG(h_ok(h), "hidden size must be 8, 16, 32, 64 or 128");
     if (N <= 0) return QT_OK;
     const int grid = qt_lstm_bwd_blocks(N, h);
-    QT_ARG(ld_gh >= h && ld_gc >= h && ld_gh % 4 == 0 && ld_gc % 4 == 0 && ld_go % 4 == 0 && ld_c % 4 == 0, "bad row stride");
+    QT_ARG((!gHn || ld_gh >= h) && (!gCn || ld_gc >= h) && ld_gh % 4 == 0 && ld_gc % 4 == 0 && ld_go % 4 == 0 && ld_c % 4 == 0, "bad row stride");
     QT_DISPATCH_LPN(h, k_lstm_bwd, grid, stream, gO, gHn, gCn, gates, Craw, Cprev, wc, ln, N, n_dev, h, ld_go, ld_gh, ld_gc,
                     ld_c, gG, gCprev, part, accumulate);
     QT_LAUNCHED();

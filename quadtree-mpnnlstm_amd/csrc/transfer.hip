@@ -224,7 +224,26 @@ __global__ __launch_bounds__(256) void k_sse(const float* __restrict__ out, int 
     if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+__global__ void k_sse_bwd(const float* __restrict__ out, int out_stride, const float* __restrict__ npix,
+                          const float* __restrict__ sy, const float* __restrict__ g, int Ncap, const int32_t* __restrict__ n_dev,
+                          int W, float* __restrict__ gout) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = idx / W;
+    if (i >= qt_rows(n_dev, Ncap)) return;
+    gout[idx] = (idx - i * W) == 0 ? 2.0f * g[0] * (npix[i] * out[i * out_stride] - sy[i]) : 0.0f;
+}
+
 }  // namespace
+
+extern "C" int qt_sse_bwd(const float* out, int out_stride, const float* npix, const float* sy, const float* g, int N,
+                          const int32_t* n_dev, int W, float* gout, void* stream) {
+    QT_ARG(out && npix && sy && g && gout && W >= 1 && out_stride >= 1, "bad arguments");
+    if (N <= 0) return QT_OK;
+    hipLaunchKernelGGL(k_sse_bwd, dim3(qt_cdiv((int64_t)N * W, 256)), dim3(256), 0, (hipStream_t)stream, out, out_stride, npix,
+                       sy, g, N, n_dev, W, gout);
+    QT_LAUNCHED();
+    return QT_OK;
+}
 
 extern "C" int qt_gather(const float* val, int C, const int32_t* labels, const float* inv_npix, int64_t npixels_total,
                          float* img, void* stream) {

@@ -126,6 +126,7 @@ class Decoder(nn.Module):
             y = torch.tanh(y if drop is None else y * drop.unsqueeze(1)) + X[:, :1]
             return (torch.sigmoid(y) if self.binary else y), hs, cs
         z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'])
+        # the head GEMM writes float4 rows; column 0 is the prediction (the rest is tanh(0) + X[:, 0], never read as data)
         y = ops.cheb_poly(z, pk['fc2'], mesh, self.fc_out2.K, 1, ops.ACT_TANH_RES, res=X, drop=drop, acc=pk['acc2'])[:, :1]
         if self.binary:
             y = torch.sigmoid(y)
@@ -281,12 +282,16 @@ class Seq2Seq(nn.Module):
             new = self._mesh_from_image(img0, mask, high_interest_region)
             val = ops.pool_image(img0.reshape(old.B, 1, old.P, 1), new, True)[0]
             state = ops.concat_cols([*hidden, *cell], old)
-            parts = ops.remesh_transfer(state, old, new).split([h] * (2 * L), dim=1)
+            parts = ops.split_cols(ops.remesh_transfer(state, old, new), [h] * (2 * L), new)
         else:
             new = self._mesh_from_nodes(data, old, mask, high_interest_region)
-            state = ops.concat_cols([data.expand(-1, 4).contiguous(), *hidden, *cell], old)   # 4 copies of the output keep rows float4-sized
+            # rows stay float4-sized: the head's own 4-wide output when `data` is its column 0, else 4 copies
+            b4 = data._base
+            wide = (b4 is not None and b4.dim() == 2 and b4.shape == (data.shape[0], 4) and b4.is_contiguous()
+                    and data.storage_offset() == b4.storage_offset() and data.stride(0) == 4)
+            state = ops.concat_cols([b4 if wide else data.expand(-1, 4).contiguous(), *hidden, *cell], old)
             # ONE split (its backward is one concat; separate slices would each zero-fill a full (N, 4+2Lh) gradient)
-            val4, *parts = ops.remesh_transfer(state, old, new).split([4] + [h] * (2 * L), dim=1)
+            val4, *parts = ops.split_cols(ops.remesh_transfer(state, old, new), [4] + [h] * (2 * L), new)
             val = val4[:, :1]
         g.hidden, g.cell = list(parts[:L]), list(parts[L:])
         g.pyg.x = torch.cat([val, new.posfeat], dim=-1)

@@ -107,6 +107,29 @@ class _ConcatCols(Function):
         return (None, *outs)
 
 
+class _SplitCols(Function):
+    """Column split of a node matrix into views; the backward is ONE concat kernel (torch's split backward is a
+    batched cat that moves these narrow rows at ~0.6 TB/s)."""
+
+    @staticmethod
+    def forward(ctx, t, mesh, *widths):
+        ctx.mesh, ctx.widths, ctx.rows = mesh, widths, t.shape[0]
+        ctx.set_materialize_grads(False)
+        return tuple(t.split(list(widths), dim=1))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        gs = [g if g is not None else ref.new_zeros(ctx.rows, w) for g, w in zip(gs, ctx.widths)]
+        return (concat_cols(gs, ctx.mesh), None) + (None,) * len(ctx.widths)
+
+
+def split_cols(t, widths, mesh=None):
+    if len(widths) <= 8 and all(w % 4 == 0 for w in widths) and t.is_cuda:
+        return _SplitCols.apply(t, mesh, *widths)
+    return t.split(list(widths), dim=1)
+
+
 def concat_cols(tensors, mesh=None):
     """Column concatenation on the custom kernel when every width is a multiple of 4 (else torch.cat)."""
     if len(tensors) <= 8 and all(t.dim() == 2 and t.shape[1] % 4 == 0 and t.is_cuda for t in tensors):
@@ -321,14 +344,14 @@ class _LstmCell(Function):
         ctx.save_for_backward(gates, Craw, Cprev, wc, ln)
         ctx.mesh, ctx.acc = mesh, acc
         ctx.use_idx = acc.enter() if acc is not None else 0
+        ctx.set_materialize_grads(False)         # an unused output arrives as None, not as a zero-filled (N, h) buffer
         return O, Hn, Cn
 
     @staticmethod
     def backward(ctx, gO, gHn, gCn):
         gates, Craw, Cprev, wc, ln = ctx.saved_tensors
         N, h = Craw.shape
-        (gHn, ld_gh), (gCn, ld_gc) = _rows(gHn if gHn is not None else torch.zeros_like(Craw)), \
-            _rows(gCn if gCn is not None else torch.zeros_like(Craw))
+        (gHn, ld_gh), (gCn, ld_gc) = _rows(gHn), _rows(gCn)
         (gO, ld_go), (Cprev, ld_c) = _rows(gO), _rows(Cprev)
         gG = torch.empty_like(gates)
         gCp = torch.empty_like(Craw) if Cprev is not None else None
@@ -507,7 +530,7 @@ class _StepSSE(Function):
 
     @staticmethod
     def forward(ctx, out, y, mesh):
-        assert out.dtype == torch.float32 and out.stride(1) == 1, 'out must be fp32 with unit column stride'
+        assert out.dtype == torch.float32 and out.is_contiguous(), 'out must be a contiguous fp32 matrix (column 0 is used)'
         # y: one output step of a (B, T, W, H, 1) tensor -- a strided view is fine (clip stride passed to the kernel)
         yv = y.reshape(mesh.B, mesh.P) if y.is_contiguous() else y
         if not (yv.dim() >= 2 and yv[0].is_contiguous() and yv.dtype == torch.float32):
@@ -526,11 +549,22 @@ class _StepSSE(Function):
     def backward(ctx, g):
         out, sy = ctx.saved_tensors
         mesh = ctx.mesh
-        # every partial has the same upstream gradient (they are only ever summed)
-        return (2.0 * g[:1]) * (mesh.npix.view(-1, 1) * out[:, :1] - sy[0]), None, None
+        # every partial has the same upstream gradient (they are only ever summed); full rows: column 0 = value
+        gout = torch.empty_like(out)
+        if mesh.N > 0:
+            _lib.call('qt_sse_bwd', ptr(out), out.stride(0), ptr(mesh.npix), ptr(sy), ptr(_c(g)), mesh.N, ptr(mesh.n_dev),
+                      out.shape[1], ptr(gout))
+        return gout, None, None
 
 
 def step_sse_partials(out, y, mesh):
+    """`out` (N, 1); when it is column 0 of a wider contiguous matrix (the head's 4-wide output) the op runs on that
+    matrix, so the gradient is written once as full rows instead of slice_backward's zero-fill + copy."""
+    base = out._base
+    if (base is not None and base.dim() == 2 and out.dim() == 2 and out.shape[1] == 1 and base.is_contiguous()
+            and base.shape[0] == out.shape[0] and out.storage_offset() == base.storage_offset()
+            and out.stride(0) == base.shape[1] and base.dtype == torch.float32):
+        out = base
     return _StepSSE.apply(out, y, mesh)
 
 

@@ -80,7 +80,7 @@ def make_batch(config_id, clip0, batch, t_in, t_out, **kw):
         c = make_clip(1000 * config_id + clip0 + i, n_frames=t_in + t_out, **kw)
         xs.append(c[:t_in])
         ys.append(c[-t_out:])
-    return np.stack(xs), np.stack(ys)
+    return np.ascontiguousarray(np.stack(xs)), np.ascontiguousarray(np.stack(ys))
 
 
 def make_ice_like(seed, shape=(128, 128), channels=5, n_frames=18):
