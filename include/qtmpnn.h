@@ -148,6 +148,12 @@ int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, const float* 
 int qt_wgrad_blocks(int N);
 int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, const float* S, int Ks,
              const float* G, int Co, int N, const int32_t* n_dev, int accumulate, float* part, void* stream);
+/* qt_wgrad for up to 16 uses of one weight (the rollout steps of a pass) in ONE launch: host arrays of nseg device
+ * pointers / capacities, shared (Ka, Ca, Ks, Co).  part: (qt_wgrad_group_blocks(nseg, N), Ka*Ca + Ks, Co), overwritten. */
+int qt_wgrad_group_blocks(int nseg, const int* N);
+int qt_wgrad_group(int nseg, const float* const* a0, const float* const* a_rest, const float* const* S,
+                   const float* const* G, const int* N, const int32_t* const* n_dev, int Ka, int Ca, int Ks, int Co,
+                   float* part, void* stream);
 /* out[j] = sum_i part[i*len + j], i < nblk */
 int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream);
 

@@ -388,11 +388,9 @@ __global__ __launch_bounds__(256) void k_gemm_fwd3(GemmArgs g) {
     }
 }
 
-// MODE 1: part[blockIdx.z] = A[rows]^T @ G[rows] over this block's row chunk.  Block = 128 features x 64
-// columns of the weight gradient, wave w owns features [32w, 32w+32); the reduction runs over node rows in
-// passes of 32 rows: float4 global loads -> registers (prefetch of the next pass) -> double-buffered LDS.
 constexpr int WR = 32;
-__global__ __launch_bounds__(256) void k_gemm_wgrad(GemmArgs g) {
+__device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __restrict__ G, int M, int NB, int64_t rbeg,
+                                           int64_t rend, float* obase, int accumulate) {
     __shared__ float As[2][WR][BM];
     __shared__ float Gs[2][WR][BN];
     __shared__ const float* qptr[MAXQ];
@@ -400,10 +398,8 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(GemmArgs g) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l32 = lane & 31, half = lane >> 5;
     const int f0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
-    const int64_t rbeg = (int64_t)blockIdx.z * g.row0_step;
-    const int64_t rend = min((int64_t)qt_rows(g.n_dev, g.A.N), rbeg + g.row0_step);
-    const int nquad = g.M >> 2;
-    build_quad_table(g.A, qptr, qstr, nquad);
+    const int nquad = M >> 2;
+    build_quad_table(A, qptr, qstr, nquad);
     __syncthreads();
     // staging roles: A tile = 32 rows x 32 quads -> 4 float4 per thread; G tile = 32 rows x 16 quads -> 2 per thread
     const int a_row = t >> 3, a_q = (t & 7) * 4;           // 4 consecutive quads of one row
@@ -422,7 +418,7 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(GemmArgs g) {
         for (int u = 0; u < 2; ++u) {
             const int jq = (g_q + u) * 4;
             pg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rg < rend && j0 + jq < g.NB) pg[u] = *reinterpret_cast<const float4*>(g.B + rg * g.NB + j0 + jq);
+            if (rg < rend && j0 + jq < NB) pg[u] = *reinterpret_cast<const float4*>(G + rg * NB + j0 + jq);
         }
     };
     auto stash = [&](int buf) {
@@ -453,23 +449,56 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(GemmArgs g) {
             buf ^= 1;
         }
     }
-    float* obase = g.out + (int64_t)blockIdx.z * g.M * g.NB;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
         const int j = j0 + jt * 32 + l32;
-        if (j >= g.NB) continue;
+        if (j >= NB) continue;
         float old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {      // all slab reads first: 16 independent loads in flight
             const int i = f0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            old[r] = (g.accumulate && i < g.M) ? obase[(int64_t)i * g.NB + j] : 0.0f;
+            old[r] = (accumulate && i < M) ? obase[(int64_t)i * NB + j] : 0.0f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = f0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (i < g.M) obase[(int64_t)i * g.NB + j] = old[r] + (jt == 0 ? acc0[r] : acc1[r]);
+            if (i < M) obase[(int64_t)i * NB + j] = old[r] + (jt == 0 ? acc0[r] : acc1[r]);
         }
     }
+}
+
+// MODE 1: part[blockIdx.z] = A[rows]^T @ G[rows] over this block's row chunk.  Block = 128 features x 64
+// columns of the weight gradient, wave w owns features [32w, 32w+32); the reduction runs over node rows in
+// passes of 32 rows: float4 global loads -> registers (prefetch of the next pass) -> double-buffered LDS.
+__global__ __launch_bounds__(256) void k_gemm_wgrad(GemmArgs g) {
+    const int64_t rbeg = (int64_t)blockIdx.z * g.row0_step;
+    const int64_t rend = min((int64_t)qt_rows(g.n_dev, g.A.N), rbeg + g.row0_step);
+    wgrad_body(g.A, g.B, g.M, g.NB, rbeg, rend, g.out + (int64_t)blockIdx.z * g.M * g.NB, g.accumulate);
+}
+
+// The same reduction for up to 16 uses of ONE weight in a single launch (the rollout steps of a pass): z-blocks
+// [zend[s-1], zend[s]) walk the node rows of use s; every z-block owns its slab, qt_colsum adds them in fixed order.
+constexpr int MAXSEG = 16;
+struct WgradGroup {
+    const float* a0[MAXSEG];
+    const float* a_rest[MAXSEG];
+    const float* S[MAXSEG];
+    const float* G[MAXSEG];
+    const int32_t* n_dev[MAXSEG];
+    int N[MAXSEG], zend[MAXSEG];
+    int nseg, Ka, Ca, Ks, Co, rows;
+    float* part;
+};
+__global__ __launch_bounds__(256) void k_gemm_wgrad_group(WgradGroup w) {
+    int s = 0;
+    while (s + 1 < w.nseg && (int)blockIdx.z >= w.zend[s]) ++s;
+    const int zl = blockIdx.z - (s ? w.zend[s - 1] : 0);
+    PlaneSrc A;
+    A.a0 = w.a0[s]; A.a_rest = w.a_rest[s]; A.S = w.S[s]; A.Ka = w.Ka; A.Ca = w.Ca; A.Ks = w.Ks; A.N = w.N[s];
+    const int M = w.Ka * w.Ca + w.Ks;
+    const int64_t rbeg = (int64_t)zl * w.rows;
+    const int64_t rend = min((int64_t)qt_rows(w.n_dev[s], w.N[s]), rbeg + w.rows);
+    wgrad_body(A, w.G[s], M, w.Co, rbeg, rend, w.part + (int64_t)blockIdx.z * M * w.Co, 0);
 }
 
 // 32 columns x 8 row groups per workgroup; fixed summation order (deterministic)
@@ -487,6 +516,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ part, 
 }
 
 constexpr int WGRAD_ROWS = 512;
+constexpr int WGRAD_GROUP_ROWS = 2048;
 
 }  // namespace
 
@@ -568,6 +598,41 @@ extern "C" int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, co
     g.accumulate = accumulate;
     hipLaunchKernelGGL(k_gemm_wgrad, dim3(qt_cdiv(g.M, BM), qt_cdiv(Co, BN), qt_cdiv(N, WGRAD_ROWS)), dim3(256), 0,
                        (hipStream_t)stream, g);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_wgrad_group_blocks(int nseg, const int* N) {
+    int z = 0;
+    for (int i = 0; i < nseg; ++i) z += N[i] > 0 ? qt_cdiv(N[i], WGRAD_GROUP_ROWS) : 0;
+    return z;
+}
+
+extern "C" int qt_wgrad_group(int nseg, const float* const* a0, const float* const* a_rest, const float* const* S,
+                              const float* const* G, const int* N, const int32_t* const* n_dev, int Ka, int Ca, int Ks, int Co,
+                              float* part, void* stream) {
+    QT_ARG(nseg >= 1 && nseg <= MAXSEG && a0 && G && N && n_dev && part, "1..16 uses per launch");
+    QT_ARG(Ka >= 1 && Ca >= 1 && Co >= 1 && (Ka == 1 || a_rest) && (Ks == 0 || S), "bad arguments");
+    QT_ARG(Ca % 4 == 0 && Ks % 4 == 0 && Co % 4 == 0, "Ca, Ks and Co must be multiples of 4 (float4 operands)");
+    QT_ARG((Ka * Ca + Ks) / 4 <= MAXQ, "reduction dimension too large (max 512)");
+    WgradGroup w;
+    int z = 0, k = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (N[i] <= 0) continue;
+        QT_ARG(a0[i] && G[i] && (Ka == 1 || a_rest[i]) && (Ks == 0 || S[i]), "null operand");
+        QT_ARG((((uintptr_t)a0[i] | (uintptr_t)(Ka > 1 ? a_rest[i] : nullptr) | (uintptr_t)(Ks ? S[i] : nullptr) | (uintptr_t)G[i]) & 15) == 0,
+               "operands must be 16-byte aligned");
+        w.a0[k] = a0[i]; w.a_rest[k] = Ka > 1 ? a_rest[i] : nullptr; w.S[k] = Ks ? S[i] : nullptr; w.G[k] = G[i];
+        w.n_dev[k] = n_dev[i]; w.N[k] = N[i];
+        z += qt_cdiv(N[i], WGRAD_GROUP_ROWS);
+        w.zend[k] = z;
+        ++k;
+    }
+    if (k == 0) return QT_OK;
+    for (int i = k; i < MAXSEG; ++i) { w.a0[i] = w.a_rest[i] = w.S[i] = w.G[i] = nullptr; w.n_dev[i] = nullptr; w.N[i] = 0; w.zend[i] = z; }
+    w.nseg = k; w.Ka = Ka; w.Ca = Ca; w.Ks = Ks; w.Co = Co; w.rows = WGRAD_GROUP_ROWS; w.part = part;
+    const int M = Ka * Ca + Ks;
+    hipLaunchKernelGGL(k_gemm_wgrad_group, dim3(qt_cdiv(M, BM), qt_cdiv(Co, BN), z), dim3(256), 0, (hipStream_t)stream, w);
     QT_LAUNCHED();
     return QT_OK;
 }

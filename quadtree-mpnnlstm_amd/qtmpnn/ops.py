@@ -54,10 +54,10 @@ class GradAcc:
     forward use -- the last one to run in the backward pass, because the recurrent state chains the uses --
     reduces the slabs and hands the gradient to autograd.
     """
-    __slots__ = ('uses', 'done', 'part', 'wt')
+    __slots__ = ('uses', 'done', 'part', 'wt', 'pending')
 
     def __init__(self):
-        self.uses, self.done, self.part, self.wt = 0, 0, None, None
+        self.uses, self.done, self.part, self.wt, self.pending = 0, 0, None, None, []
 
     def enter(self):
         self.uses += 1
@@ -220,14 +220,35 @@ class _ChebPoly(Function):
                     _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), ksp, ptr(G), Co, N, ptr(mesh.n_dev), 0, ptr(part))
                     _lib.call('qt_colsum', ptr(part), nblk, W.numel(), ptr(gW))
             else:
-                nblk = _lib.value('qt_wgrad_blocks', mesh.B * mesh.P)         # capacity: the same slab count for every mesh
-                part = acc.slab(Z, nblk, W.numel())
-                if N > 0:
-                    _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), ksp, ptr(G), Co, N, ptr(mesh.n_dev), 1, ptr(part))
+                # deferred: the weight gradient is off the critical path, so all uses of this pass (<= 16 per launch) are
+                # reduced together by the last backward -- one long launch instead of one short one per rollout step
+                acc.pending.append((Z, TZ, S, G, N, mesh.n_dev))
                 if acc.leave(ctx.use_idx):
-                    gW = torch.empty_like(W)
-                    _lib.call('qt_colsum', ptr(part), nblk, W.numel(), ptr(gW))
+                    gW = _wgrad_group(acc.pending, W, K, C, ksp, Co)
+                    acc.pending = []
         return gZ, gW, gres, None, None, None, None, None, None
+
+
+def _wgrad_group(uses, W, K, C, ksp, Co):
+    import ctypes
+    uses = [u for u in uses if u[4] > 0]
+    if not uses:
+        return torch.zeros_like(W)
+    chunks = [uses[i:i + 16] for i in range(0, len(uses), 16)]
+    counts = []
+    for ch in chunks:
+        Ns = (ctypes.c_int * len(ch))(*[u[4] for u in ch])
+        counts.append((Ns, _lib.value('qt_wgrad_group_blocks', len(ch), Ns)))
+    part = W.new_empty(sum(c for _, c in counts), W.shape[0], Co)
+    off = 0
+    for ch, (Ns, nb) in zip(chunks, counts):
+        vp = ctypes.c_void_p * len(ch)
+        arr = lambda i: vp(*[(u[i].data_ptr() if u[i] is not None else None) for u in ch])
+        _lib.call('qt_wgrad_group', len(ch), arr(0), arr(1), arr(2), arr(3), Ns, arr(5), K, C, ksp, Co, ptr(part[off:]))
+        off += nb
+    gW = torch.empty_like(W)
+    _lib.call('qt_colsum', ptr(part), part.shape[0], W.numel(), ptr(gW))
+    return gW
 
 
 def pad_bias_rows(W, Ks):
