@@ -105,13 +105,16 @@ int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, int
  *            value(p) = img[b, s, p, c] (src_labels == NULL; img laid out (B, S, n*m, C), out row = s*N + node)
  *                     = src_val[src_labels[b,p], c] * (src_inv ? 1/src_npix[..] : 1)     (remesh transfer,
  *                       seq2seq.py:440-442 + :474-477 fused; its backward swaps the roles of the meshes).
- * One workgroup per 64x64 tile and clip; deterministic (no atomics).
+ * cell == NULL: one workgroup per 64x64 tile and clip does every node.  cell (N, 4) = (row, col, size, clip) given:
+ * nodes of up to 4x4 pixels are reduced node by node (thread = node x float4 chunk, whole-row gathers and stores) and
+ * the tile kernel only handles nodes of 8x8 pixels and more.  Deterministic either way (fixed order, no atomics).
  */
 int qt_gather(const float* val, int C, const int32_t* labels, const float* inv_npix,
               int64_t npixels_total, float* img, void* stream);
 int qt_pool(const float* img, int S, int64_t img_clip_stride /* floats between clips, 0 = dense */, const float* src_val, const int32_t* src_labels, const float* src_npix, int src_inv,
             int C, const int32_t* labels, const uint8_t* level, const float* npix, int mean,
-            int B, int n, int m, int N, float* out, int out_stride, int out_coff, void* stream);
+            int B, int n, int m, int N, const int32_t* cell /* or NULL */, const int32_t* n_dev,
+            float* out, int out_stride, int out_coff, void* stream);
 
 /* masked MSE, model/mpnnlstm.py:243-246: partial[b*ntile + tile] = sum over the tile's unmasked pixels of
  * (out[labels[p]] - y[p])^2 ; y (B, n*m).  Pixels with label < 0 are the masked ones. */
