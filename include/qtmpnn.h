@@ -173,6 +173,12 @@ int qt_lstm_fwd(const float* G, const float* Cprev, int ld_c /* row stride of Cp
                 const float* b, const float* ln,
                 int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw,
                 void* stream);
+/* qt_dense (act none, Kb = 1, Cb = 4h) with qt_lstm_fwd as its epilogue, for hidden size 16: the gate pre-activations stay in
+ * LDS.  Same results as the two calls (same arithmetic in the same order). */
+int qt_dense_lstm(const float* a0, const float* a_rest, int Ka, int Ca, const float* W, const float* S, int Ks,
+                  const float* Ws, int h, int N, const int32_t* n_dev, const float* Cprev, int ld_c,
+                  const float* wc, const float* b, const float* ln, float* O, float* Hn, float* Cn,
+                  float* gates, float* Craw, void* stream);
 /* gO, gHn, gCn may each be NULL (that output was not used: zero gradient).  part: (nblk, 11*h) partial sums [g_wc(3h) | g_b(4h) | g_ln(4h)], nblk = qt_lstm_bwd_blocks(N, h) */
 int qt_lstm_bwd_blocks(int N, int h);
 int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,   /* row strides */

@@ -3,13 +3,18 @@
 //   k_gemm_fwd / k_gemm_wgrad -- fp32 MFMA (32x32x2) GEMMs: the gate GEMM Y = [T_0 .. T_{K-1} | S] W and its
 //              data gradient; the weight gradient split over row blocks
 //   k_colsum -- fixed-order reduction of per-block partial sums
-#include "qt_common.h"
+#include "qt_cell.h"
 #include <cstdlib>
 
 namespace {
 
 // ------------------------------------------------------------------ message aggregate
-template <int VEC>
+// Thread = (RPT consecutive rows) x (one VEC-wide channel chunk), chunk index fastest.  The kernel is a chain of three
+// dependent loads (rowptr -> col/nrm -> x rows) and is latency bound: at the bench shape (N = 1.2e5, C = 20) one row per
+// thread needs 9.2 workgroups per CU -- more than the 8 that are resident -- and the leftover second round cost a whole
+// extra chain (10.8 us against 8.0 us at C = 16).  Two rows per thread keep every launch of the path inside one
+// resident round with twice the loads in flight per thread.
+template <int VEC, int RPT, int EPT>
 __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                               const float* __restrict__ nrm, int Ncap, const int32_t* __restrict__ n_dev,
                                               int C, const float* __restrict__ x, float alpha, const float* p, float beta,
@@ -21,54 +26,100 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
     // [x * chunk, (x+1) * chunk) keeps a node's neighbours (close in the reversed-Morton order) in the L2 that reads them.
     const int blk = xcd_chunk ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int64_t idx = (int64_t)blk * 256 + threadIdx.x;
-    const int64_t row = idx / nch;
-    if (row >= qt_rows(n_dev, Ncap)) return;
-    const int ch = (int)(idx % nch) * VEC;
-    float acc[VEC];
+    const int64_t rp = idx / nch;
+    const int rows = qt_rows(n_dev, Ncap);
+    if (rp * RPT >= rows) return;
+    const int ch = (int)(idx - rp * nch) * VEC;
+    int e0[RPT], e1[RPT];
+    int64_t row[RPT];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-    const int e1 = rowptr[row + 1];
-    // 4 edges per trip: the index/weight loads, then the 4 neighbour gathers, are independent and stay in flight
-    // together (quadtree rows have ~4 neighbours, so most rows finish in one trip).  Tried and rejected (round 1):
-    // staging each 64-row run of the reversed-Morton node order in LDS so that the ~87 % internal neighbours are
-    // LDS reads -- 12.2 us vs 11.2 us per launch at N = 1.2e5, C = 20: the gather is not L2-bandwidth bound.
-    for (int e = rowptr[row]; e < e1; e += 4) {
-        int cj[4];
-        float w[4];
+    for (int u = 0; u < RPT; ++u) {
+        row[u] = rp * RPT + u;
+        const bool ok = row[u] < rows;
+        if (!ok) row[u] = rows - 1;                // duplicate of a valid row; its result is not stored
+        e0[u] = ok ? rowptr[row[u]] : 0;
+        e1[u] = ok ? rowptr[row[u] + 1] : 0;
+    }
+    float acc[RPT][VEC];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool ok = e + u < e1;
-            cj[u] = ok ? col[e + u] : (int)row;
-            w[u] = ok ? nrm[e + u] : 0.0f;
+    for (int u = 0; u < RPT; ++u)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[u][k] = 0.0f;
+    // 4 edges per trip: the index/weight loads, then the neighbour gathers, are independent and stay in flight together
+    // (quadtree rows have ~4 neighbours, so most rows finish in the first trip, which is issued for all RPT rows at once).
+    // Tried and rejected (round 1): staging each 64-row run of the reversed-Morton node order in LDS so that the ~87 %
+    // internal neighbours are LDS reads -- 12.2 us vs 11.2 us per launch at N = 1.2e5, C = 20.
+    auto trip = [&](const int (&eb)[RPT], bool (&more)[RPT]) {
+        int cj[RPT][EPT];
+        float w[RPT][EPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u)
+#pragma unroll
+            for (int v = 0; v < EPT; ++v) {
+                const bool ok = eb[u] + v < e1[u];
+                cj[u][v] = ok ? col[eb[u] + v] : (int)row[u];
+                w[u][v] = ok ? nrm[eb[u] + v] : 0.0f;
+            }
+        if constexpr (VEC == 4) {
+            float4 f[RPT][EPT];
+#pragma unroll
+            for (int u = 0; u < RPT; ++u)
+#pragma unroll
+                for (int v = 0; v < EPT; ++v) f[u][v] = *reinterpret_cast<const float4*>(x + (int64_t)cj[u][v] * C + ch);
+#pragma unroll
+            for (int u = 0; u < RPT; ++u)
+#pragma unroll
+                for (int v = 0; v < EPT; ++v) {
+                    acc[u][0] += w[u][v] * f[u][v].x; acc[u][1] += w[u][v] * f[u][v].y;
+                    acc[u][2] += w[u][v] * f[u][v].z; acc[u][3] += w[u][v] * f[u][v].w;
+                }
+        } else {
+            float f[RPT][EPT];
+#pragma unroll
+            for (int u = 0; u < RPT; ++u)
+#pragma unroll
+                for (int v = 0; v < EPT; ++v) f[u][v] = x[(int64_t)cj[u][v] * C + ch];
+#pragma unroll
+            for (int u = 0; u < RPT; ++u)
+#pragma unroll
+                for (int v = 0; v < EPT; ++v) acc[u][0] += w[u][v] * f[u][v];
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) more[u] = eb[u] + EPT < e1[u];
+    };
+    int eb[RPT];
+    bool more[RPT];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        eb[u] = e0[u];
+        any |= e0[u] < e1[u];
+    }
+    while (any) {
+        trip(eb, more);
+        any = false;
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            eb[u] = more[u] ? eb[u] + EPT : e1[u];       // a finished row keeps an empty edge range
+            any |= more[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        if (rp * RPT + u >= rows) continue;
+        const int64_t o = row[u] * C + ch;
+        float r[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            r[k] = alpha * acc[u][k];
+            if (p) r[k] += beta * p[o + k];
+            if (q) r[k] += gamma * q[o + k];
         }
         if constexpr (VEC == 4) {
-            float4 f[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) f[u] = *reinterpret_cast<const float4*>(x + (int64_t)cj[u] * C + ch);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc[0] += w[u] * f[u].x; acc[1] += w[u] * f[u].y; acc[2] += w[u] * f[u].z; acc[3] += w[u] * f[u].w;
-            }
+            *reinterpret_cast<float4*>(out + o) = make_float4(r[0], r[1], r[2], r[3]);
         } else {
-            float f[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) f[u] = x[(int64_t)cj[u] * C + ch];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[0] += w[u] * f[u];
+            out[o] = r[0];
         }
-    }
-    const int64_t o = row * C + ch;
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        float r = alpha * acc[k];
-        if (p) r += beta * p[o + k];
-        if (q) r += gamma * q[o + k];
-        acc[k] = r;
-    }
-    if constexpr (VEC == 4) {
-        *reinterpret_cast<float4*>(out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    } else {
-        out[o] = acc[0];
     }
 }
 
@@ -104,6 +155,13 @@ struct GemmArgs {
     int64_t row0_step;  // wgrad: rows per block
     const int32_t* n_dev;  // valid node rows on the device (NULL: A.N)
     int accumulate;        // wgrad: add into part instead of overwriting (sums several uses of one weight)
+    // gate GEMM with the LSTM cell as its epilogue (k_gemm_fwd<2, 128, true>): the (N, 4h) pre-activations never leave LDS
+    const float* Cprev;
+    const float* wc;
+    const float* bias;
+    const float* ln;
+    int ld_c, h;
+    float *O, *Hn, *Cn, *gates, *Craw;
 };
 
 // ---- fp32 MFMA tiles (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 64 FLOP/clk/SIMD).
@@ -144,7 +202,7 @@ __device__ __forceinline__ void build_quad_table(const PlaneSrc& A, const float*
 // MODE 0: out planes = act(A @ W).  Block = 128 node rows x (32 NT) output columns, wave w owns rows [32w, 32w+32).
 // A fragments go global -> VGPR directly (float4 per lane and k-quad); only W is staged in LDS (KWT x 32 NT floats).
 // NT = 2 for NB <= 64 (gate GEMM), NT = 4 for wide outputs (the data gradient, NB = K*C) so A is read only once.
-template <int NT, int KWT>
+template <int NT, int KWT, bool CELL = false>
 __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgroups per CU: all N/128 blocks of the
                                                                       // bench shape are resident at once (<= 128 registers)
     constexpr int BNT = 32 * NT;
@@ -216,9 +274,51 @@ __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgr
             }
         }
     }
+    float* Cs = Bt;                              // 128 rows x 64 columns per pass
+    if constexpr (CELL) {
+        // LSTM epilogue (h = 16: four adjacent lanes own a node, as in k_lstm_fwd).  The 128 x 64 gate tile goes through
+        // LDS in two halves of 64 rows with a row pitch of 80 floats: the 4 rows a 16-lane ds_read_b128 phase touches
+        // then start 16 banks apart.  Same arithmetic, in the same order, as qt_dense followed by qt_lstm_fwd.
+        static_assert(NT == 2, "the fused cell needs all four gates of a node in one block");
+        constexpr int CP = 80;
+        static_assert(BNT * PITCH >= 64 * CP, "LDS staging tile does not fit in the W buffer");
+        using namespace qtcell;
+        const int h = g.h;                       // == 16
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            __syncthreads();
+            if ((wave >> 1) == hf) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Cs[((wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + u * 32 + l32] = acc[u][r];
+            }
+            __syncthreads();
+            const int row = t >> 2, j0 = (t & 3) * 4;
+            const int64_t node = i0 + hf * 64 + row;
+            const bool ok = node < rows;
+            const float* cs = Cs + row * CP + j0;
+            const F4 gi = ld4(cs), gf = ld4(cs + h), gc = ld4(cs + 2 * h), go = ld4(cs + 3 * h);
+            F4 cp = {{0, 0, 0, 0}};
+            if (ok && g.Cprev) cp = ld4(g.Cprev + node * g.ld_c + j0);
+            const CellOut r = cell_forward<4>(gi, gf, gc, go, cp, g.wc, g.bias, g.ln, h, j0);
+            if (ok) {
+                st4(g.O + node * h + j0, r.Og);
+                st4(g.Hn + node * h + j0, r.hn);
+                st4(g.Cn + node * h + j0, r.cn);
+                float* gs = g.gates + node * 4 * h + j0;
+                st4(gs, r.I);
+                st4(gs + h, r.F);
+                st4(gs + 2 * h, r.T);
+                st4(gs + 3 * h, r.Og);
+                st4(g.Craw + node * h + j0, r.Cr);
+            }
+        }
+        return;
+    }
     // Epilogue: an MFMA accumulator holds one COLUMN per lane; staging the tile in LDS (the W buffer is free now) lets
     // every thread write float4 pieces of output ROWS instead (4x fewer, 16-byte wide, row-contiguous stores).
-    float* Cs = Bt;                              // 128 rows x 64 columns per pass
     static_assert(BNT * PITCH >= BM * 64, "LDS staging tile does not fit in the W buffer");
 #pragma unroll
     for (int h2 = 0; h2 < NT / 2; ++h2) {        // two 32-column MFMA tiles per pass
@@ -535,10 +635,14 @@ extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* n
         chunk = qt_cdiv(grid, 8);
         grid = chunk * 8;           // surplus workgroups fall past the row count and exit
     }
-    if (v4)
-        hipLaunchKernelGGL(k_spmm<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, C, x, alpha, p, beta, q, gamma, out, chunk);
-    else
-        hipLaunchKernelGGL(k_spmm<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, C, x, alpha, p, beta, q, gamma, out, chunk);
+    // Edges per trip: a trip is two dependent loads (col/nrm, then the x rows), and the few rows with many neighbours
+    // (a 4x4 cell next to 1x1 cells has 16) set the length of the whole launch.  8 per trip: 6.6 -> 4.5 us at C = 4,
+    // 9.3 -> 7.5 us at C = 16 (N = 1.2e5, inside a hipGraph); wider rows are bandwidth bound and prefer fewer registers.
+#define QT_SPMM_LAUNCH(V, R, E) hipLaunchKernelGGL((k_spmm<V, R, E>), dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, C, x, alpha, p, beta, q, gamma, out, chunk)
+    if (v4 && C <= 20) QT_SPMM_LAUNCH(4, 1, 8);
+    else if (v4) QT_SPMM_LAUNCH(4, 1, 4);
+    else QT_SPMM_LAUNCH(1, 1, 8);
+#undef QT_SPMM_LAUNCH
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -556,7 +660,7 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
     QT_ARG((((uintptr_t)a0 | (uintptr_t)a_rest | (uintptr_t)S | (uintptr_t)W) & 15) == 0, "operands must be 16-byte aligned");
     QT_ARG(act != QT_ACT_TANH_RES || res, "QT_ACT_TANH_RES needs res");
     if (N <= 0) return QT_OK;
-    GemmArgs g;
+    GemmArgs g = {};
     g.A.a0 = a0; g.A.a_rest = a_rest; g.A.S = S; g.A.Ka = Ka; g.A.Ca = Ca; g.A.Ks = Ks; g.A.N = N;
     g.B = W; g.M = N; g.K = Ka * Ca + Ks; g.NB = Kb * Cb;
     g.Kb = Kb; g.Cb = Cb; g.act = act; g.res = res; g.res_stride = res_stride; g.drop = drop; g.out = out; g.row0_step = 0; g.n_dev = n_dev; g.accumulate = 0;
@@ -578,6 +682,32 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
     return QT_OK;
 }
 
+extern "C" int qt_dense_lstm(const float* a0, const float* a_rest, int Ka, int Ca, const float* W, const float* S, int Ks,
+                             const float* Ws, int h, int N, const int32_t* n_dev, const float* Cprev, int ld_c,
+                             const float* wc, const float* b, const float* ln, float* O, float* Hn, float* Cn,
+                             float* gates, float* Craw, void* stream) {
+    QT_ARG(a0 && W && wc && b && O && Hn && Cn && gates && Craw && Ka >= 1 && Ca >= 1, "bad arguments");
+    QT_ARG(h == 16, "the fused gate GEMM + cell covers hidden size 16 (use qt_dense + qt_lstm_fwd otherwise)");
+    QT_ARG(Ka == 1 || a_rest, "a_rest missing");
+    QT_ARG((Ks == 0) || (S && Ws), "S / Ws missing");
+    QT_ARG(Ks == 0 || Ws == W + (int64_t)Ka * Ca * 4 * h, "Ws must follow W contiguously ([W ; Ws] is one matrix)");
+    QT_ARG(Ca % 4 == 0 && Ks % 4 == 0, "Ca and Ks must be multiples of 4 (float4 operands)");
+    QT_ARG((Ka * Ca + Ks) / 4 <= MAXQ, "reduction dimension too large (max 512)");
+    QT_ARG((((uintptr_t)a0 | (uintptr_t)a_rest | (uintptr_t)S | (uintptr_t)W | (uintptr_t)Cprev) & 15) == 0 && ld_c % 4 == 0,
+           "operands must be 16-byte aligned");
+    if (N <= 0) return QT_OK;
+    GemmArgs g = {};
+    g.A.a0 = a0; g.A.a_rest = a_rest; g.A.S = S; g.A.Ka = Ka; g.A.Ca = Ca; g.A.Ks = Ks; g.A.N = N;
+    g.B = W; g.M = N; g.K = Ka * Ca + Ks; g.NB = 4 * h;
+    g.Kb = 1; g.Cb = 4 * h; g.act = QT_ACT_NONE; g.res = nullptr; g.res_stride = 0; g.drop = nullptr; g.out = nullptr;
+    g.row0_step = 0; g.n_dev = n_dev; g.accumulate = 0;
+    g.Cprev = Cprev; g.wc = wc; g.bias = b; g.ln = ln; g.ld_c = ld_c; g.h = h;
+    g.O = O; g.Hn = Hn; g.Cn = Cn; g.gates = gates; g.Craw = Craw;
+    hipLaunchKernelGGL((k_gemm_fwd<2, 128, true>), dim3(qt_cdiv(N, BM), 1, 1), dim3(256), 0, (hipStream_t)stream, g);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
 extern "C" int qt_wgrad_blocks(int N) { return N > 0 ? qt_cdiv(N, WGRAD_ROWS) : 0; }
 
 extern "C" int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, const float* S, int Ks, const float* G,
@@ -589,7 +719,7 @@ extern "C" int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, co
     QT_ARG((Ka * Ca + Ks) / 4 <= MAXQ, "reduction dimension too large (max 512)");
     QT_ARG((((uintptr_t)a0 | (uintptr_t)a_rest | (uintptr_t)S | (uintptr_t)G) & 15) == 0, "operands must be 16-byte aligned");
     if (N <= 0) return QT_OK;
-    GemmArgs g;
+    GemmArgs g = {};
     g.A.a0 = a0; g.A.a_rest = a_rest; g.A.S = S; g.A.Ka = Ka; g.A.Ca = Ca; g.A.Ks = Ks; g.A.N = N;
     g.B = G; g.M = Ka * Ca + Ks; g.K = N; g.NB = Co;
     g.Kb = 1; g.Cb = Co; g.act = QT_ACT_NONE; g.res = nullptr; g.res_stride = 0; g.drop = nullptr; g.out = part;

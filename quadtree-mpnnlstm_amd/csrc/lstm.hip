@@ -6,66 +6,10 @@
 // statistics are xor-shuffle reductions inside that lane group.  Parameter gradients are
 // accumulated per thread, reduced over the wave with shuffles and over the workgroup
 // through LDS in a fixed order, and leave as one partial row per workgroup.
-#include "qt_common.h"
+#include "qt_cell.h"
 
 namespace {
-
-constexpr float LN_EPS = 1e-5f;
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-template <int LPN>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int d = 1; d < LPN; d <<= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-
-struct F4 {
-    float v[4];
-};
-__device__ __forceinline__ F4 ld4(const float* p) {
-    const float4 f = *reinterpret_cast<const float4*>(p);
-    return F4{{f.x, f.y, f.z, f.w}};
-}
-__device__ __forceinline__ void st4(float* p, const F4& a) {
-    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
-}
-
-// y = gamma * xhat + beta over the group's h values; returns xhat and rstd
-template <int LPN>
-__device__ __forceinline__ void layer_norm(const F4& x, int h, F4* xhat, float* rstd) {
-    const float mean = group_sum<LPN>((x.v[0] + x.v[1]) + (x.v[2] + x.v[3])) / (float)h;
-    float sq = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float d = x.v[k] - mean;
-        sq += d * d;
-    }
-    const float var = group_sum<LPN>(sq) / (float)h;
-    *rstd = 1.0f / sqrtf(var + LN_EPS);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) xhat->v[k] = (x.v[k] - mean) * (*rstd);
-}
-
-// gx = rstd * (gxh - mean(gxh) - xhat * mean(gxh * xhat)),  gxh = gy * gamma
-template <int LPN>
-__device__ __forceinline__ F4 layer_norm_bwd(const F4& gy, const F4& gamma, const F4& xhat, float rstd, int h) {
-    F4 gxh;
-    float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        gxh.v[k] = gy.v[k] * gamma.v[k];
-        s1 += gxh.v[k];
-        s2 += gxh.v[k] * xhat.v[k];
-    }
-    s1 = group_sum<LPN>(s1) / (float)h;
-    s2 = group_sum<LPN>(s2) / (float)h;
-    F4 gx;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gx.v[k] = rstd * (gxh.v[k] - s1 - xhat.v[k] * s2);
-    return gx;
-}
+using namespace qtcell;
 
 template <int LPN>
 __global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, const float* __restrict__ Cprev,
@@ -82,31 +26,8 @@ __global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, c
     const F4 gi = ld4(g), gf = ld4(g + h), gc = ld4(g + 2 * h), go = ld4(g + 3 * h);
     F4 cp = {{0, 0, 0, 0}};
     if (Cprev) cp = ld4(Cprev + node * ld_c + j0);
-    const F4 wci = ld4(wc + j0), wcf = ld4(wc + h + j0), wco = ld4(wc + 2 * h + j0);
-    const F4 bi = ld4(b + j0), bf = ld4(b + h + j0), bc = ld4(b + 2 * h + j0), bo = ld4(b + 3 * h + j0);
-    F4 I, F, T, Og, Cr, Hr;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        I.v[k] = sigmoidf_(gi.v[k] + wci.v[k] * cp.v[k] + bi.v[k]);
-        F.v[k] = sigmoidf_(gf.v[k] + wcf.v[k] * cp.v[k] + bf.v[k]);
-        T.v[k] = tanhf(gc.v[k] + bc.v[k]);
-        Cr.v[k] = F.v[k] * cp.v[k] + I.v[k] * T.v[k];
-        Og.v[k] = sigmoidf_(go.v[k] + wco.v[k] * Cr.v[k] + bo.v[k]);
-        Hr.v[k] = Og.v[k] * tanhf(Cr.v[k]);
-    }
-    F4 hn = Hr, cn = Cr;
-    if (ln) {
-        F4 xh, xc;
-        float rh, rc;
-        layer_norm<LPN>(Hr, h, &xh, &rh);
-        layer_norm<LPN>(Cr, h, &xc, &rc);
-        const F4 gh = ld4(ln + j0), bh = ld4(ln + h + j0), gcn = ld4(ln + 2 * h + j0), bcn = ld4(ln + 3 * h + j0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            hn.v[k] = gh.v[k] * xh.v[k] + bh.v[k];
-            cn.v[k] = gcn.v[k] * xc.v[k] + bcn.v[k];
-        }
-    }
+    const CellOut r = cell_forward<LPN>(gi, gf, gc, go, cp, wc, b, ln, h, j0);
+    const F4 &I = r.I, &F = r.F, &T = r.T, &Og = r.Og, &Cr = r.Cr, &hn = r.hn, &cn = r.cn;
     st4(O + node * h + j0, Og);
     st4(Hn + node * h + j0, hn);
     st4(Cn + node * h + j0, cn);

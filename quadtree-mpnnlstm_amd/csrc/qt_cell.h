@@ -1,0 +1,104 @@
+// Device helpers of the peephole graph-LSTM cell shared by lstm.hip (stand-alone cell kernels) and cheb.hip (the gate GEMM
+// with the cell fused into its epilogue): model/model.py:394-428 + the LayerNorms of model/seq2seq.py:64-75, 140-151.
+#pragma once
+#include "qt_common.h"
+
+namespace qtcell {
+
+constexpr float LN_EPS = 1e-5f;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int LPN>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int d = 1; d < LPN; d <<= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+struct F4 {
+    float v[4];
+};
+__device__ __forceinline__ F4 ld4(const float* p) {
+    const float4 f = *reinterpret_cast<const float4*>(p);
+    return F4{{f.x, f.y, f.z, f.w}};
+}
+__device__ __forceinline__ void st4(float* p, const F4& a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+
+// y = gamma * xhat + beta over the group's h values; returns xhat and rstd
+template <int LPN>
+__device__ __forceinline__ void layer_norm(const F4& x, int h, F4* xhat, float* rstd) {
+    const float mean = group_sum<LPN>((x.v[0] + x.v[1]) + (x.v[2] + x.v[3])) / (float)h;
+    float sq = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float d = x.v[k] - mean;
+        sq += d * d;
+    }
+    const float var = group_sum<LPN>(sq) / (float)h;
+    *rstd = 1.0f / sqrtf(var + LN_EPS);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xhat->v[k] = (x.v[k] - mean) * (*rstd);
+}
+
+// gx = rstd * (gxh - mean(gxh) - xhat * mean(gxh * xhat)),  gxh = gy * gamma
+template <int LPN>
+__device__ __forceinline__ F4 layer_norm_bwd(const F4& gy, const F4& gamma, const F4& xhat, float rstd, int h) {
+    F4 gxh;
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        gxh.v[k] = gy.v[k] * gamma.v[k];
+        s1 += gxh.v[k];
+        s2 += gxh.v[k] * xhat.v[k];
+    }
+    s1 = group_sum<LPN>(s1) / (float)h;
+    s2 = group_sum<LPN>(s2) / (float)h;
+    F4 gx;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gx.v[k] = rstd * (gxh.v[k] - s1 - xhat.v[k] * s2);
+    return gx;
+}
+
+// One cell update for 4 hidden units of a node (this lane's slice j0 .. j0+3 of the h channels; the node's h/4 lanes are
+// adjacent, LayerNorm statistics are shuffles inside that group -- every lane of the group must call this).
+struct CellOut {
+    F4 I, F, T, Og, Cr, hn, cn;
+};
+template <int LPN>
+__device__ __forceinline__ CellOut cell_forward(const F4& gi, const F4& gf, const F4& gc, const F4& go, const F4& cp,
+                                                const float* __restrict__ wc, const float* __restrict__ b,
+                                                const float* __restrict__ ln, int h, int j0) {
+    const F4 wci = ld4(wc + j0), wcf = ld4(wc + h + j0), wco = ld4(wc + 2 * h + j0);
+    const F4 bi = ld4(b + j0), bf = ld4(b + h + j0), bc = ld4(b + 2 * h + j0), bo = ld4(b + 3 * h + j0);
+    CellOut r;
+    F4 Hr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        r.I.v[k] = sigmoidf_(gi.v[k] + wci.v[k] * cp.v[k] + bi.v[k]);
+        r.F.v[k] = sigmoidf_(gf.v[k] + wcf.v[k] * cp.v[k] + bf.v[k]);
+        r.T.v[k] = tanhf(gc.v[k] + bc.v[k]);
+        r.Cr.v[k] = r.F.v[k] * cp.v[k] + r.I.v[k] * r.T.v[k];
+        r.Og.v[k] = sigmoidf_(go.v[k] + wco.v[k] * r.Cr.v[k] + bo.v[k]);
+        Hr.v[k] = r.Og.v[k] * tanhf(r.Cr.v[k]);
+    }
+    r.hn = Hr;
+    r.cn = r.Cr;
+    if (ln) {
+        F4 xh, xc;
+        float rh, rc;
+        layer_norm<LPN>(Hr, h, &xh, &rh);
+        layer_norm<LPN>(r.Cr, h, &xc, &rc);
+        const F4 gh = ld4(ln + j0), bh = ld4(ln + h + j0), gcn = ld4(ln + 2 * h + j0), bcn = ld4(ln + 3 * h + j0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r.hn.v[k] = gh.v[k] * xh.v[k] + bh.v[k];
+            r.cn.v[k] = gcn.v[k] * xc.v[k] + bcn.v[k];
+        }
+    }
+    return r;
+}
+
+}  // namespace qtcell

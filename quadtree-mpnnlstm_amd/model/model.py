@@ -229,8 +229,7 @@ class GConvLSTM(nn.Module):
                            for g in self.GATES], dim=1)
             return ops.lstm_cell(G, C, pk.wc, pk.b, pk.ln, mesh, pk.acc_p)
         Z = ops.concat_cols([X, H], mesh) if H is not None else X
-        G = ops.cheb_poly(Z, pk.W, mesh, pk.K, pk.Ks, acc=pk.acc_w)
-        return ops.lstm_cell(G, C, pk.wc, pk.b, pk.ln, mesh, pk.acc_p)
+        return ops.gate_cell(Z, pk.W, C, pk.wc, pk.b, pk.ln, mesh, pk.K, pk.Ks, pk.acc_w, pk.acc_p)
 
     def forward(self, X, edge_index, edge_weight=None, H=None, C=None):
         pad = (-X.shape[1]) % 4

@@ -138,6 +138,62 @@ def concat_cols(tensors, mesh=None):
 
 
 # ------------------------------------------------------------------------------ ChebConv stacks
+def _cheb_planes(Z, mesh, K):
+    """T_1 .. T_{K-1} of the Chebyshev recurrence on Z (T_0 = Z itself): (max(K-1, 1), N, C)."""
+    N, C = Z.shape
+    TZ = Z.new_empty(max(K - 1, 1), N, C)
+    for k in range(1, K):
+        if k == 1:
+            spmm(mesh, Z, 1.0, None, 0.0, None, 0.0, TZ[0], C)
+        else:
+            spmm(mesh, TZ[k - 2], 2.0, Z if k == 2 else TZ[k - 3], -1.0, None, 0.0, TZ[k - 1], C)
+    return TZ
+
+
+def _cheb_backward(Z, TZ, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW):
+    """(gZ, gW) of Y = [T_0 .. T_{K-1} | S] W from G = dL/dY (N, Co)."""
+    N, C = Z.shape
+    Co = W.shape[1]
+    gZ = None
+    if need_gZ and N > 0:
+        if acc is None:
+            Wt = W[:K * C].t().contiguous()
+        else:                                    # the transposed weight is shared by every use of W in this pass
+            if acc.wt is None:
+                acc.wt = W[:K * C].t().contiguous()
+            Wt = acc.wt
+        gT = Z.new_empty(K, N, C)
+        _lib.call('qt_dense', ptr(G), None, 1, Co, ptr(Wt), None, 0, None, K, C, N, ptr(mesh.n_dev), ACT_NONE, None, 0,
+                  None, ptr(gT))
+        # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
+        for k in range(K - 2, 0, -1):
+            spmm(mesh, gT[k + 1], 2.0, gT[k], 1.0, gT[k + 2] if k + 2 < K else None, -1.0, gT[k], C)
+        if K > 1:
+            spmm(mesh, gT[1], 1.0, gT[0], 1.0, gT[2] if K > 2 else None, -1.0, gT[0], C)
+        gZ = gT[0]
+    elif need_gZ:
+        gZ = torch.zeros_like(Z)
+    gW = None
+    if need_gW:
+        ksp = (Ks + 3) // 4 * 4
+        S = mesh.cheb_ones(Ks) if Ks else None
+        if acc is None:
+            gW = torch.empty_like(W) if N > 0 else torch.zeros_like(W)
+            if N > 0:
+                nblk = _lib.value('qt_wgrad_blocks', N)
+                part = Z.new_empty(nblk, W.shape[0], Co)
+                _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), ksp, ptr(G), Co, N, ptr(mesh.n_dev), 0, ptr(part))
+                _lib.call('qt_colsum', ptr(part), nblk, W.numel(), ptr(gW))
+        else:
+            # deferred: the weight gradient is off the critical path, so all uses of this pass (<= 16 per launch) are
+            # reduced together by the last backward -- one long launch instead of one short one per rollout step
+            acc.pending.append((Z, TZ, S, G, N, mesh.n_dev))
+            if acc.leave(use_idx):
+                gW = _wgrad_group(acc.pending, W, K, C, ksp, Co)
+                acc.pending = []
+    return gZ, gW
+
+
 class _ChebPoly(Function):
     """Y = act( sum_k T_k(L^) Z M_k + S Bm ),  W = [M_0; ...; M_{K-1}; Bm]  ((K*C + Ks), Co).
 
@@ -155,12 +211,7 @@ class _ChebPoly(Function):
         Co = W.shape[1]
         ksp = (Ks + 3) // 4 * 4
         assert W.shape[0] == K * C + ksp, f'weight rows {W.shape[0]} != {K}*{C}+{ksp}'
-        TZ = Z.new_empty(max(K - 1, 1), N, C)
-        for k in range(1, K):
-            if k == 1:
-                spmm(mesh, Z, 1.0, None, 0.0, None, 0.0, TZ[0], C)
-            else:
-                spmm(mesh, TZ[k - 2], 2.0, Z if k == 2 else TZ[k - 3], -1.0, None, 0.0, TZ[k - 1], C)
+        TZ = _cheb_planes(Z, mesh, K)
         S = mesh.cheb_ones(Ks) if Ks else None
         Y = Z.new_empty(N, Co)
         drop = _c(drop)
@@ -188,44 +239,7 @@ class _ChebPoly(Function):
             if N > 0:
                 _lib.call('qt_act_bwd', ptr(gin), ptr(Y), ptr(res), res.stride(0) if res is not None else 0, ptr(drop), act, N,
                           ptr(mesh.n_dev), Co, ptr(G), ptr(gres))
-        gZ = None
-        if ctx.needs_input_grad[0] and N > 0:
-            if ctx.acc is None:
-                Wt = W[:K * C].t().contiguous()
-            else:                                    # the transposed weight is shared by every use of W in this pass
-                if ctx.acc.wt is None:
-                    ctx.acc.wt = W[:K * C].t().contiguous()
-                Wt = ctx.acc.wt
-            gT = Z.new_empty(K, N, C)
-            _lib.call('qt_dense', ptr(G), None, 1, Co, ptr(Wt), None, 0, None, K, C, N, ptr(mesh.n_dev), ACT_NONE, None, 0,
-                      None, ptr(gT))
-            # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
-            for k in range(K - 2, 0, -1):
-                spmm(mesh, gT[k + 1], 2.0, gT[k], 1.0, gT[k + 2] if k + 2 < K else None, -1.0, gT[k], C)
-            if K > 1:
-                spmm(mesh, gT[1], 1.0, gT[0], 1.0, gT[2] if K > 2 else None, -1.0, gT[0], C)
-            gZ = gT[0]
-        elif ctx.needs_input_grad[0]:
-            gZ = torch.zeros_like(Z)
-        gW = None
-        if ctx.needs_input_grad[1]:
-            acc = ctx.acc
-            ksp = (Ks + 3) // 4 * 4
-            S = mesh.cheb_ones(Ks) if Ks else None
-            if acc is None:
-                gW = torch.empty_like(W) if N > 0 else torch.zeros_like(W)
-                if N > 0:
-                    nblk = _lib.value('qt_wgrad_blocks', N)
-                    part = Z.new_empty(nblk, W.shape[0], Co)
-                    _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), ksp, ptr(G), Co, N, ptr(mesh.n_dev), 0, ptr(part))
-                    _lib.call('qt_colsum', ptr(part), nblk, W.numel(), ptr(gW))
-            else:
-                # deferred: the weight gradient is off the critical path, so all uses of this pass (<= 16 per launch) are
-                # reduced together by the last backward -- one long launch instead of one short one per rollout step
-                acc.pending.append((Z, TZ, S, G, N, mesh.n_dev))
-                if acc.leave(ctx.use_idx):
-                    gW = _wgrad_group(acc.pending, W, K, C, ksp, Co)
-                    acc.pending = []
+        gZ, gW = _cheb_backward(Z, TZ, W, G, mesh, K, Ks, ctx.acc, ctx.use_idx, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return gZ, gW, gres, None, None, None, None, None, None
 
 
@@ -371,30 +385,79 @@ class _LstmCell(Function):
     @staticmethod
     def backward(ctx, gO, gHn, gCn):
         gates, Craw, Cprev, wc, ln = ctx.saved_tensors
-        N, h = Craw.shape
-        (gHn, ld_gh), (gCn, ld_gc) = _rows(gHn), _rows(gCn)
-        (gO, ld_go), (Cprev, ld_c) = _rows(gO), _rows(Cprev)
-        gG = torch.empty_like(gates)
-        gCp = torch.empty_like(Craw) if Cprev is not None else None
-        acc, mesh = ctx.acc, ctx.mesh
-        if acc is None:
-            nblk = max(_lib.value('qt_lstm_bwd_blocks', N, h), 1)
-            part = Craw.new_empty(nblk, 11 * h)
-        else:
-            nblk = max(_lib.value('qt_lstm_bwd_blocks', mesh.B * mesh.P, h), 1)
-            part = acc.slab(Craw, nblk, 11 * h)
-        if N > 0:
-            _lib.call('qt_lstm_bwd', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Craw), ptr(Cprev),
-                      ld_c, ptr(wc), ptr(ln), N, ptr(mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part), 0 if acc is None else 1)
-        if acc is not None and not acc.leave(ctx.use_idx):
-            return gG, gCp, None, None, None, None, None
-        psum = Craw.new_empty(11 * h)
-        if N > 0 or acc is not None:
-            _lib.call('qt_colsum', ptr(part), nblk, 11 * h, ptr(psum))
-        else:
-            psum.zero_()
-        psum = psum.view(11, h)
-        return gG, gCp, psum[0:3], psum[3:7], (psum[7:11] if ln is not None else None), None, None
+        return (*_lstm_backward(gO, gHn, gCn, gates, Craw, Cprev, wc, ln, ctx.mesh, ctx.acc, ctx.use_idx), None, None)
+
+
+def _lstm_backward(gO, gHn, gCn, gates, Craw, Cprev, wc, ln, mesh, acc, use_idx):
+    """(gG, gCprev, g_wc, g_b, g_ln) of the cell; the parameter gradients are None until the pass's last backward."""
+    N, h = Craw.shape
+    (gHn, ld_gh), (gCn, ld_gc) = _rows(gHn), _rows(gCn)
+    (gO, ld_go), (Cprev, ld_c) = _rows(gO), _rows(Cprev)
+    gG = torch.empty_like(gates)
+    gCp = torch.empty_like(Craw) if Cprev is not None else None
+    if acc is None:
+        nblk = max(_lib.value('qt_lstm_bwd_blocks', N, h), 1)
+        part = Craw.new_empty(nblk, 11 * h)
+    else:
+        nblk = max(_lib.value('qt_lstm_bwd_blocks', mesh.B * mesh.P, h), 1)
+        part = acc.slab(Craw, nblk, 11 * h)
+    if N > 0:
+        _lib.call('qt_lstm_bwd', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Craw), ptr(Cprev),
+                  ld_c, ptr(wc), ptr(ln), N, ptr(mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part), 0 if acc is None else 1)
+    if acc is not None and not acc.leave(use_idx):
+        return gG, gCp, None, None, None
+    psum = Craw.new_empty(11 * h)
+    if N > 0 or acc is not None:
+        _lib.call('qt_colsum', ptr(part), nblk, 11 * h, ptr(psum))
+    else:
+        psum.zero_()
+    psum = psum.view(11, h)
+    return gG, gCp, psum[0:3], psum[3:7], (psum[7:11] if ln is not None else None)
+
+
+class _GateCell(Function):
+    """cheb_poly (no activation) + lstm_cell as one op for hidden size 16: the gate GEMM runs the cell in its epilogue
+    (qt_dense_lstm), so the (N, 4h) pre-activations are never written.  Backward = the two backward passes."""
+
+    @staticmethod
+    def forward(ctx, Z, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w, acc_p):
+        _lib.require_cuda(Z, 'node features')
+        Z, W, wc, b, ln = _c(Z.float()), _c(W.float()), _c(wc), _c(b), _c(ln)
+        N, C = Z.shape
+        h = W.shape[1] // 4
+        ksp = (Ks + 3) // 4 * 4
+        assert W.shape[0] == K * C + ksp, f'weight rows {W.shape[0]} != {K}*{C}+{ksp}'
+        TZ = _cheb_planes(Z, mesh, K)
+        S = mesh.cheb_ones(Ks) if Ks else None
+        Cprev, ld_c = _rows(Cprev)
+        O, Hn, Cn, Craw = (Z.new_empty(N, h) for _ in range(4))
+        gates = Z.new_empty(N, 4 * h)
+        _lib.call('qt_dense_lstm', ptr(Z), ptr(TZ), K, C, ptr(W), ptr(S), ksp, ptr(W[K * C:]) if Ks else None, h, N,
+                  ptr(mesh.n_dev), ptr(Cprev), ld_c, ptr(wc), ptr(b), ptr(ln), ptr(O), ptr(Hn), ptr(Cn), ptr(gates), ptr(Craw))
+        ctx.save_for_backward(Z, TZ, W, gates, Craw, Cprev, wc, ln)
+        ctx.mesh, ctx.K, ctx.Ks, ctx.acc_w, ctx.acc_p = mesh, K, Ks, acc_w, acc_p
+        ctx.use_w = acc_w.enter() if acc_w is not None else 0
+        ctx.use_p = acc_p.enter() if acc_p is not None else 0
+        ctx.set_materialize_grads(False)
+        return O, Hn, Cn
+
+    @staticmethod
+    def backward(ctx, gO, gHn, gCn):
+        Z, TZ, W, gates, Craw, Cprev, wc, ln = ctx.saved_tensors
+        gG, gCp, gwc, gb, gln = _lstm_backward(gO, gHn, gCn, gates, Craw, Cprev, wc, ln, ctx.mesh, ctx.acc_p, ctx.use_p)
+        gZ, gW = _cheb_backward(Z, TZ, W, gG, ctx.mesh, ctx.K, ctx.Ks, ctx.acc_w, ctx.use_w, ctx.needs_input_grad[0],
+                                ctx.needs_input_grad[1])
+        return gZ, gW, gCp, gwc, gb, gln, None, None, None, None, None
+
+
+def gate_cell(Z, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w=None, acc_p=None):
+    """(O, LayerNorm_h(H'), LayerNorm_c(C')) of one GConvLSTM update from Z = [X | H] and the packed gate weights W."""
+    if W.shape[0] == K * Z.shape[1] + Ks and Ks % 4:
+        W = pad_bias_rows(W, Ks)
+    if W.shape[1] == 64 and Z.is_cuda:
+        return _GateCell.apply(Z, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w, acc_p)
+    G = cheb_poly(Z, W, mesh, K, Ks, acc=acc_w)
+    return lstm_cell(G, Cprev, wc, b, ln, mesh, acc_p)
 
 
 def lstm_cell(G, Cprev, wc, b, ln, mesh, acc=None):

@@ -379,3 +379,30 @@ def test_bf16x3_gemm_matches_fp32_gemm():
         assert out.returncode == 0, out.stderr[-2000:]
         errs[mode] = float(out.stdout.split('RELERR')[1])
     assert errs['0'] < 2e-6 and errs['1'] < 2e-6, errs
+
+
+@pytest.mark.parametrize('with_c', [True, False])
+def test_fused_gate_cell_equals_gemm_then_cell(with_c):
+    """qt_dense_lstm (the cell as the gate GEMM's epilogue, h = 16) == qt_dense followed by qt_lstm_fwd, bit for bit,
+    forward and every gradient; a node count that is not a multiple of the 128-row tile."""
+    from qtmpnn import ops
+    mesh, _ = _mesh_64(5, noise=0.03, B=2)
+    torch.manual_seed(3)
+    h, C, K, Ks = 16, 20, 3, 1
+    mk = lambda *s: torch.randn(*s, device=dev()).requires_grad_(True)
+    Z, W = mk(mesh.N, C), mk(K * C + 4, 4 * h)
+    Cp = mk(mesh.N, h) if with_c else None
+    wc, b, ln = mk(3, h), mk(4, h), mk(4, h)
+    gs = [torch.randn(mesh.N, h, device=dev()) for _ in range(3)]
+    ins = [t for t in (Z, W, Cp, wc, b, ln) if t is not None]
+
+    def run(fused):
+        if fused:
+            outs = ops.gate_cell(Z, W, Cp, wc, b, ln, mesh, K, Ks)
+        else:
+            outs = ops.lstm_cell(ops.cheb_poly(Z, W, mesh, K, Ks), Cp, wc, b, ln, mesh)
+        grads = torch.autograd.grad(outs, ins, gs)
+        return [o.detach() for o in outs] + list(grads)
+
+    for a, r in zip(run(True), run(False)):
+        assert torch.equal(a, r)

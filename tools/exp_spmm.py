@@ -22,3 +22,18 @@ for C in (4, 16, 20, 32, 68):
     t0 = timeit(lambda: spmm(mesh, Z, 1.0, None, 0.0, None, 0.0, out, C))
     by = 4.0 * (N + 1) + 8.0 * mesh.E + 8.0 * N * C
     print(f'N {N} E {mesh.E} C {C}: with addend {t1:.2f} us ({(by + 4.0 * N * C) / t1 / 1e3:.0f} GB/s incl addend)  plain {t0:.2f} us ({by / t0 / 1e3:.0f} GB/s)')
+print('--- inside a hipGraph (100 launches per replay)')
+for C in (4, 16, 20, 32, 68):
+    Z = torch.randn(N, C, device=dev); out = torch.empty(N, C, device=dev); p_ = torch.randn(N, C, device=dev)
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        spmm(mesh, Z, 2.0, p_, -1.0, None, 0.0, out, C)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(100):
+            spmm(mesh, Z, 2.0, p_, -1.0, None, 0.0, out, C)
+    g.replay(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); g.replay(); b.record(); b.synchronize()
+    print(f'N graph C {C}: {a.elapsed_time(b) * 10:.2f} us per launch')
