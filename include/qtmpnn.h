@@ -63,7 +63,7 @@ int qt_abi_version(void);
  * raises IndexError otherwise, :222-229).
  */
 int qt_quadtree_stage1(const float* src, int src_rows, int src_cols,
-                       const float* nodeval, const int32_t* old_labels,
+                       const float* nodeval, int nodeval_stride /* floats between node values */, const int32_t* old_labels,
                        int B, int n, int m, int max_size, float thresh, int condition,
                        const uint8_t* mask, const uint8_t* hir,
                        int32_t* local_id /* (B,n,m) */, uint8_t* level /* (B,n,m) */,
@@ -71,10 +71,14 @@ int qt_quadtree_stage1(const float* src, int src_rows, int src_cols,
 int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_offsets /* exclusive scan of cnt, length B*nbase+1 */,
                        int B, int n, int m, int max_size,
                        int32_t* labels /* (B,n,m) */, const uint8_t* level, int32_t* cell /* (Nmax,4) */,
-                       int32_t* node_off /* (B+1) */, void* stream);
+                       int32_t* node_off /* (B+1) */,
+                       float size_norm, float* feat /* (Nmax,3) or NULL */, float* npix /* (Nmax) or NULL: the
+                       qt_node_features outputs, written by the same pass */, void* stream);
 
 /* exclusive scan: out[0]=0, out[i+1]=sum(in[0..i]); len+1 outputs.  tmp: (len/1024+2) int32. */
 int qt_scan_i32(const int32_t* in, int32_t* out, int64_t len, int32_t* tmp, void* stream);
+/* in-place exclusive scan of sums[0..nblk) by one workgroup; sums[nblk] = grand total */
+int qt_scan_top(int32_t* sums, int nblk, void* stream);
 
 /* static node features {col centroid / m, row centroid / n, npix / size_norm} (image_to_graph :657-668,
  * utils.py:37-45) and npix; feat (N, 3), npix (N). */
@@ -84,16 +88,19 @@ int qt_node_features(const int32_t* cell, int N, const int32_t* n_dev, int n, in
 /* ---------------------------------------------------------------- adjacency
  * get_adj + dist, model/graph_functions.py:261-363, and the ChebConv normalisation that PyG
  * recomputes in every conv call (torch_geometric ChebConv.__norm__, restated in oracle/).
- * stage1 counts distinct neighbours per (node, side) -> cnt4 (4N); scan; stage2 fills col and
- * w = centroid distance * resolution; stage3 computes deg, dis and nrm = -dis_i w dis_j.
+ * qt_edges_count: distinct neighbours per (node, side) -> cnt4, plus the total of every 1024-thread workgroup -> sums
+ *   (nblk = qt_edges_blocks(N) entries; cnt4 holds nblk*1024 ints).  qt_scan_top(sums, nblk) turns them into offsets.
+ * qt_edges_fill: rowptr (N+1), col, w = centroid distance * resolution, and dis[i] = 1/sqrt(sum of row i's weights).
+ * qt_edges_norm: nrm[e] = -dis_i w_e dis_j.
  */
+int qt_edges_blocks(int N);
 int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, const int32_t* n_dev, int n, int m,
-                   int32_t* cnt4, void* stream);
-int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* off4 /* scan of cnt4, 4N+1 */,
+                   int32_t* cnt4, int32_t* sums /* nblk+1 */, void* stream);
+int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* cnt4, const int32_t* sums /* scanned */,
                   int N, const int32_t* n_dev, int n, int m, float resolution,
-                  int32_t* rowptr /* N+1 */, int32_t* col, float* w, void* stream);
-int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, int N, const int32_t* n_dev,
-                  float* dis /* N */, float* nrm, void* stream);
+                  int32_t* rowptr /* N+1 */, int32_t* col, float* w, float* dis /* N */, void* stream);
+int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, const float* dis, int N,
+                  const int32_t* n_dev, float* nrm, void* stream);
 
 /* ---------------------------------------------------------------- mesh <-> image transfers
  * flatten / unflatten, model/graph_functions.py:391-419, 451-458, by labels instead of the dense
@@ -198,6 +205,10 @@ int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, const
  * convolutions; here they share one Chebyshev pass) and the re-mesh state matrix. */
 int qt_concat(const float* const* srcs, const int* widths, const int* lds, int nsrc, int N, const int32_t* n_dev,
               float* out, void* stream);
+
+/* decoder input after a re-mesh, model/seq2seq.py:484-487: out (N, 4) = [val4[:, 0] | posfeat (N, 3)]; posfeat == NULL
+ * writes [val4[:, 0], 0, 0, 0] (the gradient of the same op with respect to val4). */
+int qt_decoder_input(const float* val4, const float* posfeat, int N, const int32_t* n_dev, float* out, void* stream);
 
 /* backward of the qt_dense epilogue activations: G = gY * act'(Y) (QT_ACT_RELU, QT_ACT_TANH_RES with res / drop as in
  * qt_dense); gres (N, res_stride) or NULL receives the gradient of the residual operand (column 0 = gY[:, 0], rest 0). */

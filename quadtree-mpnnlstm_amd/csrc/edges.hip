@@ -40,65 +40,73 @@ __device__ __forceinline__ void centroid(int4 cl, int n, int m, float res, float
     *yy = ((float)cl.x + 0.5f * (float)(hh - 1)) * res;
 }
 
-__global__ void k_edges_count(const int32_t* __restrict__ labels, const int32_t* __restrict__ cell, int Ncap,
-                              const int32_t* __restrict__ n_dev, int n, int m, int32_t* __restrict__ cnt4) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 4 * Ncap) return;
-    if (idx >= 4 * qt_rows(n_dev, Ncap)) {
-        cnt4[idx] = 0;      // capacity rows beyond N: keep the prefix sum flat
-        return;
-    }
-    const int4 cl = reinterpret_cast<const int4*>(cell)[idx >> 2];
-    const SideWalk w = side_walk(cl, idx & 3, n, m);
-    const int32_t* L = labels + (int64_t)w.b * n * m;
-    int prev = -1, cnt = 0;
-    for (int k = 0; k < w.len; ++k) {
-        const int lab = L[(int64_t)(w.r + k * w.dr) * m + (w.c + k * w.dc)];
-        if (lab >= 0 && lab != prev) ++cnt;
-        prev = lab;
-    }
-    cnt4[idx] = cnt;
-}
+// One (node, side) per thread, 1024 per workgroup.  The count pass also leaves the per-workgroup totals (`sums`), the
+// fill pass turns them (after qt_scan_top) plus a workgroup scan of its own counts into edge offsets: no scan kernels
+// over the 4N counts, and the degree normalisation 1/sqrt(sum of the row's weights) falls out of the fill walk.
+constexpr int ET = 1024;
 
-__global__ void k_edges_fill(const int32_t* __restrict__ labels, const int32_t* __restrict__ cell,
-                             const int32_t* __restrict__ off4, int Ncap, const int32_t* __restrict__ n_dev, int n, int m,
-                             float res, int32_t* __restrict__ rowptr, int32_t* __restrict__ col, float* __restrict__ wgt) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = qt_rows(n_dev, Ncap);
-    if (idx >= 4 * Ncap) return;
-    if (idx == 0) rowptr[N] = off4[4 * N];
-    if (idx >= 4 * N) {     // rows N .. Ncap of rowptr all point at the end (empty rows)
-        if ((idx & 3) == 0) rowptr[(idx >> 2) + 1] = off4[4 * N];
-        return;
-    }
-    const int node = idx >> 2;
-    const int4 cl = reinterpret_cast<const int4*>(cell)[node];
-    if ((idx & 3) == 0) rowptr[node] = off4[idx];
-    const SideWalk w = side_walk(cl, idx & 3, n, m);
-    const int32_t* L = labels + (int64_t)w.b * n * m;
-    float xx, yy;
-    centroid(cl, n, m, res, &xx, &yy);
-    int prev = -1, e = off4[idx];
-    for (int k = 0; k < w.len; ++k) {
-        const int lab = L[(int64_t)(w.r + k * w.dr) * m + (w.c + k * w.dc)];
-        if (lab >= 0 && lab != prev) {
-            float x2, y2;
-            centroid(reinterpret_cast<const int4*>(cell)[lab], n, m, res, &x2, &y2);
-            col[e] = lab;
-            wgt[e] = sqrtf((yy - y2) * (yy - y2) + (xx - x2) * (xx - x2));
-            ++e;
+__global__ __launch_bounds__(ET) void k_edges_count(const int32_t* __restrict__ labels, const int32_t* __restrict__ cell,
+                                                    int Ncap, const int32_t* __restrict__ n_dev, int n, int m,
+                                                    int32_t* __restrict__ cnt4, int32_t* __restrict__ sums) {
+    __shared__ int red[16];
+    const int idx = blockIdx.x * ET + threadIdx.x;
+    int cnt = 0;
+    if (idx < 4 * qt_rows(n_dev, Ncap)) {
+        const int4 cl = reinterpret_cast<const int4*>(cell)[idx >> 2];
+        const SideWalk w = side_walk(cl, idx & 3, n, m);
+        const int32_t* L = labels + (int64_t)w.b * n * m;
+        int prev = -1;
+        for (int k = 0; k < w.len; ++k) {
+            const int lab = L[(int64_t)(w.r + k * w.dr) * m + (w.c + k * w.dc)];
+            if (lab >= 0 && lab != prev) ++cnt;
+            prev = lab;
         }
-        prev = lab;
     }
+    if (idx < 4 * Ncap) cnt4[idx] = cnt;      // capacity rows beyond N: zero, the offsets stay flat
+    int total;
+    qt_block_excl_scan(cnt, red, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-__global__ void k_edges_deg(const int32_t* __restrict__ rowptr, const float* __restrict__ w, int Ncap,
-                            const int32_t* __restrict__ n_dev, float* __restrict__ dis) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= qt_rows(n_dev, Ncap)) return;
-    float deg = 0.0f;
-    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) deg += w[e];
-    dis[i] = deg > 0.0f ? 1.0f / sqrtf(deg) : 0.0f;
+__global__ __launch_bounds__(ET) void k_edges_fill(const int32_t* __restrict__ labels, const int32_t* __restrict__ cell,
+                                                   const int32_t* __restrict__ cnt4, const int32_t* __restrict__ sums,
+                                                   int Ncap, const int32_t* __restrict__ n_dev, int n, int m, float res,
+                                                   int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                                   float* __restrict__ wgt, float* __restrict__ dis) {
+    __shared__ int red[16];
+    const int idx = blockIdx.x * ET + threadIdx.x;
+    const int N = qt_rows(n_dev, Ncap);
+    const int mine = idx < 4 * Ncap ? cnt4[idx] : 0;
+    int total;
+    int e = sums[blockIdx.x] + qt_block_excl_scan(mine, red, &total);
+    const int node = idx >> 2;
+    if ((idx & 3) == 0 && node <= Ncap) rowptr[node] = e;       // rows N .. Ncap all point at the end (empty rows)
+    float wsum = 0.0f;
+    if (idx < 4 * N) {
+        const int4 cl = reinterpret_cast<const int4*>(cell)[node];
+        const SideWalk w = side_walk(cl, idx & 3, n, m);
+        const int32_t* L = labels + (int64_t)w.b * n * m;
+        float xx, yy;
+        centroid(cl, n, m, res, &xx, &yy);
+        int prev = -1;
+        for (int k = 0; k < w.len; ++k) {
+            const int lab = L[(int64_t)(w.r + k * w.dr) * m + (w.c + k * w.dc)];
+            if (lab >= 0 && lab != prev) {
+                float x2, y2;
+                centroid(reinterpret_cast<const int4*>(cell)[lab], n, m, res, &x2, &y2);
+                const float d = sqrtf((yy - y2) * (yy - y2) + (xx - x2) * (xx - x2));
+                col[e] = lab;
+                wgt[e] = d;
+                wsum += d;
+                ++e;
+            }
+            prev = lab;
+        }
+    }
+    // the four sides of a node are four adjacent lanes: fixed-order sum (s0 + s1) + (s2 + s3)
+    wsum += __shfl_xor(wsum, 1, 64);
+    wsum += __shfl_xor(wsum, 2, 64);
+    if ((idx & 3) == 0 && idx < 4 * N) dis[node] = wsum > 0.0f ? 1.0f / sqrtf(wsum) : 0.0f;
 }
 
 __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
@@ -112,31 +120,33 @@ __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* _
 
 }  // namespace
 
+extern "C" int qt_edges_blocks(int N) { return N > 0 ? qt_cdiv(4 * (int64_t)N + 1, ET) : 0; }
+
 extern "C" int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, const int32_t* n_dev, int n, int m,
-                              int32_t* cnt4, void* stream) {
-    QT_ARG(labels && cell && cnt4, "null pointer");
+                              int32_t* cnt4, int32_t* sums, void* stream) {
+    QT_ARG(labels && cell && cnt4 && sums, "null pointer");
     if (N <= 0) return QT_OK;
-    hipLaunchKernelGGL(k_edges_count, dim3(qt_cdiv(4 * (int64_t)N, 256)), dim3(256), 0, (hipStream_t)stream, labels, cell,
-                       N, n_dev, n, m, cnt4);
+    hipLaunchKernelGGL(k_edges_count, dim3(qt_edges_blocks(N)), dim3(ET), 0, (hipStream_t)stream, labels, cell, N, n_dev, n, m,
+                       cnt4, sums);
     QT_LAUNCHED();
     return QT_OK;
 }
 
-extern "C" int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* off4, int N, const int32_t* n_dev,
-                             int n, int m, float resolution, int32_t* rowptr, int32_t* col, float* w, void* stream) {
-    QT_ARG(labels && cell && off4 && rowptr && col && w, "null pointer");
+extern "C" int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* cnt4, const int32_t* sums, int N,
+                             const int32_t* n_dev, int n, int m, float resolution, int32_t* rowptr, int32_t* col, float* w,
+                             float* dis, void* stream) {
+    QT_ARG(labels && cell && cnt4 && sums && rowptr && col && w && dis, "null pointer");
     if (N <= 0) return QT_OK;
-    hipLaunchKernelGGL(k_edges_fill, dim3(qt_cdiv(4 * (int64_t)N, 256)), dim3(256), 0, (hipStream_t)stream, labels, cell,
-                       off4, N, n_dev, n, m, resolution, rowptr, col, w);
+    hipLaunchKernelGGL(k_edges_fill, dim3(qt_edges_blocks(N)), dim3(ET), 0, (hipStream_t)stream, labels, cell, cnt4, sums, N,
+                       n_dev, n, m, resolution, rowptr, col, w, dis);
     QT_LAUNCHED();
     return QT_OK;
 }
 
-extern "C" int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, int N, const int32_t* n_dev,
-                             float* dis, float* nrm, void* stream) {
+extern "C" int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, const float* dis, int N,
+                             const int32_t* n_dev, float* nrm, void* stream) {
     QT_ARG(rowptr && col && w && dis && nrm, "null pointer");
     if (N <= 0) return QT_OK;
-    hipLaunchKernelGGL(k_edges_deg, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, w, N, n_dev, dis);
     hipLaunchKernelGGL(k_edges_nrm, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, w, dis, N, n_dev, nrm);
     QT_LAUNCHED();
     return QT_OK;

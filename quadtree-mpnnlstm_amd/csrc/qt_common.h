@@ -28,6 +28,29 @@ __device__ __forceinline__ int qt_rows(const int32_t* n_dev, int cap) { return n
 
 static inline int qt_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Exclusive scan of one int per thread over a workgroup of up to 1024 threads (blockDim.x a multiple of 64).
+// `red` is 16 ints of LDS.  Returns the exclusive prefix; *total gets the block sum.
+__device__ __forceinline__ int qt_block_excl_scan(int v, int* red, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int up = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63) red[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) {
+        int s = red[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
 // Exclusive scan of one int per thread over a 256-thread workgroup (4 waves of 64).
 // `red` is 8 ints of LDS.  Returns the exclusive prefix; *total gets the block sum.
 __device__ __forceinline__ int qt_block_excl_scan_256(int v, int* red, int* total) {

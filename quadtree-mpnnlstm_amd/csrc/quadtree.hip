@@ -37,6 +37,7 @@ struct Stage1Args {
     const float* src;
     int src_rows, src_cols;
     const float* nodeval;
+    int nodeval_stride;
     const int32_t* old_labels;
     int B, n, m, MS, nbi, nbj;
     float thresh;
@@ -50,7 +51,10 @@ struct Stage1Args {
 
 constexpr int PITCH = 66;
 
-__global__ __launch_bounds__(256) void k_quadtree_stage1(Stage1Args a) {
+// 1024 threads per base cell: the B * nbase workgroups are few (32 at the bench shape), so the phases below are
+// latency chains over the cell's 4096 pixels; with 256 threads the kernel took 39 us.
+constexpr int S1T = 1024;
+__global__ __launch_bounds__(S1T) void k_quadtree_stage1(Stage1Args a) {
     __shared__ float v[65 * PITCH];
     __shared__ uint8_t fm[65 * PITCH];
     __shared__ float D[1365];
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void k_quadtree_stage1(Stage1Args a) {
     __shared__ uint8_t split[1365];
     __shared__ uint8_t lvl[4096];
     __shared__ int flags[4096];
-    __shared__ int red[8];
+    __shared__ int red[16];
 
     const int t = threadIdx.x;
     const int MS = a.MS, W1 = MS + 1;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void k_quadtree_stage1(Stage1Args a) {
     const int64_t P = (int64_t)a.n * a.m;
 
     // ---- 1. criterion window (MS+1)^2 with the reference's clamps
-    for (int idx = t; idx < W1 * W1; idx += 256) {
+    for (int idx = t; idx < W1 * W1; idx += S1T) {
         const int r = idx / W1, c = idx % W1;
         const int gr = x0 + r, gc = y0 + c;
         float val = -INFINITY;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void k_quadtree_stage1(Stage1Args a) {
             } else {
                 const int rr = min(gr, a.n - 1), cc = min(gc, a.m - 1);
                 const int lab = a.old_labels[b * P + (int64_t)rr * a.m + cc];
-                val = lab >= 0 ? a.nodeval[lab] : 0.0f;
+                val = lab >= 0 ? a.nodeval[(int64_t)lab * a.nodeval_stride] : 0.0f;
             }
             if (a.negate) val = -val;
             if (gr < a.n && gc < a.m) {
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256) void k_quadtree_stage1(Stage1Args a) {
     int lbase = 0, prev_base = 0;
     for (int l = 1; l <= L; ++l) {
         const int nc = MS >> l;
-        for (int idx = t; idx < nc * nc; idx += 256) {
+        for (int idx = t; idx < nc * nc; idx += S1T) {
             const int i = idx / nc, j = idx % nc;
             float mx;
             uint8_t fo;
@@ -136,9 +140,9 @@ __global__ __launch_bounds__(256) void k_quadtree_stage1(Stage1Args a) {
 
     // ---- 3. leaf level of every pixel, head flags in DFS (reversed Morton) order
     const int MS2 = MS * MS;
-    for (int idx = t; idx < MS2; idx += 256) flags[idx] = 0;
+    for (int idx = t; idx < MS2; idx += S1T) flags[idx] = 0;
     __syncthreads();
-    for (int idx = t; idx < MS2; idx += 256) {
+    for (int idx = t; idx < MS2; idx += S1T) {
         const int r = idx / MS, c = idx % MS;
         int leaf = 0, off = lbase;
         for (int l = L; l >= 1; --l) {
@@ -159,12 +163,12 @@ __global__ __launch_bounds__(256) void k_quadtree_stage1(Stage1Args a) {
     __syncthreads();
 
     // ---- 4. exclusive scan over the MS^2 keys
-    const int per = (MS2 + 255) / 256;
+    const int per = (MS2 + S1T - 1) / S1T;
     const int k0 = t * per;
     int sum = 0;
     for (int k = k0; k < min(k0 + per, MS2); ++k) sum += flags[k];
     int total;
-    int run = qt_block_excl_scan_256(sum, red, &total);
+    int run = qt_block_excl_scan(sum, red, &total);
     for (int k = k0; k < min(k0 + per, MS2); ++k) {
         const int f = flags[k];
         flags[k] = run;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void k_quadtree_stage1(Stage1Args a) {
     __syncthreads();
 
     // ---- 5. per-pixel local leaf id and level (in-image pixels only)
-    for (int idx = t; idx < MS2; idx += 256) {
+    for (int idx = t; idx < MS2; idx += S1T) {
         const int r = idx / MS, c = idx % MS;
         const int gr = x0 + r, gc = y0 + c;
         if (gr >= a.n || gc >= a.m) continue;
@@ -188,10 +192,23 @@ __global__ __launch_bounds__(256) void k_quadtree_stage1(Stage1Args a) {
     if (t == 0) a.cnt[b * nbase + (nbase - 1 - base)] = total;
 }
 
+// positional encoding + size feature of a node (add_positional_encoding and the size channel, model/graph_functions.py:366-389,
+// :599-607): centroid / image extent, pixel count / size_norm
+__device__ __forceinline__ void node_features(int4 cl, int i, int n, int m, float size_norm, float* __restrict__ feat,
+                                              float* __restrict__ npix) {
+    const int hh = min(cl.x + cl.z, n) - cl.x, ww = min(cl.y + cl.z, m) - cl.y;
+    const float np_ = (float)(hh * ww);
+    feat[3 * i + 0] = ((float)cl.y + 0.5f * (float)(ww - 1)) / (float)m;
+    feat[3 * i + 1] = ((float)cl.x + 0.5f * (float)(hh - 1)) / (float)n;
+    feat[3 * i + 2] = np_ / size_norm;
+    npix[i] = np_;
+}
+
 __global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const int32_t* __restrict__ offs,
                                   int B, int n, int m, int MS, int nbj, int nbase,
                                   int32_t* __restrict__ labels, const uint8_t* __restrict__ level,
-                                  int32_t* __restrict__ cell, int32_t* __restrict__ node_off) {
+                                  int32_t* __restrict__ cell, int32_t* __restrict__ node_off, float size_norm,
+                                  float* __restrict__ feat, float* __restrict__ npix) {
     const int64_t P = (int64_t)n * m;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx <= B) node_off[idx] = offs[idx * nbase];
@@ -208,6 +225,7 @@ __global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const in
         if ((r & (s - 1)) == 0 && (c & (s - 1)) == 0) {
             int4 cl = make_int4(r, c, s, b);
             reinterpret_cast<int4*>(cell)[lab] = cl;
+            if (feat) node_features(cl, lab, n, m, size_norm, feat, npix);
         }
     }
     labels[idx] = lab;
@@ -265,23 +283,42 @@ __global__ __launch_bounds__(256) void k_scan_apply(const int32_t* __restrict__ 
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[len] = sums[gridDim.x];
 }
 
+// one workgroup: out[0] = 0, out[i+1] = in[0] + .. + in[i]
+__global__ __launch_bounds__(256) void k_scan_small(const int32_t* __restrict__ in, int len, int32_t* __restrict__ out) {
+    __shared__ int red[8];
+    int carry = 0;
+    for (int c0 = 0; c0 < len; c0 += SCAN_CHUNK) {
+        const int base = c0 + threadIdx.x * SCAN_ITEMS;
+        int vals[SCAN_ITEMS];
+        int sum = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            vals[i] = (base + i < len) ? in[base + i] : 0;
+            sum += vals[i];
+        }
+        int total;
+        int run = carry + qt_block_excl_scan_256(sum, red, &total);
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            if (base + i < len) out[base + i] = run;
+            run += vals[i];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) out[len] = carry;
+}
+
 __global__ void k_node_features(const int32_t* __restrict__ cell, int Ncap, const int32_t* __restrict__ n_dev, int n,
                                 int m, float size_norm, float* __restrict__ feat, float* __restrict__ npix) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= qt_rows(n_dev, Ncap)) return;
-    const int4 cl = reinterpret_cast<const int4*>(cell)[i];
-    const int hh = min(cl.x + cl.z, n) - cl.x, ww = min(cl.y + cl.z, m) - cl.y;
-    const float np_ = (float)(hh * ww);
-    feat[3 * i + 0] = ((float)cl.y + 0.5f * (float)(ww - 1)) / (float)m;
-    feat[3 * i + 1] = ((float)cl.x + 0.5f * (float)(hh - 1)) / (float)n;
-    feat[3 * i + 2] = np_ / size_norm;
-    npix[i] = np_;
+    node_features(reinterpret_cast<const int4*>(cell)[i], i, n, m, size_norm, feat, npix);
 }
 
 }  // namespace
 
 extern "C" int qt_quadtree_stage1(const float* src, int src_rows, int src_cols, const float* nodeval,
-                                  const int32_t* old_labels, int B, int n, int m, int max_size, float thresh,
+                                  int nodeval_stride, const int32_t* old_labels, int B, int n, int m, int max_size, float thresh,
                                   int condition, const uint8_t* mask, const uint8_t* hir, int32_t* local_id,
                                   uint8_t* level, int32_t* cnt, void* stream) {
     QT_ARG(B > 0 && n > 0 && m > 0, "empty image batch");
@@ -294,6 +331,7 @@ extern "C" int qt_quadtree_stage1(const float* src, int src_rows, int src_cols, 
     a.src_rows = src_rows;
     a.src_cols = src_cols;
     a.nodeval = nodeval;
+    a.nodeval_stride = nodeval_stride > 0 ? nodeval_stride : 1;
     a.old_labels = old_labels;
     a.B = B;
     a.n = n;
@@ -311,19 +349,20 @@ extern "C" int qt_quadtree_stage1(const float* src, int src_rows, int src_cols, 
     a.local_id = local_id;
     a.level = level;
     a.cnt = cnt;
-    hipLaunchKernelGGL(k_quadtree_stage1, dim3(B * a.nbi * a.nbj), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_quadtree_stage1, dim3(B * a.nbi * a.nbj), dim3(S1T), 0, (hipStream_t)stream, a);
     QT_LAUNCHED();
     return QT_OK;
 }
 
 extern "C" int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_offsets, int B, int n, int m,
                                   int max_size, int32_t* labels, const uint8_t* level, int32_t* cell,
-                                  int32_t* node_off, void* stream) {
+                                  int32_t* node_off, float size_norm, float* feat, float* npix, void* stream) {
     QT_ARG(local_id && cnt_offsets && labels && level && cell && node_off, "null pointer");
+    QT_ARG((feat == nullptr) == (npix == nullptr), "give both feat and npix or neither");
     const int nbi = qt_cdiv(n, max_size), nbj = qt_cdiv(m, max_size);
     const int64_t total = (int64_t)B * n * m;
     hipLaunchKernelGGL(k_quadtree_stage3, dim3(qt_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, local_id,
-                       cnt_offsets, B, n, m, max_size, nbj, nbi * nbj, labels, level, cell, node_off);
+                       cnt_offsets, B, n, m, max_size, nbj, nbi * nbj, labels, level, cell, node_off, size_norm, feat, npix);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -332,9 +371,21 @@ extern "C" int qt_scan_i32(const int32_t* in, int32_t* out, int64_t len, int32_t
     QT_ARG(in && out && tmp && len > 0, "bad scan arguments");
     const int nblk = qt_cdiv(len, SCAN_CHUNK);
     hipStream_t s = (hipStream_t)stream;
+    if (len <= 16 * SCAN_CHUNK) {            // the per-base-cell leaf counts: one workgroup, one launch
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, s, in, (int)len, out);
+        QT_LAUNCHED();
+        return QT_OK;
+    }
     hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(256), 0, s, in, len, tmp);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tmp, nblk);
     hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(256), 0, s, in, len, tmp, out);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_scan_top(int32_t* sums, int nblk, void* stream) {
+    QT_ARG(sums && nblk >= 0, "bad arguments");
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, nblk);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -292,8 +292,8 @@ class Seq2Seq(nn.Module):
             state = ops.concat_cols([b4 if wide else data.expand(-1, 4).contiguous(), *hidden, *cell], old)
             # ONE split (its backward is one concat; separate slices would each zero-fill a full (N, 4+2Lh) gradient)
             val4, *parts = ops.split_cols(ops.remesh_transfer(state, old, new), [4] + [h] * (2 * L), new)
-            val = val4[:, :1]
+            val = None
         g.hidden, g.cell = list(parts[:L]), list(parts[L:])
-        g.pyg.x = torch.cat([val, new.posfeat], dim=-1)
+        g.pyg.x = ops.decoder_input(val4, new) if val is None else torch.cat([val, new.posfeat], dim=-1)
         g.mapping, g.n_pixels_per_node = new, new.npix
         return new

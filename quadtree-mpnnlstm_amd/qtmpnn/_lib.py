@@ -16,13 +16,15 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 # name -> argument types (return type is int unless listed in _RESTYPE)
 _SIGNATURES = {
     'qt_abi_version': [],
-    'qt_quadtree_stage1': [_P, _I, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
-    'qt_quadtree_stage3': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    'qt_quadtree_stage1': [_P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
+    'qt_quadtree_stage3': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P],
     'qt_scan_i32': [_P, _P, _L, _P, _P],
     'qt_node_features': [_P, _I, _P, _I, _I, _F, _P, _P, _P],
-    'qt_edges_count': [_P, _P, _I, _P, _I, _I, _P, _P],
-    'qt_edges_fill': [_P, _P, _P, _I, _P, _I, _I, _F, _P, _P, _P, _P],
-    'qt_edges_norm': [_P, _P, _P, _I, _P, _P, _P, _P],
+    'qt_edges_blocks': [_I],
+    'qt_scan_top': [_P, _I, _P],
+    'qt_edges_count': [_P, _P, _I, _P, _I, _I, _P, _P, _P],
+    'qt_edges_fill': [_P, _P, _P, _P, _I, _P, _I, _I, _F, _P, _P, _P, _P, _P],
+    'qt_edges_norm': [_P, _P, _P, _P, _I, _P, _P, _P],
     'qt_gather': [_P, _I, _P, _P, _L, _P, _P],
     'qt_pool': [_P, _I, _L, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],
     'qt_sse': [_P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
@@ -38,6 +40,7 @@ _SIGNATURES = {
     'qt_wgrad_group_blocks': [_I, _P],
     'qt_wgrad_group': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     'qt_dense_lstm': [_P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    'qt_decoder_input': [_P, _P, _I, _P, _P, _P],
     'qt_concat': [_P, _P, _P, _I, _I, _P, _P, _P],
     'qt_act_bwd': [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P],
     'qt_attn_blocks': [_I, _I],

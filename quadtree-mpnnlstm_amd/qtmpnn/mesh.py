@@ -160,7 +160,8 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     """Quadtree-decompose B criterion images and emit the block-diagonal mesh.
 
     src  : (B, rows, cols) fp32 criterion image (edge-padded on the fly), or
-    prev : (nodeval (N_old,) fp32, old Mesh) -- the un-flattened previous output, never materialised.
+    prev : (nodeval (N_old,) fp32 -- any element stride, e.g. column 0 of a wider matrix --, old Mesh): the
+           un-flattened previous output, never materialised.
     static: size every buffer for the worst case N = B*n*m and keep the node count on the device
             (mesh.n_dev): no host sync, fixed shapes -> the whole step can be captured in a hipGraph.
     """
@@ -176,7 +177,9 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     else:
         nodeval, old = prev
         _lib.require_cuda(nodeval, 'node values')
-        nodeval = nodeval.detach().contiguous().float()
+        nodeval = nodeval.detach().float()
+        if nodeval.dim() != 1 or (nodeval.numel() > 1 and nodeval.stride(0) < 1):
+            nodeval = nodeval.reshape(-1).contiguous()
         device, B, n, m = nodeval.device, old.B, old.n, old.m
     nbi, nbj = -(n // -max_size), -(m // -max_size)
     if nbi > nbj:
@@ -192,10 +195,11 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     offs = torch.empty(B * nbase + 1, **i32)
     tmp = torch.empty(B * nbase // 1024 + 8, **i32)
     if src is not None:
-        _lib.call('qt_quadtree_stage1', ptr(src), src.shape[1], src.shape[2], None, None, B, n, m, max_size,
+        _lib.call('qt_quadtree_stage1', ptr(src), src.shape[1], src.shape[2], None, 0, None, B, n, m, max_size,
                   float(thresh), CONDITIONS.index(condition), ptr(mk), ptr(hr), ptr(local_id), ptr(level), ptr(cnt))
     else:
-        _lib.call('qt_quadtree_stage1', None, 0, 0, ptr(nodeval), ptr(old.labels), B, n, m, max_size,
+        _lib.call('qt_quadtree_stage1', None, 0, 0, ptr(nodeval), nodeval.stride(0) if nodeval.numel() > 1 else 1,
+                  ptr(old.labels), B, n, m, max_size,
                   float(thresh), CONDITIONS.index(condition), ptr(mk), ptr(hr), ptr(local_id), ptr(level), ptr(cnt))
     _lib.call('qt_scan_i32', ptr(cnt), ptr(offs), B * nbase, ptr(tmp))
     N = B * n * m if static else int(offs[-1].item())     # dynamic mode: the one host sync of a mesh build
@@ -207,43 +211,50 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     ms.level = level
     ms.cell = torch.empty(max(N, 1), 4, **i32)
     ms.node_off = torch.empty(B + 1, **i32)
-    _lib.call('qt_quadtree_stage3', ptr(local_id), ptr(offs), B, n, m, max_size, ptr(ms.labels), ptr(level),
-              ptr(ms.cell), ptr(ms.node_off))
-    nd = None
-    if static:
-        ms.n_dev = ms.node_off[B:]                # view of the last entry = N
-        nd = ptr(ms.n_dev)
-    _finish_mesh(ms, device, size_norm if size_norm is not None else (max_size / 2) ** 2, resolution, nd)
-    return ms
-
-
-def _finish_mesh(ms, device, size_norm, resolution, nd):
-    """Node features and CSR adjacency of a mesh whose labels / level / cell / node_off are in place."""
-    N, n, m, B = ms.N, ms.n, ms.m, ms.B
-    i32 = dict(dtype=torch.int32, device=device)
     # static mode: rows beyond the valid count stay uninitialised -- every consumer is row local (pinned by
     # tests/test_gpu_ops.py::test_static_mode_ignores_capacity_rows)
     ms.posfeat = torch.empty(N, 3, device=device)
     ms.npix = torch.empty(N, device=device)
+    size_norm = size_norm if size_norm is not None else (max_size / 2) ** 2
+    _lib.call('qt_quadtree_stage3', ptr(local_id), ptr(offs), B, n, m, max_size, ptr(ms.labels), ptr(level),
+              ptr(ms.cell), ptr(ms.node_off), float(size_norm), ptr(ms.posfeat), ptr(ms.npix))
+    nd = None
+    if static:
+        ms.n_dev = ms.node_off[B:]                # view of the last entry = N
+        nd = ptr(ms.n_dev)
+    _finish_mesh(ms, device, None, resolution, nd)
+    return ms
+
+
+def _finish_mesh(ms, device, size_norm, resolution, nd):
+    """CSR adjacency (and, when size_norm is given, the node features) of a mesh whose labels / level / cell / node_off
+    are in place: count -> scan of the per-workgroup totals -> fill (+ degree) -> normalise, four launches."""
+    N, n, m, B = ms.N, ms.n, ms.m, ms.B
+    i32 = dict(dtype=torch.int32, device=device)
+    if size_norm is not None:
+        ms.posfeat = torch.empty(N, 3, device=device)
+        ms.npix = torch.empty(N, device=device)
     ms.rowptr = torch.zeros(N + 1, **i32) if N == 0 else torch.empty(N + 1, **i32)   # k_edges_fill writes every entry
     ms.dis = torch.empty(N, device=device)
     if N == 0:
         ms.col = torch.empty(0, **i32)
         ms.w = ms.nrm = torch.empty(0, device=device)
         return
-    _lib.call('qt_node_features', ptr(ms.cell), N, nd, n, m, float(size_norm), ptr(ms.posfeat), ptr(ms.npix))
-    cnt4 = torch.empty(4 * N, **i32)
-    off4 = torch.empty(4 * N + 1, **i32)
-    tmp4 = torch.empty(4 * N // 1024 + 8, **i32)
-    _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4))
-    _lib.call('qt_scan_i32', ptr(cnt4), ptr(off4), 4 * N, ptr(tmp4))
+    if size_norm is not None:
+        _lib.call('qt_node_features', ptr(ms.cell), N, nd, n, m, float(size_norm), ptr(ms.posfeat), ptr(ms.npix))
+    nblk = _lib.value('qt_edges_blocks', N)
+    cnt4 = torch.empty(nblk * 1024, **i32)
+    sums = torch.empty(nblk + 1, **i32)
+    _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4), ptr(sums))
+    _lib.call('qt_scan_top', ptr(sums), nblk)
     emax = 4 * B * n * m                          # every directed edge owns >= 1 of the 4*P pixel adjacencies
     ms.col = torch.empty(emax, **i32)
     ms.w = torch.empty(emax, device=device)
     ms.nrm = torch.empty(emax, device=device)
-    _lib.call('qt_edges_fill', ptr(ms.labels), ptr(ms.cell), ptr(off4), N, nd, n, m, float(resolution),
-              ptr(ms.rowptr), ptr(ms.col), ptr(ms.w))
-    _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), N, nd, ptr(ms.dis), ptr(ms.nrm))
+    _lib.call('qt_edges_fill', ptr(ms.labels), ptr(ms.cell), ptr(cnt4), ptr(sums), N, nd, n, m, float(resolution),
+              ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis))
+    _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm))
+
 
 _PIXEL_MESHES = {}
 

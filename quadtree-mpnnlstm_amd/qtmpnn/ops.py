@@ -16,6 +16,13 @@ def _c(t):
     return t if t is None or t.is_contiguous() else t.contiguous()
 
 
+def _row_stride(t):
+    """Row stride of a 2-D operand in floats (0 for None); a 1-row view may carry any stride(0)."""
+    if t is None:
+        return 0
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
 def _rows(t):
     """(tensor, row stride) for a 2-D fp32 operand whose rows are dense and 16-byte aligned -- column slices of a
     wider matrix (views produced by split / cat backward) are passed to the kernels as they are, without a copy."""
@@ -216,7 +223,7 @@ class _ChebPoly(Function):
         Y = Z.new_empty(N, Co)
         drop = _c(drop)
         _lib.call('qt_dense', ptr(Z), ptr(TZ), K, C, ptr(W), ptr(S), ksp, ptr(W[K * C:]) if Ks else None, 1, Co, N,
-                  ptr(mesh.n_dev), act, ptr(res), res.stride(0) if res is not None else 0, ptr(drop), ptr(Y))
+                  ptr(mesh.n_dev), act, ptr(res), _row_stride(res), ptr(drop), ptr(Y))
         ctx.mesh, ctx.K, ctx.Ks, ctx.act, ctx.acc = mesh, K, Ks, act, acc
         ctx.use_idx = acc.enter() if acc is not None else 0
         ctx.save_for_backward(Z, TZ, W, Y if act != ACT_NONE else None, res, drop)
@@ -237,7 +244,7 @@ class _ChebPoly(Function):
                 assert res.is_contiguous() and res.shape[1] <= Co
                 gres = torch.empty_like(res)
             if N > 0:
-                _lib.call('qt_act_bwd', ptr(gin), ptr(Y), ptr(res), res.stride(0) if res is not None else 0, ptr(drop), act, N,
+                _lib.call('qt_act_bwd', ptr(gin), ptr(Y), ptr(res), _row_stride(res), ptr(drop), act, N,
                           ptr(mesh.n_dev), Co, ptr(G), ptr(gres))
         gZ, gW = _cheb_backward(Z, TZ, W, G, mesh, K, Ks, ctx.acc, ctx.use_idx, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return gZ, gW, gres, None, None, None, None, None, None
@@ -529,11 +536,16 @@ class _PoolImage(Function):
 
     @staticmethod
     def forward(ctx, img, mesh, mean):
-        img = _c(img.float())
+        img = img.float()
         B, S, P, C = img.shape
+        clip_stride = 0
+        if B > 1 and img[0].is_contiguous() and img.stride(0) >= S * P * C:
+            clip_stride = img.stride(0)          # e.g. one time step of a (B, T, P, C) tensor: no copy
+        else:
+            img = _c(img)
         out = img.new_empty(S, mesh.N, C)
         if mesh.N > 0:
-            _pool_raw(mesh, C, out, C, 0, mean, img=img, S=S)
+            _pool_raw(mesh, C, out, C, 0, mean, img=img, S=S, img_clip_stride=clip_stride)
         ctx.mesh, ctx.mean, ctx.shape = mesh, mean, img.shape
         return out
 
@@ -608,6 +620,33 @@ def remesh_transfer(val, old, new):
     return _Remesh.apply(val, old, new)
 
 
+class _DecoderInput(Function):
+    """[val4[:, 0] | posfeat] (N, 4): the decoder's next input (model/seq2seq.py:484-487) from the transferred 4-wide
+    output; one kernel each way instead of slice + cat and slice_backward's zero-fill + copy."""
+
+    @staticmethod
+    def forward(ctx, val4, mesh):
+        val4 = _c(val4)
+        out = val4.new_empty(val4.shape)           # (empty_like would keep the odd strides of a 1-row view)
+        if mesh.N > 0:
+            _lib.call('qt_decoder_input', ptr(val4), ptr(mesh.posfeat), mesh.N, ptr(mesh.n_dev), ptr(out))
+        ctx.mesh = mesh
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mesh = ctx.mesh
+        g = _c(g)
+        gv = g.new_empty(g.shape)
+        if mesh.N > 0:
+            _lib.call('qt_decoder_input', ptr(g), None, mesh.N, ptr(mesh.n_dev), ptr(gv))
+        return gv, None
+
+
+def decoder_input(val4, mesh):
+    return _DecoderInput.apply(val4, mesh)
+
+
 # ------------------------------------------------------------------------------ loss
 class _StepSSE(Function):
     """Per-block partial sums over clips and unmasked pixels of (out[label] - y)^2 for one output step
@@ -637,7 +676,7 @@ class _StepSSE(Function):
         # every partial has the same upstream gradient (they are only ever summed); full rows: column 0 = value
         gout = torch.empty_like(out)
         if mesh.N > 0:
-            _lib.call('qt_sse_bwd', ptr(out), out.stride(0), ptr(mesh.npix), ptr(sy), ptr(_c(g)), mesh.N, ptr(mesh.n_dev),
+            _lib.call('qt_sse_bwd', ptr(out), out.stride(0), ptr(mesh.npix), ptr(sy), ptr(g.reshape(-1)[:1]), mesh.N, ptr(mesh.n_dev),
                       out.shape[1], ptr(gout))
         return gout, None, None
 
