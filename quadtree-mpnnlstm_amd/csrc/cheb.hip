@@ -489,15 +489,23 @@ __global__ __launch_bounds__(256) void k_gemm_fwd3(GemmArgs g) {
 }
 
 constexpr int WR = 32;
+// FW feature waves x (4 / FW) row groups, CT column tiles of 32.  The MFMA count per pass is what bounds this kernel, so
+// a narrow weight must not pay for the full 128 x 64 tile: with FW < 4 the spare waves take a share of every pass's rows
+// (their partial tiles are added through LDS at the end, in a fixed order), with CT = 1 the second column tile is skipped.
+template <int FW, int CT>
 __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __restrict__ G, int M, int NB, int64_t rbeg,
                                            int64_t rend, float* obase, int accumulate) {
-    __shared__ float As[2][WR][BM];
-    __shared__ float Gs[2][WR][BN];
+    constexpr int RG = 4 / FW;             // row groups
+    constexpr int KS = WR / 2 / RG;        // k-steps (2 rows each) per row group and pass
+    constexpr int BMF = FW * 32;           // features per block
+    __shared__ __attribute__((aligned(16))) float As[2][WR][BM];
+    __shared__ __attribute__((aligned(16))) float Gs[2][WR][BN];
     __shared__ const float* qptr[MAXQ];
     __shared__ int qstr[MAXQ];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l32 = lane & 31, half = lane >> 5;
-    const int f0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    const int fw = wave % FW, rg = wave / FW;
+    const int f0 = blockIdx.x * BMF, j0 = blockIdx.y * BN;
     const int nquad = M >> 2;
     build_quad_table(A, qptr, qstr, nquad);
     __syncthreads();
@@ -511,14 +519,14 @@ __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __res
         for (int u = 0; u < 4; ++u) {
             const int Q = (f0 >> 2) + a_q + u;
             pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ra < rend && Q < nquad) pa[u] = gload4(qptr[Q] + ra * qstr[Q]);
+            if (ra < rend && Q < nquad && a_q + u < BMF / 4) pa[u] = gload4(qptr[Q] + ra * qstr[Q]);
         }
-        const int64_t rg = r0 + g_row;
+        const int64_t rgw = r0 + g_row;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int jq = (g_q + u) * 4;
             pg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rg < rend && j0 + jq < NB) pg[u] = *reinterpret_cast<const float4*>(G + rg * NB + j0 + jq);
+            if (rgw < rend && j0 + jq < NB && jq < CT * 32) pg[u] = *reinterpret_cast<const float4*>(G + rgw * NB + j0 + jq);
         }
     };
     auto stash = [&](int buf) {
@@ -527,7 +535,11 @@ __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __res
 #pragma unroll
         for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Gs[buf][g_row][(g_q + u) * 4]) = pg[u];
     };
-    f32x16 acc0 = {0}, acc1 = {0};
+    f32x16 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
     if (rbeg < rend) {
         fetch(rbeg);
         stash(0);
@@ -537,43 +549,63 @@ __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __res
             const bool more = r0 + WR < rend;
             if (more) fetch(r0 + WR);
 #pragma unroll
-            for (int ks = 0; ks < WR / 2; ++ks) {
-                const float a = As[buf][2 * ks + half][wave * 32 + l32];
-                const float b0 = Gs[buf][2 * ks + half][l32];
-                const float b1 = Gs[buf][2 * ks + half][32 + l32];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            for (int k = 0; k < KS; ++k) {
+                const int ks = rg * KS + k;
+                const float a = As[buf][2 * ks + half][fw * 32 + l32];
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Gs[buf][2 * ks + half][c * 32 + l32], acc[c], 0, 0, 0);
             }
             if (more) stash(buf ^ 1);
             __syncthreads();
             buf ^= 1;
         }
     }
+    if constexpr (RG > 1) {
+        // add the row groups' partial tiles: groups 1.. park theirs in LDS (the A buffers are free), group 0 adds in order
+        float* red = &As[0][0][0];
+        static_assert((RG - 1) * FW * CT * 16 * 64 <= 2 * WR * BM, "partial tiles do not fit in the A buffers");
+        if (rg > 0) {
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((((rg - 1) * FW + fw) * CT + c) * 16 + r) * 64 + lane] = acc[c][r];
+        }
+        __syncthreads();
+        if (rg > 0) return;
+#pragma unroll
+        for (int g2 = 1; g2 < RG; ++g2)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] += red[((((g2 - 1) * FW + fw) * CT + c) * 16 + r) * 64 + lane];
+    }
+#pragma unroll
+    for (int jt = 0; jt < CT; ++jt) {
         const int j = j0 + jt * 32 + l32;
         if (j >= NB) continue;
         float old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {      // all slab reads first: 16 independent loads in flight
-            const int i = f0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int i = f0 + fw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             old[r] = (accumulate && i < M) ? obase[(int64_t)i * NB + j] : 0.0f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int i = f0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (i < M) obase[(int64_t)i * NB + j] = old[r] + (jt == 0 ? acc0[r] : acc1[r]);
+            const int i = f0 + fw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (i < M) obase[(int64_t)i * NB + j] = old[r] + acc[jt][r];
         }
     }
 }
 
-// MODE 1: part[blockIdx.z] = A[rows]^T @ G[rows] over this block's row chunk.  Block = 128 features x 64
-// columns of the weight gradient, wave w owns features [32w, 32w+32); the reduction runs over node rows in
-// passes of 32 rows: float4 global loads -> registers (prefetch of the next pass) -> double-buffered LDS.
+// MODE 1: part[blockIdx.z] = A[rows]^T @ G[rows] over this block's row chunk.  Block = 32 FW features x 32 CT
+// columns of the weight gradient; the reduction runs over node rows in passes of 32 rows: float4 global loads ->
+// registers (prefetch of the next pass) -> double-buffered LDS.
+template <int FW, int CT>
 __global__ __launch_bounds__(256) void k_gemm_wgrad(GemmArgs g) {
     const int64_t rbeg = (int64_t)blockIdx.z * g.row0_step;
     const int64_t rend = min((int64_t)qt_rows(g.n_dev, g.A.N), rbeg + g.row0_step);
-    wgrad_body(g.A, g.B, g.M, g.NB, rbeg, rend, g.out + (int64_t)blockIdx.z * g.M * g.NB, g.accumulate);
+    wgrad_body<FW, CT>(g.A, g.B, g.M, g.NB, rbeg, rend, g.out + (int64_t)blockIdx.z * g.M * g.NB, g.accumulate);
 }
 
 // The same reduction for up to 16 uses of ONE weight in a single launch (the rollout steps of a pass): z-blocks
@@ -589,6 +621,7 @@ struct WgradGroup {
     int nseg, Ka, Ca, Ks, Co, rows;
     float* part;
 };
+template <int FW, int CT>
 __global__ __launch_bounds__(256) void k_gemm_wgrad_group(WgradGroup w) {
     int s = 0;
     while (s + 1 < w.nseg && (int)blockIdx.z >= w.zend[s]) ++s;
@@ -598,7 +631,7 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_group(WgradGroup w) {
     const int M = w.Ka * w.Ca + w.Ks;
     const int64_t rbeg = (int64_t)zl * w.rows;
     const int64_t rend = min((int64_t)qt_rows(w.n_dev[s], w.N[s]), rbeg + w.rows);
-    wgrad_body(A, w.G[s], M, w.Co, rbeg, rend, w.part + (int64_t)blockIdx.z * M * w.Co, 0);
+    wgrad_body<FW, CT>(A, w.G[s], M, w.Co, rbeg, rend, w.part + (int64_t)blockIdx.z * M * w.Co, 0);
 }
 
 // 32 columns x 8 row groups per workgroup; fixed summation order (deterministic)
@@ -615,6 +648,19 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ part, 
         out[c] = ((sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl])) + ((sm[4][cl] + sm[5][cl]) + (sm[6][cl] + sm[7][cl]));
 }
 
+// tile variant by weight shape: feature waves 1 / 2 / 4 for up to 32 / 64 / more features, one column tile up to 32 columns
+inline int wgrad_fw(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
+#define QT_WGRAD_DISPATCH(K, M_, Co_, grid_, stream_, arg_)                                                         \
+    do {                                                                                                            \
+        const int fw_ = wgrad_fw(M_);                                                                               \
+        const bool one_ = (Co_) <= 32;                                                                              \
+        if (fw_ == 1 && one_) hipLaunchKernelGGL((K<1, 1>), grid_, dim3(256), 0, (hipStream_t)(stream_), arg_);     \
+        else if (fw_ == 1) hipLaunchKernelGGL((K<1, 2>), grid_, dim3(256), 0, (hipStream_t)(stream_), arg_);        \
+        else if (fw_ == 2 && one_) hipLaunchKernelGGL((K<2, 1>), grid_, dim3(256), 0, (hipStream_t)(stream_), arg_); \
+        else if (fw_ == 2) hipLaunchKernelGGL((K<2, 2>), grid_, dim3(256), 0, (hipStream_t)(stream_), arg_);        \
+        else if (one_) hipLaunchKernelGGL((K<4, 1>), grid_, dim3(256), 0, (hipStream_t)(stream_), arg_);            \
+        else hipLaunchKernelGGL((K<4, 2>), grid_, dim3(256), 0, (hipStream_t)(stream_), arg_);                      \
+    } while (0)
 constexpr int WGRAD_ROWS = 512;
 constexpr int WGRAD_GROUP_ROWS = 2048;
 
@@ -726,8 +772,8 @@ extern "C" int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, co
     g.row0_step = WGRAD_ROWS;
     g.n_dev = n_dev;
     g.accumulate = accumulate;
-    hipLaunchKernelGGL(k_gemm_wgrad, dim3(qt_cdiv(g.M, BM), qt_cdiv(Co, BN), qt_cdiv(N, WGRAD_ROWS)), dim3(256), 0,
-                       (hipStream_t)stream, g);
+    const dim3 grid(qt_cdiv(g.M, wgrad_fw(g.M) * 32), qt_cdiv(Co, BN), qt_cdiv(N, WGRAD_ROWS));
+    QT_WGRAD_DISPATCH(k_gemm_wgrad, g.M, Co, grid, stream, g);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -762,7 +808,8 @@ extern "C" int qt_wgrad_group(int nseg, const float* const* a0, const float* con
     for (int i = k; i < MAXSEG; ++i) { w.a0[i] = w.a_rest[i] = w.S[i] = w.G[i] = nullptr; w.n_dev[i] = nullptr; w.N[i] = 0; w.zend[i] = z; }
     w.nseg = k; w.Ka = Ka; w.Ca = Ca; w.Ks = Ks; w.Co = Co; w.rows = WGRAD_GROUP_ROWS; w.part = part;
     const int M = Ka * Ca + Ks;
-    hipLaunchKernelGGL(k_gemm_wgrad_group, dim3(qt_cdiv(M, BM), qt_cdiv(Co, BN), z), dim3(256), 0, (hipStream_t)stream, w);
+    const dim3 grid(qt_cdiv(M, wgrad_fw(M) * 32), qt_cdiv(Co, BN), z);
+    QT_WGRAD_DISPATCH(k_gemm_wgrad_group, M, Co, grid, stream, w);
     QT_LAUNCHED();
     return QT_OK;
 }
