@@ -512,53 +512,62 @@ __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __res
     // staging roles: A tile = 32 rows x 32 quads -> 4 float4 per thread; G tile = 32 rows x 16 quads -> 2 per thread
     const int a_row = t >> 3, a_q = (t & 7) * 4;           // 4 consecutive quads of one row
     const int g_row = t >> 3, g_q = (t & 7) * 2;
-    float4 pa[4], pg[2];
-    auto fetch = [&](int64_t r0) {
+    // two passes of operands in flight: the rows of this kernel come from HBM (activations saved by the forward pass),
+    // and with one pass of prefetch every group of weights ran at ~3 TB/s whatever its MFMA load
+    float4 pa[2][4], pg[2][2];
+    auto fetch = [&](int64_t r0, float4 (&qa)[4], float4 (&qg)[2]) {
         const int64_t ra = r0 + a_row;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int Q = (f0 >> 2) + a_q + u;
-            pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ra < rend && Q < nquad && a_q + u < BMF / 4) pa[u] = gload4(qptr[Q] + ra * qstr[Q]);
+            qa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ra < rend && Q < nquad && a_q + u < BMF / 4) qa[u] = gload4(qptr[Q] + ra * qstr[Q]);
         }
         const int64_t rgw = r0 + g_row;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int jq = (g_q + u) * 4;
-            pg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rgw < rend && j0 + jq < NB && jq < CT * 32) pg[u] = *reinterpret_cast<const float4*>(G + rgw * NB + j0 + jq);
+            qg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rgw < rend && j0 + jq < NB && jq < CT * 32) qg[u] = gload4(G + rgw * NB + j0 + jq);
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const float4 (&qa)[4], const float4 (&qg)[2]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(&As[buf][a_row][(a_q + u) * 4]) = pa[u];
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(&As[buf][a_row][(a_q + u) * 4]) = qa[u];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Gs[buf][g_row][(g_q + u) * 4]) = pg[u];
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Gs[buf][g_row][(g_q + u) * 4]) = qg[u];
     };
     f32x16 acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    auto mfma_pass = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int ks = rg * KS + k;
+            const float a = As[buf][2 * ks + half][fw * 32 + l32];
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Gs[buf][2 * ks + half][c * 32 + l32], acc[c], 0, 0, 0);
+        }
+    };
     if (rbeg < rend) {
-        fetch(rbeg);
-        stash(0);
+        // LDS buffer b holds pass p (p even: b = 0), register set (p + 1) & 1 holds pass p + 1, set p & 1 is loaded with
+        // pass p + 2 while pass p is multiplied; rows past `rend` load as zeros, so the tail needs no special case
+        fetch(rbeg, pa[0], pg[0]);
+        fetch(rbeg + WR, pa[1], pg[1]);
+        stash(0, pa[0], pg[0]);
         __syncthreads();
-        int buf = 0;
-        for (int64_t r0 = rbeg; r0 < rend; r0 += WR) {
-            const bool more = r0 + WR < rend;
-            if (more) fetch(r0 + WR);
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                const int ks = rg * KS + k;
-                const float a = As[buf][2 * ks + half][fw * 32 + l32];
-#pragma unroll
-                for (int c = 0; c < CT; ++c)
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Gs[buf][2 * ks + half][c * 32 + l32], acc[c], 0, 0, 0);
-            }
-            if (more) stash(buf ^ 1);
+        for (int64_t r0 = rbeg; r0 < rend; r0 += 2 * WR) {
+            fetch(r0 + 2 * WR, pa[0], pg[0]);
+            mfma_pass(0);
+            stash(1, pa[1], pg[1]);
             __syncthreads();
-            buf ^= 1;
+            fetch(r0 + 3 * WR, pa[1], pg[1]);
+            mfma_pass(1);                        // an all-zero pass when r0 + WR >= rend
+            stash(0, pa[0], pg[0]);
+            __syncthreads();
         }
     }
     if constexpr (RG > 1) {

@@ -72,6 +72,13 @@ __global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
     unsigned lv_pack[4] = {0, 0, 0, 0};
     float sscale[16];
     bool big = false;
+    // big-only mode: a node of 8x8 pixels or more covers whole 4x4 blocks, so the block's first pixel tells whether any
+    // of its 16 pixels is this kernel's business
+    bool mine = true;
+    if (a.big_only) {
+        const int r = R0 + 4 * br, c = C0 + 4 * bc;
+        mine = r < a.n && c < a.m && lvl_img[(int64_t)r * a.m + c] >= 3;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
             lab[q] = -1;
             slab[q] = -1;
             sscale[q] = 1.0f;
-            if (r < a.n && c < a.m) {
+            if (mine && r < a.n && c < a.m) {
                 const int64_t p = (int64_t)r * a.m + c;
                 lab[q] = lab_img[p];
                 const unsigned lv = lvl_img[p];
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) void k_pool_nodes(PoolArgs a) {
             const int r = cl.x + dr, c = cl.y + dc;
             if (r >= a.n || c >= a.m) continue;
             const int64_t p = (int64_t)r * a.m + c;
-            if (a.labels[base + p] != (int)i) continue;
+            if (cl.z > 1 && a.labels[base + p] != (int)i) continue;      // (a single-pixel node owns its pixel)
             if (a.src_labels) {
                 const int sl = a.src_labels[base + p];
                 if (sl < 0) continue;

@@ -522,8 +522,8 @@ def _pool_raw(mesh, C, out, out_stride, out_coff, mean, img=None, S=1, src_val=N
               img_clip_stride=0):
     _lib.call('qt_pool', ptr(img), S, img_clip_stride, ptr(src_val), ptr(src_mesh.labels) if src_mesh is not None else None,
               ptr(src_mesh.npix) if src_mesh is not None else None, int(src_inv), C, ptr(mesh.labels), ptr(mesh.level),
-              ptr(mesh.npix), int(mean), mesh.B, mesh.n, mesh.m, mesh.N, ptr(mesh.cell), ptr(mesh.n_dev), ptr(out), out_stride,
-              out_coff)
+              ptr(mesh.npix), int(mean), mesh.B, mesh.n, mesh.m, mesh.N, ptr(mesh.cell) if C >= 4 else None, ptr(mesh.n_dev),
+              ptr(out), out_stride, out_coff)       # 1-channel transfers: the tile kernel alone is one launch and faster
 
 
 def _gather_raw(mesh, val, C, inv_npix, img):
