@@ -162,7 +162,15 @@ struct GemmArgs {
     const float* ln;
     int ld_c, h;
     float *O, *Hn, *Cn, *gates, *Craw;
+#ifdef QT_GEMM_TIMING
+    long long* dbg;
+#endif
 };
+#ifdef QT_GEMM_TIMING
+#define QT_STAMP(i) do { if (g.dbg && threadIdx.x == 0) g.dbg[(int64_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define QT_STAMP(i) do {} while (0)
+#endif
 
 // ---- fp32 MFMA tiles (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 64 FLOP/clk/SIMD).
 // Operand maps (cdna_hip_programming.md section 3): lane l holds A[i = l & 31][k = l >> 5] and
@@ -218,6 +226,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgr
     const int j0 = blockIdx.y * BNT;
     const int64_t rows = qt_rows(g.n_dev, g.M);      // g.M stays the plane stride (capacity)
     if (i0 >= rows) return;
+    QT_STAMP(0);
     const int nquad = g.K >> 2;
     build_quad_table(g.A, qptr, qstr, nquad);
     const int64_t my_row = i0 + wave * 32 + l32;
@@ -230,6 +239,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgr
     for (int k0 = 0; k0 < g.K; k0 += KWT) {
         const int kn = min(KWT, g.K - k0);           // multiple of 4
         __syncthreads();                              // table ready / previous pass done with Bs
+        QT_STAMP(1);
         // W chunk -> LDS first (small, L2 resident) ...
         for (int e = t; e < kn * (BNT / 4); e += 256) {
             const int kb = e / (BNT / 4), jq = (e % (BNT / 4)) * 4;
@@ -245,6 +255,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgr
             *reinterpret_cast<float4*>(&Bt[c * PITCH + kq]) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
+        QT_STAMP(2);
         // ... then the MFMA stream.  The A quads (quad 2 j + half of this lane's row) come straight from global memory
         // through a 4-deep register ring loaded four k-groups ahead; the loop is a plain runtime loop with NO branch
         // around the MFMAs (conditionals there made hipcc shuttle the accumulators between VGPRs and AGPRs: 1088
@@ -274,6 +285,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgr
             }
         }
     }
+    QT_STAMP(3);
     float* Cs = Bt;                              // 128 rows x 64 columns per pass
     if constexpr (CELL) {
         // LSTM epilogue (h = 16: four adjacent lanes own a node, as in k_lstm_fwd).  The 128 x 64 gate tile goes through
@@ -331,6 +343,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgr
                 Cs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + u * 32 + l32] = acc[nt][r];
         }
         __syncthreads();
+        QT_STAMP(4);
 #pragma unroll
         for (int u = 0; u < BM * 16 / 256; ++u) {
             const int e = t + 256 * u;
@@ -350,6 +363,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgr
             *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
         }
     }
+    QT_STAMP(5);
 }
 
 // ---- bf16x3 variant of the forward / data-gradient GEMM -------------------------------------------------------------
@@ -675,6 +689,11 @@ constexpr int WGRAD_GROUP_ROWS = 2048;
 
 }  // namespace
 
+#ifdef QT_GEMM_TIMING
+static long long* g_dbg = nullptr;       // diagnostics build only (tools/exp_gemm_timing.py)
+extern "C" void qt_gemm_timing_buffer(long long* p) { g_dbg = p; }
+#endif
+
 extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, const int32_t* n_dev, int C,
                        const float* x, float alpha, const float* p, float beta, const float* q, float gamma, float* out,
                        void* stream) {
@@ -718,6 +737,9 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
     GemmArgs g = {};
     g.A.a0 = a0; g.A.a_rest = a_rest; g.A.S = S; g.A.Ka = Ka; g.A.Ca = Ca; g.A.Ks = Ks; g.A.N = N;
     g.B = W; g.M = N; g.K = Ka * Ca + Ks; g.NB = Kb * Cb;
+#ifdef QT_GEMM_TIMING
+    g.dbg = g_dbg;
+#endif
     g.Kb = Kb; g.Cb = Cb; g.act = act; g.res = res; g.res_stride = res_stride; g.drop = drop; g.out = out; g.row0_step = 0; g.n_dev = n_dev; g.accumulate = 0;
     // default: exact fp32 MFMA (bit-for-bit a k-ordered fmaf chain).  QT_GEMM_BF16X3=1 opts into the bf16x3 split
     // kernels (fp32-level error, ~8 % faster on these memory/latency-shaped GEMMs: measured 27.7 vs 30.1 us).
