@@ -142,6 +142,14 @@ int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, 
             const float* x, float alpha, const float* p, float beta, const float* q, float gamma,
             float* out, void* stream);
 
+/* qt_spmm for rows stored as two matrices side by side, [a (N, Ca) | b (N, Cb)], in ONE launch (Cb == 0: only part a):
+ * the recurrent cells propagate Z = [X | H] as X and H, never concatenated.  Widths multiples of 4; p / q given for
+ * both parts or for neither.  x / p / q may be column views of wider matrices (row strides). */
+int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, const int32_t* n_dev,
+             int Ca, const float* xa, int ldxa, const float* pa, int ldpa, const float* qa, int ldqa, float* outa,
+             int Cb, const float* xb, int ldxb, const float* pb, int ldpb, const float* qb, int ldqb, float* outb,
+             float alpha, float beta, float gamma, void* stream);   /* ld*: row strides in floats, 0 = dense; out rows are dense */
+
 /* qt_dense: out planes = act( [A planes | S] @ [W ; Ws] ), the gate GEMM.
  *   A: Ka planes, plane k at a0 (k == 0) or a_rest + (k-1)*N*Ca, each (N, Ca)   (T_0 = Z stays in the caller's tensor)
  *   W: (Ka*Ca, Kb*Cb) row-major;  S: (N, Ks) or NULL with Ws (Ks, Kb*Cb)
@@ -152,18 +160,29 @@ int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, const float* 
              const float* S, int Ks, const float* Ws, int Kb, int Cb, int N, const int32_t* n_dev,
              int act, const float* res, int res_stride, const float* drop, float* out, void* stream);
 
+/* qt_dense2: qt_dense whose input planes and output planes may each be two matrices side by side:
+ *   input plane k = [a (N, Ca) | b (N, Cab)] (a0 / a0b for k = 0, a_rest / a_restb (Ka-1, N, .) for the rest; Cab == 0: none);
+ *   output plane j = [out (N, Cb) | outb (N, Cbb)] (Cbb == 0: none).  W rows follow the logical order (k, [a | b]),
+ *   W columns the logical order (j, [out | outb]).  lda0 / lda0b: row strides of plane 0 in floats (0 = dense), so that
+ *   plane 0 may be a column view of a wider matrix.  qt_dense is the Cab = Cbb = 0, dense case. */
+int qt_dense2(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb, int Ka, int Ca, int Cab,
+              const float* W, const float* S, int Ks, const float* Ws, int Kb, int Cb, int Cbb, int N,
+              const int32_t* n_dev, int act, const float* res, int res_stride, const float* drop, float* out, float* outb,
+              void* stream);
+
 /* qt_wgrad: partial sums of [A planes | S]^T @ G over row blocks, then qt_colsum over the blocks.
  *   G (N, Co); part (nblk, Ka*Ca + Ks, Co) with nblk = qt_wgrad_blocks(N).  accumulate != 0 adds into part
  *   (each block owns its slab, so the sum over several uses of one weight keeps a fixed order).  */
 int qt_wgrad_blocks(int N);
-int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, const float* S, int Ks,
-             const float* G, int Co, int N, const int32_t* n_dev, int accumulate, float* part, void* stream);
+int qt_wgrad(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb, int Ka, int Ca, int Cab,
+             const float* S, int Ks, const float* G, int Co, int N, const int32_t* n_dev, int accumulate, float* part,
+             void* stream);      /* planes in two parts as in qt_dense2 (Cab == 0: one part) */
 /* qt_wgrad for up to 16 uses of one weight (the rollout steps of a pass) in ONE launch: host arrays of nseg device
  * pointers / capacities, shared (Ka, Ca, Ks, Co).  part: (qt_wgrad_group_blocks(nseg, N), Ka*Ca + Ks, Co), overwritten. */
 int qt_wgrad_group_blocks(int nseg, const int* N);
-int qt_wgrad_group(int nseg, const float* const* a0, const float* const* a_rest, const float* const* S,
-                   const float* const* G, const int* N, const int32_t* const* n_dev, int Ka, int Ca, int Ks, int Co,
-                   float* part, void* stream);
+int qt_wgrad_group(int nseg, const float* const* a0, const int* lda0, const float* const* a_rest, const float* const* a0b,
+                   const int* lda0b, const float* const* a_restb, const float* const* S, const float* const* G, const int* N,
+                   const int32_t* const* n_dev, int Ka, int Ca, int Cab, int Ks, int Co, float* part, void* stream);
 /* out[j] = sum_i part[i*len + j], i < nblk */
 int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream);
 
@@ -181,8 +200,10 @@ int qt_lstm_fwd(const float* G, const float* Cprev, int ld_c /* row stride of Cp
                 int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw,
                 void* stream);
 /* qt_dense (act none, Kb = 1, Cb = 4h) with qt_lstm_fwd as its epilogue, for hidden size 16: the gate pre-activations stay in
- * LDS.  Same results as the two calls (same arithmetic in the same order). */
-int qt_dense_lstm(const float* a0, const float* a_rest, int Ka, int Ca, const float* W, const float* S, int Ks,
+ * LDS.  Same results as the two calls (same arithmetic in the same order).  Planes in two parts as in qt_dense2; O may be
+ * NULL (the raw output gate is also gates[:, 3h:4h]). */
+int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb, int Ka, int Ca, int Cab,
+                  const float* W, const float* S, int Ks,
                   const float* Ws, int h, int N, const int32_t* n_dev, const float* Cprev, int ld_c,
                   const float* wc, const float* b, const float* ln, float* O, float* Hn, float* Cn,
                   float* gates, float* Craw, void* stream);
@@ -193,12 +214,15 @@ int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_gh, const f
                 int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
                 void* stream);
 
-/* decoder head input, model/seq2seq.py:160-165: Z (N, hp) = [relu(LayerNorm_o(O)) | concat | 0...], hp >= h+1 */
-int qt_head_fwd(const float* O, const float* ln_o /* (2,h) */, const float* concat /* (N) or NULL */,
-                int N, const int32_t* n_dev, int h, int hp, float* Z, void* stream);
-/* gO (N,h), gconcat (N) or NULL; part (nblk, 2h) partial sums of g_ln_o, nblk = qt_lstm_bwd_blocks(N, h) */
-int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, const int32_t* n_dev, int h, int hp,
-                float* gO, float* gconcat, float* part, int accumulate, void* stream);
+/* decoder head input, model/seq2seq.py:160-165: Z (N, hp) = [relu(LayerNorm_o(O)) | concat | 0...], hp >= h+1.
+ * Zb != NULL: the same row as two matrices, Z (N, h) and Zb (N, hp - h).  O rows have stride ld_o floats (0 = h): the raw
+ * output gate may be read in place from the saved gate activations, gates[:, 3h:4h]. */
+int qt_head_fwd(const float* O, int ld_o, const float* ln_o /* (2,h) */, const float* concat /* (N) or NULL */,
+                int N, const int32_t* n_dev, int h, int hp, float* Z, float* Zb, void* stream);
+/* gZ / gZb laid out like Z / Zb; gO (N,h), gconcat (N) or NULL; part (nblk, 2h) partial sums of g_ln_o,
+ * nblk = qt_lstm_bwd_blocks(N, h) */
+int qt_head_bwd(const float* gZ, const float* gZb, const float* O, int ld_o, const float* ln_o, int N, const int32_t* n_dev,
+                int h, int hp, float* gO, float* gconcat, float* part, int accumulate, void* stream);
 
 /* out (N, sum widths) = [src_0 | src_1 | ...] for up to 8 row-strided fp32 sources (host arrays of nsrc device pointers,
  * widths and row strides, all multiples of 4): Z = [X | H] of GConvLSTM (model/model.py:394-424 feed X and H to separate

@@ -14,17 +14,32 @@ namespace {
 // thread needs 9.2 workgroups per CU -- more than the 8 that are resident -- and the leftover second round cost a whole
 // extra chain (10.8 us against 8.0 us at C = 16).  Two rows per thread keep every launch of the path inside one
 // resident round with twice the loads in flight per thread.
+// One launch serves one or two column parts of the same rows (x, p, q, out of width C each): Z = [X | H] of the
+// recurrent cells is propagated as its two matrices, never concatenated.  Part b's workgroups follow part a's.
+struct SpmmPart {
+    const float* x;
+    const float* p;
+    const float* q;
+    float* out;
+    int C, ldx, ldp, ldq, xcd_chunk;      // row strides of x / p / q in floats (out rows are dense)
+};
 template <int VEC, int RPT, int EPT>
 __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                               const float* __restrict__ nrm, int Ncap, const int32_t* __restrict__ n_dev,
-                                              int C, const float* __restrict__ x, float alpha, const float* p, float beta,
-                                              const float* q, float gamma,
-                                              float* out,    // out may alias p or q (in-place Clenshaw step)
-                                              int xcd_chunk) {
+                                              SpmmPart pa, SpmmPart pb, int nblk_a,     // workgroups [nblk_a, ..) do part b
+                                              float alpha, float beta, float gamma) {
+    const bool second = (int)blockIdx.x >= nblk_a;
+    const SpmmPart& P = second ? pb : pa;
+    const int C = P.C, ldx = P.ldx, xcd_chunk = P.xcd_chunk;
+    const float* __restrict__ x = P.x;
+    const float* p = P.p;
+    const float* q = P.q;
+    float* out = P.out;                     // out may alias p or q (in-place Clenshaw step)
+    const int bid = second ? (int)blockIdx.x - nblk_a : (int)blockIdx.x;
     const int nch = C / VEC;
     // Workgroups are dealt round-robin to the 8 XCDs, each with a private L2.  Giving XCD x the contiguous node range
     // [x * chunk, (x+1) * chunk) keeps a node's neighbours (close in the reversed-Morton order) in the L2 that reads them.
-    const int blk = xcd_chunk ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int blk = xcd_chunk ? (bid & 7) * xcd_chunk + (bid >> 3) : bid;
     const int64_t idx = (int64_t)blk * 256 + threadIdx.x;
     const int64_t rp = idx / nch;
     const int rows = qt_rows(n_dev, Ncap);
@@ -65,7 +80,7 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
 #pragma unroll
             for (int u = 0; u < RPT; ++u)
 #pragma unroll
-                for (int v = 0; v < EPT; ++v) f[u][v] = *reinterpret_cast<const float4*>(x + (int64_t)cj[u][v] * C + ch);
+                for (int v = 0; v < EPT; ++v) f[u][v] = *reinterpret_cast<const float4*>(x + (int64_t)cj[u][v] * ldx + ch);
 #pragma unroll
             for (int u = 0; u < RPT; ++u)
 #pragma unroll
@@ -78,7 +93,7 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
 #pragma unroll
             for (int u = 0; u < RPT; ++u)
 #pragma unroll
-                for (int v = 0; v < EPT; ++v) f[u][v] = x[(int64_t)cj[u][v] * C + ch];
+                for (int v = 0; v < EPT; ++v) f[u][v] = x[(int64_t)cj[u][v] * ldx + ch];
 #pragma unroll
             for (int u = 0; u < RPT; ++u)
 #pragma unroll
@@ -112,8 +127,8 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             r[k] = alpha * acc[u][k];
-            if (p) r[k] += beta * p[o + k];
-            if (q) r[k] += gamma * q[o + k];
+            if (p) r[k] += beta * p[row[u] * P.ldp + ch + k];
+            if (q) r[k] += gamma * q[row[u] * P.ldq + ch + k];
         }
         if constexpr (VEC == 4) {
             *reinterpret_cast<float4*>(out + o) = make_float4(r[0], r[1], r[2], r[3]);
@@ -124,22 +139,17 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
 }
 
 // ------------------------------------------------------------------ tiled GEMM
-// Node-feature operand made of Ka planes (N, Ca) plus an optional (N, Ks) block.
+// Node-feature operand made of Ka planes plus an optional (N, Ks) block.  A plane is one (N, Ca) matrix or two matrices side
+// by side, (N, Ca) | (N, Cab): the recurrent cells feed Z = [X | H] without ever concatenating it -- rows of 64 bytes (H)
+// and 16 bytes (X) also keep every 4-lane group of a gather inside one row, which rows of 80 bytes do not.
 struct PlaneSrc {
-    const float* a0;
-    const float* a_rest;
+    const float* a0;        // plane 0, part a (N, Ca)
+    const float* a_rest;    // planes 1 .. Ka-1, part a (Ka-1, N, Ca)
+    const float* a0b;       // part b of the same planes: (N, Cab) and (Ka-1, N, Cab); Cab == 0: none
+    const float* a_restb;
     const float* S;
-    int Ka, Ca, Ks, N;
-    __device__ __forceinline__ float at(int64_t row, int k) const {
-        const int kc = Ka * Ca;
-        if (k < kc) {
-            const int pl = k / Ca, ch = k - pl * Ca;
-            const float* base = pl == 0 ? a0 : a_rest + (int64_t)(pl - 1) * N * Ca;
-            return base[row * Ca + ch];
-        }
-        return S[row * Ks + (k - kc)];
-    }
-    __device__ __forceinline__ int width() const { return Ka * Ca + Ks; }
+    int Ka, Ca, Cab, Ks, N;
+    int lda0, lda0b;        // row strides of plane 0 (column views of wider matrices are passed as they are)
 };
 
 struct GemmArgs {
@@ -152,6 +162,8 @@ struct GemmArgs {
     int res_stride;
     const float* drop;
     float* out;
+    float* outb;        // forward: second column part of every output plane, (Kb, M, Cbb); Cbb == 0: none
+    int Cbb;
     int64_t row0_step;  // wgrad: rows per block
     const int32_t* n_dev;  // valid node rows on the device (NULL: A.N)
     int accumulate;        // wgrad: add into part instead of overwriting (sums several uses of one weight)
@@ -195,11 +207,17 @@ __device__ __forceinline__ float4 gload4(const float* p) {
 // Quad table: quad Q of a node row lives at qptr[Q] + row * qstr[Q] (plane Q*4/Ca of the operand, or S).
 __device__ __forceinline__ void build_quad_table(const PlaneSrc& A, const float** qptr, int* qstr, int nquad) {
     for (int Q = threadIdx.x; Q < nquad; Q += 256) {
-        const int k = 4 * Q, kc = A.Ka * A.Ca;
+        const int ct = A.Ca + A.Cab;
+        const int k = 4 * Q, kc = A.Ka * ct;
         if (k < kc) {
-            const int pl = k / A.Ca, c = k - pl * A.Ca;
-            qptr[Q] = (pl == 0 ? A.a0 : A.a_rest + (int64_t)(pl - 1) * A.N * A.Ca) + c;
-            qstr[Q] = A.Ca;
+            const int pl = k / ct, c = k - pl * ct;
+            if (c < A.Ca) {
+                qptr[Q] = (pl == 0 ? A.a0 : A.a_rest + (int64_t)(pl - 1) * A.N * A.Ca) + c;
+                qstr[Q] = pl == 0 ? A.lda0 : A.Ca;
+            } else {
+                qptr[Q] = (pl == 0 ? A.a0b : A.a_restb + (int64_t)(pl - 1) * A.N * A.Cab) + (c - A.Ca);
+                qstr[Q] = pl == 0 ? A.lda0b : A.Cab;
+            }
         } else {
             qptr[Q] = A.S + (k - kc);
             qstr[Q] = A.Ks;
@@ -316,7 +334,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgr
             if (ok && g.Cprev) cp = ld4(g.Cprev + node * g.ld_c + j0);
             const CellOut r = cell_forward<4>(gi, gf, gc, go, cp, g.wc, g.bias, g.ln, h, j0);
             if (ok) {
-                st4(g.O + node * h + j0, r.Og);
+                if (g.O) st4(g.O + node * h + j0, r.Og);
                 st4(g.Hn + node * h + j0, r.hn);
                 st4(g.Cn + node * h + j0, r.cn);
                 float* gs = g.gates + node * 4 * h + j0;
@@ -359,8 +377,12 @@ __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgr
                 const float d = g.drop ? g.drop[i] : 1.0f, rs = g.res[i * g.res_stride];
                 v.x = tanhf(d * v.x) + rs; v.y = tanhf(d * v.y) + rs; v.z = tanhf(d * v.z) + rs; v.w = tanhf(d * v.w) + rs;
             }
-            const int pl = j / g.Cb, ch = j - pl * g.Cb;          // Cb % 4 == 0: a float4 never straddles two planes
-            *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+            const int ct = g.Cb + g.Cbb;
+            const int pl = j / ct, ch = j - pl * ct;              // Cb, Cbb % 4 == 0: a float4 never straddles two parts
+            if (ch < g.Cb)
+                *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+            else
+                *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + i * g.Cbb + (ch - g.Cb)) = v;
         }
     }
     QT_STAMP(5);
@@ -496,8 +518,12 @@ __global__ __launch_bounds__(256) void k_gemm_fwd3(GemmArgs g) {
                 const float d = g.drop ? g.drop[i] : 1.0f, rs = g.res[i * g.res_stride];
                 v.x = tanhf(d * v.x) + rs; v.y = tanhf(d * v.y) + rs; v.z = tanhf(d * v.z) + rs; v.w = tanhf(d * v.w) + rs;
             }
-            const int pl = j / g.Cb, ch = j - pl * g.Cb;
-            *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+            const int ct = g.Cb + g.Cbb;
+            const int pl = j / ct, ch = j - pl * ct;
+            if (ch < g.Cb)
+                *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+            else
+                *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + i * g.Cbb + (ch - g.Cb)) = v;
         }
     }
 }
@@ -637,11 +663,13 @@ constexpr int MAXSEG = 16;
 struct WgradGroup {
     const float* a0[MAXSEG];
     const float* a_rest[MAXSEG];
+    const float* a0b[MAXSEG];
+    const float* a_restb[MAXSEG];
     const float* S[MAXSEG];
     const float* G[MAXSEG];
     const int32_t* n_dev[MAXSEG];
-    int N[MAXSEG], zend[MAXSEG];
-    int nseg, Ka, Ca, Ks, Co, rows;
+    int N[MAXSEG], zend[MAXSEG], lda0[MAXSEG], lda0b[MAXSEG];
+    int nseg, Ka, Ca, Cab, Ks, Co, rows;
     float* part;
 };
 template <int FW, int CT>
@@ -650,8 +678,9 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_group(WgradGroup w) {
     while (s + 1 < w.nseg && (int)blockIdx.z >= w.zend[s]) ++s;
     const int zl = blockIdx.z - (s ? w.zend[s - 1] : 0);
     PlaneSrc A;
-    A.a0 = w.a0[s]; A.a_rest = w.a_rest[s]; A.S = w.S[s]; A.Ka = w.Ka; A.Ca = w.Ca; A.Ks = w.Ks; A.N = w.N[s];
-    const int M = w.Ka * w.Ca + w.Ks;
+    A.a0 = w.a0[s]; A.a_rest = w.a_rest[s]; A.a0b = w.a0b[s]; A.a_restb = w.a_restb[s]; A.S = w.S[s];
+    A.Ka = w.Ka; A.Ca = w.Ca; A.Cab = w.Cab; A.Ks = w.Ks; A.N = w.N[s]; A.lda0 = w.lda0[s]; A.lda0b = w.lda0b[s];
+    const int M = w.Ka * (w.Ca + w.Cab) + w.Ks;
     const int64_t rbeg = (int64_t)zl * w.rows;
     const int64_t rend = min((int64_t)qt_rows(w.n_dev[s], w.N[s]), rbeg + w.rows);
     wgrad_body<FW, CT>(A, w.G[s], M, w.Co, rbeg, rend, w.part + (int64_t)blockIdx.z * M * w.Co, 0);
@@ -689,10 +718,67 @@ constexpr int WGRAD_GROUP_ROWS = 2048;
 
 }  // namespace
 
+// shared argument checks / operand setup of the node-feature operand
+static int plane_src(PlaneSrc* A, const char* fn, const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b,
+                     const float* a_restb, int Ka, int Ca, int Cab, const float* S, int Ks, int N) {
+    const bool ok = a0 && Ka >= 1 && Ca >= 1 && Cab >= 0 && (Ka == 1 || a_rest) && (Cab == 0 || (a0b && (Ka == 1 || a_restb))) &&
+                    (Ks == 0 || S) && Ca % 4 == 0 && Cab % 4 == 0 && Ks % 4 == 0 && lda0 % 4 == 0 && lda0b % 4 == 0 && (Ka * (Ca + Cab) + Ks) / 4 <= MAXQ &&
+                    (((uintptr_t)a0 | (uintptr_t)a_rest | (uintptr_t)a0b | (uintptr_t)a_restb | (uintptr_t)S) & 15) == 0;
+    if (!ok) {
+        qt_set_error("%s: bad node-feature operand (planes / parts must be 16-byte aligned with widths that are multiples of 4, "
+                     "reduction dimension <= 512)", fn);
+        return QT_E_ARG;
+    }
+    A->a0 = a0; A->a_rest = a_rest; A->a0b = Cab ? a0b : nullptr; A->a_restb = Cab ? a_restb : nullptr; A->S = S;
+    A->Ka = Ka; A->Ca = Ca; A->Cab = Cab; A->Ks = Ks; A->N = N;
+    A->lda0 = lda0 > 0 ? lda0 : Ca; A->lda0b = lda0b > 0 ? lda0b : Cab;
+    return QT_OK;
+}
+
 #ifdef QT_GEMM_TIMING
 static long long* g_dbg = nullptr;       // diagnostics build only (tools/exp_gemm_timing.py)
 extern "C" void qt_gemm_timing_buffer(long long* p) { g_dbg = p; }
 #endif
+
+static int spmm_part(SpmmPart* P, int* nblk, int N, int C, const float* x, int ldx, const float* p, int ldp, const float* q,
+                     int ldq, float* out) {
+    P->x = x; P->p = p; P->q = q; P->out = out; P->C = C;
+    P->ldx = ldx > 0 ? ldx : C; P->ldp = ldp > 0 ? ldp : C; P->ldq = ldq > 0 ? ldq : C;
+    int grid = qt_cdiv((int64_t)N * (C / 4), 256);
+    static const bool xcd = getenv("QT_SPMM_FLAT") == nullptr;
+    P->xcd_chunk = 0;
+    if (xcd && grid >= 64) {
+        P->xcd_chunk = qt_cdiv(grid, 8);
+        grid = P->xcd_chunk * 8;    // surplus workgroups fall past the row count and exit
+    }
+    *nblk = grid;
+    return 0;
+}
+
+extern "C" int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, const int32_t* n_dev, int Ca,
+                        const float* xa, int ldxa, const float* pa, int ldpa, const float* qa, int ldqa, float* outa, int Cb,
+                        const float* xb, int ldxb, const float* pb, int ldpb, const float* qb, int ldqb, float* outb,
+                        float alpha, float beta, float gamma, void* stream) {
+    QT_ARG((ldxa | ldpa | ldqa | ldxb | ldpb | ldqb) % 4 == 0, "row strides must be multiples of 4");
+    QT_ARG(rowptr && col && nrm && xa && outa && Ca > 0 && Ca % 4 == 0 && Cb >= 0 && Cb % 4 == 0, "bad arguments");
+    QT_ARG(Cb == 0 || (xb && outb && (pb != nullptr) == (pa != nullptr) && (qb != nullptr) == (qa != nullptr)),
+           "part b must mirror part a");
+    QT_ARG(xa != outa && (Cb == 0 || xb != outb), "out must not alias x");
+    QT_ARG((((uintptr_t)xa | (uintptr_t)outa | (uintptr_t)pa | (uintptr_t)qa | (uintptr_t)xb | (uintptr_t)outb | (uintptr_t)pb |
+             (uintptr_t)qb) & 15) == 0, "operands must be 16-byte aligned");
+    if (N <= 0) return QT_OK;
+    SpmmPart A, B = {};
+    int na = 0, nb = 0;
+    spmm_part(&A, &na, N, Ca, xa, ldxa, pa, ldpa, qa, ldqa, outa);
+    if (Cb) spmm_part(&B, &nb, N, Cb, xb, ldxb, pb, ldpb, qb, ldqb, outb);
+    // 8 edges per trip for narrow rows (see qt_spmm); the wider part decides
+    if (max(Ca, Cb) <= 20)
+        hipLaunchKernelGGL((k_spmm<4, 1, 8>), dim3(na + nb), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, na, alpha, beta, gamma);
+    else
+        hipLaunchKernelGGL((k_spmm<4, 1, 4>), dim3(na + nb), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, na, alpha, beta, gamma);
+    QT_LAUNCHED();
+    return QT_OK;
+}
 
 extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, const int32_t* n_dev, int C,
                        const float* x, float alpha, const float* p, float beta, const float* q, float gamma, float* out,
@@ -701,42 +787,36 @@ extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* n
     QT_ARG(x != out, "out must not alias x");
     if (N <= 0) return QT_OK;
     const bool v4 = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)p | (uintptr_t)q) % 16) == 0);
-    const int nch = v4 ? C / 4 : C;
-    int grid = qt_cdiv((int64_t)N * nch, 256);
-    static const bool xcd = getenv("QT_SPMM_FLAT") == nullptr;
-    int chunk = 0;
-    if (xcd && grid >= 64) {
-        chunk = qt_cdiv(grid, 8);
-        grid = chunk * 8;           // surplus workgroups fall past the row count and exit
-    }
+    if (v4) return qt_spmm2(rowptr, col, nrm, N, n_dev, C, x, 0, p, 0, q, 0, out, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, alpha, beta, gamma, stream);
+    // scalar rows (C not a multiple of 4): one float per thread
+    SpmmPart A, B = {};
+    A.x = x; A.p = p; A.q = q; A.out = out; A.C = C; A.ldx = A.ldp = A.ldq = C; A.xcd_chunk = 0;
+    const int grid = qt_cdiv((int64_t)N * C, 256);
     // Edges per trip: a trip is two dependent loads (col/nrm, then the x rows), and the few rows with many neighbours
     // (a 4x4 cell next to 1x1 cells has 16) set the length of the whole launch.  8 per trip: 6.6 -> 4.5 us at C = 4,
     // 9.3 -> 7.5 us at C = 16 (N = 1.2e5, inside a hipGraph); wider rows are bandwidth bound and prefer fewer registers.
-#define QT_SPMM_LAUNCH(V, R, E) hipLaunchKernelGGL((k_spmm<V, R, E>), dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, C, x, alpha, p, beta, q, gamma, out, chunk)
-    if (v4 && C <= 20) QT_SPMM_LAUNCH(4, 1, 8);
-    else if (v4) QT_SPMM_LAUNCH(4, 1, 4);
-    else QT_SPMM_LAUNCH(1, 1, 8);
-#undef QT_SPMM_LAUNCH
+    hipLaunchKernelGGL((k_spmm<1, 1, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, grid, alpha, beta, gamma);
     QT_LAUNCHED();
     return QT_OK;
 }
 
-extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, const float* W, const float* S, int Ks,
-                        const float* Ws, int Kb, int Cb, int N, const int32_t* n_dev, int act, const float* res,
-                        int res_stride, const float* drop, float* out, void* stream) {
-    QT_ARG(a0 && W && out && Ka >= 1 && Ca >= 1 && Kb >= 1 && Cb >= 1, "bad arguments");
-    QT_ARG(Ka == 1 || a_rest, "a_rest missing");
-    QT_ARG((Ks == 0) || (S && Ws), "S / Ws missing");
-    QT_ARG(Ks == 0 || Ws == W + (int64_t)Ka * Ca * Kb * Cb, "Ws must follow W contiguously ([W ; Ws] is one matrix)");
-    QT_ARG(act == QT_ACT_NONE || Kb == 1, "activation needs Kb == 1");
-    QT_ARG(Ca % 4 == 0 && Ks % 4 == 0 && Cb % 4 == 0, "Ca, Ks and Cb must be multiples of 4 (float4 operands)");
-    QT_ARG((Ka * Ca + Ks) / 4 <= MAXQ, "reduction dimension too large (max 512)");
-    QT_ARG((((uintptr_t)a0 | (uintptr_t)a_rest | (uintptr_t)S | (uintptr_t)W) & 15) == 0, "operands must be 16-byte aligned");
+extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb, int Ka,
+                         int Ca, int Cab,
+                         const float* W, const float* S, int Ks, const float* Ws, int Kb, int Cb, int Cbb, int N,
+                         const int32_t* n_dev, int act, const float* res, int res_stride, const float* drop, float* out,
+                         float* outb, void* stream) {
+    QT_ARG(W && out && Kb >= 1 && Cb >= 1 && Cbb >= 0 && (Cbb == 0 || outb), "bad arguments");
+    QT_ARG((Ks == 0) || Ws, "Ws missing");
+    QT_ARG(Ks == 0 || Ws == W + (int64_t)Ka * (Ca + Cab) * Kb * (Cb + Cbb), "Ws must follow W contiguously ([W ; Ws] is one matrix)");
+    QT_ARG(act == QT_ACT_NONE || (Kb == 1 && Cbb == 0), "activation needs one undivided output plane");
+    QT_ARG(Cb % 4 == 0 && Cbb % 4 == 0, "Cb and Cbb must be multiples of 4 (float4 stores)");
+    QT_ARG(((uintptr_t)W & 15) == 0, "W must be 16-byte aligned");
     QT_ARG(act != QT_ACT_TANH_RES || res, "QT_ACT_TANH_RES needs res");
-    if (N <= 0) return QT_OK;
     GemmArgs g = {};
-    g.A.a0 = a0; g.A.a_rest = a_rest; g.A.S = S; g.A.Ka = Ka; g.A.Ca = Ca; g.A.Ks = Ks; g.A.N = N;
-    g.B = W; g.M = N; g.K = Ka * Ca + Ks; g.NB = Kb * Cb;
+    if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N)) return rc;
+    if (N <= 0) return QT_OK;
+    g.B = W; g.M = N; g.K = Ka * (Ca + Cab) + Ks; g.NB = Kb * (Cb + Cbb);
+    g.outb = outb; g.Cbb = Cbb;
 #ifdef QT_GEMM_TIMING
     g.dbg = g_dbg;
 #endif
@@ -759,23 +839,27 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
     return QT_OK;
 }
 
-extern "C" int qt_dense_lstm(const float* a0, const float* a_rest, int Ka, int Ca, const float* W, const float* S, int Ks,
+extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, const float* W, const float* S, int Ks,
+                        const float* Ws, int Kb, int Cb, int N, const int32_t* n_dev, int act, const float* res,
+                        int res_stride, const float* drop, float* out, void* stream) {
+    return qt_dense2(a0, 0, a_rest, nullptr, 0, nullptr, Ka, Ca, 0, W, S, Ks, Ws, Kb, Cb, 0, N, n_dev, act, res, res_stride, drop, out,
+                     nullptr, stream);
+}
+
+extern "C" int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb,
+                             int Ka, int Ca, int Cab, const float* W, const float* S, int Ks,
                              const float* Ws, int h, int N, const int32_t* n_dev, const float* Cprev, int ld_c,
                              const float* wc, const float* b, const float* ln, float* O, float* Hn, float* Cn,
                              float* gates, float* Craw, void* stream) {
-    QT_ARG(a0 && W && wc && b && O && Hn && Cn && gates && Craw && Ka >= 1 && Ca >= 1, "bad arguments");
+    QT_ARG(W && wc && b && Hn && Cn && gates && Craw, "bad arguments");
     QT_ARG(h == 16, "the fused gate GEMM + cell covers hidden size 16 (use qt_dense + qt_lstm_fwd otherwise)");
-    QT_ARG(Ka == 1 || a_rest, "a_rest missing");
-    QT_ARG((Ks == 0) || (S && Ws), "S / Ws missing");
-    QT_ARG(Ks == 0 || Ws == W + (int64_t)Ka * Ca * 4 * h, "Ws must follow W contiguously ([W ; Ws] is one matrix)");
-    QT_ARG(Ca % 4 == 0 && Ks % 4 == 0, "Ca and Ks must be multiples of 4 (float4 operands)");
-    QT_ARG((Ka * Ca + Ks) / 4 <= MAXQ, "reduction dimension too large (max 512)");
-    QT_ARG((((uintptr_t)a0 | (uintptr_t)a_rest | (uintptr_t)S | (uintptr_t)W | (uintptr_t)Cprev) & 15) == 0 && ld_c % 4 == 0,
-           "operands must be 16-byte aligned");
-    if (N <= 0) return QT_OK;
+    QT_ARG((Ks == 0) || Ws, "Ws missing");
+    QT_ARG(Ks == 0 || Ws == W + (int64_t)Ka * (Ca + Cab) * 4 * h, "Ws must follow W contiguously ([W ; Ws] is one matrix)");
+    QT_ARG((((uintptr_t)W | (uintptr_t)Cprev) & 15) == 0 && ld_c % 4 == 0, "operands must be 16-byte aligned");
     GemmArgs g = {};
-    g.A.a0 = a0; g.A.a_rest = a_rest; g.A.S = S; g.A.Ka = Ka; g.A.Ca = Ca; g.A.Ks = Ks; g.A.N = N;
-    g.B = W; g.M = N; g.K = Ka * Ca + Ks; g.NB = 4 * h;
+    if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N)) return rc;
+    if (N <= 0) return QT_OK;
+    g.B = W; g.M = N; g.K = Ka * (Ca + Cab) + Ks; g.NB = 4 * h;
     g.Kb = 1; g.Cb = 4 * h; g.act = QT_ACT_NONE; g.res = nullptr; g.res_stride = 0; g.drop = nullptr; g.out = nullptr;
     g.row0_step = 0; g.n_dev = n_dev; g.accumulate = 0;
     g.Cprev = Cprev; g.wc = wc; g.bias = b; g.ln = ln; g.ld_c = ld_c; g.h = h;
@@ -787,18 +871,15 @@ extern "C" int qt_dense_lstm(const float* a0, const float* a_rest, int Ka, int C
 
 extern "C" int qt_wgrad_blocks(int N) { return N > 0 ? qt_cdiv(N, WGRAD_ROWS) : 0; }
 
-extern "C" int qt_wgrad(const float* a0, const float* a_rest, int Ka, int Ca, const float* S, int Ks, const float* G,
-                        int Co, int N, const int32_t* n_dev, int accumulate, float* part, void* stream) {
-    QT_ARG(a0 && G && part && Ka >= 1 && Ca >= 1 && Co >= 1, "bad arguments");
-    QT_ARG(Ka == 1 || a_rest, "a_rest missing");
-    QT_ARG(Ks == 0 || S, "S missing");
-    QT_ARG(Ca % 4 == 0 && Ks % 4 == 0 && Co % 4 == 0, "Ca, Ks and Co must be multiples of 4 (float4 operands)");
-    QT_ARG((Ka * Ca + Ks) / 4 <= MAXQ, "reduction dimension too large (max 512)");
-    QT_ARG((((uintptr_t)a0 | (uintptr_t)a_rest | (uintptr_t)S | (uintptr_t)G) & 15) == 0, "operands must be 16-byte aligned");
-    if (N <= 0) return QT_OK;
+extern "C" int qt_wgrad(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb, int Ka,
+                        int Ca, int Cab,
+                        const float* S, int Ks, const float* G, int Co, int N, const int32_t* n_dev, int accumulate,
+                        float* part, void* stream) {
+    QT_ARG(G && part && Co >= 1 && Co % 4 == 0 && ((uintptr_t)G & 15) == 0, "bad arguments");
     GemmArgs g = {};
-    g.A.a0 = a0; g.A.a_rest = a_rest; g.A.S = S; g.A.Ka = Ka; g.A.Ca = Ca; g.A.Ks = Ks; g.A.N = N;
-    g.B = G; g.M = Ka * Ca + Ks; g.K = N; g.NB = Co;
+    if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N)) return rc;
+    if (N <= 0) return QT_OK;
+    g.B = G; g.M = Ka * (Ca + Cab) + Ks; g.K = N; g.NB = Co;
     g.Kb = 1; g.Cb = Co; g.act = QT_ACT_NONE; g.res = nullptr; g.res_stride = 0; g.drop = nullptr; g.out = part;
     g.row0_step = WGRAD_ROWS;
     g.n_dev = n_dev;
@@ -815,30 +896,37 @@ extern "C" int qt_wgrad_group_blocks(int nseg, const int* N) {
     return z;
 }
 
-extern "C" int qt_wgrad_group(int nseg, const float* const* a0, const float* const* a_rest, const float* const* S,
-                              const float* const* G, const int* N, const int32_t* const* n_dev, int Ka, int Ca, int Ks, int Co,
-                              float* part, void* stream) {
+extern "C" int qt_wgrad_group(int nseg, const float* const* a0, const int* lda0, const float* const* a_rest,
+                              const float* const* a0b, const int* lda0b, const float* const* a_restb, const float* const* S, const float* const* G, const int* N,
+                              const int32_t* const* n_dev, int Ka, int Ca, int Cab, int Ks, int Co, float* part, void* stream) {
     QT_ARG(nseg >= 1 && nseg <= MAXSEG && a0 && G && N && n_dev && part, "1..16 uses per launch");
-    QT_ARG(Ka >= 1 && Ca >= 1 && Co >= 1 && (Ka == 1 || a_rest) && (Ks == 0 || S), "bad arguments");
-    QT_ARG(Ca % 4 == 0 && Ks % 4 == 0 && Co % 4 == 0, "Ca, Ks and Co must be multiples of 4 (float4 operands)");
-    QT_ARG((Ka * Ca + Ks) / 4 <= MAXQ, "reduction dimension too large (max 512)");
+    QT_ARG(Ka >= 1 && Ca >= 1 && Cab >= 0 && Co >= 1 && (Ka == 1 || a_rest) && (Ks == 0 || S) && (Cab == 0 || (a0b && (Ka == 1 || a_restb))),
+           "bad arguments");
+    QT_ARG(Co % 4 == 0, "Co must be a multiple of 4 (float4 operands)");
     WgradGroup w;
     int z = 0, k = 0;
     for (int i = 0; i < nseg; ++i) {
         if (N[i] <= 0) continue;
-        QT_ARG(a0[i] && G[i] && (Ka == 1 || a_rest[i]) && (Ks == 0 || S[i]), "null operand");
-        QT_ARG((((uintptr_t)a0[i] | (uintptr_t)(Ka > 1 ? a_rest[i] : nullptr) | (uintptr_t)(Ks ? S[i] : nullptr) | (uintptr_t)G[i]) & 15) == 0,
-               "operands must be 16-byte aligned");
-        w.a0[k] = a0[i]; w.a_rest[k] = Ka > 1 ? a_rest[i] : nullptr; w.S[k] = Ks ? S[i] : nullptr; w.G[k] = G[i];
+        PlaneSrc A;
+        if (int rc = plane_src(&A, __func__, a0[i], lda0 ? lda0[i] : 0, Ka > 1 ? a_rest[i] : nullptr, Cab ? a0b[i] : nullptr,
+                               (Cab && lda0b) ? lda0b[i] : 0, (Cab && Ka > 1) ? a_restb[i] : nullptr, Ka, Ca, Cab,
+                               Ks ? S[i] : nullptr, Ks, N[i]))
+            return rc;
+        QT_ARG(G[i] && ((uintptr_t)G[i] & 15) == 0, "G must be 16-byte aligned");
+        w.a0[k] = A.a0; w.a_rest[k] = A.a_rest; w.a0b[k] = A.a0b; w.a_restb[k] = A.a_restb; w.S[k] = A.S; w.G[k] = G[i];
+        w.lda0[k] = A.lda0; w.lda0b[k] = A.lda0b;
         w.n_dev[k] = n_dev[i]; w.N[k] = N[i];
         z += qt_cdiv(N[i], WGRAD_GROUP_ROWS);
         w.zend[k] = z;
         ++k;
     }
     if (k == 0) return QT_OK;
-    for (int i = k; i < MAXSEG; ++i) { w.a0[i] = w.a_rest[i] = w.S[i] = w.G[i] = nullptr; w.n_dev[i] = nullptr; w.N[i] = 0; w.zend[i] = z; }
-    w.nseg = k; w.Ka = Ka; w.Ca = Ca; w.Ks = Ks; w.Co = Co; w.rows = WGRAD_GROUP_ROWS; w.part = part;
-    const int M = Ka * Ca + Ks;
+    for (int i = k; i < MAXSEG; ++i) {
+        w.a0[i] = w.a_rest[i] = w.a0b[i] = w.a_restb[i] = w.S[i] = w.G[i] = nullptr;
+        w.n_dev[i] = nullptr; w.N[i] = 0; w.zend[i] = z; w.lda0[i] = w.lda0b[i] = 0;
+    }
+    w.nseg = k; w.Ka = Ka; w.Ca = Ca; w.Cab = Cab; w.Ks = Ks; w.Co = Co; w.rows = WGRAD_GROUP_ROWS; w.part = part;
+    const int M = Ka * (Ca + Cab) + Ks;
     const dim3 grid(qt_cdiv(M, wgrad_fw(M) * 32), qt_cdiv(Co, BN), z);
     QT_WGRAD_DISPATCH(k_gemm_wgrad_group, M, Co, grid, stream, w);
     QT_LAUNCHED();

@@ -155,12 +155,13 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, 
 template <int LPN>
 __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ O, const float* __restrict__ ln_o,
                                                   const float* __restrict__ concat, int Ncap,
-                                                  const int32_t* __restrict__ n_dev, int h, int hp, float* __restrict__ Z) {
+                                                  const int32_t* __restrict__ n_dev, int h, int ld_o, int hp,
+                                                  float* __restrict__ Z, float* __restrict__ Zb) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t node = gid / LPN;
     if (node >= qt_rows(n_dev, Ncap)) return;
     const int li = (int)(gid % LPN), j0 = li * 4;
-    const F4 x = ld4(O + node * h + j0);
+    const F4 x = ld4(O + node * ld_o + j0);
     F4 xh;
     float r;
     layer_norm<LPN>(x, h, &xh, &r);
@@ -168,15 +169,22 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ O, c
     F4 y;
 #pragma unroll
     for (int k = 0; k < 4; ++k) y.v[k] = fmaxf(gm.v[k] * xh.v[k] + bt.v[k], 0.0f);
+    if (Zb) {               // two matrices: (N, h) and (N, hp - h)
+        st4(Z + node * h + j0, y);
+        if (li == 0)
+            for (int j = h; j < hp; ++j) Zb[node * (hp - h) + (j - h)] = (j == h && concat) ? concat[node] : 0.0f;
+        return;
+    }
     st4(Z + node * hp + j0, y);
     if (li == 0)
         for (int j = h; j < hp; ++j) Z[node * hp + j] = (j == h && concat) ? concat[node] : 0.0f;
 }
 
 template <int LPN>
-__global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ gZ, const float* __restrict__ O,
-                                                  const float* __restrict__ ln_o, int Ncap,
-                                                  const int32_t* __restrict__ n_dev, int h, int hp, float* __restrict__ gO,
+__global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ gZ, const float* __restrict__ gZb,
+                                                  const float* __restrict__ O, const float* __restrict__ ln_o, int Ncap,
+                                                  const int32_t* __restrict__ n_dev, int h, int ld_o, int hp,
+                                                  float* __restrict__ gO,
                                                   float* __restrict__ gconcat, float* __restrict__ part, int accumulate) {
     __shared__ float sm[4 * LPN * 2 * 4];
     const int N = qt_rows(n_dev, Ncap);
@@ -187,11 +195,11 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ gZ, 
     for (int k = 0; k < 4; ++k) acc[0][k] = acc[1][k] = 0.0f;
     const int64_t stride = (int64_t)gridDim.x * (256 / LPN);
     for (int64_t node = (int64_t)blockIdx.x * (256 / LPN) + threadIdx.x / LPN; node < N; node += stride) {
-        const F4 x = ld4(O + node * h + j0);
+        const F4 x = ld4(O + node * ld_o + j0);
         F4 xh;
         float r;
         layer_norm<LPN>(x, h, &xh, &r);
-        F4 gy = ld4(gZ + node * hp + j0);
+        F4 gy = ld4(gZ + node * (gZb ? h : hp) + j0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (gm.v[k] * xh.v[k] + bt.v[k] <= 0.0f) gy.v[k] = 0.0f;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ gZ, 
             acc[1][k] += gy.v[k];
         }
         st4(gO + node * h + j0, layer_norm_bwd<LPN>(gy, gm, xh, r, h));
-        if (li == 0 && gconcat) gconcat[node] = gZ[node * hp + h];
+        if (li == 0 && gconcat) gconcat[node] = gZb ? gZb[node * (hp - h)] : gZ[node * hp + h];
     }
     block_param_reduce<LPN, 2>(acc, h, sm, part + (int64_t)blockIdx.x * 2 * h, accumulate);
 }
@@ -306,24 +314,29 @@ extern "C" int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_
     return QT_OK;
 }
 
-extern "C" int qt_head_fwd(const float* O, const float* ln_o, const float* concat, int N, const int32_t* n_dev, int h,
-                           int hp, float* Z, void* stream) {
+extern "C" int qt_head_fwd(const float* O, int ld_o, const float* ln_o, const float* concat, int N, const int32_t* n_dev, int h,
+                           int hp, float* Z, float* Zb, void* stream) {
     QT_ARG(O && ln_o && Z, "null pointer");
-    QT_ARG(h_ok(h) && hp >= h && hp % 4 == 0, "bad h / hp");
+    QT_ARG(h_ok(h) && hp >= h && hp % 4 == 0 && (!Zb || hp > h), "bad h / hp");
+    if (ld_o <= 0) ld_o = h;
+    QT_ARG(ld_o % 4 == 0 && ((uintptr_t)O & 15) == 0, "O rows must be 16-byte aligned");
     if (N <= 0) return QT_OK;
     const int grid = qt_cdiv((int64_t)N * lanes_per_node(h), 256);
-    QT_DISPATCH_LPN(h, k_head_fwd, grid, stream, O, ln_o, concat, N, n_dev, h, hp, Z);
+    QT_DISPATCH_LPN(h, k_head_fwd, grid, stream, O, ln_o, concat, N, n_dev, h, ld_o, hp, Z, Zb);
     QT_LAUNCHED();
     return QT_OK;
 }
 
-extern "C" int qt_head_bwd(const float* gZ, const float* O, const float* ln_o, int N, const int32_t* n_dev, int h, int hp,
-                           float* gO, float* gconcat, float* part, int accumulate, void* stream) {
+extern "C" int qt_head_bwd(const float* gZ, const float* gZb, const float* O, int ld_o, const float* ln_o, int N,
+                           const int32_t* n_dev, int h, int hp, float* gO, float* gconcat, float* part, int accumulate,
+                           void* stream) {
     QT_ARG(gZ && O && ln_o && gO && part, "null pointer");
-    QT_ARG(h_ok(h) && hp >= h && hp % 4 == 0, "bad h / hp");
+    QT_ARG(h_ok(h) && hp >= h && hp % 4 == 0 && (!gZb || hp > h), "bad h / hp");
+    if (ld_o <= 0) ld_o = h;
+    QT_ARG(ld_o % 4 == 0 && ((uintptr_t)O & 15) == 0, "O rows must be 16-byte aligned");
     if (N <= 0) return QT_OK;
     const int grid = qt_lstm_bwd_blocks(N, h);
-    QT_DISPATCH_LPN(h, k_head_bwd, grid, stream, gZ, O, ln_o, N, n_dev, h, hp, gO, gconcat, part, accumulate);
+    QT_DISPATCH_LPN(h, k_head_bwd, grid, stream, gZ, gZb, O, ln_o, N, n_dev, h, ld_o, hp, gO, gconcat, part, accumulate);
     QT_LAUNCHED();
     return QT_OK;
 }

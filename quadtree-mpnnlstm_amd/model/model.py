@@ -228,8 +228,7 @@ class GConvLSTM(nn.Module):
             G = torch.cat([getattr(self, f'conv_x_{g}')(X, mesh) + getattr(self, f'conv_h_{g}')(Hz, mesh)
                            for g in self.GATES], dim=1)
             return ops.lstm_cell(G, C, pk.wc, pk.b, pk.ln, mesh, pk.acc_p)
-        Z = ops.concat_cols([X, H], mesh) if H is not None else X
-        return ops.gate_cell(Z, pk.W, C, pk.wc, pk.b, pk.ln, mesh, pk.K, pk.Ks, pk.acc_w, pk.acc_p)
+        return ops.gate_cell(X, H, pk.W, C, pk.wc, pk.b, pk.ln, mesh, pk.K, pk.Ks, pk.acc_w, pk.acc_p)
 
     def forward(self, X, edge_index, edge_weight=None, H=None, C=None):
         pad = (-X.shape[1]) % 4

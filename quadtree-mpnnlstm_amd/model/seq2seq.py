@@ -118,11 +118,11 @@ class Decoder(nn.Module):
             # beyond-reference: HEAD crashes here (fc_out1 expects hidden+1 channels, seq2seq.py:115,164);
             # the decoder's current input value is used as the 1-channel concat (what :471,484 intended)
             concat_layers = X[:, :1]
-        z = ops.head_input(out, pk['ln_o'], concat_layers, self.head_width, mesh, pk['acc_o'])
+        z = ops.head_input(out, pk['ln_o'], concat_layers, self.head_width, mesh, pk['acc_o'])    # (N, h), (N, 4)
         if drop is None and self.training and self.dropout.p > 0:
-            drop = self.dropout_masks(1, z.shape[0], z.device)[0]
+            drop = self.dropout_masks(1, z[0].shape[0], z[0].device)[0]
         if pk['fc1'] is None:           # attention head (TransformerConv): activations as plain tensor ops
-            y = self.fc_out2(torch.relu(self.fc_out1(z, mesh)), mesh)
+            y = self.fc_out2(torch.relu(self.fc_out1(torch.cat(z, dim=1), mesh)), mesh)
             y = torch.tanh(y if drop is None else y * drop.unsqueeze(1)) + X[:, :1]
             return (torch.sigmoid(y) if self.binary else y), hs, cs
         z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'])

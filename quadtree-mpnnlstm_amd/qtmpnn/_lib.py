@@ -29,25 +29,27 @@ _SIGNATURES = {
     'qt_pool': [_P, _I, _L, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],
     'qt_sse': [_P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
     'qt_spmm': [_P, _P, _P, _I, _P, _I, _P, _F, _P, _F, _P, _F, _P, _P],
+    'qt_dense2': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P],
+    'qt_spmm2': [_P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _F, _F, _F, _P],
     'qt_dense': [_P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P],
     'qt_wgrad_blocks': [_I],
-    'qt_wgrad': [_P, _P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P],
+    'qt_wgrad': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P],
     'qt_colsum': [_P, _I, _L, _P, _P],
     'qt_lstm_fwd': [_P, _P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     'qt_lstm_bwd_blocks': [_I, _I],
     'qt_lstm_bwd': [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P],
     'qt_sse_bwd': [_P, _I, _P, _P, _P, _I, _P, _I, _P, _P],
     'qt_wgrad_group_blocks': [_I, _P],
-    'qt_wgrad_group': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
-    'qt_dense_lstm': [_P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    'qt_wgrad_group': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    'qt_dense_lstm': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'qt_decoder_input': [_P, _P, _I, _P, _P, _P],
     'qt_concat': [_P, _P, _P, _I, _I, _P, _P, _P],
     'qt_act_bwd': [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P],
     'qt_attn_blocks': [_I, _I],
     'qt_attn_fwd': [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _P],
     'qt_attn_bwd': [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _P, _P, _P, _P],
-    'qt_head_fwd': [_P, _P, _P, _I, _P, _I, _I, _P, _P],
-    'qt_head_bwd': [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
+    'qt_head_fwd': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P],
+    'qt_head_bwd': [_P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
 }
 _PLAIN = {'qt_abi_version', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_attn_blocks'}  # return a value, not an error code
 

@@ -155,6 +155,24 @@ def spmm(mesh, x, alpha, p, beta, q, gamma, out, C):
               ptr(p), beta, ptr(q), gamma, ptr(out))
 
 
+def spmm2(mesh, xs, alpha, ps, beta, qs, gamma, outs):
+    """The same product for rows kept as one or two matrices side by side: xs / ps / qs / outs are lists of 1 or 2 operands
+    (ps / qs may be None); x / p / q operands may be column views of wider matrices (row-strided), outs are dense."""
+    def op(ts, i):
+        if ts is None or i >= len(ts) or ts[i] is None:
+            return None, 0
+        t = ts[i]
+        return ptr(t), (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+    args = []
+    for i in range(2):
+        if i < len(xs):
+            (x, ldx), (p, ldp), (q, ldq) = op(xs, i), op(ps, i), op(qs, i)
+            args += [xs[i].shape[1], x, ldx, p, ldp, q, ldq, ptr(outs[i])]
+        else:
+            args += [0, None, 0, None, 0, None, 0, None]
+    _lib.call('qt_spmm2', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), mesh.N, ptr(mesh.n_dev), *args, alpha, beta, gamma)
+
+
 def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition='max_larger_than', mask=None,
                high_interest_region=None, max_size=64, resolution=0.25, size_norm=None, device=None, static=False):
     """Quadtree-decompose B criterion images and emit the block-diagonal mesh.

@@ -7,7 +7,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import ptr
-from .mesh import spmm
+from .mesh import spmm, spmm2
 
 ACT_NONE, ACT_RELU, ACT_TANH_RES = 0, 1, 2
 
@@ -145,23 +145,47 @@ def concat_cols(tensors, mesh=None):
 
 
 # ------------------------------------------------------------------------------ ChebConv stacks
-def _cheb_planes(Z, mesh, K):
-    """T_1 .. T_{K-1} of the Chebyshev recurrence on Z (T_0 = Z itself): (max(K-1, 1), N, C)."""
-    N, C = Z.shape
-    TZ = Z.new_empty(max(K - 1, 1), N, C)
+# A node-feature operand Z is a list of one or two matrices side by side, e.g. [X (N, 4), H (N, 16)] for Z = [X | H] of a
+# recurrent cell: the parts are never concatenated, and each may be a column view of a wider matrix (row-strided).
+def _zparts(Za, Zb):
+    parts = [_rows(Za.float())]
+    if Zb is not None:
+        parts.append(_rows(Zb.float()))
+    return [t for t, _ in parts]
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
+def _plane_args(Zs, TZs):
+    """(a0, lda0, a_rest, a0b, lda0b, a_restb) of the C ABI."""
+    a = [ptr(Zs[0]), _ld(Zs[0]), ptr(TZs[0])]
+    if len(Zs) > 1:
+        return a + [ptr(Zs[1]), _ld(Zs[1]), ptr(TZs[1])]
+    return a + [None, 0, None]
+
+
+def _cheb_planes(Zs, mesh, K):
+    """T_1 .. T_{K-1} of the Chebyshev recurrence on Z (T_0 = Z itself): per part (max(K-1, 1), N, C)."""
+    N = Zs[0].shape[0]
+    TZs = [Z.new_empty(max(K - 1, 1), N, Z.shape[1]) for Z in Zs]
     for k in range(1, K):
         if k == 1:
-            spmm(mesh, Z, 1.0, None, 0.0, None, 0.0, TZ[0], C)
+            spmm2(mesh, Zs, 1.0, None, 0.0, None, 0.0, [T[0] for T in TZs])
         else:
-            spmm(mesh, TZ[k - 2], 2.0, Z if k == 2 else TZ[k - 3], -1.0, None, 0.0, TZ[k - 1], C)
-    return TZ
+            spmm2(mesh, [T[k - 2] for T in TZs], 2.0, Zs if k == 2 else [T[k - 3] for T in TZs], -1.0, None, 0.0,
+                  [T[k - 1] for T in TZs])
+    return TZs
 
 
-def _cheb_backward(Z, TZ, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW):
-    """(gZ, gW) of Y = [T_0 .. T_{K-1} | S] W from G = dL/dY (N, Co)."""
-    N, C = Z.shape
+def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW):
+    """(gZ parts, gW) of Y = [T_0 .. T_{K-1} | S] W from G = dL/dY (N, Co)."""
+    N = Zs[0].shape[0]
+    Cs = [Z.shape[1] for Z in Zs]
+    C = sum(Cs)
     Co = W.shape[1]
-    gZ = None
+    gZs = None
     if need_gZ and N > 0:
         if acc is None:
             Wt = W[:K * C].t().contiguous()
@@ -169,17 +193,20 @@ def _cheb_backward(Z, TZ, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW):
             if acc.wt is None:
                 acc.wt = W[:K * C].t().contiguous()
             Wt = acc.wt
-        gT = Z.new_empty(K, N, C)
-        _lib.call('qt_dense', ptr(G), None, 1, Co, ptr(Wt), None, 0, None, K, C, N, ptr(mesh.n_dev), ACT_NONE, None, 0,
-                  None, ptr(gT))
+        gTs = [Zs[0].new_empty(K, N, c) for c in Cs]
+        _lib.call('qt_dense2', ptr(G), 0, None, None, 0, None, 1, Co, 0, ptr(Wt), None, 0, None, K, Cs[0],
+                  Cs[1] if len(Cs) > 1 else 0, N, ptr(mesh.n_dev), ACT_NONE, None, 0, None, ptr(gTs[0]),
+                  ptr(gTs[1]) if len(Cs) > 1 else None)
         # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
         for k in range(K - 2, 0, -1):
-            spmm(mesh, gT[k + 1], 2.0, gT[k], 1.0, gT[k + 2] if k + 2 < K else None, -1.0, gT[k], C)
+            spmm2(mesh, [g[k + 1] for g in gTs], 2.0, [g[k] for g in gTs], 1.0,
+                  [g[k + 2] for g in gTs] if k + 2 < K else None, -1.0, [g[k] for g in gTs])
         if K > 1:
-            spmm(mesh, gT[1], 1.0, gT[0], 1.0, gT[2] if K > 2 else None, -1.0, gT[0], C)
-        gZ = gT[0]
+            spmm2(mesh, [g[1] for g in gTs], 1.0, [g[0] for g in gTs], 1.0, [g[2] for g in gTs] if K > 2 else None, -1.0,
+                  [g[0] for g in gTs])
+        gZs = [g[0] for g in gTs]
     elif need_gZ:
-        gZ = torch.zeros_like(Z)
+        gZs = [torch.zeros_like(Z) for Z in Zs]
     gW = None
     if need_gW:
         ksp = (Ks + 3) // 4 * 4
@@ -188,21 +215,22 @@ def _cheb_backward(Z, TZ, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW):
             gW = torch.empty_like(W) if N > 0 else torch.zeros_like(W)
             if N > 0:
                 nblk = _lib.value('qt_wgrad_blocks', N)
-                part = Z.new_empty(nblk, W.shape[0], Co)
-                _lib.call('qt_wgrad', ptr(Z), ptr(TZ), K, C, ptr(S), ksp, ptr(G), Co, N, ptr(mesh.n_dev), 0, ptr(part))
+                part = Zs[0].new_empty(nblk, W.shape[0], Co)
+                _lib.call('qt_wgrad', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(S), ksp, ptr(G), Co, N,
+                          ptr(mesh.n_dev), 0, ptr(part))
                 _lib.call('qt_colsum', ptr(part), nblk, W.numel(), ptr(gW))
         else:
             # deferred: the weight gradient is off the critical path, so all uses of this pass (<= 16 per launch) are
             # reduced together by the last backward -- one long launch instead of one short one per rollout step
-            acc.pending.append((Z, TZ, S, G, N, mesh.n_dev))
+            acc.pending.append((Zs, TZs, S, G, N, mesh.n_dev))
             if acc.leave(use_idx):
-                gW = _wgrad_group(acc.pending, W, K, C, ksp, Co)
+                gW = _wgrad_group(acc.pending, W, K, Cs, ksp, Co)
                 acc.pending = []
-    return gZ, gW
+    return gZs, gW
 
 
 class _ChebPoly(Function):
-    """Y = act( sum_k T_k(L^) Z M_k + S Bm ),  W = [M_0; ...; M_{K-1}; Bm]  ((K*C + Ks), Co).
+    """Y = act( sum_k T_k(L^) Z M_k + S Bm ),  W = [M_0; ...; M_{K-1}; Bm]  ((K*C + Ks), Co),  Z = [Za | Zb].
 
     One call evaluates what the reference spreads over many ChebConv modules
     (model/model.py:59-97, :394-424): the Chebyshev recurrence runs once on Z = [X | H] for
@@ -211,50 +239,59 @@ class _ChebPoly(Function):
     """
 
     @staticmethod
-    def forward(ctx, Z, W, res, drop, mesh, K, Ks, act, acc):
-        _lib.require_cuda(Z, 'node features')
-        Z, W = _c(Z.float()), _c(W.float())
-        N, C = Z.shape
+    def forward(ctx, Za, Zb, W, res, drop, mesh, K, Ks, act, acc):
+        _lib.require_cuda(Za, 'node features')
+        Zs, W = _zparts(Za, Zb), _c(W.float())
+        N = Zs[0].shape[0]
+        Cs = [Z.shape[1] for Z in Zs]
         Co = W.shape[1]
         ksp = (Ks + 3) // 4 * 4
-        assert W.shape[0] == K * C + ksp, f'weight rows {W.shape[0]} != {K}*{C}+{ksp}'
-        TZ = _cheb_planes(Z, mesh, K)
+        assert W.shape[0] == K * sum(Cs) + ksp, f'weight rows {W.shape[0]} != {K}*{sum(Cs)}+{ksp}'
+        TZs = _cheb_planes(Zs, mesh, K)
         S = mesh.cheb_ones(Ks) if Ks else None
-        Y = Z.new_empty(N, Co)
+        Y = Zs[0].new_empty(N, Co)
         drop = _c(drop)
-        _lib.call('qt_dense', ptr(Z), ptr(TZ), K, C, ptr(W), ptr(S), ksp, ptr(W[K * C:]) if Ks else None, 1, Co, N,
-                  ptr(mesh.n_dev), act, ptr(res), _row_stride(res), ptr(drop), ptr(Y))
-        ctx.mesh, ctx.K, ctx.Ks, ctx.act, ctx.acc = mesh, K, Ks, act, acc
+        _lib.call('qt_dense2', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(W), ptr(S), ksp,
+                  ptr(W[K * sum(Cs):]) if Ks else None, 1, Co, 0, N, ptr(mesh.n_dev), act, ptr(res), _row_stride(res), ptr(drop),
+                  ptr(Y), None)
+        ctx.mesh, ctx.K, ctx.Ks, ctx.act, ctx.acc, ctx.nz = mesh, K, Ks, act, acc, len(Zs)
         ctx.use_idx = acc.enter() if acc is not None else 0
-        ctx.save_for_backward(Z, TZ, W, Y if act != ACT_NONE else None, res, drop)
+        ctx.save_for_backward(*Zs, *TZs, W, Y if act != ACT_NONE else None, res, drop)
         return Y
 
     @staticmethod
     def backward(ctx, gY):
-        Z, TZ, W, Y, res, drop = ctx.saved_tensors
+        nz = ctx.nz
+        saved = ctx.saved_tensors
+        Zs, TZs = list(saved[:nz]), list(saved[nz:2 * nz])
+        W, Y, res, drop = saved[2 * nz:]
         mesh, K, Ks, act = ctx.mesh, ctx.K, ctx.Ks, ctx.act
-        N, C = Z.shape
+        N = Zs[0].shape[0]
         Co = W.shape[1]
         G = _c(gY.float())
         gres = None
         if act != ACT_NONE:
             gin = G
             G = torch.empty_like(gin)
-            if act == ACT_TANH_RES and ctx.needs_input_grad[2]:
+            if act == ACT_TANH_RES and ctx.needs_input_grad[3]:
                 assert res.is_contiguous() and res.shape[1] <= Co
                 gres = torch.empty_like(res)
             if N > 0:
                 _lib.call('qt_act_bwd', ptr(gin), ptr(Y), ptr(res), _row_stride(res), ptr(drop), act, N,
                           ptr(mesh.n_dev), Co, ptr(G), ptr(gres))
-        gZ, gW = _cheb_backward(Z, TZ, W, G, mesh, K, Ks, ctx.acc, ctx.use_idx, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return gZ, gW, gres, None, None, None, None, None, None
+        gZs, gW = _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, ctx.acc, ctx.use_idx,
+                                 ctx.needs_input_grad[0] or ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        gZa = gZs[0] if gZs is not None else None
+        gZb = gZs[1] if gZs is not None and nz > 1 else None
+        return gZa, gZb, gW, gres, None, None, None, None, None, None
 
 
-def _wgrad_group(uses, W, K, C, ksp, Co):
+def _wgrad_group(uses, W, K, Cs, ksp, Co):
     import ctypes
     uses = [u for u in uses if u[4] > 0]
     if not uses:
         return torch.zeros_like(W)
+    two = len(Cs) > 1
     chunks = [uses[i:i + 16] for i in range(0, len(uses), 16)]
     counts = []
     for ch in chunks:
@@ -263,9 +300,14 @@ def _wgrad_group(uses, W, K, C, ksp, Co):
     part = W.new_empty(sum(c for _, c in counts), W.shape[0], Co)
     off = 0
     for ch, (Ns, nb) in zip(chunks, counts):
-        vp = ctypes.c_void_p * len(ch)
-        arr = lambda i: vp(*[(u[i].data_ptr() if u[i] is not None else None) for u in ch])
-        _lib.call('qt_wgrad_group', len(ch), arr(0), arr(1), arr(2), arr(3), Ns, arr(5), K, C, ksp, Co, ptr(part[off:]))
+        vp, ip = ctypes.c_void_p * len(ch), ctypes.c_int * len(ch)
+        pa = lambda f: vp(*[(f(u).data_ptr() if f(u) is not None else None) for u in ch])
+        _lib.call('qt_wgrad_group', len(ch),
+                  pa(lambda u: u[0][0]), ip(*[_ld(u[0][0]) for u in ch]), pa(lambda u: u[1][0]),
+                  pa(lambda u: u[0][1]) if two else None, ip(*[_ld(u[0][1]) for u in ch]) if two else None,
+                  pa(lambda u: u[1][1]) if two else None,
+                  pa(lambda u: u[2]), pa(lambda u: u[3]), Ns, pa(lambda u: u[5]), K, Cs[0], Cs[1] if two else 0, ksp, Co,
+                  ptr(part[off:]))
         off += nb
     gW = torch.empty_like(W)
     _lib.call('qt_colsum', ptr(part), part.shape[0], W.numel(), ptr(gW))
@@ -279,10 +321,13 @@ def pad_bias_rows(W, Ks):
 
 
 def cheb_poly(Z, W, mesh, K, Ks, act=ACT_NONE, res=None, drop=None, acc=None):
-    """W: ((K*C + Ks [padded to a multiple of 4]), Co).  acc: GradAcc shared by all uses of W in this pass."""
-    if W.shape[0] == K * Z.shape[1] + Ks and Ks % 4:
+    """Z: one (N, C) matrix or a pair (Za, Zb) standing for [Za | Zb].  W: ((K*C + Ks [padded to a multiple of 4]), Co).
+    acc: GradAcc shared by all uses of W in this pass."""
+    Za, Zb = Z if isinstance(Z, (tuple, list)) else (Z, None)
+    C = Za.shape[1] + (Zb.shape[1] if Zb is not None else 0)
+    if W.shape[0] == K * C + Ks and Ks % 4:
         W = pad_bias_rows(W, Ks)
-    return _ChebPoly.apply(Z, W, res, drop, mesh, K, Ks, act, acc)
+    return _ChebPoly.apply(Za, Zb, W, res, drop, mesh, K, Ks, act, acc)
 
 
 def compose_chebconvs(weights, biases):
@@ -424,46 +469,57 @@ def _lstm_backward(gO, gHn, gCn, gates, Craw, Cprev, wc, ln, mesh, acc, use_idx)
 
 class _GateCell(Function):
     """cheb_poly (no activation) + lstm_cell as one op for hidden size 16: the gate GEMM runs the cell in its epilogue
-    (qt_dense_lstm), so the (N, 4h) pre-activations are never written.  Backward = the two backward passes."""
+    (qt_dense_lstm), so the (N, 4h) pre-activations are never written.  Z = [Za | Zb] (Zb may be None).  The raw output
+    gate O is returned as a column view of the saved gate activations.  Backward = the two backward passes."""
 
     @staticmethod
-    def forward(ctx, Z, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w, acc_p):
-        _lib.require_cuda(Z, 'node features')
-        Z, W, wc, b, ln = _c(Z.float()), _c(W.float()), _c(wc), _c(b), _c(ln)
-        N, C = Z.shape
+    def forward(ctx, Za, Zb, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w, acc_p):
+        _lib.require_cuda(Za, 'node features')
+        Zs = _zparts(Za, Zb)
+        W, wc, b, ln = _c(W.float()), _c(wc), _c(b), _c(ln)
+        N = Zs[0].shape[0]
+        Cs = [Z.shape[1] for Z in Zs]
         h = W.shape[1] // 4
         ksp = (Ks + 3) // 4 * 4
-        assert W.shape[0] == K * C + ksp, f'weight rows {W.shape[0]} != {K}*{C}+{ksp}'
-        TZ = _cheb_planes(Z, mesh, K)
+        assert W.shape[0] == K * sum(Cs) + ksp, f'weight rows {W.shape[0]} != {K}*{sum(Cs)}+{ksp}'
+        TZs = _cheb_planes(Zs, mesh, K)
         S = mesh.cheb_ones(Ks) if Ks else None
         Cprev, ld_c = _rows(Cprev)
-        O, Hn, Cn, Craw = (Z.new_empty(N, h) for _ in range(4))
-        gates = Z.new_empty(N, 4 * h)
-        _lib.call('qt_dense_lstm', ptr(Z), ptr(TZ), K, C, ptr(W), ptr(S), ksp, ptr(W[K * C:]) if Ks else None, h, N,
-                  ptr(mesh.n_dev), ptr(Cprev), ld_c, ptr(wc), ptr(b), ptr(ln), ptr(O), ptr(Hn), ptr(Cn), ptr(gates), ptr(Craw))
-        ctx.save_for_backward(Z, TZ, W, gates, Craw, Cprev, wc, ln)
-        ctx.mesh, ctx.K, ctx.Ks, ctx.acc_w, ctx.acc_p = mesh, K, Ks, acc_w, acc_p
+        Hn, Cn, Craw = (Zs[0].new_empty(N, h) for _ in range(3))
+        gates = Zs[0].new_empty(N, 4 * h)
+        _lib.call('qt_dense_lstm', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(W), ptr(S), ksp,
+                  ptr(W[K * sum(Cs):]) if Ks else None, h, N, ptr(mesh.n_dev), ptr(Cprev), ld_c, ptr(wc), ptr(b), ptr(ln),
+                  None, ptr(Hn), ptr(Cn), ptr(gates), ptr(Craw))
+        ctx.save_for_backward(*Zs, *TZs, W, gates, Craw, Cprev, wc, ln)
+        ctx.mesh, ctx.K, ctx.Ks, ctx.acc_w, ctx.acc_p, ctx.nz = mesh, K, Ks, acc_w, acc_p, len(Zs)
         ctx.use_w = acc_w.enter() if acc_w is not None else 0
         ctx.use_p = acc_p.enter() if acc_p is not None else 0
         ctx.set_materialize_grads(False)
-        return O, Hn, Cn
+        return gates[:, 3 * h:], Hn, Cn
 
     @staticmethod
     def backward(ctx, gO, gHn, gCn):
-        Z, TZ, W, gates, Craw, Cprev, wc, ln = ctx.saved_tensors
+        nz = ctx.nz
+        saved = ctx.saved_tensors
+        Zs, TZs = list(saved[:nz]), list(saved[nz:2 * nz])
+        W, gates, Craw, Cprev, wc, ln = saved[2 * nz:]
         gG, gCp, gwc, gb, gln = _lstm_backward(gO, gHn, gCn, gates, Craw, Cprev, wc, ln, ctx.mesh, ctx.acc_p, ctx.use_p)
-        gZ, gW = _cheb_backward(Z, TZ, W, gG, ctx.mesh, ctx.K, ctx.Ks, ctx.acc_w, ctx.use_w, ctx.needs_input_grad[0],
-                                ctx.needs_input_grad[1])
-        return gZ, gW, gCp, gwc, gb, gln, None, None, None, None, None
+        gZs, gW = _cheb_backward(Zs, TZs, W, gG, ctx.mesh, ctx.K, ctx.Ks, ctx.acc_w, ctx.use_w,
+                                 ctx.needs_input_grad[0] or ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        gZa = gZs[0] if gZs is not None else None
+        gZb = gZs[1] if gZs is not None and nz > 1 else None
+        return gZa, gZb, gW, gCp, gwc, gb, gln, None, None, None, None, None
 
 
-def gate_cell(Z, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w=None, acc_p=None):
-    """(O, LayerNorm_h(H'), LayerNorm_c(C')) of one GConvLSTM update from Z = [X | H] and the packed gate weights W."""
-    if W.shape[0] == K * Z.shape[1] + Ks and Ks % 4:
+def gate_cell(X, H, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w=None, acc_p=None):
+    """(O, LayerNorm_h(H'), LayerNorm_c(C')) of one GConvLSTM update from Z = [X | H] (H may be None) and the packed
+    gate weights W; X and H are passed as they are (column views of wider matrices included), never concatenated."""
+    C = X.shape[1] + (H.shape[1] if H is not None else 0)
+    if W.shape[0] == K * C + Ks and Ks % 4:
         W = pad_bias_rows(W, Ks)
-    if W.shape[1] == 64 and Z.is_cuda:
-        return _GateCell.apply(Z, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w, acc_p)
-    G = cheb_poly(Z, W, mesh, K, Ks, acc=acc_w)
+    if W.shape[1] == 64 and X.is_cuda:
+        return _GateCell.apply(X, H, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w, acc_p)
+    G = cheb_poly((X, H), W, mesh, K, Ks, acc=acc_w)
     return lstm_cell(G, Cprev, wc, b, ln, mesh, acc_p)
 
 
@@ -473,25 +529,27 @@ def lstm_cell(G, Cprev, wc, b, ln, mesh, acc=None):
 
 # ------------------------------------------------------------------------------ decoder head input
 class _Head(Function):
-    """[relu(LayerNorm_o(O)) | concat | 0-pad] (model/seq2seq.py:160-165)."""
+    """[relu(LayerNorm_o(O)) | concat | 0-pad] (model/seq2seq.py:160-165) as two matrices: (N, h) and (N, hp - h).
+    O may be a column view (the raw output gate inside the saved gate activations)."""
 
     @staticmethod
     def forward(ctx, O, ln_o, concat, hp, mesh, acc):
-        O, ln_o, concat = _c(O), _c(ln_o), _c(concat)
+        (O, ld_o), ln_o, concat = _rows(O), _c(ln_o), _c(concat)
         N, h = O.shape
-        Z = O.new_empty(N, hp)
-        _lib.call('qt_head_fwd', ptr(O), ptr(ln_o), ptr(concat), N, ptr(mesh.n_dev), h, hp, ptr(Z))
+        Za, Zb = O.new_empty(N, h), O.new_empty(N, hp - h)
+        _lib.call('qt_head_fwd', ptr(O), ld_o, ptr(ln_o), ptr(concat), N, ptr(mesh.n_dev), h, hp, ptr(Za), ptr(Zb))
         ctx.save_for_backward(O, ln_o)
         ctx.hp, ctx.has_concat, ctx.mesh, ctx.acc = hp, concat is not None, mesh, acc
         ctx.use_idx = acc.enter() if acc is not None else 0
-        return Z
+        return Za, Zb
 
     @staticmethod
-    def backward(ctx, gZ):
+    def backward(ctx, gZa, gZb):
         O, ln_o = ctx.saved_tensors
+        O, ld_o = _rows(O)
         N, h = O.shape
-        gZ = _c(gZ)
-        gO = torch.empty_like(O)
+        gZa, gZb = _c(gZa), _c(gZb)
+        gO = O.new_empty(N, h)
         gcat = O.new_empty(N, 1) if ctx.has_concat else None
         acc, mesh = ctx.acc, ctx.mesh
         if acc is None:
@@ -501,8 +559,8 @@ class _Head(Function):
             nblk = max(_lib.value('qt_lstm_bwd_blocks', mesh.B * mesh.P, h), 1)
             part = acc.slab(O, nblk, 2 * h)
         if N > 0:
-            _lib.call('qt_head_bwd', ptr(gZ), ptr(O), ptr(ln_o), N, ptr(mesh.n_dev), h, ctx.hp, ptr(gO), ptr(gcat),
-                      ptr(part), 0 if acc is None else 1)
+            _lib.call('qt_head_bwd', ptr(gZa), ptr(gZb), ptr(O), ld_o, ptr(ln_o), N, ptr(mesh.n_dev), h, ctx.hp, ptr(gO),
+                      ptr(gcat), ptr(part), 0 if acc is None else 1)
         if acc is not None and not acc.leave(ctx.use_idx):
             return gO, None, gcat, None, None, None
         psum = O.new_empty(2 * h)
@@ -514,6 +572,7 @@ class _Head(Function):
 
 
 def head_input(O, ln_o, concat, hp, mesh, acc=None):
+    """-> (Za (N, h), Zb (N, hp - h)), the two column parts of the head's input."""
     return _Head.apply(O, ln_o, concat, hp, mesh, acc)
 
 

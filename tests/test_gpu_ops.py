@@ -196,7 +196,7 @@ def test_head_kernel_vs_torch():
     ln = torch.randn(2, h, device=dev(), requires_grad=True)
     cc = torch.randn(N, 1, device=dev(), requires_grad=True)
     from qtmpnn.mesh import Mesh
-    z = ops.head_input(O, ln, cc, h + 4, Mesh())
+    z = torch.cat(ops.head_input(O, ln, cc, h + 4, Mesh()), dim=1)        # two column parts: (N, h) | (N, 4)
     ref = torch.cat([torch.relu(torch.nn.functional.layer_norm(O, (h,), ln[0], ln[1], 1e-5)), cc,
                      torch.zeros(N, 3, device=dev())], dim=1)
     close(z, ref, atol=2e-5)
@@ -383,8 +383,9 @@ def test_bf16x3_gemm_matches_fp32_gemm():
 
 @pytest.mark.parametrize('with_c', [True, False])
 def test_fused_gate_cell_equals_gemm_then_cell(with_c):
-    """qt_dense_lstm (the cell as the gate GEMM's epilogue, h = 16) == qt_dense followed by qt_lstm_fwd, bit for bit,
-    forward and every gradient; a node count that is not a multiple of the 128-row tile."""
+    """qt_dense_lstm (the cell as the gate GEMM's epilogue, h = 16) on Z given as two row-strided column views [X | H]
+    == qt_dense on the whole Z followed by qt_lstm_fwd, bit for bit, forward and every gradient; a node count that is
+    not a multiple of the 128-row tile."""
     from qtmpnn import ops
     mesh, _ = _mesh_64(5, noise=0.03, B=2)
     torch.manual_seed(3)
@@ -398,7 +399,7 @@ def test_fused_gate_cell_equals_gemm_then_cell(with_c):
 
     def run(fused):
         if fused:
-            outs = ops.gate_cell(Z, W, Cp, wc, b, ln, mesh, K, Ks)
+            outs = ops.gate_cell(Z[:, :4], Z[:, 4:], W, Cp, wc, b, ln, mesh, K, Ks)
         else:
             outs = ops.lstm_cell(ops.cheb_poly(Z, W, mesh, K, Ks), Cp, wc, b, ln, mesh)
         grads = torch.autograd.grad(outs, ins, gs)
