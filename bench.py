@@ -58,30 +58,31 @@ def spmm_roofline(nfp, batch, mask, reps=10):
     One extra (untimed) eager training step records every spmm launch of the real workload (mesh, channel count,
     which addends).  Each recorded launch is then re-issued `reps` times back to back between two events on the
     same stream with same-shaped operands, and the per-launch averages are summed, so the figure covers exactly
-    the launch mix of one training step.  Algorithmic bytes per launch: 4(N+1) + 8E' + 8NC."""
+    the launch mix of one training step.  Algorithmic bytes per launch: 4(N+1) + 8E' + 8NC, C = the
+    channels of all column parts the launch propagates (Z = [X | H] travels as two matrices in one launch)."""
     import torch
     from qtmpnn import mesh as qmesh, ops
     records = []
-    orig = qmesh.spmm
+    orig = qmesh.spmm2
 
-    def spy(ms, x, alpha, p, beta, q, gamma, out, C):
-        records.append((ms, C, p is not None, q is not None))
-        orig(ms, x, alpha, p, beta, q, gamma, out, C)
-    qmesh.spmm = ops.spmm = spy
+    def spy(ms, xs, alpha, ps, beta, qs, gamma, outs):
+        records.append((ms, tuple(x.shape[1] for x in xs), ps is not None, qs is not None))
+        orig(ms, xs, alpha, ps, beta, qs, gamma, outs)
+    qmesh.spmm2 = ops.spmm2 = spy
     try:
         nfp.train_step(*batch, mask)
         torch.cuda.synchronize()
     finally:
-        qmesh.spmm = ops.spmm = orig
+        qmesh.spmm2 = ops.spmm2 = orig
     dev = batch[0].device
     bufs = {}
     tot_us, tot_bytes = 0.0, 0.0
-    for ms, C, has_p, has_q in records:
-        key = (ms.N, C)
+    for ms, Cs, has_p, has_q in records:
+        key = (ms.N, Cs)
         if key not in bufs:
-            bufs[key] = [torch.randn(ms.N, C, device=dev) for _ in range(4)]
+            bufs[key] = [[torch.randn(ms.N, c, device=dev) for c in Cs] for _ in range(4)]
         x, p, q, out = bufs[key]
-        args = (ms, x, 2.0, p if has_p else None, -1.0, q if has_q else None, 1.0, out, C)
+        args = (ms, x, 2.0, p if has_p else None, -1.0, q if has_q else None, 1.0, out)
         orig(*args)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -91,7 +92,7 @@ def spmm_roofline(nfp, batch, mask, reps=10):
         b.synchronize()
         tot_us += a.elapsed_time(b) * 1e3 / reps
         nv = ms.n_valid                      # static mode: ms.N is the capacity, the count lives on the device
-        tot_bytes += 4.0 * (nv + 1) + 8.0 * ms.E + 8.0 * nv * C
+        tot_bytes += 4.0 * (nv + 1) + 8.0 * ms.E + 8.0 * nv * sum(Cs)
     n = len(records)
     achieved = tot_bytes / (tot_us * 1e-6) / 1e9
     traffic = None           # HBM-side bytes per launch from the committed PMC passes (cannot be collected in-process)
