@@ -232,7 +232,8 @@ int qt_concat(const float* const* srcs, const int* widths, const int* lds, int n
 
 /* decoder input after a re-mesh, model/seq2seq.py:484-487: out (N, 4) = [val4[:, 0] | posfeat (N, 3)]; posfeat == NULL
  * writes [val4[:, 0], 0, 0, 0] (the gradient of the same op with respect to val4). */
-int qt_decoder_input(const float* val4, const float* posfeat, int N, const int32_t* n_dev, float* out, void* stream);
+int qt_decoder_input(const float* val4, int ld /* row stride of val4 in floats, 0 = 4 */, const float* posfeat, int N,
+                     const int32_t* n_dev, float* out, void* stream);
 
 /* backward of the qt_dense epilogue activations: G = gY * act'(Y) (QT_ACT_RELU, QT_ACT_TANH_RES with res / drop as in
  * qt_dense); gres (N, res_stride) or NULL receives the gradient of the residual operand (column 0 = gY[:, 0], rest 0). */

@@ -253,11 +253,11 @@ __global__ void k_concat(ConcatArgs a, int Ncap, const int32_t* __restrict__ n_d
 }
 
 // out[i] = (val4[i].x, pos[i]) -- or (val4[i].x, 0, 0, 0) when pos == NULL (the backward of the same op)
-__global__ void k_decoder_input(const float* __restrict__ val4, const float* __restrict__ pos, int Ncap,
+__global__ void k_decoder_input(const float* __restrict__ val4, int ld, const float* __restrict__ pos, int Ncap,
                                 const int32_t* __restrict__ n_dev, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= qt_rows(n_dev, Ncap)) return;
-    float4 o = make_float4(val4[4 * (int64_t)i], 0.0f, 0.0f, 0.0f);
+    float4 o = make_float4(val4[ld * (int64_t)i], 0.0f, 0.0f, 0.0f);
     if (pos) {
         o.y = pos[3 * (int64_t)i];
         o.z = pos[3 * (int64_t)i + 1];
@@ -374,10 +374,12 @@ extern "C" int qt_concat(const float* const* srcs, const int* widths, const int*
     return QT_OK;
 }
 
-extern "C" int qt_decoder_input(const float* val4, const float* posfeat, int N, const int32_t* n_dev, float* out, void* stream) {
+extern "C" int qt_decoder_input(const float* val4, int ld, const float* posfeat, int N, const int32_t* n_dev, float* out,
+                                void* stream) {
     QT_ARG(val4 && out && ((uintptr_t)out & 15) == 0, "bad arguments");
+    if (ld <= 0) ld = 4;
     if (N <= 0) return QT_OK;
-    hipLaunchKernelGGL(k_decoder_input, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, val4, posfeat, N, n_dev, out);
+    hipLaunchKernelGGL(k_decoder_input, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, val4, ld, posfeat, N, n_dev, out);
     QT_LAUNCHED();
     return QT_OK;
 }

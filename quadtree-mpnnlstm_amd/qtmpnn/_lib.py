@@ -42,7 +42,7 @@ _SIGNATURES = {
     'qt_wgrad_group_blocks': [_I, _P],
     'qt_wgrad_group': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     'qt_dense_lstm': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    'qt_decoder_input': [_P, _P, _I, _P, _P, _P],
+    'qt_decoder_input': [_P, _I, _P, _I, _P, _P, _P],
     'qt_concat': [_P, _P, _P, _I, _I, _P, _P, _P],
     'qt_act_bwd': [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P],
     'qt_attn_blocks': [_I, _I],

@@ -685,10 +685,10 @@ class _DecoderInput(Function):
 
     @staticmethod
     def forward(ctx, val4, mesh):
-        val4 = _c(val4)
+        val4, ld = _rows(val4)                     # a column view of the transferred state is read in place
         out = val4.new_empty(val4.shape)           # (empty_like would keep the odd strides of a 1-row view)
         if mesh.N > 0:
-            _lib.call('qt_decoder_input', ptr(val4), ptr(mesh.posfeat), mesh.N, ptr(mesh.n_dev), ptr(out))
+            _lib.call('qt_decoder_input', ptr(val4), ld, ptr(mesh.posfeat), mesh.N, ptr(mesh.n_dev), ptr(out))
         ctx.mesh = mesh
         return out
 
@@ -698,7 +698,7 @@ class _DecoderInput(Function):
         g = _c(g)
         gv = g.new_empty(g.shape)
         if mesh.N > 0:
-            _lib.call('qt_decoder_input', ptr(g), None, mesh.N, ptr(mesh.n_dev), ptr(gv))
+            _lib.call('qt_decoder_input', ptr(g), 4, None, mesh.N, ptr(mesh.n_dev), ptr(gv))
         return gv, None
 
 
