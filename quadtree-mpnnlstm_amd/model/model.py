@@ -38,6 +38,17 @@ class ChebConv(nn.Module):
         tail = nn.functional.pad(b.unsqueeze(0), (0, cout - self.out_channels, 0, 3))        # bias row + 3 zero rows
         return torch.cat([w.reshape(self.K * cin, cout), tail], dim=0)
 
+    # -- the same matrix as a data-movement layout over stand-in tensors (ops.PackPlan) -------------------------------
+    def plan_params(self):
+        return [lin.weight for lin in self.lins] + [self.bias]
+
+    def plan_layout(self, T, fill, in_pad=None, out_pad=None):
+        cin, cout = in_pad or self.in_channels, out_pad or self.out_channels
+        w = torch.stack(T[:self.K]).transpose(1, 2)                                          # (K, in, out)
+        w = nn.functional.pad(w, (0, cout - self.out_channels, 0, cin - self.in_channels), value=fill)
+        tail = nn.functional.pad(T[self.K].unsqueeze(0), (0, cout - self.out_channels, 0, 3), value=fill)
+        return torch.cat([w.reshape(self.K * cin, cout), tail], dim=0)
+
     def forward(self, x, edge_index, edge_weight=None):
         mesh = _need_mesh(edge_index)
         pad = (-x.shape[1]) % 4
@@ -205,15 +216,79 @@ class GConvLSTM(nn.Module):
             acc_p = ops.GradAcc()
             return [PackedCell(None, 0, 0, wc, b, ln, None, acc_p) for _ in variants]
         Px, bx = self._branch('conv_x')
+        Ph, bh = self._branch('conv_h')
+        wc = torch.cat([self.w_c_i, self.w_c_f, self.w_c_o], dim=0)
+        b = torch.cat([self.b_i, self.b_f, self.b_c, self.b_o], dim=0)
+        return self._assemble(Px, bx, Ph, bh, wc, b, in_pad, ln, variants, ops.GradAcc())
+
+    # -- packing through one gather (ops.PackPlan): plain ChebConv stacks only ------------------------------------------
+    @property
+    def plannable(self):
+        return all(type(c) is ChebConv and c.bias is not None for g in self.GATES for br in ('conv_x', 'conv_h')
+                   for c in getattr(self, f'{br}_{g}').convolutions)
+
+    def plan_params(self):
+        ps = []
+        for br in ('conv_x', 'conv_h'):
+            for g in self.GATES:
+                for conv in getattr(self, f'{br}_{g}').convolutions:
+                    ps += conv.plan_params()
+        return ps + [self.w_c_i, self.w_c_f, self.w_c_o, self.b_i, self.b_f, self.b_c, self.b_o]
+
+    def plan_layout(self, T, fill, prefix, in_pad=None, variants=(True,)):
+        """Outputs (named with `prefix`): wc (3, h), b (4, h) and, for one conv layer per stack, the gate matrix W of
+        every requested variant as (x-bias member, h-bias member) sums; for deeper stacks the per-layer weight / bias
+        stacks of both branches, which compose_chebconvs then combines."""
+        L, h = self.n_conv_layers, self.out_channels
+        K = len(self.conv_x_i.convolutions[0].lins)
+        per = K + 1
+
+        def Wt(bi, l):       # (4, K, in, h)
+            w = torch.stack([T[((bi * 4 + gi) * L + l) * per + k] for gi in range(4) for k in range(K)])
+            return w.view(4, K, *w.shape[1:]).transpose(-1, -2)
+
+        def Bs(bi, l):       # (4, h)
+            return torch.stack([T[((bi * 4 + gi) * L + l) * per + K] for gi in range(4)])
+
+        tail = T[2 * 4 * L * per:]
+        out = {prefix + 'wc': torch.cat(tail[0:3], dim=0), prefix + 'b': torch.cat(tail[3:7], dim=0)}
+        if L > 1:
+            for bi, br in enumerate('xh'):
+                for l in range(L):
+                    out[f'{prefix}P{br}{l}'] = Wt(bi, l)
+                    out[f'{prefix}B{br}{l}'] = Bs(bi, l)
+            return out
+        Px, Ph = Wt(0, 0), Wt(1, 0)
+        cin = in_pad or self.in_channels
+        if cin > self.in_channels:
+            Px = nn.functional.pad(Px, (0, 0, 0, cin - self.in_channels), value=fill)
+        rows = lambda bs: nn.functional.pad(bs.unsqueeze(1).permute(1, 0, 2).reshape(1, 4 * h), (0, 0, 0, 3), value=fill)
+        for with_h in variants:
+            M = torch.cat([Px, Ph], dim=2) if with_h else Px
+            Wm = M.permute(1, 2, 0, 3).reshape(K * M.shape[2], 4 * h)
+            out[f'{prefix}W{int(with_h)}'] = (torch.cat([Wm, rows(Bs(0, 0))], dim=0),
+                                              torch.cat([torch.full_like(Wm, fill), rows(Bs(1, 0))], dim=0))
+        return out
+
+    def pack_from(self, outs, prefix, in_pad=None, ln=None, variants=(True,)):
+        """PackedCells from the outputs of a plan built with plan_layout (same arguments)."""
+        L, h = self.n_conv_layers, self.out_channels
+        wc, b = outs[prefix + 'wc'], outs[prefix + 'b']
+        acc_p = ops.GradAcc()
+        if L == 1:
+            K = len(self.conv_x_i.convolutions[0].lins)
+            return [PackedCell(outs[f'{prefix}W{int(v)}'], K, 1, wc, b, ln, ops.GradAcc(), acc_p) for v in variants]
+        Px, bx = ops.compose_chebconvs([outs[f'{prefix}Px{l}'] for l in range(L)], [outs[f'{prefix}Bx{l}'] for l in range(L)])
+        Ph, bh = ops.compose_chebconvs([outs[f'{prefix}Ph{l}'] for l in range(L)], [outs[f'{prefix}Bh{l}'] for l in range(L)])
+        return self._assemble(Px, bx, Ph, bh, wc, b, in_pad, ln, variants, acc_p)
+
+    def _assemble(self, Px, bx, Ph, bh, wc, b, in_pad, ln, variants, acc_p):
+        h = self.out_channels
         cin = in_pad or self.in_channels
         if cin > self.in_channels:
             Px = nn.functional.pad(Px, (0, 0, 0, cin - self.in_channels))
-        Ph, bh = self._branch('conv_h')
         K, Ks = Px.shape[1], bx.shape[1]
         bias_rows = nn.functional.pad((bx + ops.unalias(bh)).permute(1, 0, 2).reshape(Ks, 4 * h), (0, 0, 0, (-Ks) % 4))
-        wc = torch.cat([self.w_c_i, self.w_c_f, self.w_c_o], dim=0)
-        b = torch.cat([self.b_i, self.b_f, self.b_c, self.b_o], dim=0)
-        acc_p = ops.GradAcc()
         out = []
         for with_h in variants:
             M = torch.cat([Px, Ph], dim=2) if with_h else Px           # (4, K, C, h)

@@ -39,9 +39,35 @@ class Encoder(nn.Module):
 
     def pack(self, in_pad):
         """Per-forward weight packing: layer 0 with and without a hidden state, upper layers without."""
+        if all(r.plannable for r in self.rnns):
+            return self._pack_planned(in_pad)
         ln = _ln_params(self.norm_h, self.norm_c)
         first, cont = self.rnns[0].pack(in_pad, ln, (False, True))
         return dict(first=first, cont=cont, upper=[r.pack(None, ln, (False,))[0] for r in self.rnns[1:]])
+
+    def _pack_planned(self, in_pad):
+        """The same through ONE parameter gather for the whole encoder (ops.PackPlan, cached per input width)."""
+        plans = self.__dict__.setdefault('_plans', {})
+        key = (in_pad, self.norm_h.weight.device)
+        if key not in plans:
+            counts = [len(r.plan_params()) for r in self.rnns]
+
+            def layout(T, fill):
+                out, o = {}, 0
+                for i, (r, n) in enumerate(zip(self.rnns, counts)):
+                    out.update(r.plan_layout(T[o:o + n], fill, f'r{i}.', in_pad if i == 0 else None,
+                                             (False, True) if i == 0 else (False,)))
+                    o += n
+                out['ln'] = torch.stack(T[o:o + 4])
+                return out
+            params = [p for r in self.rnns for p in r.plan_params()] + [self.norm_h.weight, self.norm_h.bias,
+                                                                        self.norm_c.weight, self.norm_c.bias]
+            plans[key] = ops.PackPlan(params, layout)
+        outs = plans[key]()
+        ln = outs['ln']
+        first, cont = self.rnns[0].pack_from(outs, 'r0.', in_pad, ln, (False, True))
+        return dict(first=first, cont=cont,
+                    upper=[r.pack_from(outs, f'r{i + 1}.', None, ln, (False,))[0] for i, r in enumerate(self.rnns[1:])])
 
     def run(self, X, mesh, H, C, pk):
         """One encoder step on packed weights; returns per-layer lists (no stacking on the hot path)."""
@@ -90,12 +116,46 @@ class Decoder(nn.Module):
         return self.hidden_size + 4          # [relu(norm_o(O)) | concat | 0 0 0] keeps rows 16-byte aligned
 
     def pack(self, in_pad):
+        from model.model import ChebConv
+        if all(r.plannable for r in self.rnns) and type(self.fc_out1) is ChebConv and type(self.fc_out2) is ChebConv:
+            return self._pack_planned(in_pad)
         ln = _ln_params(self.norm_h, self.norm_c)
         series = hasattr(self.fc_out1, 'packed')
         return dict(ln_o=_ln_params(self.norm_o), acc_o=ops.GradAcc(),
                     rnns=[r.pack(in_pad if i == 0 else None, ln, (True,))[0] for i, r in enumerate(self.rnns)],
                     fc1=self.fc_out1.packed(self.head_width, self.hidden_size) if series else None, acc1=ops.GradAcc(),
                     fc2=self.fc_out2.packed(self.hidden_size, 4) if series else None, acc2=ops.GradAcc())
+
+    def _pack_planned(self, in_pad):
+        """The same through ONE parameter gather for the whole decoder (ops.PackPlan, cached per input width)."""
+        plans = self.__dict__.setdefault('_plans', {})
+        key = (in_pad, self.norm_h.weight.device)
+        if key not in plans:
+            counts = [len(r.plan_params()) for r in self.rnns]
+            n1, n2 = len(self.fc_out1.plan_params()), len(self.fc_out2.plan_params())
+
+            def layout(T, fill):
+                out, o = {}, 0
+                for i, (r, n) in enumerate(zip(self.rnns, counts)):
+                    out.update(r.plan_layout(T[o:o + n], fill, f'r{i}.', in_pad if i == 0 else None, (True,)))
+                    o += n
+                out['fc1'] = self.fc_out1.plan_layout(T[o:o + n1], fill, self.head_width, self.hidden_size)
+                o += n1
+                out['fc2'] = self.fc_out2.plan_layout(T[o:o + n2], fill, self.hidden_size, 4)
+                o += n2
+                out['ln'] = torch.stack(T[o:o + 4])
+                out['ln_o'] = torch.stack(T[o + 4:o + 6])
+                return out
+            params = ([p for r in self.rnns for p in r.plan_params()] + self.fc_out1.plan_params() + self.fc_out2.plan_params()
+                      + [self.norm_h.weight, self.norm_h.bias, self.norm_c.weight, self.norm_c.bias,
+                         self.norm_o.weight, self.norm_o.bias])
+            plans[key] = ops.PackPlan(params, layout)
+        outs = plans[key]()
+        ln = outs['ln']
+        return dict(ln_o=outs['ln_o'], acc_o=ops.GradAcc(),
+                    rnns=[r.pack_from(outs, f'r{i}.', in_pad if i == 0 else None, ln, (True,))[0]
+                          for i, r in enumerate(self.rnns)],
+                    fc1=outs['fc1'], acc1=ops.GradAcc(), fc2=outs['fc2'], acc2=ops.GradAcc())
 
     def dropout_masks(self, steps, rows, device):
         """Inverted-dropout multipliers for `steps` decoder steps at once (one RNG launch instead of one per step);

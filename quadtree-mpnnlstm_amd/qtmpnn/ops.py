@@ -86,6 +86,87 @@ class GradAcc:
         return True
 
 
+# ------------------------------------------------------------------------------ parameter packing
+class PackPlan:
+    """Gathers the many small parameter tensors of a module (238 in the reference model) into its packed weight matrices
+    with a handful of launches, forward and backward.
+
+    `layout(T, fill)` receives stand-ins for the parameters -- index tensors of the parameters' shapes -- and returns
+    {name: tensor | (tensor, tensor)} built ONLY with data-movement ops (stack / cat / permute / reshape / transpose / pad
+    with `fill`); a tuple means the sum of its two members.  The plan records, for every output element, which parameter
+    elements it is made of; the forward is then `flat[src0] + flat[src1]` on the concatenated parameters and the backward
+    the transposed gather, whose result is handed to autograd as per-parameter views (no stack / unbind / slice
+    backward / AccumulateGrad copies: ~200 tiny kernels per training step with per-tensor torch ops)."""
+
+    def __init__(self, params, layout):
+        self.params = list(params)
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        n_flat = offs[-1]
+        T = [torch.arange(o, o + n, dtype=torch.int64).view(p.shape) for o, n, p in zip(offs, sizes, self.params)]
+        outs = layout(T, -1)
+        self.names, self.shapes, self.out_offs = [], [], [0]
+        src = []
+        for name, v in outs.items():
+            a, b = v if isinstance(v, tuple) else (v, None)
+            self.names.append(name)
+            self.shapes.append(tuple(a.shape))
+            sa = a.reshape(-1)
+            sb = b.reshape(-1) if b is not None else torch.full_like(sa, -1)
+            src.append(torch.stack([sa, sb], dim=1))
+            self.out_offs.append(self.out_offs[-1] + sa.numel())
+        src = torch.cat(src)                                  # (n_out, 2), -1 = zero
+        n_out = src.shape[0]
+        inv = torch.full((n_flat, 2), -1, dtype=torch.int64)
+        fill_count = torch.zeros(n_flat, dtype=torch.int64)
+        pos = torch.arange(n_out, dtype=torch.int64)
+        for c in range(2):
+            col = src[:, c]
+            ok = col >= 0
+            for j, i in zip(col[ok].tolist(), pos[ok].tolist()):
+                k = int(fill_count[j])
+                assert k < 2, 'a parameter element may feed at most two packed elements'
+                inv[j, k] = i
+                fill_count[j] = k + 1
+        self.two_src = bool((src[:, 1] >= 0).any())
+        self.two_inv = bool((inv[:, 1] >= 0).any())
+        self.src = torch.where(src >= 0, src, torch.full_like(src, n_flat)).t().contiguous().to(dev)       # zero slot
+        self.inv = torch.where(inv >= 0, inv, torch.full_like(inv, n_out)).t().contiguous().to(dev)
+        self.offs, self.n_flat, self.n_out, self.device = offs, n_flat, n_out, dev
+        self.zero1 = torch.zeros(1, device=dev)
+
+    def __call__(self):
+        outs = _PackGather.apply(self, *self.params)
+        return dict(zip(self.names, outs))
+
+
+class _PackGather(Function):
+    @staticmethod
+    def forward(ctx, plan, *params):
+        flat = torch.cat([p.reshape(-1) for p in params] + [plan.zero1])
+        out = flat[plan.src[0]]
+        if plan.two_src:
+            out = out + flat[plan.src[1]]
+        ctx.plan = plan
+        ctx.set_materialize_grads(False)
+        return tuple(out[a:b].view(shp) for a, b, shp in zip(plan.out_offs[:-1], plan.out_offs[1:], plan.shapes))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        plan = ctx.plan
+        parts = []
+        for g, a, b in zip(gs, plan.out_offs[:-1], plan.out_offs[1:]):
+            parts.append(g.reshape(-1) if g is not None else plan.zero1.expand(b - a))
+        gcat = torch.cat(parts + [plan.zero1])
+        gflat = gcat[plan.inv[0]]
+        if plan.two_inv:
+            gflat = gflat + gcat[plan.inv[1]]
+        return (None, *[gflat[a:b].view(p.shape) for a, b, p in zip(plan.offs[:-1], plan.offs[1:], plan.params)])
+
+
 # ------------------------------------------------------------------------------ column concatenation
 class _ConcatCols(Function):
     """[t_0 | t_1 | ...] for 2-D fp32 node matrices (row-strided views welcome); backward = column views, no copy."""
