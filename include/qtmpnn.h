@@ -123,6 +123,14 @@ int qt_pool(const float* img, int S, int64_t img_clip_stride /* floats between c
             int B, int n, int m, int N, const int32_t* cell /* or NULL */, const int32_t* n_dev,
             float* out, int out_stride, int out_coff, void* stream);
 
+/* qt_pool's mesh -> mesh transfer with the source node values given as up to 8 matrices side by side (host arrays of nparts
+ * device pointers, widths and row strides, all multiples of 4): the state [out | H_0 .. | C_0 ..] is transferred across a
+ * re-mesh (model/seq2seq.py:440-442, 474-477) without being concatenated first.  out: dense (N, sum widths). */
+int qt_remesh(const float* const* src_parts, const int* widths, const int* lds, int nparts,
+              const int32_t* src_labels, const float* src_npix, int src_inv, const int32_t* labels, const uint8_t* level,
+              const float* npix, int mean, int B, int n, int m, int N, const int32_t* cell, const int32_t* n_dev, float* out,
+              void* stream);
+
 /* masked MSE, model/mpnnlstm.py:243-246: partial[b*ntile + tile] = sum over the tile's unmasked pixels of
  * (out[labels[p]] - y[p])^2 ; y (B, n*m).  Pixels with label < 0 are the masked ones. */
 int qt_sse(const float* out, int out_stride, const int32_t* labels, const float* y, int64_t y_clip_stride,

@@ -15,7 +15,9 @@ struct PoolArgs {
     const float* img;
     int S;
     int64_t img_clip_stride;   // floats between clips of img (S*P*C when dense)
-    const float* src_val;
+    const float* src_val;      // source node values: one (N_src, C) matrix, or
+    const float* part[8];      // up to 8 matrices side by side (row strides part_ld, widths as float4 prefix part_end)
+    int part_ld[8], part_end[8], nparts;
     const int32_t* src_labels;
     const float* src_npix;
     int src_inv;
@@ -37,6 +39,15 @@ template <int VEC>
 struct Vec {
     float v[VEC];
 };
+
+// address of channel chunk `ch` (VEC floats) of source node `sl`
+template <int VEC>
+__device__ __forceinline__ const float* src_chunk(const PoolArgs& a, int64_t sl, int ch) {
+    if (VEC == 1 || a.nparts == 0) return a.src_val + sl * a.C + ch * VEC;
+    int s = 0;
+    while (ch >= a.part_end[s]) ++s;
+    return a.part[s] + sl * a.part_ld[s] + (ch - (s ? a.part_end[s - 1] : 0)) * 4;
+}
 
 template <int VEC>
 __device__ __forceinline__ Vec<VEC> vload(const float* p) {
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
                 for (int k = 0; k < VEC; ++k) x.v[k] = 0.0f;
                 if (a.src_labels) {
                     if (slab[q] >= 0) {
-                        x = vload<VEC>(a.src_val + (int64_t)slab[q] * a.C + ch * VEC);
+                        x = vload<VEC>(src_chunk<VEC>(a, slab[q], ch));
 #pragma unroll
                         for (int k = 0; k < VEC; ++k) x.v[k] *= sscale[q];
                     }
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(256) void k_pool_nodes(PoolArgs a) {
             if (a.src_labels) {
                 const int sl = a.src_labels[base + p];
                 if (sl < 0) continue;
-                const Vec<VEC> x = vload<VEC>(a.src_val + (int64_t)sl * a.C + ch * VEC);
+                const Vec<VEC> x = vload<VEC>(src_chunk<VEC>(a, sl, ch));
                 const float sc = a.src_inv ? 1.0f / a.src_npix[sl] : 1.0f;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc.v[k] += x.v[k] * sc;
@@ -299,6 +310,29 @@ extern "C" int qt_sse_bwd(const float* out, int out_stride, const float* npix, c
     return QT_OK;
 }
 
+static int pool_launch(PoolArgs& a, bool v4, const int32_t* cell, const int32_t* n_dev, hipStream_t stream) {
+    const int total = a.S * (v4 ? a.C / 4 : a.C);
+    a.cell = cell; a.n_dev = n_dev; a.big_only = cell != nullptr;
+    if (cell) {
+        const int grid = qt_cdiv((int64_t)a.N * total, 256);
+        if (v4)
+            hipLaunchKernelGGL(k_pool_nodes<4>, dim3(grid), dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL(k_pool_nodes<1>, dim3(grid), dim3(256), 0, stream, a);
+        QT_LAUNCHED();
+    }
+    const int blocks = a.B * a.tiles_r * a.tiles_c;
+    int gy = total;
+    if (blocks * gy > 2048) gy = max(1, 2048 / blocks);
+    if (gy > total) gy = total;
+    if (v4)
+        hipLaunchKernelGGL(k_pool<4>, dim3(blocks, gy), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_pool<1>, dim3(blocks, gy), dim3(256), 0, stream, a);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
 extern "C" int qt_gather(const float* val, int C, const int32_t* labels, const float* inv_npix, int64_t npixels_total,
                          float* img, void* stream) {
     QT_ARG(val && labels && img && C > 0, "bad arguments");
@@ -324,33 +358,42 @@ extern "C" int qt_pool(const float* img, int S, int64_t img_clip_stride, const f
     QT_ARG(!src_inv || src_npix, "src_inv needs src_npix");
     QT_ARG(out_stride >= out_coff + C, "output row too short");
     if (N <= 0) return QT_OK;
-    PoolArgs a;
+    PoolArgs a = {};
     a.img = img; a.S = img ? S : 1; a.img_clip_stride = img_clip_stride > 0 ? img_clip_stride : (int64_t)a.S * n * m * C; a.src_val = src_val; a.src_labels = src_labels; a.src_npix = src_npix;
     a.src_inv = src_inv; a.C = C; a.labels = labels; a.level = level; a.npix = npix; a.mean = mean;
     a.B = B; a.n = n; a.m = m; a.N = N; a.out = out; a.out_stride = out_stride; a.out_coff = out_coff;
     a.tiles_r = qt_cdiv(n, 64); a.tiles_c = qt_cdiv(m, 64);
+    a.nparts = 0;
     const float* srcp = img ? img : src_val;
     const bool v4 = (C % 4 == 0) && ((uintptr_t)srcp % 16 == 0) && (img_clip_stride % 4 == 0);
-    const int total = a.S * (v4 ? C / 4 : C);
-    a.cell = cell; a.n_dev = n_dev; a.big_only = cell != nullptr;
-    if (cell) {
-        const int grid = qt_cdiv((int64_t)N * total, 256);
-        if (v4)
-            hipLaunchKernelGGL(k_pool_nodes<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-        else
-            hipLaunchKernelGGL(k_pool_nodes<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-        QT_LAUNCHED();
+    return pool_launch(a, v4, cell, n_dev, (hipStream_t)stream);
+}
+
+extern "C" int qt_remesh(const float* const* src_parts, const int* widths, const int* lds, int nparts,
+                         const int32_t* src_labels, const float* src_npix, int src_inv, const int32_t* labels,
+                         const uint8_t* level, const float* npix, int mean, int B, int n, int m, int N, const int32_t* cell,
+                         const int32_t* n_dev, float* out, void* stream) {
+    QT_ARG(src_parts && widths && lds && nparts >= 1 && nparts <= 8 && src_labels && labels && level && out && B > 0, "bad arguments");
+    QT_ARG(!mean || npix, "mean pooling needs npix");
+    QT_ARG(!src_inv || src_npix, "src_inv needs src_npix");
+    PoolArgs a = {};
+    int c4 = 0;
+    for (int i = 0; i < nparts; ++i) {
+        QT_ARG(src_parts[i] && widths[i] > 0 && widths[i] % 4 == 0 && lds[i] % 4 == 0 && lds[i] >= widths[i] &&
+               ((uintptr_t)src_parts[i] & 15) == 0, "source parts must be 16-byte aligned with widths / strides that are multiples of 4");
+        a.part[i] = src_parts[i];
+        a.part_ld[i] = lds[i];
+        c4 += widths[i] / 4;
+        a.part_end[i] = c4;
     }
-    const int blocks = B * a.tiles_r * a.tiles_c;
-    int gy = total;
-    if (blocks * gy > 2048) gy = max(1, 2048 / blocks);
-    if (gy > total) gy = total;
-    if (v4)
-        hipLaunchKernelGGL(k_pool<4>, dim3(blocks, gy), dim3(256), 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(k_pool<1>, dim3(blocks, gy), dim3(256), 0, (hipStream_t)stream, a);
-    QT_LAUNCHED();
-    return QT_OK;
+    for (int i = nparts; i < 8; ++i) { a.part[i] = nullptr; a.part_ld[i] = 0; a.part_end[i] = c4; }
+    a.nparts = nparts;
+    if (N <= 0) return QT_OK;
+    a.img = nullptr; a.S = 1; a.img_clip_stride = 0; a.src_val = src_parts[0]; a.src_labels = src_labels; a.src_npix = src_npix;
+    a.src_inv = src_inv; a.C = 4 * c4; a.labels = labels; a.level = level; a.npix = npix; a.mean = mean;
+    a.B = B; a.n = n; a.m = m; a.N = N; a.out = out; a.out_stride = 4 * c4; a.out_coff = 0;
+    a.tiles_r = qt_cdiv(n, 64); a.tiles_c = qt_cdiv(m, 64);
+    return pool_launch(a, true, cell, n_dev, (hipStream_t)stream);
 }
 
 extern "C" int qt_sse(const float* out, int out_stride, const int32_t* labels, const float* y, int64_t y_clip_stride,

@@ -341,17 +341,16 @@ class Seq2Seq(nn.Module):
             img0 = teacher_input[..., 0].reshape(old.B, old.n, old.m).float()
             new = self._mesh_from_image(img0, mask, high_interest_region)
             val = ops.pool_image(img0.reshape(old.B, 1, old.P, 1), new, True)[0]
-            state = ops.concat_cols([*hidden, *cell], old)
-            parts = ops.split_cols(ops.remesh_transfer(state, old, new), [h] * (2 * L), new)
+            parts = ops.remesh_transfer([*hidden, *cell], old, new, [h] * (2 * L))
         else:
             new = self._mesh_from_nodes(data, old, mask, high_interest_region)
             # rows stay float4-sized: the head's own 4-wide output when `data` is its column 0, else 4 copies
             b4 = data._base
             wide = (b4 is not None and b4.dim() == 2 and b4.shape == (data.shape[0], 4) and b4.is_contiguous()
                     and data.storage_offset() == b4.storage_offset() and data.stride(0) == 4)
-            state = ops.concat_cols([b4 if wide else data.expand(-1, 4).contiguous(), *hidden, *cell], old)
-            # ONE split (its backward is one concat; separate slices would each zero-fill a full (N, 4+2Lh) gradient)
-            val4, *parts = ops.split_cols(ops.remesh_transfer(state, old, new), [4] + [h] * (2 * L), new)
+            # the state goes across as its parts and comes back as column views of one matrix: nothing is concatenated
+            val4, *parts = ops.remesh_transfer([b4 if wide else data.expand(-1, 4).contiguous(), *hidden, *cell], old, new,
+                                               [4] + [h] * (2 * L))
             val = None
         g.hidden, g.cell = list(parts[:L]), list(parts[L:])
         g.pyg.x = ops.decoder_input(val4, new) if val is None else torch.cat([val, new.posfeat], dim=-1)

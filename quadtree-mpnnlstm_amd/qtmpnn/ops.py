@@ -731,9 +731,62 @@ def gather_pixels(val, mesh):
     return _Gather.apply(val, mesh)
 
 
+def _remesh_raw(dst, src, parts, out, src_inv, mean):
+    """out (dst.N, sum widths) = per-node reduction over dst's pixels of [parts...][src.labels[p]] (qt_remesh)."""
+    import ctypes
+    n = len(parts)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in parts])
+    widths = (ctypes.c_int * n)(*[t.shape[1] for t in parts])
+    lds = (ctypes.c_int * n)(*[_ld(t) for t in parts])
+    _lib.call('qt_remesh', ptrs, widths, lds, n, ptr(src.labels), ptr(src.npix), int(src_inv), ptr(dst.labels), ptr(dst.level),
+              ptr(dst.npix), int(mean), dst.B, dst.n, dst.m, dst.N, ptr(dst.cell), ptr(dst.n_dev), ptr(out))
+
+
 class _Remesh(Function):
-    """State transfer between meshes: new node = mean over its pixels of the old node value
-    (unflatten + flatten of model/seq2seq.py:440-442, 474-477 fused; no image is materialised)."""
+    """State transfer between meshes: new node = mean over its pixels of the old node value (unflatten + flatten of
+    model/seq2seq.py:440-442, 474-477 fused; no image is materialised).  The state is given as up to 8 matrices side by
+    side (row-strided column views welcome) and comes back as column views of ONE transferred matrix, split by
+    `out_widths`: neither the forward nor the backward concatenates anything."""
+
+    @staticmethod
+    def forward(ctx, old, new, out_widths, *vals):
+        parts = [_rows(v.float())[0] for v in vals]
+        C = sum(t.shape[1] for t in parts)
+        assert sum(out_widths) == C and len(parts) <= 8 and len(out_widths) <= 8
+        out = parts[0].new_empty(new.N, C)
+        if new.N > 0:
+            _remesh_raw(new, old, parts, out, False, True)
+        ctx.old, ctx.new, ctx.in_widths, ctx.out_widths = old, new, [t.shape[1] for t in parts], out_widths
+        ctx.set_materialize_grads(False)
+        return tuple(out.split(list(out_widths), dim=1))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        old, new = ctx.old, ctx.new
+        ref = next(g for g in gs if g is not None)
+        parts = [_rows(g)[0] if g is not None else ref.new_zeros(new.N, w) for g, w in zip(gs, ctx.out_widths)]
+        gval = ref.new_empty(old.N, sum(ctx.in_widths))
+        if old.N > 0:
+            _remesh_raw(old, new, parts, gval, True, False)
+        return (None, None, None, *gval.split(ctx.in_widths, dim=1))
+
+
+def remesh_transfer(vals, old, new, out_widths=None):
+    """vals: one (N_old, C) matrix or a list of column parts (widths multiples of 4); returns the transferred state as
+    one matrix (out_widths None) or as the list of its column parts."""
+    single = not isinstance(vals, (list, tuple))
+    vals = [vals] if single else list(vals)
+    C = sum(v.shape[1] for v in vals)
+    if any(v.shape[1] % 4 for v in vals) or len(vals) > 8:            # odd widths: one matrix through qt_pool
+        assert out_widths is None or list(out_widths) == [C]
+        v = vals[0] if len(vals) == 1 else torch.cat(vals, dim=1)
+        return _RemeshOne.apply(v, old, new)
+    outs = _Remesh.apply(old, new, tuple(out_widths) if out_widths is not None else (C,), *vals)
+    return outs[0] if out_widths is None else list(outs)
+
+
+class _RemeshOne(Function):
+    """The same for one matrix of any width (qt_pool)."""
 
     @staticmethod
     def forward(ctx, val, old, new):
@@ -754,10 +807,6 @@ class _Remesh(Function):
         if old.N > 0:
             _pool_raw(old, C, out, C, 0, False, src_val=g, src_mesh=new, src_inv=True)
         return out, None, None
-
-
-def remesh_transfer(val, old, new):
-    return _Remesh.apply(val, old, new)
 
 
 class _DecoderInput(Function):

@@ -71,6 +71,14 @@ def test_remesh_transfer_vs_oracle():
     (gv,) = torch.autograd.grad(out, val, g.to(dev()))
     (gr,) = torch.autograd.grad(ref, vc, g)
     close(gv, gr, atol=1e-4)
+    # the same state given as row-strided column parts and returned as parts: bit-identical, no concatenation
+    wide = torch.randn(old.N, 20, device=dev())
+    wide[:, 4:12] = val.detach()
+    pa, pb = wide[:, 4:8].requires_grad_(True), wide[:, 8:12].requires_grad_(True)
+    oa, ob = ops.remesh_transfer([pa, pb], old, new, [4, 4])
+    assert torch.equal(torch.cat([oa, ob], dim=1), out.detach())
+    ga, gb = torch.autograd.grad([oa, ob], [pa, pb], [g[:, :4].to(dev()), g[:, 4:].to(dev())])
+    assert torch.equal(torch.cat([ga, gb], dim=1), gv)
 
 
 @pytest.mark.parametrize('n_conv', [1, 2, 3])
