@@ -415,3 +415,22 @@ def test_fused_gate_cell_equals_gemm_then_cell(with_c):
 
     for a, r in zip(run(True), run(False)):
         assert torch.equal(a, r)
+
+
+def test_spmm_two_row_strided_parts_equal_one_matrix():
+    """qt_spmm2 on [Xa | Xb] given as row-strided column views (with strided addends) == qt_spmm on the concatenated
+    matrix, bit for bit: the parts only change where a row's floats live."""
+    from qtmpnn.mesh import spmm, spmm2
+    mesh, _ = _mesh_64(7, noise=0.03, B=2)
+    torch.manual_seed(0)
+    N = mesh.N
+    wide_x, wide_p = torch.randn(N, 36, device=dev()), torch.randn(N, 28, device=dev())
+    xa, xb = wide_x[:, 8:12], wide_x[:, 16:32]               # widths 4 and 16, row stride 36
+    pa, pb = wide_p[:, 4:8], wide_p[:, 12:28]
+    qa, qb = torch.randn(N, 4, device=dev()), torch.randn(N, 16, device=dev())
+    oa, ob = torch.empty(N, 4, device=dev()), torch.empty(N, 16, device=dev())
+    spmm2(mesh, [xa, xb], 2.0, [pa, pb], -1.0, [qa, qb], 0.5, [oa, ob])
+    x, p, q = (torch.cat(t, dim=1).contiguous() for t in ((xa, xb), (pa, pb), (qa, qb)))
+    ref = torch.empty(N, 20, device=dev())
+    spmm(mesh, x, 2.0, p, -1.0, q, 0.5, ref, 20)
+    assert torch.equal(torch.cat([oa, ob], dim=1), ref)

@@ -142,3 +142,38 @@ def test_unsupported_variants_raise_clearly():
         Seq2Seq(16, 0.1, 0.1, convolution_type='GATConv')
     with pytest.raises(AssertionError):
         Seq2Seq(16, 0.1, 0.1, convolution_type='NoSuchConv')
+
+
+@pytest.mark.parametrize('n_conv', [1, 2])
+def test_pack_plan_equals_per_tensor_packing(n_conv):
+    """ops.PackPlan (one gather of all parameters through recorded index maps) == the per-tensor stack / cat packing,
+    values and every parameter gradient; also the ChebConv head matrix with padding."""
+    import torch
+    from model.model import ChebConv, GConvLSTM
+    from qtmpnn import ops
+    torch.manual_seed(0)
+    cell = GConvLSTM(4, 16, n_conv, 'ChebConv')
+    for p in cell.parameters():
+        p.data.normal_()
+    ref = cell.pack(4, None, (False, True))
+    params = cell.plan_params()
+    plan = ops.PackPlan(params, lambda T, fill: cell.plan_layout(T, fill, 'c.', 4, (False, True)))
+    got = cell.pack_from(plan(), 'c.', 4, None, (False, True))
+    for r, g in zip(ref, got):
+        assert (r.K, r.Ks) == (g.K, g.Ks) and torch.allclose(r.W, g.W, atol=1e-6)
+        assert torch.equal(r.wc, g.wc) and torch.equal(r.b, g.b)
+
+    def probe(cells):
+        return sum((c.W * torch.linspace(-1, 1, c.W.numel()).view_as(c.W)).sum() for c in cells) + 2 * cells[0].wc.sum() + 3 * cells[0].b.sum()
+    gr = torch.autograd.grad(probe(ref), params, allow_unused=True)
+    gg = torch.autograd.grad(probe(got), params, allow_unused=True)
+    for a, b in zip(gr, gg):
+        assert (a is None and b is None) or torch.allclose(a, b, atol=1e-5)
+    # gradients handed out by the plan are disjoint views (clip_grad_norm_ scales them in place)
+    ptrs = sorted((g.data_ptr(), g.numel() * 4) for g in gg if g is not None)
+    assert all(p0 + n0 <= p1 for (p0, n0), (p1, _) in zip(ptrs, ptrs[1:]))
+    conv = ChebConv(17, 16)
+    for p in conv.parameters():
+        p.data.normal_()
+    plan = ops.PackPlan(conv.plan_params(), lambda T, fill: {'w': conv.plan_layout(T, fill, 20, 16)})
+    assert torch.equal(plan()['w'], conv.packed(20, 16))
