@@ -687,18 +687,31 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_group(WgradGroup w) {
     wgrad_body<FW, CT>(A, w.G[s], M, w.Co, rbeg, rend, w.part + (int64_t)blockIdx.z * M * w.Co, 0);
 }
 
-// 32 columns x 8 row groups per workgroup; fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ part, int nblk, int64_t len, float* __restrict__ out) {
-    __shared__ float sm[8][33];
+// 32 columns x 32 row groups per workgroup, four slabs in flight per thread; fixed summation order (deterministic).
+// (With 8 row groups and one load in flight the 640 slabs of a grouped weight gradient took 30 us: a latency chain.)
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part, int nblk, int64_t len, float* __restrict__ out) {
+    __shared__ float sm[32][33];
     const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
     const int64_t c = (int64_t)blockIdx.x * 32 + cl;
-    float acc = 0.0f;
-    if (c < len)
-        for (int i = r; i < nblk; i += 8) acc += part[(int64_t)i * len + c];
-    sm[r][cl] = acc;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    if (c < len) {
+        int i = r;
+        for (; i + 96 < nblk; i += 128) {
+            a0 += part[(int64_t)i * len + c];
+            a1 += part[(int64_t)(i + 32) * len + c];
+            a2 += part[(int64_t)(i + 64) * len + c];
+            a3 += part[(int64_t)(i + 96) * len + c];
+        }
+        for (; i < nblk; i += 32) a0 += part[(int64_t)i * len + c];
+    }
+    sm[r][cl] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (r == 0 && c < len)
-        out[c] = ((sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl])) + ((sm[4][cl] + sm[5][cl]) + (sm[6][cl] + sm[7][cl]));
+    if (r == 0 && c < len) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += sm[k][cl];
+        out[c] = s;
+    }
 }
 
 // tile variant by weight shape: feature waves 1 / 2 / 4 for up to 32 / 64 / more features, one column tile up to 32 columns
@@ -937,7 +950,7 @@ extern "C" int qt_wgrad_group(int nseg, const float* const* a0, const int* lda0,
 
 extern "C" int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream) {
     QT_ARG(part && out && len > 0 && nblk >= 0, "bad arguments");
-    hipLaunchKernelGGL(k_colsum, dim3(qt_cdiv(len, 32)), dim3(256), 0, (hipStream_t)stream, part, nblk, len, out);
+    hipLaunchKernelGGL(k_colsum, dim3(qt_cdiv(len, 32)), dim3(1024), 0, (hipStream_t)stream, part, nblk, len, out);
     QT_LAUNCHED();
     return QT_OK;
 }
