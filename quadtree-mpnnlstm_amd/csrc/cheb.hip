@@ -728,7 +728,7 @@ inline int wgrad_fw(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
         else hipLaunchKernelGGL((K<4, 2>), grid_, dim3(256), 0, (hipStream_t)(stream_), arg_);                      \
     } while (0)
 constexpr int WGRAD_ROWS = 512;
-constexpr int WGRAD_GROUP_ROWS = 2048;
+constexpr int WGRAD_GROUP_ROWS = 1024;
 
 }  // namespace
 
