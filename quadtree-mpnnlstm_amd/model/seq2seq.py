@@ -49,7 +49,9 @@ class Encoder(nn.Module):
         """The same through ONE parameter gather for the whole encoder (ops.PackPlan, cached per input width)."""
         plans = self.__dict__.setdefault('_plans', {})
         key = (in_pad, self.norm_h.weight.device)
-        if key not in plans:
+        params = [p for r in self.rnns for p in r.plan_params()] + [self.norm_h.weight, self.norm_h.bias,
+                                                                    self.norm_c.weight, self.norm_c.bias]
+        if key not in plans or not plans[key].same_params(params):       # (a re-assigned Parameter invalidates the plan)
             counts = [len(r.plan_params()) for r in self.rnns]
 
             def layout(T, fill):
@@ -60,8 +62,6 @@ class Encoder(nn.Module):
                     o += n
                 out['ln'] = torch.stack(T[o:o + 4])
                 return out
-            params = [p for r in self.rnns for p in r.plan_params()] + [self.norm_h.weight, self.norm_h.bias,
-                                                                        self.norm_c.weight, self.norm_c.bias]
             plans[key] = ops.PackPlan(params, layout)
         outs = plans[key]()
         ln = outs['ln']
@@ -130,7 +130,10 @@ class Decoder(nn.Module):
         """The same through ONE parameter gather for the whole decoder (ops.PackPlan, cached per input width)."""
         plans = self.__dict__.setdefault('_plans', {})
         key = (in_pad, self.norm_h.weight.device)
-        if key not in plans:
+        params = ([p for r in self.rnns for p in r.plan_params()] + self.fc_out1.plan_params() + self.fc_out2.plan_params()
+                  + [self.norm_h.weight, self.norm_h.bias, self.norm_c.weight, self.norm_c.bias,
+                     self.norm_o.weight, self.norm_o.bias])
+        if key not in plans or not plans[key].same_params(params):
             counts = [len(r.plan_params()) for r in self.rnns]
             n1, n2 = len(self.fc_out1.plan_params()), len(self.fc_out2.plan_params())
 
@@ -146,9 +149,6 @@ class Decoder(nn.Module):
                 out['ln'] = torch.stack(T[o:o + 4])
                 out['ln_o'] = torch.stack(T[o + 4:o + 6])
                 return out
-            params = ([p for r in self.rnns for p in r.plan_params()] + self.fc_out1.plan_params() + self.fc_out2.plan_params()
-                      + [self.norm_h.weight, self.norm_h.bias, self.norm_c.weight, self.norm_c.bias,
-                         self.norm_o.weight, self.norm_o.bias])
             plans[key] = ops.PackPlan(params, layout)
         outs = plans[key]()
         ln = outs['ln']

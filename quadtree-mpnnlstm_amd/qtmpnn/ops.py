@@ -138,6 +138,9 @@ class PackPlan:
         self.offs, self.n_flat, self.n_out, self.device = offs, n_flat, n_out, dev
         self.zero1 = torch.zeros(1, device=dev)
 
+    def same_params(self, params):
+        return len(params) == len(self.params) and all(a is b for a, b in zip(params, self.params))
+
     def __call__(self):
         outs = _PackGather.apply(self, *self.params)
         return dict(zip(self.names, outs))
