@@ -40,10 +40,18 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
     const int nch = C / VEC;
     // Workgroups are dealt round-robin to the 8 XCDs, each with a private L2.  Giving XCD x the contiguous node range
     // [x * chunk, (x+1) * chunk) keeps a node's neighbours (close in the reversed-Morton order) in the L2 that reads them.
-    const int blk = xcd_chunk ? (bid & 7) * xcd_chunk + (bid >> 3) : bid;
+    // The chunk is an eighth of the VALID rows (read on the device in static mode), not of the capacity the grid was
+    // sized for: otherwise the last XCDs idle whenever a mesh has fewer nodes than pixels.
+    const int rows = qt_rows(n_dev, Ncap);
+    int blk = bid;
+    if (xcd_chunk) {
+        const int nblk = (int)(((int64_t)((rows + RPT - 1) / RPT) * nch + 255) >> 8);
+        const int chunk = (nblk + 7) >> 3;
+        if ((bid >> 3) >= chunk) return;
+        blk = (bid & 7) * chunk + (bid >> 3);
+    }
     const unsigned idx = (unsigned)blk * 256u + threadIdx.x;      // N * nch < 2^31 (checked by the host entry): 32-bit
     const int64_t rp = idx / (unsigned)nch;                        // division, a fraction of the 64-bit one's cost
-    const int rows = qt_rows(n_dev, Ncap);
     if (rp * RPT >= rows) return;
     const int ch = (int)(idx - (unsigned)rp * (unsigned)nch) * VEC;
     int e0[RPT], e1[RPT];
