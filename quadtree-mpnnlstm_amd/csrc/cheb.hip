@@ -397,6 +397,69 @@ __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgr
     QT_STAMP(5);
 }
 
+// ---- skinny shapes: few output columns (the decoder head: 16 or 4) or a short reduction (its data gradients: K = 16 or 4).
+// The MFMA kernel's fixed costs (W staging, barriers, the LDS round trip of the epilogue: ~15 us) dwarf such a product; here a
+// wave owns 64 rows x 4 output columns, reads its A quads straight from global memory and the matching 4 x 4 block of W
+// through scalar loads (wave uniform), and accumulates with plain fp32 FMAs -- the VALU has the fp32 MFMA's FLOP rate.
+// RPB = 64: the 4 waves of a workgroup take 4 column quads of the same 64 rows (their A loads meet in L1); RPB = 256: one
+// column quad in all (NB = 4).
+template <int RPB>
+__global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g) {
+    __shared__ const float* qptr[MAXQ];
+    __shared__ int qstr[MAXQ];
+    const int t = threadIdx.x;
+    const int64_t rows = qt_rows(g.n_dev, g.M);
+    const int64_t row0 = (int64_t)blockIdx.x * RPB;
+    if (row0 >= rows) return;
+    const int nquad = g.K >> 2;
+    build_quad_table(g.A, qptr, qstr, nquad);
+    __syncthreads();
+    const int cq = __builtin_amdgcn_readfirstlane(RPB == 64 ? (int)blockIdx.y * 4 + (t >> 6) : (int)blockIdx.y);
+    const int j = cq * 4;
+    if (j >= g.NB) return;
+    const int64_t row = row0 + (RPB == 64 ? (t & 63) : t);
+    const bool ok = row < rows;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* __restrict__ Wc = g.B + j;
+    auto step = [&](const float4& a, int Q) {
+        const float4 w0 = *reinterpret_cast<const float4*>(Wc + (int64_t)(4 * Q + 0) * g.NB);
+        const float4 w1 = *reinterpret_cast<const float4*>(Wc + (int64_t)(4 * Q + 1) * g.NB);
+        const float4 w2 = *reinterpret_cast<const float4*>(Wc + (int64_t)(4 * Q + 2) * g.NB);
+        const float4 w3 = *reinterpret_cast<const float4*>(Wc + (int64_t)(4 * Q + 3) * g.NB);
+        acc.x = fmaf(a.x, w0.x, acc.x); acc.y = fmaf(a.x, w0.y, acc.y); acc.z = fmaf(a.x, w0.z, acc.z); acc.w = fmaf(a.x, w0.w, acc.w);
+        acc.x = fmaf(a.y, w1.x, acc.x); acc.y = fmaf(a.y, w1.y, acc.y); acc.z = fmaf(a.y, w1.z, acc.z); acc.w = fmaf(a.y, w1.w, acc.w);
+        acc.x = fmaf(a.z, w2.x, acc.x); acc.y = fmaf(a.z, w2.y, acc.y); acc.z = fmaf(a.z, w2.z, acc.z); acc.w = fmaf(a.z, w2.w, acc.w);
+        acc.x = fmaf(a.w, w3.x, acc.x); acc.y = fmaf(a.w, w3.y, acc.y); acc.z = fmaf(a.w, w3.z, acc.z); acc.w = fmaf(a.w, w3.w, acc.w);
+    };
+    auto lda = [&](int Q) {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && Q < nquad) r = gload4(qptr[Q] + row * qstr[Q]);
+        return r;
+    };
+    for (int Q = 0; Q < nquad; Q += 4) {            // four A quads in flight
+        const float4 a0 = lda(Q), a1 = lda(Q + 1), a2 = lda(Q + 2), a3 = lda(Q + 3);
+        step(a0, Q);
+        if (Q + 1 < nquad) step(a1, Q + 1);
+        if (Q + 2 < nquad) step(a2, Q + 2);
+        if (Q + 3 < nquad) step(a3, Q + 3);
+    }
+    if (!ok) return;
+    float4 v = acc;
+    if (g.act == QT_ACT_RELU) {
+        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+    }
+    if (g.act == QT_ACT_TANH_RES) {
+        const float d = g.drop ? g.drop[row] : 1.0f, rs = g.res[row * g.res_stride];
+        v.x = tanhf(d * v.x) + rs; v.y = tanhf(d * v.y) + rs; v.z = tanhf(d * v.z) + rs; v.w = tanhf(d * v.w) + rs;
+    }
+    const int ct = g.Cb + g.Cbb;
+    const int pl = j / ct, ch = j - pl * ct;
+    if (ch < g.Cb)
+        *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + row * g.Cb + ch) = v;
+    else
+        *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + row * g.Cbb + (ch - g.Cb)) = v;
+}
+
 // ---- bf16x3 variant of the forward / data-gradient GEMM -------------------------------------------------------------
 // fp32 MFMA runs at the VALU FLOP rate on gfx950 and bounds k_gemm_fwd.  Here every fp32 operand
 // is split into three bf16 terms (x = hi + mid + lo, each rounded to nearest) and a product group is six bf16 MFMAs
@@ -847,7 +910,13 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
     // default: exact fp32 MFMA (bit-for-bit a k-ordered fmaf chain).  QT_GEMM_BF16X3=1 opts into the bf16x3 split
     // kernels (fp32-level error, ~8 % faster on these memory/latency-shaped GEMMs: measured 27.7 vs 30.1 us).
     static const bool exact_fp32 = getenv("QT_GEMM_BF16X3") == nullptr;
-    if (exact_fp32) {
+    static const bool no_skinny = getenv("QT_GEMM_NO_SKINNY") != nullptr;
+    if (!no_skinny && g.NB <= 16) {       // (wide outputs of short reductions measured slower here: 24.5 vs 14.5 us)
+        if (g.NB <= 4)
+            hipLaunchKernelGGL((k_gemm_skinny<256>), dim3(qt_cdiv(N, 256), 1, 1), dim3(256), 0, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL((k_gemm_skinny<64>), dim3(qt_cdiv(N, 64), qt_cdiv(g.NB, 16), 1), dim3(256), 0, (hipStream_t)stream, g);
+    } else if (exact_fp32) {
         if (g.NB > 64)
             hipLaunchKernelGGL((k_gemm_fwd<4, 64>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128), 1), dim3(256), 0, (hipStream_t)stream, g);
         else
