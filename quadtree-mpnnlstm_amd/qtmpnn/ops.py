@@ -198,29 +198,6 @@ class _ConcatCols(Function):
         return (None, *outs)
 
 
-class _SplitCols(Function):
-    """Column split of a node matrix into views; the backward is ONE concat kernel (torch's split backward is a
-    batched cat that moves these narrow rows at ~0.6 TB/s)."""
-
-    @staticmethod
-    def forward(ctx, t, mesh, *widths):
-        ctx.mesh, ctx.widths, ctx.rows = mesh, widths, t.shape[0]
-        ctx.set_materialize_grads(False)
-        return tuple(t.split(list(widths), dim=1))
-
-    @staticmethod
-    def backward(ctx, *gs):
-        ref = next(g for g in gs if g is not None)
-        gs = [g if g is not None else ref.new_zeros(ctx.rows, w) for g, w in zip(gs, ctx.widths)]
-        return (concat_cols(gs, ctx.mesh), None) + (None,) * len(ctx.widths)
-
-
-def split_cols(t, widths, mesh=None):
-    if len(widths) <= 8 and all(w % 4 == 0 for w in widths) and t.is_cuda:
-        return _SplitCols.apply(t, mesh, *widths)
-    return t.split(list(widths), dim=1)
-
-
 def concat_cols(tensors, mesh=None):
     """Column concatenation on the custom kernel when every width is a multiple of 4 (else torch.cat)."""
     if len(tensors) <= 8 and all(t.dim() == 2 and t.shape[1] % 4 == 0 and t.is_cuda for t in tensors):

@@ -434,3 +434,16 @@ def test_spmm_two_row_strided_parts_equal_one_matrix():
     ref = torch.empty(N, 20, device=dev())
     spmm(mesh, x, 2.0, p, -1.0, q, 0.5, ref, 20)
     assert torch.equal(torch.cat([oa, ob], dim=1), ref)
+
+
+def test_concat_cols_kernel():
+    """qt_concat: column concatenation of row-strided sources == torch.cat, and the backward hands out column views."""
+    from qtmpnn import ops
+    torch.manual_seed(0)
+    wide = torch.randn(1000, 24, device=dev())
+    a, b, c = wide[:, 4:8].requires_grad_(True), torch.randn(1000, 16, device=dev(), requires_grad=True), wide[:, 12:20].requires_grad_(True)
+    out = ops.concat_cols([a, b, c])
+    assert torch.equal(out, torch.cat([a, b, c], dim=1))
+    g = torch.randn_like(out)
+    ga, gb, gc = torch.autograd.grad(out, [a, b, c], g)
+    assert torch.equal(ga, g[:, :4]) and torch.equal(gb, g[:, 4:20]) and torch.equal(gc, g[:, 20:])
