@@ -227,8 +227,11 @@ def create_static_heterogeneous_graph(image_shape, max_grid_size, mask, high_int
 
 def create_static_homogeneous_graph(image_shape, max_grid_size, mask, use_edge_attrs=True, resolution=0.25, device=None):
     """Uniform preset mesh with fully masked cells removed (graph_functions.py:707-737)."""
-    raise NotImplementedError('create_static_homogeneous_graph is not built yet (SURVEY.md 8(f) row 2); the '
-                              'heterogeneous preset mesh and the pixelwise mesh are')
+    from qtmpnn.mesh import build_homogeneous_mesh
+    n, m = image_shape
+    mesh = build_homogeneous_mesh(n, m, max_grid_size, mask, 1, device or _device_of(), resolution)
+    return dict(edge_index=mesh.edge_index(True), edge_attrs=mesh.edge_attrs(use_edge_attrs, resolution),
+                graph_nodes=np.arange(mesh.N), mapping=mesh, n_pixels_per_node=mesh.npix)
 
 
 def plot_contours(ax, labels):

@@ -50,6 +50,8 @@ class Mesh:
         self.n_dev = None        # device int32[1] with the valid node count when N is a capacity (static mode)
         self.pixelwise = False   # every unmasked pixel is a node (thresh = -inf); unflatten then NaN-fills the mask
         self.recipe = None       # arguments that rebuild a data-independent mesh for another batch size
+        self.loss_mask = None    # (n, m) u8 when the labels do not encode the mask (homogeneous preset mesh): the loss
+        self.npix_valid = None   # masks pixels explicitly and counts a node's unmasked pixels
 
     # -- sizes ------------------------------------------------------------------
     @property
@@ -272,6 +274,35 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
     _lib.call('qt_edges_fill', ptr(ms.labels), ptr(ms.cell), ptr(cnt4), ptr(sums), N, nd, n, m, float(resolution),
               ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis))
     _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm))
+
+
+def build_homogeneous_mesh(n, m, max_size, mask, B=1, device=None, resolution=0.25):
+    """Uniform preset mesh of max_size x max_size cells (clipped at the image border) with the cells that lie entirely under
+    `mask` removed and the rest renumbered in the same order (create_static_homogeneous_graph,
+    model/graph_functions.py:707-737).  A partly masked cell keeps ALL its pixels -- the reference builds it without the
+    mask -- so its labels do not encode the mask: `loss_mask` / `npix_valid` carry it for the masked loss."""
+    base = build_mesh(src=torch.zeros(B, n, m, device=device), thresh=float('inf'), mask=None, max_size=max_size,
+                      resolution=resolution)
+    mk = _as_u8(mask, device, (n, m))
+    keep_px = torch.ones(n, m, device=device) if mk is None else (mk == 0).float()
+    lab = base.labels.view(B, -1).long()
+    cnt = torch.zeros(base.N, device=device).index_add_(0, lab.view(-1), keep_px.view(1, -1).expand(B, -1).reshape(-1))
+    kept = cnt > 0
+    new_id = torch.cumsum(kept.int(), 0, dtype=torch.int32) - 1
+    ms = Mesh()
+    ms.B, ms.n, ms.m, ms.max_size, ms.resolution, ms.mask = B, n, m, max_size, resolution, mk
+    ms.N = int(kept.sum().item())
+    ms.labels = torch.where(kept[lab], new_id[lab], torch.full_like(new_id[lab], -1)).view(B, n, m).contiguous()
+    ms.level = base.level
+    ms.cell = base.cell[kept].contiguous() if ms.N else base.cell[:1].clone()
+    per_clip = torch.zeros(B, dtype=torch.int32, device=device).index_add_(0, base.cell[kept][:, 3].long(),
+                                                                           torch.ones(ms.N, dtype=torch.int32, device=device))
+    ms.node_off = torch.cat([torch.zeros(1, dtype=torch.int32, device=device), torch.cumsum(per_clip, 0, dtype=torch.int32)])
+    ms.loss_mask = mk
+    ms.npix_valid = cnt[kept].contiguous()
+    ms.recipe = lambda b: build_homogeneous_mesh(n, m, max_size, mask, b, device, resolution)
+    _finish_mesh(ms, device, (max_size / 2) ** 2, resolution, None)
+    return ms
 
 
 _PIXEL_MESHES = {}

@@ -853,6 +853,13 @@ class _StepSSE(Function):
 def step_sse_partials(out, y, mesh):
     """`out` (N, 1); when it is column 0 of a wider contiguous matrix (the head's 4-wide output) the op runs on that
     matrix, so the gradient is written once as full rows instead of slice_backward's zero-fill + copy."""
+    if mesh.loss_mask is not None:
+        # homogeneous preset mesh: partly masked cells keep all their pixels, so the mask is applied per pixel
+        # (composition of differentiable ops; this preset-mesh path is not the tuned one)
+        keep = (mesh.loss_mask == 0).float().view(1, mesh.P)
+        img = gather_pixels(out[:, :1], mesh).view(mesh.B, mesh.P)
+        d = (img - y.reshape(mesh.B, mesh.P).float()) * keep
+        return (d * d).sum().view(1)
     base = out._base
     if (base is not None and base.dim() == 2 and out.dim() == 2 and out.shape[1] == 1 and base.is_contiguous()
             and base.shape[0] == out.shape[0] and out.storage_offset() == base.storage_offset()

@@ -326,7 +326,15 @@ def rollout_fixed_mesh(name, x, y, concat, mask, hidden, n_layers, n_conv, t_in,
     model.train()
     xt, yt, ct = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(concat)
     gs, extra = None, {}
-    if static is not None:
+    if static is not None and static[1] == 'homogeneous':
+        # uniform preset mesh, fully masked cells removed (graph_functions.py:707-737); partly masked cells keep ALL their pixels
+        gs = RG.create_static_homogeneous_graph(x.shape[1:3], static[0], mask, use_edge_attrs=False)
+        mp = gs['mapping'].numpy()
+        extra = dict(static_labels=np.where(mp.sum(0) > 0, mp.argmax(0), -1).reshape(x.shape[1:3]).astype(np.int32),
+                     static_npix=gs['n_pixels_per_node'].numpy(), max_grid_size=np.int64(static[0]))
+        ei, at = sort_edges(gs['edge_index'], gs['edge_attrs'])
+        extra.update(static_edges=ei, static_dist=at)
+    elif static is not None:
         gs = RG.create_static_heterogeneous_graph(x.shape[1:3], static[0], mask, high_interest_region=static[1], use_edge_attrs=False)
         mp = gs['mapping'].numpy()
         extra = dict(static_labels=np.where(mp.sum(0) > 0, mp.argmax(0), -1).reshape(x.shape[1:3]).astype(np.int32),
@@ -359,6 +367,15 @@ def fixed_meshes():
     hir = np.zeros_like(m); hir[10:20, 30:44] = True
     rollout_fixed_mesh('static48x64', f[:2], f[2:5, ..., :1].copy(), concat, m, hidden=8, n_layers=2, n_conv=1, t_in=2, t_out=3,
                        static=(8, hir), seed=71)
+
+
+def homogeneous_mesh():
+    f, m = synthetic.make_ice_like(19, shape=(48, 64), channels=3, n_frames=5)
+    m = m.copy()
+    m[:8, :16] = True                       # two whole 8x8 cells under the mask: they must disappear from the mesh
+    concat = f[2:5, ..., :1].copy() * 0.5
+    rollout_fixed_mesh('homog48x64', f[:2], f[2:5, ..., :1].copy(), concat, m, hidden=8, n_layers=1, n_conv=2, t_in=2, t_out=3,
+                       static=(8, 'homogeneous'), seed=72)
 
 
 # ------------------------------------------------------------------ trainer parity features
@@ -487,6 +504,8 @@ if __name__ == '__main__':
         rollouts()
     if only in ('', 'fixed'):
         fixed_meshes()
+    if only in ('', 'homog'):
+        homogeneous_mesh()
     if only in ('', 'variants'):
         rollout_variants()
     if only in ('', 'transformer'):

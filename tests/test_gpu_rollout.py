@@ -273,6 +273,28 @@ def test_static_mesh_rollout_golden():
     assert abs(float(loss2) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
 
 
+def test_homogeneous_mesh_rollout_golden():
+    """uniform preset mesh with fully masked cells removed (create_static_homogeneous_graph); partly
+    masked cells keep all their pixels, so the loss masks per pixel -- against the reference trace."""
+    from model.graph_functions import create_static_homogeneous_graph
+    g = golden('fixed_homog48x64.npz')
+    build = lambda: create_static_homogeneous_graph((48, 64), int(g['max_grid_size']), g['mask'], use_edge_attrs=False, device=dev())
+    model, outs, meshes, loss, gs = _run_fixed(g, build)
+    mesh = gs['mapping']
+    assert np.array_equal(mesh.labels[0].cpu().numpy(), g['static_labels'])
+    assert np.array_equal(gs['n_pixels_per_node'].cpu().numpy(), g['static_npix'])
+    assert np.array_equal(gs['edge_index'].cpu().numpy(), g['static_edges'])
+    close(gs['edge_attrs'], g['static_dist'], atol=2e-5)
+    for i, o in enumerate(outs):
+        close(o, g[f'out_{i}'], msg=f'step {i}')
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    loss.backward()
+    _check_grads(model, g)
+    model2, outs2, meshes2, loss2, _ = _run_fixed(g, build, batch=2)
+    assert meshes2[0].B == 2 and meshes2[0].N == 2 * mesh.N
+    assert abs(float(loss2) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+
+
 @pytest.mark.parametrize('cfg', ['cfg3_mnist128', 'cfg4_ice128', 'cfg5_ice256'])
 def test_baseline_config_shapes_train(cfg):
     """BASELINE.json configs[2..4] at their full image sizes (reduced batch): one eager training step must run, give a
