@@ -621,9 +621,12 @@ __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __res
     const int nquad = M >> 2;
     build_quad_table(A, qptr, qstr, nquad);
     __syncthreads();
-    // staging roles: A tile = 32 rows x 32 quads -> 4 float4 per thread; G tile = 32 rows x 16 quads -> 2 per thread
-    const int a_row = t >> 3, a_q = (t & 7) * 4;           // 4 consecutive quads of one row
-    const int g_row = t >> 3, g_q = (t & 7) * 2;
+    // staging roles: A tile = 32 rows x 32 quads -> 4 float4 per thread; G tile = 32 rows x 16 quads -> 2 per thread.
+    // Within one load instruction the 8 threads of a row take 8 CONSECUTIVE quads (128 contiguous bytes where the quads
+    // share a plane part); giving each thread 4 consecutive quads instead made every 4-lane group of the texture addresser
+    // span four 64-byte segments.
+    const int a_row = t >> 3, a_q = t & 7;
+    const int g_row = t >> 3, g_q = t & 7;
     // two passes of operands in flight: the rows of this kernel come from HBM (activations saved by the forward pass),
     // and with one pass of prefetch every group of weights ran at ~3 TB/s whatever its MFMA load
     float4 pa[2][4], pg[2][2];
@@ -631,23 +634,24 @@ __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __res
         const int64_t ra = r0 + a_row;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int Q = (f0 >> 2) + a_q + u;
+            const int ql = u * 8 + a_q;
+            const int Q = (f0 >> 2) + ql;
             qa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ra < rend && Q < nquad && a_q + u < BMF / 4) qa[u] = gload4(qptr[Q] + ra * qstr[Q]);
+            if (ra < rend && Q < nquad && ql < BMF / 4) qa[u] = gload4(qptr[Q] + ra * qstr[Q]);
         }
         const int64_t rgw = r0 + g_row;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int jq = (g_q + u) * 4;
+            const int jq = (u * 8 + g_q) * 4;
             qg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rgw < rend && j0 + jq < NB && jq < CT * 32) qg[u] = gload4(G + rgw * NB + j0 + jq);
         }
     };
     auto stash = [&](int buf, const float4 (&qa)[4], const float4 (&qg)[2]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(&As[buf][a_row][(a_q + u) * 4]) = qa[u];
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(&As[buf][a_row][(u * 8 + a_q) * 4]) = qa[u];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Gs[buf][g_row][(g_q + u) * 4]) = qg[u];
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Gs[buf][g_row][(u * 8 + g_q) * 4]) = qg[u];
     };
     f32x16 acc[CT];
 #pragma unroll
