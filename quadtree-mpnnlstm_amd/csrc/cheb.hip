@@ -85,18 +85,25 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
                 w[u][v] = ok ? nrm[eb[u] + v] : 0.0f;
             }
         if constexpr (VEC == 4) {
-            float4 f[RPT][EPT];
+            // gathers in groups of 4 edges: the first group always (slots beyond the row's edges re-read the row itself with
+            // weight 0), a further group only for the lanes whose row reaches it -- one branch per group, so a row with 4
+            // neighbours costs the texture addresser 4 gathers, not EPT, while the index loads of all EPT slots (issued
+            // above) stay off the critical path of the rows with many neighbours
 #pragma unroll
-            for (int u = 0; u < RPT; ++u)
+            for (int v0 = 0; v0 < EPT; v0 += 4) {
 #pragma unroll
-                for (int v = 0; v < EPT; ++v) f[u][v] = *reinterpret_cast<const float4*>(x + (int64_t)cj[u][v] * ldx + ch);
+                for (int u = 0; u < RPT; ++u) {
+                    if (v0 > 0 && eb[u] + v0 >= e1[u]) continue;
+                    float4 f[4];
 #pragma unroll
-            for (int u = 0; u < RPT; ++u)
+                    for (int v = 0; v < 4; ++v) f[v] = *reinterpret_cast<const float4*>(x + (int64_t)cj[u][v0 + v] * ldx + ch);
 #pragma unroll
-                for (int v = 0; v < EPT; ++v) {
-                    acc[u][0] += w[u][v] * f[u][v].x; acc[u][1] += w[u][v] * f[u][v].y;
-                    acc[u][2] += w[u][v] * f[u][v].z; acc[u][3] += w[u][v] * f[u][v].w;
+                    for (int v = 0; v < 4; ++v) {
+                        acc[u][0] += w[u][v0 + v] * f[v].x; acc[u][1] += w[u][v0 + v] * f[v].y;
+                        acc[u][2] += w[u][v0 + v] * f[v].z; acc[u][3] += w[u][v0 + v] * f[v].w;
+                    }
                 }
+            }
         } else {
             float f[RPT][EPT];
 #pragma unroll
