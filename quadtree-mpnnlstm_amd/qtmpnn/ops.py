@@ -247,17 +247,29 @@ def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW):
     C = sum(Cs)
     Co = W.shape[1]
     gZs = None
+    need = list(need_gZ) if isinstance(need_gZ, (list, tuple)) else [bool(need_gZ)] * len(Zs)
+    need_gZ = any(need)
     if need_gZ and N > 0:
-        if acc is None:
-            Wt = W[:K * C].t().contiguous()
-        else:                                    # the transposed weight is shared by every use of W in this pass
-            if acc.wt is None:
-                acc.wt = W[:K * C].t().contiguous()
-            Wt = acc.wt
-        gTs = [Zs[0].new_empty(K, N, c) for c in Cs]
-        _lib.call('qt_dense2', ptr(G), 0, None, None, 0, None, 1, Co, 0, ptr(Wt), None, 0, None, K, Cs[0],
-                  Cs[1] if len(Cs) > 1 else 0, N, ptr(mesh.n_dev), ACT_NONE, None, 0, None, ptr(gTs[0]),
-                  ptr(gTs[1]) if len(Cs) > 1 else None)
+        # only the column parts whose input wants a gradient are propagated (the encoder's X is data: the K-1 Clenshaw
+        # launches of its cells then carry H's 16 channels alone, and the data-gradient GEMM is narrower)
+        live = [i for i, f in enumerate(need) if f]
+        key = 'wt' if len(live) == len(Zs) else f'wt{live[0]}'
+        Wt = None if acc is None else acc.wt.get(key) if isinstance(acc.wt, dict) else None
+        if Wt is None:
+            Wk = W[:K * C].view(K, C, Co)
+            if len(live) < len(Zs):
+                lo = sum(Cs[:live[0]])
+                Wk = Wk[:, lo:lo + Cs[live[0]]]
+            Wt = Wk.reshape(-1, Co).t().contiguous()        # shared by every use of W in this pass
+            if acc is not None:
+                if not isinstance(acc.wt, dict):
+                    acc.wt = {}
+                acc.wt[key] = Wt
+        Cl = [Cs[i] for i in live]
+        gTs = [Zs[0].new_empty(K, N, c) for c in Cl]
+        _lib.call('qt_dense2', ptr(G), 0, None, None, 0, None, 1, Co, 0, ptr(Wt), None, 0, None, K, Cl[0],
+                  Cl[1] if len(Cl) > 1 else 0, N, ptr(mesh.n_dev), ACT_NONE, None, 0, None, ptr(gTs[0]),
+                  ptr(gTs[1]) if len(Cl) > 1 else None)
         # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
         for k in range(K - 2, 0, -1):
             spmm2(mesh, [g[k + 1] for g in gTs], 2.0, [g[k] for g in gTs], 1.0,
@@ -265,9 +277,11 @@ def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW):
         if K > 1:
             spmm2(mesh, [g[1] for g in gTs], 1.0, [g[0] for g in gTs], 1.0, [g[2] for g in gTs] if K > 2 else None, -1.0,
                   [g[0] for g in gTs])
-        gZs = [g[0] for g in gTs]
+        gZs = [None] * len(Zs)
+        for i, g in zip(live, gTs):
+            gZs[i] = g[0]
     elif need_gZ:
-        gZs = [torch.zeros_like(Z) for Z in Zs]
+        gZs = [torch.zeros_like(Z) if f else None for Z, f in zip(Zs, need)]
     gW = None
     if need_gW:
         ksp = (Ks + 3) // 4 * 4
@@ -341,7 +355,7 @@ class _ChebPoly(Function):
                 _lib.call('qt_act_bwd', ptr(gin), ptr(Y), ptr(res), _row_stride(res), ptr(drop), act, N,
                           ptr(mesh.n_dev), Co, ptr(G), ptr(gres))
         gZs, gW = _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, ctx.acc, ctx.use_idx,
-                                 ctx.needs_input_grad[0] or ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+                                 list(ctx.needs_input_grad[:nz]), ctx.needs_input_grad[2])
         gZa = gZs[0] if gZs is not None else None
         gZb = gZs[1] if gZs is not None and nz > 1 else None
         return gZa, gZb, gW, gres, None, None, None, None, None, None
@@ -575,7 +589,7 @@ class _GateCell(Function):
         W, gates, Craw, Cprev, wc, ln = saved[2 * nz:]
         gG, gCp, gwc, gb, gln = _lstm_backward(gO, gHn, gCn, gates, Craw, Cprev, wc, ln, ctx.mesh, ctx.acc_p, ctx.use_p)
         gZs, gW = _cheb_backward(Zs, TZs, W, gG, ctx.mesh, ctx.K, ctx.Ks, ctx.acc_w, ctx.use_w,
-                                 ctx.needs_input_grad[0] or ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+                                 list(ctx.needs_input_grad[:nz]), ctx.needs_input_grad[2])
         gZa = gZs[0] if gZs is not None else None
         gZb = gZs[1] if gZs is not None and nz > 1 else None
         return gZa, gZb, gW, gCp, gwc, gb, gln, None, None, None, None, None
