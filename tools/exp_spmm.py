@@ -37,3 +37,21 @@ for C in (4, 16, 20, 32, 68):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); g.replay(); b.record(); b.synchronize()
     print(f'N graph C {C}: {a.elapsed_time(b) * 10:.2f} us per launch')
+print('--- two column parts in one launch (hipGraph, 100 launches per replay)')
+from qtmpnn.mesh import spmm2
+for Ca, Cb in ((4, 16), (16, 16)):
+    xs = [torch.randn(N, Ca, device=dev), torch.randn(N, Cb, device=dev)]
+    ps = [torch.randn(N, Ca, device=dev), torch.randn(N, Cb, device=dev)]
+    outs = [torch.empty(N, Ca, device=dev), torch.empty(N, Cb, device=dev)]
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        spmm2(mesh, xs, 2.0, ps, -1.0, None, 0.0, outs)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(100):
+            spmm2(mesh, xs, 2.0, ps, -1.0, None, 0.0, outs)
+    g.replay(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); g.replay(); b.record(); b.synchronize()
+    print(f'N graph parts {Ca}+{Cb}: {a.elapsed_time(b) * 10:.2f} us per launch')
