@@ -207,7 +207,7 @@ int qt_lstm_fwd(const float* G, const float* Cprev, int ld_c /* row stride of Cp
                 const float* b, const float* ln,
                 int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw,
                 void* stream);
-/* qt_dense (act none, Kb = 1, Cb = 4h) with qt_lstm_fwd as its epilogue, for hidden size 16: the gate pre-activations stay in
+/* qt_dense (act none, Kb = 1, Cb = 4h) with qt_lstm_fwd as its epilogue, for hidden sizes 8, 16, 32: the gate pre-activations stay in
  * LDS.  Same results as the two calls (same arithmetic in the same order).  Planes in two parts as in qt_dense2; O may be
  * NULL (the raw output gate is also gates[:, 3h:4h]). */
 int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb, int Ka, int Ca, int Cab,

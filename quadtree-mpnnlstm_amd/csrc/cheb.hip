@@ -244,7 +244,7 @@ __device__ __forceinline__ void build_quad_table(const PlaneSrc& A, const float*
 // MODE 0: out planes = act(A @ W).  Block = 128 node rows x (32 NT) output columns, wave w owns rows [32w, 32w+32).
 // A fragments go global -> VGPR directly (float4 per lane and k-quad); only W is staged in LDS (KWT x 32 NT floats).
 // NT = 2 for NB <= 64 (gate GEMM), NT = 4 for wide outputs (the data gradient, NB = K*C) so A is read only once.
-template <int NT, int KWT, bool CELL = false>
+template <int NT, int KWT, int CELL = 0>     // CELL: 0 = plain epilogue, else the lanes per node (h / 4) of the fused LSTM cell
 __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgroups per CU: all N/128 blocks of the
                                                                       // bench shape are resident at once (<= 128 registers)
     constexpr int BNT = 32 * NT;
@@ -321,34 +321,37 @@ __global__ __launch_bounds__(256, 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgr
     }
     QT_STAMP(3);
     float* Cs = Bt;                              // 128 rows x 64 columns per pass
-    if constexpr (CELL) {
-        // LSTM epilogue (h = 16: four adjacent lanes own a node, as in k_lstm_fwd).  The 128 x 64 gate tile goes through
-        // LDS in two halves of 64 rows with a row pitch of 80 floats: the 4 rows a 16-lane ds_read_b128 phase touches
-        // then start 16 banks apart.  Same arithmetic, in the same order, as qt_dense followed by qt_lstm_fwd.
-        static_assert(NT == 2, "the fused cell needs all four gates of a node in one block");
-        constexpr int CP = 80;
-        static_assert(BNT * PITCH >= 64 * CP, "LDS staging tile does not fit in the W buffer");
+    if constexpr (CELL != 0) {
+        // LSTM epilogue: h / 4 adjacent lanes own a node, as in k_lstm_fwd (h = 8, 16 with NT = 2; h = 32 with NT = 4: all
+        // four gates of a node sit in this block's 32 NT columns).  The gate tile goes through LDS 256 / (h/4) rows at a
+        // time with a row pitch of 5 h floats: the rows a 16-lane ds_read_b128 phase touches then start h banks apart.
+        // Same arithmetic, in the same order, as qt_dense followed by qt_lstm_fwd.
         using namespace qtcell;
-        const int h = g.h;                       // == 16
+        constexpr int lpn = CELL;                // 2, 4 or 8 lanes per node
+        constexpr int h = 4 * lpn;
+        constexpr int CP = 5 * h;
+        constexpr int RP = 256 / lpn;            // rows per pass: 128, 64 or 32
+        static_assert(4 * h <= 32 * NT && BNT * PITCH >= RP * CP, "gate tile does not fit");
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
+        for (int r0 = 0; r0 < BM; r0 += RP) {
             __syncthreads();
-            if ((wave >> 1) == hf) {
+            if (wave * 32 >= r0 && wave * 32 < r0 + RP) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < NT; ++u)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        Cs[((wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + u * 32 + l32] = acc[u][r];
+                        if (u * 32 < 4 * h)      // (h = 8: the second 32-column tile is padding)
+                            Cs[(wave * 32 - r0 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + u * 32 + l32] = acc[u][r];
             }
             __syncthreads();
-            const int row = t >> 2, j0 = (t & 3) * 4;
-            const int64_t node = i0 + hf * 64 + row;
+            const int row = t / lpn, j0 = (t - row * lpn) * 4;
+            const int64_t node = i0 + r0 + row;
             const bool ok = node < rows;
             const float* cs = Cs + row * CP + j0;
             const F4 gi = ld4(cs), gf = ld4(cs + h), gc = ld4(cs + 2 * h), go = ld4(cs + 3 * h);
             F4 cp = {{0, 0, 0, 0}};
             if (ok && g.Cprev) cp = ld4(g.Cprev + node * g.ld_c + j0);
-            const CellOut r = cell_forward<4>(gi, gf, gc, go, cp, g.wc, g.bias, g.ln, h, j0);
+            const CellOut r = cell_forward<lpn>(gi, gf, gc, go, cp, g.wc, g.bias, g.ln, h, j0);
             if (ok) {
                 if (g.O) st4(g.O + node * h + j0, r.Og);
                 st4(g.Hn + node * h + j0, r.hn);
@@ -955,7 +958,7 @@ extern "C" int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, con
                              const float* wc, const float* b, const float* ln, float* O, float* Hn, float* Cn,
                              float* gates, float* Craw, void* stream) {
     QT_ARG(W && wc && b && Hn && Cn && gates && Craw, "bad arguments");
-    QT_ARG(h == 16, "the fused gate GEMM + cell covers hidden size 16 (use qt_dense + qt_lstm_fwd otherwise)");
+    QT_ARG(h == 8 || h == 16 || h == 32, "the fused gate GEMM + cell covers hidden sizes 8, 16 and 32 (qt_dense + qt_lstm_fwd otherwise)");
     QT_ARG((Ks == 0) || Ws, "Ws missing");
     QT_ARG(Ks == 0 || Ws == W + (int64_t)Ka * (Ca + Cab) * 4 * h, "Ws must follow W contiguously ([W ; Ws] is one matrix)");
     QT_ARG((((uintptr_t)W | (uintptr_t)Cprev) & 15) == 0 && ld_c % 4 == 0, "operands must be 16-byte aligned");
@@ -967,7 +970,13 @@ extern "C" int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, con
     g.row0_step = 0; g.n_dev = n_dev; g.accumulate = 0;
     g.Cprev = Cprev; g.wc = wc; g.bias = b; g.ln = ln; g.ld_c = ld_c; g.h = h;
     g.O = O; g.Hn = Hn; g.Cn = Cn; g.gates = gates; g.Craw = Craw;
-    hipLaunchKernelGGL((k_gemm_fwd<2, 128, true>), dim3(qt_cdiv(N, BM), 1, 1), dim3(256), 0, (hipStream_t)stream, g);
+    const dim3 grid(qt_cdiv(N, BM), 1, 1);
+    if (h == 32)
+        hipLaunchKernelGGL((k_gemm_fwd<4, 64, 8>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    else if (h == 16)
+        hipLaunchKernelGGL((k_gemm_fwd<2, 128, 4>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL((k_gemm_fwd<2, 128, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
     QT_LAUNCHED();
     return QT_OK;
 }

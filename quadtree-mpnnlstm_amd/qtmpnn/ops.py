@@ -552,7 +552,7 @@ def _lstm_backward(gO, gHn, gCn, gates, Craw, Cprev, wc, ln, mesh, acc, use_idx)
 
 
 class _GateCell(Function):
-    """cheb_poly (no activation) + lstm_cell as one op for hidden size 16: the gate GEMM runs the cell in its epilogue
+    """cheb_poly (no activation) + lstm_cell as one op for hidden sizes 8, 16, 32: the gate GEMM runs the cell in its epilogue
     (qt_dense_lstm), so the (N, 4h) pre-activations are never written.  Z = [Za | Zb] (Zb may be None).  The raw output
     gate O is returned as a column view of the saved gate activations.  Backward = the two backward passes."""
 
@@ -601,7 +601,7 @@ def gate_cell(X, H, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w=None, acc_p=None):
     C = X.shape[1] + (H.shape[1] if H is not None else 0)
     if W.shape[0] == K * C + Ks and Ks % 4:
         W = pad_bias_rows(W, Ks)
-    if W.shape[1] == 64 and X.is_cuda:
+    if W.shape[1] in (32, 64, 128) and X.is_cuda:
         return _GateCell.apply(X, H, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w, acc_p)
     G = cheb_poly((X, H), W, mesh, K, Ks, acc=acc_w)
     return lstm_cell(G, Cprev, wc, b, ln, mesh, acc_p)

@@ -389,15 +389,15 @@ def test_bf16x3_gemm_matches_fp32_gemm():
     assert errs['0'] < 2e-6 and errs['1'] < 2e-6, errs
 
 
-@pytest.mark.parametrize('with_c', [True, False])
-def test_fused_gate_cell_equals_gemm_then_cell(with_c):
-    """qt_dense_lstm (the cell as the gate GEMM's epilogue, h = 16) on Z given as two row-strided column views [X | H]
+@pytest.mark.parametrize('with_c,h', [(True, 16), (False, 16), (True, 8), (True, 32)])
+def test_fused_gate_cell_equals_gemm_then_cell(with_c, h):
+    """qt_dense_lstm (the cell as the gate GEMM's epilogue, h = 8 / 16 / 32) on Z given as two row-strided column views [X | H]
     == qt_dense on the whole Z followed by qt_lstm_fwd, bit for bit, forward and every gradient; a node count that is
     not a multiple of the 128-row tile."""
     from qtmpnn import ops
     mesh, _ = _mesh_64(5, noise=0.03, B=2)
     torch.manual_seed(3)
-    h, C, K, Ks = 16, 20, 3, 1
+    C, K, Ks = 4 + h, 3, 1
     mk = lambda *s: torch.randn(*s, device=dev()).requires_grad_(True)
     Z, W = mk(mesh.N, C), mk(K * C + 4, 4 * h)
     Cp = mk(mesh.N, h) if with_c else None

@@ -39,7 +39,7 @@ for C in (4, 16, 20, 32, 68):
     print(f'N graph C {C}: {a.elapsed_time(b) * 10:.2f} us per launch')
 print('--- two column parts in one launch (hipGraph, 100 launches per replay)')
 from qtmpnn.mesh import spmm2
-for Ca, Cb in ((4, 16), (16, 16)):
+for Ca, Cb in ((4, 16), (16, 4), (16, 16)):
     xs = [torch.randn(N, Ca, device=dev), torch.randn(N, Cb, device=dev)]
     ps = [torch.randn(N, Ca, device=dev), torch.randn(N, Cb, device=dev)]
     outs = [torch.empty(N, Ca, device=dev), torch.empty(N, Cb, device=dev)]
