@@ -1,0 +1,50 @@
+"""Throughput of the other BASELINE.json configurations on one GPU (informational; bench.py stays on configs[1]).
+
+    python tools/bench_configs.py [cfg3|cfg4] [steps]
+cfg3: Moving-MNIST-like 128x128, 2 digits, in=10/out=20, 8 clips per GPU (the per-GPU share of the 8-GPU config).
+cfg4: ice-like 128x128 patches, 5 channels, in=12/out=6, 16 clips, land mask, transform_func, hidden 32, 1 layer, 3 conv layers.
+"""
+import json, os, sys, time
+ROOT = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'quadtree-mpnnlstm_amd'))
+import numpy as np, torch
+from model.mpnnlstm import NextFramePredictorS2S
+from qtmpnn import synthetic
+dev = torch.device('cuda', 0)
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg3'
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+torch.manual_seed(1)
+if cfg == 'cfg3':
+    B, t_in, t_out, shape = 8, 10, 20, (128, 128)
+    kw, thresh, tf, feat = dict(hidden_size=16, dropout=0.1, n_layers=2), 0.1, None, 1
+    mask = np.zeros(shape, dtype=bool)
+    def batch(i):
+        x, y = synthetic.make_batch(3, i * B, B, t_in, t_out, n_digits=2, pixel_noise=0.05, canvas=shape)
+        return x, y
+else:
+    B, t_in, t_out, shape = 16, 12, 6, (128, 128)
+    kw, thresh, feat = dict(hidden_size=32, dropout=0.1, n_layers=1, n_conv_layers=3), 0.15, 5
+    tf = lambda a: abs(abs(a - 0.5) - 0.5)
+    mask = synthetic.make_ice_like(40, shape=shape, channels=5, n_frames=2)[1]
+    def batch(i):
+        clips = [synthetic.make_ice_like(1000 * i + k, shape=shape, channels=5, n_frames=t_in + t_out)[0] for k in range(B)]
+        return np.stack([c[:t_in] for c in clips]), np.stack([c[t_in:, ..., :1] for c in clips])
+nfp = NextFramePredictorS2S(thresh=thresh, input_features=feat, input_timesteps=t_in, output_timesteps=t_out, device=dev,
+                            transform_func=tf, model_kwargs=kw)
+nfp.initiate_training(lr=0.01, lr_decay=0.95, capturable=True)
+nfp.model.train()
+pool = []
+for i in range(2):
+    x, y = batch(i)
+    pool.append((torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), torch.zeros(B, t_out, *shape, 1, device=dev)))
+step = nfp.make_graphed_step(*pool[0], mask=mask, warmup=2)
+for i in range(3):
+    l = step(*pool[i % 2])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(steps):
+    l = step(*pool[i % 2])
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(json.dumps({'config': cfg, 'frames_per_s': round(B * (t_in + t_out) * steps / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 2),
+                  'clips': B, 'shape': shape, 't_in': t_in, 't_out': t_out, 'loss': round(float(l), 5), 'launch': 'hipGraph replay'}))
