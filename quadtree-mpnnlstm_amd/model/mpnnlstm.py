@@ -149,7 +149,7 @@ class NextFramePredictorS2S:
         return losses
 
     def make_graphed_step(self, x, y, concat_layers=None, mask=None, high_interest_region=None, max_norm=10.0,
-                          warmup=2):
+                          warmup=2, graph_structure=None):
         """Capture one whole training step in hipGraphs and return `step(x, y, concat) -> loss`.
 
         The rollout is data dependent (every decoder step re-meshes on its own output), so the capture runs in
@@ -174,7 +174,7 @@ class NextFramePredictorS2S:
 
         def fwd_bwd():
             self.optimizer.zero_grad(set_to_none=True)
-            loss = self.forward_loss(sx, sy, sc, mask, high_interest_region)
+            loss = self.forward_loss(sx, sy, sc, mask, high_interest_region, graph_structure)
             loss.backward()
             return loss.detach()
 
@@ -186,7 +186,7 @@ class NextFramePredictorS2S:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                fwd_bwd()
+                self.last_warmup_loss = fwd_bwd()        # (a real training step on this batch)
                 if multi:
                     allreduce_gradients(params, self.process_group)
                 update()
@@ -225,10 +225,18 @@ class NextFramePredictorS2S:
         return step
 
     def train(self, loader_train, loader_test, climatology=None, n_epochs=200, lr=0.01, lr_decay=0.95, mask=None,
-              high_interest_region=None, truncated_backprop=45, graph_structure=None):
+              high_interest_region=None, truncated_backprop=45, graph_structure=None, use_graph=False):
+        """The reference's training loop (mpnnlstm.py:186-387).  use_graph=True (beyond the reference; needs
+        truncated_backprop in (0, None)) replays the whole training step as a hipGraph: one graph is captured per
+        distinct batch shape on first sight (that batch's own update runs eagerly just before the capture) and the learning-rate
+        schedule keeps working because the capturable optimizer holds lr in a device tensor that StepLR updates in place."""
         image_shape = loader_train.dataset.image_shape
+        truncate_ = truncated_backprop not in (0, None)
+        if use_graph and truncate_:
+            raise ValueError('use_graph=True needs truncated_backprop=0 (the truncated loop re-runs the encoder per chunk)')
         if not self.training_initiated:
-            self.initiate_training(lr, lr_decay)
+            self.initiate_training(lr, lr_decay, capturable=use_graph)
+        graphed = {}
         if mask is not None:
             assert mask.shape == image_shape, f'Mask and image shapes do not match. Got {mask.shape} and {image_shape}'
         truncate = truncated_backprop not in (0, None)
@@ -244,6 +252,14 @@ class NextFramePredictorS2S:
                     loss = self.truncated_backward(x, y, concat, mask, high_interest_region, graph_structure,
                                                    truncated_backprop)[-1]
                     self.optimizer.step()                 # no gradient clipping in this branch (:311 is commented out)
+                elif use_graph:
+                    key = (tuple(x.shape), tuple(y.shape), None if concat is None else tuple(concat.shape))
+                    if key not in graphed:      # first sight of this batch shape: its update runs eagerly, then the capture
+                        graphed[key] = self.make_graphed_step(x, y, concat, mask=mask, high_interest_region=high_interest_region,
+                                                              warmup=1, graph_structure=graph_structure)
+                        loss = self.last_warmup_loss
+                    else:
+                        loss = graphed[key](x, y, concat)
                 else:
                     loss = self.train_step(x, y, concat, mask, high_interest_region, graph_structure)
                 self.writer.add_scalar('Loss/train', loss.item(), batch_step)

@@ -404,3 +404,33 @@ def test_transformer_rollout_golden():
     assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
     loss.backward()
     _check_grads(model, g)
+
+
+def test_train_loop_with_graph_replay_matches_eager_loop():
+    """NextFramePredictorS2S.train(use_graph=True): the reference's epoch loop with the step replayed as a hipGraph gives the
+    eager loop's losses (one update per batch, learning-rate schedule included) on a tiny in-memory loader."""
+    from model.mpnnlstm import NextFramePredictorS2S
+    from qtmpnn import synthetic
+
+    class DS:
+        image_shape = (64, 64)
+
+    class Loader(list):
+        dataset = DS()
+
+    x, y = synthetic.make_batch(5, 0, 4, 3, 2, n_digits=1, pixel_noise=0.0)
+    items = [(torch.from_numpy(x[i:i + 2]), torch.from_numpy(y[i:i + 2]), torch.zeros(1)) for i in (0, 2)]
+    mask = np.zeros((64, 64), dtype=bool)
+
+    def run(use_graph):
+        torch.manual_seed(4)
+        nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=3, output_timesteps=2, device=dev(),
+                                    model_kwargs=dict(hidden_size=8, dropout=0.0, n_layers=1))
+        nfp.train(Loader(items), Loader(items[:1]), n_epochs=4, lr=0.01, lr_decay=0.5, mask=mask, truncated_backprop=0,
+                  use_graph=use_graph)
+        return nfp.train_loss, nfp.test_loss
+
+    (tr_g, te_g), (tr_e, te_e) = run(True), run(False)
+    # (capacity-sized launches sum some reductions in another order than exact-size ones: 1e-4-level drift after 8 updates)
+    for a, b in zip(tr_g + te_g, tr_e + te_e):
+        assert abs(a - b) <= 1e-3 * abs(b) + 1e-7, (tr_g, tr_e, te_g, te_e)
