@@ -39,6 +39,8 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-clips', type=int, default=10)
     ap.add_argument('--eager', action='store_true', help='Python-driven launches instead of hipGraph replay')
+    ap.add_argument('--host-inputs', action='store_true',
+                    help='keep the batches in pinned host memory and copy them in every step (PCIe-inclusive rate; informational)')
     return ap.parse_args()
 
 
@@ -186,6 +188,7 @@ def main():
                                     pixel_noise=args.noise, canvas=CANVAS)
         pool.append((torch.from_numpy(x).to(device), torch.from_numpy(y).to(device),
                      torch.zeros(args.batch, T_OUT, *CANVAS, 1, device=device)))
+    host_pool = [tuple(t.cpu().pin_memory() for t in b) for b in pool] if args.host_inputs else None
 
     log(f'rank {rank}: {n_pool} batches of {args.batch} clips resident on {device}')
 
@@ -207,7 +210,10 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = step(*pool[i % n_pool])
+        if host_pool is not None:
+            loss = step(*(t.to(device, non_blocking=True) for t in host_pool[i % n_pool]))
+        else:
+            loss = step(*pool[i % n_pool])
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -227,7 +233,7 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: Moving-MNIST-like 64x64, 2 digits, in=10/out=10, '
                                    f'{args.batch} clips per GPU, pixel noise {args.noise}, thresh {THRESH}, hidden {HIDDEN}, '
                                    f'{N_LAYERS} layers, ChebConv K=3, dropout {DROPOUT}, Adam',
-                       'global_batch': global_batch, 'frames_per_clip': T_IN + T_OUT, 'parallelism': f'dp{world}', 'launch': 'eager' if args.eager else 'hipGraph replay',
+                       'global_batch': global_batch, 'frames_per_clip': T_IN + T_OUT, 'parallelism': f'dp{world}', 'launch': 'eager' if args.eager else 'hipGraph replay', 'inputs': 'pinned host memory, copied every step' if args.host_inputs else 'resident in HBM',
                        'final_loss': round(float(loss), 6)},
         }
         log(f'timed {args.steps} steps in {dt:.3f} s')
