@@ -620,7 +620,12 @@ __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __res
     constexpr int RG = 4 / FW;             // row groups
     constexpr int KS = WR / 2 / RG;        // k-steps (2 rows each) per row group and pass
     constexpr int BMF = FW * 32;           // features per block
-    __shared__ __attribute__((aligned(16))) float As[2][WR][BM];
+    // A tiles hold only the BMF features this block owns (narrow weights then fit 4 workgroups per CU); the same floats
+    // later park the row groups' partial tiles
+    constexpr int RED_FLOATS = (RG - 1) * FW * CT * 16 * 64;
+    constexpr int AS_FLOATS = 2 * WR * BMF > RED_FLOATS ? 2 * WR * BMF : RED_FLOATS;
+    __shared__ __attribute__((aligned(16))) float As_pool[AS_FLOATS];
+    auto As = [&](int buf, int row, int col) -> float& { return As_pool[(buf * WR + row) * BMF + col]; };
     __shared__ __attribute__((aligned(16))) float Gs[2][WR][BN];
     __shared__ const float* qptr[MAXQ];
     __shared__ int qstr[MAXQ];
@@ -659,7 +664,8 @@ __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __res
     };
     auto stash = [&](int buf, const float4 (&qa)[4], const float4 (&qg)[2]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(&As[buf][a_row][(u * 8 + a_q) * 4]) = qa[u];
+        for (int u = 0; u < 4; ++u)
+            if ((u * 8 + a_q) * 4 < BMF) *reinterpret_cast<float4*>(&As(buf, a_row, (u * 8 + a_q) * 4)) = qa[u];
 #pragma unroll
         for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Gs[buf][g_row][(u * 8 + g_q) * 4]) = qg[u];
     };
@@ -672,7 +678,7 @@ __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __res
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const int ks = rg * KS + k;
-            const float a = As[buf][2 * ks + half][fw * 32 + l32];
+            const float a = As(buf, 2 * ks + half, fw * 32 + l32);
 #pragma unroll
             for (int c = 0; c < CT; ++c)
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Gs[buf][2 * ks + half][c * 32 + l32], acc[c], 0, 0, 0);
@@ -698,8 +704,7 @@ __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __res
     }
     if constexpr (RG > 1) {
         // add the row groups' partial tiles: groups 1.. park theirs in LDS (the A buffers are free), group 0 adds in order
-        float* red = &As[0][0][0];
-        static_assert((RG - 1) * FW * CT * 16 * 64 <= 2 * WR * BM, "partial tiles do not fit in the A buffers");
+        float* red = As_pool;
         if (rg > 0) {
 #pragma unroll
             for (int c = 0; c < CT; ++c)
