@@ -25,7 +25,10 @@ struct SpmmPart {
     int C, ldx, ldp, ldq, xcd_chunk;      // row strides of x / p / q in floats (out rows are dense)
 };
 template <int VEC, int RPT, int EPT>
-__global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+#ifndef QT_SPMM_BS
+#define QT_SPMM_BS 64      // one wave per workgroup: 11.08 ms per training step against 11.12 (128) and 11.18 (256)
+#endif
+__global__ __launch_bounds__(QT_SPMM_BS) void k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                               const float* __restrict__ nrm, int Ncap, const int32_t* __restrict__ n_dev,
                                               SpmmPart pa, SpmmPart pb, int nblk_a,     // workgroups [nblk_a, ..) do part b
                                               float alpha, float beta, float gamma) {
@@ -45,12 +48,12 @@ __global__ __launch_bounds__(256) void k_spmm(const int32_t* __restrict__ rowptr
     const int rows = qt_rows(n_dev, Ncap);
     int blk = bid;
     if (xcd_chunk) {
-        const int nblk = (int)(((int64_t)((rows + RPT - 1) / RPT) * nch + 255) >> 8);
+        const int nblk = (int)(((int64_t)((rows + RPT - 1) / RPT) * nch + QT_SPMM_BS - 1) / QT_SPMM_BS);
         const int chunk = (nblk + 7) >> 3;
         if ((bid >> 3) >= chunk) return;
         blk = (bid & 7) * chunk + (bid >> 3);
     }
-    const unsigned idx = (unsigned)blk * 256u + threadIdx.x;      // N * nch < 2^31 (checked by the host entry): 32-bit
+    const unsigned idx = (unsigned)blk * (unsigned)QT_SPMM_BS + threadIdx.x;      // N * nch < 2^31 (checked by the host entry): 32-bit
     const int64_t rp = idx / (unsigned)nch;                        // division, a fraction of the 64-bit one's cost
     if (rp * RPT >= rows) return;
     const int ch = (int)(idx - (unsigned)rp * (unsigned)nch) * VEC;
@@ -848,7 +851,7 @@ static int spmm_part(SpmmPart* P, int* nblk, int N, int C, const float* x, int l
                      int ldq, float* out) {
     P->x = x; P->p = p; P->q = q; P->out = out; P->C = C;
     P->ldx = ldx > 0 ? ldx : C; P->ldp = ldp > 0 ? ldp : C; P->ldq = ldq > 0 ? ldq : C;
-    int grid = qt_cdiv((int64_t)N * (C / 4), 256);
+    int grid = qt_cdiv((int64_t)N * (C / 4), QT_SPMM_BS);
     static const bool xcd = getenv("QT_SPMM_FLAT") == nullptr;
     P->xcd_chunk = 0;
     if (xcd && grid >= 64) {
@@ -878,9 +881,9 @@ extern "C" int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* 
     if (Cb) spmm_part(&B, &nb, N, Cb, xb, ldxb, pb, ldpb, qb, ldqb, outb);
     // 8 edges per trip for narrow rows (see qt_spmm); the wider part decides
     if (max(Ca, Cb) <= 20)
-        hipLaunchKernelGGL((k_spmm<4, 1, 8>), dim3(na + nb), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, na, alpha, beta, gamma);
+        hipLaunchKernelGGL((k_spmm<4, 1, 8>), dim3(na + nb), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, na, alpha, beta, gamma);
     else
-        hipLaunchKernelGGL((k_spmm<4, 1, 4>), dim3(na + nb), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, na, alpha, beta, gamma);
+        hipLaunchKernelGGL((k_spmm<4, 1, 4>), dim3(na + nb), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, na, alpha, beta, gamma);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -896,11 +899,11 @@ extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* n
     // scalar rows (C not a multiple of 4): one float per thread
     SpmmPart A, B = {};
     A.x = x; A.p = p; A.q = q; A.out = out; A.C = C; A.ldx = A.ldp = A.ldq = C; A.xcd_chunk = 0;
-    const int grid = qt_cdiv((int64_t)N * C, 256);
+    const int grid = qt_cdiv((int64_t)N * C, QT_SPMM_BS);
     // Edges per trip: a trip is two dependent loads (col/nrm, then the x rows), and the few rows with many neighbours
     // (a 4x4 cell next to 1x1 cells has 16) set the length of the whole launch.  8 per trip: 6.6 -> 4.5 us at C = 4,
     // 9.3 -> 7.5 us at C = 16 (N = 1.2e5, inside a hipGraph); wider rows are bandwidth bound and prefer fewer registers.
-    hipLaunchKernelGGL((k_spmm<1, 1, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, grid, alpha, beta, gamma);
+    hipLaunchKernelGGL((k_spmm<1, 1, 8>), dim3(grid), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, grid, alpha, beta, gamma);
     QT_LAUNCHED();
     return QT_OK;
 }
