@@ -208,10 +208,13 @@ __global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
 // kernel above touches 16 bytes of every row per workgroup and has only B * tiles workgroups of pixel-serial work:
 // 39 us for 68 channels at 64x64x32, against a ~16 us stream.)  Masked pixels inside a cell carry another label.
 template <int VEC>
-__global__ __launch_bounds__(256) void k_pool_nodes(PoolArgs a) {
+#ifndef QT_NODES_BS
+#define QT_NODES_BS 256
+#endif
+__global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
     const int nch = a.C / VEC;
     const int per = (a.src_labels ? 1 : a.S) * nch;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t idx = (int64_t)blockIdx.x * QT_NODES_BS + threadIdx.x;
     const int64_t i = idx / per;
     if (i >= qt_rows(a.n_dev, a.N)) return;
     const int rem = (int)(idx - i * per);
@@ -314,11 +317,11 @@ static int pool_launch(PoolArgs& a, bool v4, const int32_t* cell, const int32_t*
     const int total = a.S * (v4 ? a.C / 4 : a.C);
     a.cell = cell; a.n_dev = n_dev; a.big_only = cell != nullptr;
     if (cell) {
-        const int grid = qt_cdiv((int64_t)a.N * total, 256);
+        const int grid = qt_cdiv((int64_t)a.N * total, QT_NODES_BS);
         if (v4)
-            hipLaunchKernelGGL(k_pool_nodes<4>, dim3(grid), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(k_pool_nodes<4>, dim3(grid), dim3(QT_NODES_BS), 0, stream, a);
         else
-            hipLaunchKernelGGL(k_pool_nodes<1>, dim3(grid), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(k_pool_nodes<1>, dim3(grid), dim3(QT_NODES_BS), 0, stream, a);
         QT_LAUNCHED();
     }
     const int blocks = a.B * a.tiles_r * a.tiles_c;
