@@ -248,7 +248,10 @@ __device__ __forceinline__ void build_quad_table(const PlaneSrc& A, const float*
 // A fragments go global -> VGPR directly (float4 per lane and k-quad); only W is staged in LDS (KWT x 32 NT floats).
 // NT = 2 for NB <= 64 (gate GEMM), NT = 4 for wide outputs (the data gradient, NB = K*C) so A is read only once.
 template <int NT, int KWT, int CELL = 0>     // CELL: 0 = plain epilogue, else the lanes per node (h / 4) of the fused LSTM cell
-__global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : 4) void k_gemm_fwd(GemmArgs g) {   // 4 workgroups per CU: all N/128 blocks of the
+#ifndef QT_GEMM_OCC
+#define QT_GEMM_OCC 4
+#endif
+__global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : QT_GEMM_OCC) void k_gemm_fwd(GemmArgs g) {   // 4 workgroups per CU: all N/128 blocks of the
                                                                       // bench shape are resident at once (<= 128 registers)
     constexpr int BNT = 32 * NT;
     constexpr int PITCH = KWT + 4;      // == 4 (mod 64) floats: the 16 lanes of a ds_read_b128 group hit distinct banks
@@ -821,7 +824,10 @@ inline int wgrad_fw(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
         else hipLaunchKernelGGL((K<4, 2>), grid_, dim3(256), 0, (hipStream_t)(stream_), arg_);                      \
     } while (0)
 constexpr int WGRAD_ROWS = 512;
-constexpr int WGRAD_GROUP_ROWS = 1024;
+#ifndef QT_WG_ROWS
+#define QT_WG_ROWS 512      // 11.02 ms per training step against 11.07 (1024) and 11.20 (256)
+#endif
+constexpr int WGRAD_GROUP_ROWS = QT_WG_ROWS;
 
 }  // namespace
 
