@@ -886,7 +886,10 @@ extern "C" int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* 
     spmm_part(&A, &na, N, Ca, xa, ldxa, pa, ldpa, qa, ldqa, outa);
     if (Cb) spmm_part(&B, &nb, N, Cb, xb, ldxb, pb, ldpb, qb, ldqb, outb);
     // 8 edges per trip for narrow rows (see qt_spmm); the wider part decides
-    if (max(Ca, Cb) <= 20)
+#ifndef QT_EPT8_MAXC
+#define QT_EPT8_MAXC 20
+#endif
+    if (max(Ca, Cb) <= QT_EPT8_MAXC)
         hipLaunchKernelGGL((k_spmm<4, 1, 8>), dim3(na + nb), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, na, alpha, beta, gamma);
     else
         hipLaunchKernelGGL((k_spmm<4, 1, 4>), dim3(na + nb), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, na, alpha, beta, gamma);

@@ -296,7 +296,10 @@ extern "C" int qt_lstm_fwd(const float* G, const float* Cprev, int ld_c, const f
 extern "C" int qt_lstm_bwd_blocks(int N, int h) {
     if (N <= 0 || !h_ok(h)) return 0;
     const int need = qt_cdiv((int64_t)N * lanes_per_node(h), 256);
-    return need < 512 ? need : 512;
+#ifndef QT_LSTM_BLOCKS
+#define QT_LSTM_BLOCKS 512
+#endif
+    return need < QT_LSTM_BLOCKS ? need : QT_LSTM_BLOCKS;
 }
 
 extern "C" int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,
