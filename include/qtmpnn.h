@@ -172,9 +172,11 @@ int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, const float* 
  *   input plane k = [a (N, Ca) | b (N, Cab)] (a0 / a0b for k = 0, a_rest / a_restb (Ka-1, N, .) for the rest; Cab == 0: none);
  *   output plane j = [out (N, Cb) | outb (N, Cbb)] (Cbb == 0: none).  W rows follow the logical order (k, [a | b]),
  *   W columns the logical order (j, [out | outb]).  lda0 / lda0b: row strides of plane 0 in floats (0 = dense), so that
- *   plane 0 may be a column view of a wider matrix.  qt_dense is the Cab = Cbb = 0, dense case. */
+ *   plane 0 may be a column view of a wider matrix.  With WT the weight chunk is staged in LDS by straight 16-byte copies
+ *   (the data gradient passes the forward weight itself here: (W^T)^T).  qt_dense is the Cab = Cbb = 0, dense case. */
 int qt_dense2(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb, int Ka, int Ca, int Cab,
-              const float* W, const float* S, int Ks, const float* Ws, int Kb, int Cb, int Cbb, int N,
+              const float* W, const float* WT /* optional: [W ; Ws]^T, (Kb*(Cb+Cbb), K) row-major; W may then be NULL */,
+              const float* S, int Ks, const float* Ws, int Kb, int Cb, int Cbb, int N,
               const int32_t* n_dev, int act, const float* res, int res_stride, const float* drop, float* out, float* outb,
               void* stream);
 
@@ -211,7 +213,7 @@ int qt_lstm_fwd(const float* G, const float* Cprev, int ld_c /* row stride of Cp
  * LDS.  Same results as the two calls (same arithmetic in the same order).  Planes in two parts as in qt_dense2; O may be
  * NULL (the raw output gate is also gates[:, 3h:4h]). */
 int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb, int Ka, int Ca, int Cab,
-                  const float* W, const float* S, int Ks,
+                  const float* W, const float* WT /* optional transpose, as in qt_dense2 */, const float* S, int Ks,
                   const float* Ws, int h, int N, const int32_t* n_dev, const float* Cprev, int ld_c,
                   const float* wc, const float* b, const float* ln, float* O, float* Hn, float* Cn,
                   float* gates, float* Craw, void* stream);

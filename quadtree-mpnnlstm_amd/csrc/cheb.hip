@@ -174,6 +174,7 @@ struct PlaneSrc {
 struct GemmArgs {
     PlaneSrc A;        // forward: left operand rows = nodes; wgrad: transposed use
     const float* B;    // forward: W (K, NB); wgrad: G (N, NB)
+    const float* BT;   // forward, optional: W^T (NB, K) -- staged with straight float4 copies instead of a transposing scatter
     int M, K, NB;      // output M x NB, reduction K
     // forward epilogue
     int Kb, Cb, act;
@@ -281,14 +282,25 @@ __global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : QT_GEMM_OCC) void
         __syncthreads();                              // table ready / previous pass done with Bs
         QT_STAMP(1);
         // W chunk -> LDS first (small, L2 resident) ...
-        for (int e = t; e < kn * (BNT / 4); e += 256) {
-            const int kb = e / (BNT / 4), jq = (e % (BNT / 4)) * 4;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j0 + jq < g.NB) w = *reinterpret_cast<const float4*>(g.B + (int64_t)(k0 + kb) * g.NB + j0 + jq);
-            Bt[(jq + 0) * PITCH + kb] = w.x;
-            Bt[(jq + 1) * PITCH + kb] = w.y;
-            Bt[(jq + 2) * PITCH + kb] = w.z;
-            Bt[(jq + 3) * PITCH + kb] = w.w;
+        if (g.BT) {
+            // ... from W^T: a column's k run is contiguous in memory and in LDS (conflict-free 16-byte stores)
+            const int kqn = kn >> 2;
+            for (int e = t; e < BNT * kqn; e += 256) {
+                const int c = e / kqn, kq = e - c * kqn;
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j0 + c < g.NB) w = *reinterpret_cast<const float4*>(g.BT + (int64_t)(j0 + c) * g.K + k0 + 4 * kq);
+                *reinterpret_cast<float4*>(&Bt[c * PITCH + 4 * kq]) = w;
+            }
+        } else {
+            for (int e = t; e < kn * (BNT / 4); e += 256) {
+                const int kb = e / (BNT / 4), jq = (e % (BNT / 4)) * 4;
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j0 + jq < g.NB) w = *reinterpret_cast<const float4*>(g.B + (int64_t)(k0 + kb) * g.NB + j0 + jq);
+                Bt[(jq + 0) * PITCH + kb] = w.x;
+                Bt[(jq + 1) * PITCH + kb] = w.y;
+                Bt[(jq + 2) * PITCH + kb] = w.z;
+                Bt[(jq + 3) * PITCH + kb] = w.w;
+            }
         }
         for (int e = t; e < BNT * ((KWT - kn) / 4); e += 256) {          // zero the k tail of a short last pass
             const int c = e / ((KWT - kn) / 4), kq = kn + (e % ((KWT - kn) / 4)) * 4;
@@ -919,20 +931,20 @@ extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* n
 
 extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb, int Ka,
                          int Ca, int Cab,
-                         const float* W, const float* S, int Ks, const float* Ws, int Kb, int Cb, int Cbb, int N,
+                         const float* W, const float* WT, const float* S, int Ks, const float* Ws, int Kb, int Cb, int Cbb, int N,
                          const int32_t* n_dev, int act, const float* res, int res_stride, const float* drop, float* out,
                          float* outb, void* stream) {
-    QT_ARG(W && out && Kb >= 1 && Cb >= 1 && Cbb >= 0 && (Cbb == 0 || outb), "bad arguments");
-    QT_ARG((Ks == 0) || Ws, "Ws missing");
-    QT_ARG(Ks == 0 || Ws == W + (int64_t)Ka * (Ca + Cab) * Kb * (Cb + Cbb), "Ws must follow W contiguously ([W ; Ws] is one matrix)");
+    QT_ARG((W || WT) && out && Kb >= 1 && Cb >= 1 && Cbb >= 0 && (Cbb == 0 || outb), "bad arguments");
+    QT_ARG((Ks == 0) || Ws || WT, "Ws missing");
+    QT_ARG(Ks == 0 || WT || Ws == W + (int64_t)Ka * (Ca + Cab) * Kb * (Cb + Cbb), "Ws must follow W contiguously ([W ; Ws] is one matrix)");
     QT_ARG(act == QT_ACT_NONE || (Kb == 1 && Cbb == 0), "activation needs one undivided output plane");
     QT_ARG(Cb % 4 == 0 && Cbb % 4 == 0, "Cb and Cbb must be multiples of 4 (float4 stores)");
-    QT_ARG(((uintptr_t)W & 15) == 0, "W must be 16-byte aligned");
+    QT_ARG((((uintptr_t)W | (uintptr_t)WT) & 15) == 0, "W / WT must be 16-byte aligned");
     QT_ARG(act != QT_ACT_TANH_RES || res, "QT_ACT_TANH_RES needs res");
     GemmArgs g = {};
     if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N)) return rc;
     if (N <= 0) return QT_OK;
-    g.B = W; g.M = N; g.K = Ka * (Ca + Cab) + Ks; g.NB = Kb * (Cb + Cbb);
+    g.B = W; g.BT = WT; g.M = N; g.K = Ka * (Ca + Cab) + Ks; g.NB = Kb * (Cb + Cbb);
     g.outb = outb; g.Cbb = Cbb;
 #ifdef QT_GEMM_TIMING
     g.dbg = g_dbg;
@@ -942,7 +954,7 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
     // kernels (fp32-level error, ~8 % faster on these memory/latency-shaped GEMMs: measured 27.7 vs 30.1 us).
     static const bool exact_fp32 = getenv("QT_GEMM_BF16X3") == nullptr;
     static const bool no_skinny = getenv("QT_GEMM_NO_SKINNY") != nullptr;
-    if (!no_skinny && g.NB <= 16) {       // (wide outputs of short reductions measured slower here: 24.5 vs 14.5 us)
+    if (!no_skinny && g.NB <= 16 && W) {       // (wide outputs of short reductions measured slower here: 24.5 vs 14.5 us)
         if (g.NB <= 4)
             hipLaunchKernelGGL((k_gemm_skinny<256>), dim3(qt_cdiv(N, 256), 1, 1), dim3(256), 0, (hipStream_t)stream, g);
         else
@@ -965,24 +977,24 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
 extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, const float* W, const float* S, int Ks,
                         const float* Ws, int Kb, int Cb, int N, const int32_t* n_dev, int act, const float* res,
                         int res_stride, const float* drop, float* out, void* stream) {
-    return qt_dense2(a0, 0, a_rest, nullptr, 0, nullptr, Ka, Ca, 0, W, S, Ks, Ws, Kb, Cb, 0, N, n_dev, act, res, res_stride, drop, out,
+    return qt_dense2(a0, 0, a_rest, nullptr, 0, nullptr, Ka, Ca, 0, W, nullptr, S, Ks, Ws, Kb, Cb, 0, N, n_dev, act, res, res_stride, drop, out,
                      nullptr, stream);
 }
 
 extern "C" int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb,
-                             int Ka, int Ca, int Cab, const float* W, const float* S, int Ks,
+                             int Ka, int Ca, int Cab, const float* W, const float* WT, const float* S, int Ks,
                              const float* Ws, int h, int N, const int32_t* n_dev, const float* Cprev, int ld_c,
                              const float* wc, const float* b, const float* ln, float* O, float* Hn, float* Cn,
                              float* gates, float* Craw, void* stream) {
-    QT_ARG(W && wc && b && Hn && Cn && gates && Craw, "bad arguments");
+    QT_ARG((W || WT) && wc && b && Hn && Cn && gates && Craw, "bad arguments");
     QT_ARG(h == 8 || h == 16 || h == 32, "the fused gate GEMM + cell covers hidden sizes 8, 16 and 32 (qt_dense + qt_lstm_fwd otherwise)");
-    QT_ARG((Ks == 0) || Ws, "Ws missing");
-    QT_ARG(Ks == 0 || Ws == W + (int64_t)Ka * (Ca + Cab) * 4 * h, "Ws must follow W contiguously ([W ; Ws] is one matrix)");
-    QT_ARG((((uintptr_t)W | (uintptr_t)Cprev) & 15) == 0 && ld_c % 4 == 0, "operands must be 16-byte aligned");
+    QT_ARG((Ks == 0) || Ws || WT, "Ws missing");
+    QT_ARG(Ks == 0 || WT || Ws == W + (int64_t)Ka * (Ca + Cab) * 4 * h, "Ws must follow W contiguously ([W ; Ws] is one matrix)");
+    QT_ARG((((uintptr_t)W | (uintptr_t)WT | (uintptr_t)Cprev) & 15) == 0 && ld_c % 4 == 0, "operands must be 16-byte aligned");
     GemmArgs g = {};
     if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N)) return rc;
     if (N <= 0) return QT_OK;
-    g.B = W; g.M = N; g.K = Ka * (Ca + Cab) + Ks; g.NB = 4 * h;
+    g.B = W; g.BT = WT; g.M = N; g.K = Ka * (Ca + Cab) + Ks; g.NB = 4 * h;
     g.Kb = 1; g.Cb = 4 * h; g.act = QT_ACT_NONE; g.res = nullptr; g.res_stride = 0; g.drop = nullptr; g.out = nullptr;
     g.row0_step = 0; g.n_dev = n_dev; g.accumulate = 0;
     g.Cprev = Cprev; g.wc = wc; g.bias = b; g.ln = ln; g.ld_c = ld_c; g.h = h;

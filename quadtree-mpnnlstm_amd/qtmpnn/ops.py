@@ -64,7 +64,7 @@ class GradAcc:
     __slots__ = ('uses', 'done', 'part', 'wt', 'pending')
 
     def __init__(self):
-        self.uses, self.done, self.part, self.wt, self.pending = 0, 0, None, None, []
+        self.uses, self.done, self.part, self.wt, self.pending = 0, 0, None, {}, []
 
     def enter(self):
         self.uses += 1
@@ -240,6 +240,17 @@ def _cheb_planes(Zs, mesh, K):
     return TZs
 
 
+def _w_t(W, acc):
+    """W^T for the forward GEMM's straight-copy staging; one transpose per pass when the weight is shared (acc), none
+    for a single use (the kernel then transposes while staging)."""
+    if acc is None or W.shape[1] <= 16:
+        return None
+    Wt = acc.wt.get('T')
+    if Wt is None:
+        Wt = acc.wt['T'] = W.t().contiguous()
+    return Wt
+
+
 def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW):
     """(gZ parts, gW) of Y = [T_0 .. T_{K-1} | S] W from G = dL/dY (N, Co)."""
     N = Zs[0].shape[0]
@@ -253,21 +264,24 @@ def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW):
         # only the column parts whose input wants a gradient are propagated (the encoder's X is data: the K-1 Clenshaw
         # launches of its cells then carry H's 16 channels alone, and the data-gradient GEMM is narrower)
         live = [i for i, f in enumerate(need) if f]
-        key = 'wt' if len(live) == len(Zs) else f'wt{live[0]}'
-        Wt = None if acc is None else acc.wt.get(key) if isinstance(acc.wt, dict) else None
-        if Wt is None:
-            Wk = W[:K * C].view(K, C, Co)
+        # the data gradient multiplies by W^T, and the GEMM stages (W^T)^T = W's own rows: no transposed copy at all
+        # (except for <= 16 output columns, which the skinny VALU kernel reads as a plain (Co, K Cl) matrix)
+        Cl = [Cs[i] for i in live]
+        skinny = K * sum(Cl) <= 16
+        key = f'wb{live[0]}{len(live)}{int(skinny)}'
+        Wb = acc.wt.get(key) if acc is not None else None
+        if Wb is None:
+            Wb = W[:K * C]
             if len(live) < len(Zs):
                 lo = sum(Cs[:live[0]])
-                Wk = Wk[:, lo:lo + Cs[live[0]]]
-            Wt = Wk.reshape(-1, Co).t().contiguous()        # shared by every use of W in this pass
+                Wb = Wb.view(K, C, Co)[:, lo:lo + Cs[live[0]]].reshape(-1, Co)     # shared by every use in this pass
+            if skinny:
+                Wb = Wb.t().contiguous()
             if acc is not None:
-                if not isinstance(acc.wt, dict):
-                    acc.wt = {}
-                acc.wt[key] = Wt
-        Cl = [Cs[i] for i in live]
+                acc.wt[key] = Wb
         gTs = [Zs[0].new_empty(K, N, c) for c in Cl]
-        _lib.call('qt_dense2', ptr(G), 0, None, None, 0, None, 1, Co, 0, ptr(Wt), None, 0, None, K, Cl[0],
+        _lib.call('qt_dense2', ptr(G), 0, None, None, 0, None, 1, Co, 0, ptr(Wb) if skinny else None,
+                  None if skinny else ptr(Wb), None, 0, None, K, Cl[0],
                   Cl[1] if len(Cl) > 1 else 0, N, ptr(mesh.n_dev), ACT_NONE, None, 0, None, ptr(gTs[0]),
                   ptr(gTs[1]) if len(Cl) > 1 else None)
         # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
@@ -326,7 +340,7 @@ class _ChebPoly(Function):
         S = mesh.cheb_ones(Ks) if Ks else None
         Y = Zs[0].new_empty(N, Co)
         drop = _c(drop)
-        _lib.call('qt_dense2', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(W), ptr(S), ksp,
+        _lib.call('qt_dense2', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(W), ptr(_w_t(W, acc)), ptr(S), ksp,
                   ptr(W[K * sum(Cs):]) if Ks else None, 1, Co, 0, N, ptr(mesh.n_dev), act, ptr(res), _row_stride(res), ptr(drop),
                   ptr(Y), None)
         ctx.mesh, ctx.K, ctx.Ks, ctx.act, ctx.acc, ctx.nz = mesh, K, Ks, act, acc, len(Zs)
@@ -571,7 +585,7 @@ class _GateCell(Function):
         Cprev, ld_c = _rows(Cprev)
         Hn, Cn, Craw = (Zs[0].new_empty(N, h) for _ in range(3))
         gates = Zs[0].new_empty(N, 4 * h)
-        _lib.call('qt_dense_lstm', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(W), ptr(S), ksp,
+        _lib.call('qt_dense_lstm', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(W), ptr(_w_t(W, acc_w)), ptr(S), ksp,
                   ptr(W[K * sum(Cs):]) if Ks else None, h, N, ptr(mesh.n_dev), ptr(Cprev), ld_c, ptr(wc), ptr(b), ptr(ln),
                   None, ptr(Hn), ptr(Cn), ptr(gates), ptr(Craw))
         ctx.save_for_backward(*Zs, *TZs, W, gates, Craw, Cprev, wc, ln)
