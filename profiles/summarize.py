@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Turn a rocprofv3 `--kernel-trace --stats --output-format csv` directory into a short markdown summary.
+"""Turn a rocprofv3 `--kernel-trace --stats` output directory (csv, or the default rocpd sqlite database) into a short
+markdown summary; kernels are grouped by full name (template instances stay separate).
 
     python profiles/summarize.py gpurun_out/prof_r1f 'command line' > profiles/r01_kernel_stats.md
 """
@@ -19,9 +20,19 @@ def short(name):
     return 'torch: ' + ' '.join(dict.fromkeys(m)) if m else name[:60]
 
 
+def db_rows(path):
+    import sqlite3
+    q = ('select name, count(*), sum(end - start), min(end - start), max(end - start) from kernels group by name '
+         'order by 3 desc')
+    rows = sqlite3.connect(path).execute(q).fetchall()
+    tot = sum(r[2] for r in rows)
+    return [{'Name': n, 'Calls': c, 'TotalDurationNs': s, 'AverageNs': s / c, 'MinNs': mn, 'MaxNs': mx,
+             'Percentage': 100.0 * s / tot} for n, c, s, mn, mx in rows]
+
+
 def main(d, cmd):
-    f = glob.glob(f'{d}/**/*_kernel_stats.csv', recursive=True)[0]
-    rows = list(csv.DictReader(open(f)))
+    f = glob.glob(f'{d}/**/*_kernel_stats.csv', recursive=True)
+    rows = list(csv.DictReader(open(f[0]))) if f else db_rows(glob.glob(f'{d}/**/*_results.db', recursive=True)[0])
     tot = sum(float(r['TotalDurationNs']) for r in rows)
     calls = sum(int(r['Calls']) for r in rows)
     print(f'# rocprofv3 kernel summary\n\n`{cmd}`\n\n{calls} kernel launches, {tot / 1e6:.1f} ms of kernel time.\n')
