@@ -203,11 +203,12 @@ int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream
  *   Cprev (N, h) or NULL (zeros); wc (3, h) peepholes i, f, o; b (4, h);
  *   ln (4, h): gamma_h, beta_h, gamma_c, beta_c, or NULL for the bare cell (Hn = H', Cn = C').
  * Outputs: O (N, h) raw output gate, Hn / Cn (N, h) LayerNorm'ed states,
- *   gates (N, 4h) activated I, F, T, O and Craw (N, h) saved for the backward.
+ *   gates (N, 4h) activated I, F, T, O saved for the backward (which recomputes C' before its LayerNorm as
+ *   fma(F, Cprev, I T), the forward's own rounding, instead of reading a saved copy).
  */
 int qt_lstm_fwd(const float* G, const float* Cprev, int ld_c /* row stride of Cprev, floats */, const float* wc,
                 const float* b, const float* ln,
-                int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw,
+                int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates,
                 void* stream);
 /* qt_dense (act none, Kb = 1, Cb = 4h) with qt_lstm_fwd as its epilogue, for hidden sizes 8, 16, 32: the gate pre-activations stay in
  * LDS.  Same results as the two calls (same arithmetic in the same order).  Planes in two parts as in qt_dense2; O may be
@@ -216,11 +217,11 @@ int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, const float* a
                   const float* W, const float* WT /* optional transpose, as in qt_dense2 */, const float* S, int Ks,
                   const float* Ws, int h, int N, const int32_t* n_dev, const float* Cprev, int ld_c,
                   const float* wc, const float* b, const float* ln, float* O, float* Hn, float* Cn,
-                  float* gates, float* Craw, void* stream);
+                  float* gates, void* stream);
 /* gO, gHn, gCn may each be NULL (that output was not used: zero gradient).  part: (nblk, 11*h) partial sums [g_wc(3h) | g_b(4h) | g_ln(4h)], nblk = qt_lstm_bwd_blocks(N, h) */
 int qt_lstm_bwd_blocks(int N, int h);
 int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,   /* row strides */
-                const float* gates, const float* Craw, const float* Cprev, int ld_c, const float* wc, const float* ln,
+                const float* gates, const float* Cprev, int ld_c, const float* wc, const float* ln,
                 int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
                 void* stream);
 

@@ -193,7 +193,7 @@ struct GemmArgs {
     const float* bias;
     const float* ln;
     int ld_c, h;
-    float *O, *Hn, *Cn, *gates, *Craw;
+    float *O, *Hn, *Cn, *gates;
 #ifdef QT_GEMM_TIMING
     long long* dbg;
 #endif
@@ -379,7 +379,6 @@ __global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : QT_GEMM_OCC) void
                 st4(gs + h, r.F);
                 st4(gs + 2 * h, r.T);
                 st4(gs + 3 * h, r.Og);
-                st4(g.Craw + node * h + j0, r.Cr);
             }
         }
         return;
@@ -985,8 +984,8 @@ extern "C" int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, con
                              int Ka, int Ca, int Cab, const float* W, const float* WT, const float* S, int Ks,
                              const float* Ws, int h, int N, const int32_t* n_dev, const float* Cprev, int ld_c,
                              const float* wc, const float* b, const float* ln, float* O, float* Hn, float* Cn,
-                             float* gates, float* Craw, void* stream) {
-    QT_ARG((W || WT) && wc && b && Hn && Cn && gates && Craw, "bad arguments");
+                             float* gates, void* stream) {
+    QT_ARG((W || WT) && wc && b && Hn && Cn && gates, "bad arguments");
     QT_ARG(h == 8 || h == 16 || h == 32, "the fused gate GEMM + cell covers hidden sizes 8, 16 and 32 (qt_dense + qt_lstm_fwd otherwise)");
     QT_ARG((Ks == 0) || Ws || WT, "Ws missing");
     QT_ARG(Ks == 0 || WT || Ws == W + (int64_t)Ka * (Ca + Cab) * 4 * h, "Ws must follow W contiguously ([W ; Ws] is one matrix)");
@@ -998,7 +997,7 @@ extern "C" int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, con
     g.Kb = 1; g.Cb = 4 * h; g.act = QT_ACT_NONE; g.res = nullptr; g.res_stride = 0; g.drop = nullptr; g.out = nullptr;
     g.row0_step = 0; g.n_dev = n_dev; g.accumulate = 0;
     g.Cprev = Cprev; g.wc = wc; g.bias = b; g.ln = ln; g.ld_c = ld_c; g.h = h;
-    g.O = O; g.Hn = Hn; g.Cn = Cn; g.gates = gates; g.Craw = Craw;
+    g.O = O; g.Hn = Hn; g.Cn = Cn; g.gates = gates;
     const dim3 grid(qt_cdiv(N, BM), 1, 1);
     if (h == 32)
         hipLaunchKernelGGL((k_gemm_fwd<4, 64, 8>), grid, dim3(256), 0, (hipStream_t)stream, g);

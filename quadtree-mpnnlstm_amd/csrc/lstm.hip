@@ -16,8 +16,7 @@ __global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, c
                                                   const float* __restrict__ wc, const float* __restrict__ b,
                                                   const float* __restrict__ ln, int Ncap, const int32_t* __restrict__ n_dev,
                                                   int h, int ld_c, float* __restrict__ O, float* __restrict__ Hn,
-                                                  float* __restrict__ Cn, float* __restrict__ gates,
-                                                  float* __restrict__ Craw) {
+                                                  float* __restrict__ Cn, float* __restrict__ gates) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t node = gid / LPN;
     if (node >= qt_rows(n_dev, Ncap)) return;
@@ -27,7 +26,7 @@ __global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, c
     F4 cp = {{0, 0, 0, 0}};
     if (Cprev) cp = ld4(Cprev + node * ld_c + j0);
     const CellOut r = cell_forward<LPN>(gi, gf, gc, go, cp, wc, b, ln, h, j0);
-    const F4 &I = r.I, &F = r.F, &T = r.T, &Og = r.Og, &Cr = r.Cr, &hn = r.hn, &cn = r.cn;
+    const F4 &I = r.I, &F = r.F, &T = r.T, &Og = r.Og, &hn = r.hn, &cn = r.cn;
     st4(O + node * h + j0, Og);
     st4(Hn + node * h + j0, hn);
     st4(Cn + node * h + j0, cn);
@@ -36,7 +35,6 @@ __global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, c
     st4(gs + h, F);
     st4(gs + 2 * h, T);
     st4(gs + 3 * h, Og);
-    st4(Craw + node * h + j0, Cr);
 }
 
 // reduce NACC*4 per-thread accumulators over the workgroup; lane group layout as above
@@ -72,7 +70,7 @@ __device__ __forceinline__ void block_param_reduce(float (&acc)[NACC][4], int h,
 template <int LPN>
 __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, const float* __restrict__ gHn,
                                                   const float* __restrict__ gCn, const float* __restrict__ gates,
-                                                  const float* __restrict__ Craw, const float* __restrict__ Cprev,
+                                                  const float* __restrict__ Cprev,
                                                   const float* __restrict__ wc, const float* __restrict__ ln, int Ncap,
                                                   const int32_t* __restrict__ n_dev, int h, int ld_go, int ld_gh, int ld_gc,
                                                   int ld_c, float* __restrict__ gG, float* __restrict__ gCprev,
@@ -96,12 +94,12 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, 
     for (int64_t node = (int64_t)blockIdx.x * (256 / LPN) + threadIdx.x / LPN; node < N; node += stride) {
         const float* gs = gates + node * 4 * h + j0;
         const F4 I = ld4(gs), F = ld4(gs + h), T = ld4(gs + 2 * h), Og = ld4(gs + 3 * h);
-        const F4 Cr = ld4(Craw + node * h + j0);
         F4 cp = {{0, 0, 0, 0}};
         if (Cprev) cp = ld4(Cprev + node * ld_c + j0);
-        F4 Hr, tc;
+        F4 Cr, Hr, tc;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            Cr.v[k] = cell_craw(F.v[k], cp.v[k], I.v[k], T.v[k]);        // not saved by the forward: same fma, same bits
             tc.v[k] = tanhf(Cr.v[k]);
             Hr.v[k] = Og.v[k] * tc.v[k];
         }
@@ -281,14 +279,14 @@ inline bool h_ok(int h) { return h == 8 || h == 16 || h == 32 || h == 64 || h ==
     }
 
 extern "C" int qt_lstm_fwd(const float* G, const float* Cprev, int ld_c, const float* wc, const float* b, const float* ln,
-                           int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates, float* Craw,
+                           int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates,
                            void* stream) {
-    QT_ARG(G && wc && b && O && Hn && Cn && gates && Craw, "null pointer");
+    QT_ARG(G && wc && b && O && Hn && Cn && gates, "null pointer");
     QT_ARG(h_ok(h), "hidden size must be 8, 16, 32, 64 or 128");
     if (N <= 0) return QT_OK;
     const int grid = qt_cdiv((int64_t)N * lanes_per_node(h), 256);
     QT_ARG(!Cprev || (ld_c >= h && ld_c % 4 == 0), "bad Cprev row stride");
-    QT_DISPATCH_LPN(h, k_lstm_fwd, grid, stream, G, Cprev, wc, b, ln, N, n_dev, h, ld_c, O, Hn, Cn, gates, Craw);
+    QT_DISPATCH_LPN(h, k_lstm_fwd, grid, stream, G, Cprev, wc, b, ln, N, n_dev, h, ld_c, O, Hn, Cn, gates);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -303,15 +301,15 @@ extern "C" int qt_lstm_bwd_blocks(int N, int h) {
 }
 
 extern "C" int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,
-                           const float* gates, const float* Craw, const float* Cprev, int ld_c, const float* wc,
+                           const float* gates, const float* Cprev, int ld_c, const float* wc,
                            const float* ln, int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part,
                            int accumulate, void* stream) {
-    QT_ARG(gates && Craw && wc && gG && part, "null pointer");
+    QT_ARG(gates && wc && gG && part, "null pointer");
     QT_ARG(h_ok(h), "hidden size must be 8, 16, 32, 64 or 128");
     if (N <= 0) return QT_OK;
     const int grid = qt_lstm_bwd_blocks(N, h);
     QT_ARG((!gHn || ld_gh >= h) && (!gCn || ld_gc >= h) && ld_gh % 4 == 0 && ld_gc % 4 == 0 && ld_go % 4 == 0 && ld_c % 4 == 0, "bad row stride");
-    QT_DISPATCH_LPN(h, k_lstm_bwd, grid, stream, gO, gHn, gCn, gates, Craw, Cprev, wc, ln, N, n_dev, h, ld_go, ld_gh, ld_gc,
+    QT_DISPATCH_LPN(h, k_lstm_bwd, grid, stream, gO, gHn, gCn, gates, Cprev, wc, ln, N, n_dev, h, ld_go, ld_gh, ld_gc,
                     ld_c, gG, gCprev, part, accumulate);
     QT_LAUNCHED();
     return QT_OK;

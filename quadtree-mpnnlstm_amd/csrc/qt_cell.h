@@ -62,6 +62,10 @@ __device__ __forceinline__ F4 layer_norm_bwd(const F4& gy, const F4& gamma, cons
     return gx;
 }
 
+// C' before its LayerNorm.  The backward recomputes it from the saved gate activations instead of reading a saved copy, so
+// the rounding is pinned here (one fma, not left to the compiler's contraction choice): both sides get the same bits.
+__device__ __forceinline__ float cell_craw(float F, float cp, float I, float T) { return fmaf(F, cp, I * T); }
+
 // One cell update for 4 hidden units of a node (this lane's slice j0 .. j0+3 of the h channels; the node's h/4 lanes are
 // adjacent, LayerNorm statistics are shuffles inside that group -- every lane of the group must call this).
 struct CellOut {
@@ -80,7 +84,7 @@ __device__ __forceinline__ CellOut cell_forward(const F4& gi, const F4& gf, cons
         r.I.v[k] = sigmoidf_(gi.v[k] + wci.v[k] * cp.v[k] + bi.v[k]);
         r.F.v[k] = sigmoidf_(gf.v[k] + wcf.v[k] * cp.v[k] + bf.v[k]);
         r.T.v[k] = tanhf(gc.v[k] + bc.v[k]);
-        r.Cr.v[k] = r.F.v[k] * cp.v[k] + r.I.v[k] * r.T.v[k];
+        r.Cr.v[k] = cell_craw(r.F.v[k], cp.v[k], r.I.v[k], r.T.v[k]);
         r.Og.v[k] = sigmoidf_(go.v[k] + wco.v[k] * r.Cr.v[k] + bo.v[k]);
         Hr.v[k] = r.Og.v[k] * tanhf(r.Cr.v[k]);
     }

@@ -522,11 +522,11 @@ class _LstmCell(Function):
         h = h4 // 4
         wc, b, ln = _c(wc), _c(b), _c(ln)
         Cprev, ld_c = _rows(Cprev)
-        O, Hn, Cn, Craw = (G.new_empty(N, h) for _ in range(4))
+        O, Hn, Cn = (G.new_empty(N, h) for _ in range(3))
         gates = G.new_empty(N, h4)
         _lib.call('qt_lstm_fwd', ptr(G), ptr(Cprev), ld_c, ptr(wc), ptr(b), ptr(ln), N, ptr(mesh.n_dev), h, ptr(O),
-                  ptr(Hn), ptr(Cn), ptr(gates), ptr(Craw))
-        ctx.save_for_backward(gates, Craw, Cprev, wc, ln)
+                  ptr(Hn), ptr(Cn), ptr(gates))
+        ctx.save_for_backward(gates, Cprev, wc, ln)
         ctx.mesh, ctx.acc = mesh, acc
         ctx.use_idx = acc.enter() if acc is not None else 0
         ctx.set_materialize_grads(False)         # an unused output arrives as None, not as a zero-filled (N, h) buffer
@@ -534,29 +534,29 @@ class _LstmCell(Function):
 
     @staticmethod
     def backward(ctx, gO, gHn, gCn):
-        gates, Craw, Cprev, wc, ln = ctx.saved_tensors
-        return (*_lstm_backward(gO, gHn, gCn, gates, Craw, Cprev, wc, ln, ctx.mesh, ctx.acc, ctx.use_idx), None, None)
+        gates, Cprev, wc, ln = ctx.saved_tensors
+        return (*_lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, ctx.mesh, ctx.acc, ctx.use_idx), None, None)
 
 
-def _lstm_backward(gO, gHn, gCn, gates, Craw, Cprev, wc, ln, mesh, acc, use_idx):
+def _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, mesh, acc, use_idx):
     """(gG, gCprev, g_wc, g_b, g_ln) of the cell; the parameter gradients are None until the pass's last backward."""
-    N, h = Craw.shape
+    N, h = gates.shape[0], gates.shape[1] // 4
     (gHn, ld_gh), (gCn, ld_gc) = _rows(gHn), _rows(gCn)
     (gO, ld_go), (Cprev, ld_c) = _rows(gO), _rows(Cprev)
     gG = torch.empty_like(gates)
-    gCp = torch.empty_like(Craw) if Cprev is not None else None
+    gCp = gates.new_empty(N, h) if Cprev is not None else None
     if acc is None:
         nblk = max(_lib.value('qt_lstm_bwd_blocks', N, h), 1)
-        part = Craw.new_empty(nblk, 11 * h)
+        part = gates.new_empty(nblk, 11 * h)
     else:
         nblk = max(_lib.value('qt_lstm_bwd_blocks', mesh.B * mesh.P, h), 1)
-        part = acc.slab(Craw, nblk, 11 * h)
+        part = acc.slab(gates, nblk, 11 * h)
     if N > 0:
-        _lib.call('qt_lstm_bwd', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Craw), ptr(Cprev),
+        _lib.call('qt_lstm_bwd', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Cprev),
                   ld_c, ptr(wc), ptr(ln), N, ptr(mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part), 0 if acc is None else 1)
     if acc is not None and not acc.leave(use_idx):
         return gG, gCp, None, None, None
-    psum = Craw.new_empty(11 * h)
+    psum = gates.new_empty(11 * h)
     if N > 0 or acc is not None:
         _lib.call('qt_colsum', ptr(part), nblk, 11 * h, ptr(psum))
     else:
@@ -583,12 +583,12 @@ class _GateCell(Function):
         TZs = _cheb_planes(Zs, mesh, K)
         S = mesh.cheb_ones(Ks) if Ks else None
         Cprev, ld_c = _rows(Cprev)
-        Hn, Cn, Craw = (Zs[0].new_empty(N, h) for _ in range(3))
+        Hn, Cn = (Zs[0].new_empty(N, h) for _ in range(2))
         gates = Zs[0].new_empty(N, 4 * h)
         _lib.call('qt_dense_lstm', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(W), ptr(_w_t(W, acc_w)), ptr(S), ksp,
                   ptr(W[K * sum(Cs):]) if Ks else None, h, N, ptr(mesh.n_dev), ptr(Cprev), ld_c, ptr(wc), ptr(b), ptr(ln),
-                  None, ptr(Hn), ptr(Cn), ptr(gates), ptr(Craw))
-        ctx.save_for_backward(*Zs, *TZs, W, gates, Craw, Cprev, wc, ln)
+                  None, ptr(Hn), ptr(Cn), ptr(gates))
+        ctx.save_for_backward(*Zs, *TZs, W, gates, Cprev, wc, ln)
         ctx.mesh, ctx.K, ctx.Ks, ctx.acc_w, ctx.acc_p, ctx.nz = mesh, K, Ks, acc_w, acc_p, len(Zs)
         ctx.use_w = acc_w.enter() if acc_w is not None else 0
         ctx.use_p = acc_p.enter() if acc_p is not None else 0
@@ -600,8 +600,8 @@ class _GateCell(Function):
         nz = ctx.nz
         saved = ctx.saved_tensors
         Zs, TZs = list(saved[:nz]), list(saved[nz:2 * nz])
-        W, gates, Craw, Cprev, wc, ln = saved[2 * nz:]
-        gG, gCp, gwc, gb, gln = _lstm_backward(gO, gHn, gCn, gates, Craw, Cprev, wc, ln, ctx.mesh, ctx.acc_p, ctx.use_p)
+        W, gates, Cprev, wc, ln = saved[2 * nz:]
+        gG, gCp, gwc, gb, gln = _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, ctx.mesh, ctx.acc_p, ctx.use_p)
         gZs, gW = _cheb_backward(Zs, TZs, W, gG, ctx.mesh, ctx.K, ctx.Ks, ctx.acc_w, ctx.use_w,
                                  list(ctx.needs_input_grad[:nz]), ctx.needs_input_grad[2])
         gZa = gZs[0] if gZs is not None else None
