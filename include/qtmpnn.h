@@ -270,6 +270,24 @@ int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, cons
                 float keep, uint32_t seed, const float* g, const float* stats, float* gproj, float* Dn,
                 float* part, void* stream);
 
+/* ---------------------------------------------------------------- gate-weight packing of two-layer ChebConv stacks
+ * A GraphConv stack applies its ChebConvs with no nonlinearity in between (model/model.py:59-97, :95-96), so the eight
+ * stacks of a GConvLSTM (model/model.py:263-463) with TWO layers each are one Chebyshev series of order 2K-1 in weight
+ * space: M[k] = sum_{a,b} (delta(a+b, k) + delta(|a-b|, k)) / 2 * W0[a] W1[b].  The entries write that series straight into
+ * the packed gate matrix qt_dense_lstm multiplies with: rows k*C + c for Z = [X (cin_pad) | H (h)], then pad4(K) bias rows
+ * (the first layer's bias through the second layer, orders 0..K-1, + the second layer's bias at order 0, x and h branches
+ * summed); columns gate-major i, f, c, o.
+ *   P?0 (4, K, in, h): first-layer lins^T per gate (in = cin for x, h for h); P?1 (4, K, h, h); B?? (4, h).
+ *   W1: variant with H, ((2K-1)(cin_pad + h) + pad4(K), 4h); W0: without H, ((2K-1) cin_pad + pad4(K), 4h); either may be NULL.
+ * qt_compose2_bwd: gradients of all eight inputs from gW1 / gW0 (either may be NULL). */
+int qt_compose2_fwd(const float* Px0, const float* Bx0, const float* Px1, const float* Bx1, const float* Ph0,
+                    const float* Bh0, const float* Ph1, const float* Bh1, int K, int cin, int cin_pad, int h,
+                    float* W1, float* W0, void* stream);
+int qt_compose2_bwd(const float* Px0, const float* Bx0, const float* Px1, const float* Bx1, const float* Ph0,
+                    const float* Bh0, const float* Ph1, const float* Bh1, int K, int cin, int cin_pad, int h,
+                    const float* gW1, const float* gW0, float* gPx0, float* gBx0, float* gPx1, float* gBx1,
+                    float* gPh0, float* gBh0, float* gPh1, float* gBh1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -278,6 +278,11 @@ class GConvLSTM(nn.Module):
         if L == 1:
             K = len(self.conv_x_i.convolutions[0].lins)
             return [PackedCell(outs[f'{prefix}W{int(v)}'], K, 1, wc, b, ln, ops.GradAcc(), acc_p) for v in variants]
+        if L == 2 and wc.is_cuda:           # both branches, both variants: one launch (ops.compose2_pack)
+            stacks = [[outs[f'{prefix}{n}{br}{l}'] for l in range(L)] for n, br in (('P', 'x'), ('B', 'x'), ('P', 'h'), ('B', 'h'))]
+            Ws = ops.compose2_pack(*stacks, in_pad or self.in_channels, variants)
+            K = stacks[0][0].shape[1]
+            return [PackedCell(W, 2 * K - 1, K, wc, b, ln, ops.GradAcc(), acc_p) for W in Ws]
         Px, bx = ops.compose_chebconvs([outs[f'{prefix}Px{l}'] for l in range(L)], [outs[f'{prefix}Bx{l}'] for l in range(L)])
         Ph, bh = ops.compose_chebconvs([outs[f'{prefix}Ph{l}'] for l in range(L)], [outs[f'{prefix}Bh{l}'] for l in range(L)])
         return self._assemble(Px, bx, Ph, bh, wc, b, in_pad, ln, variants, acc_p)

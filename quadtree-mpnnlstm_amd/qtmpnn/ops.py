@@ -447,6 +447,46 @@ def compose_chebconvs(weights, biases):
     return P, beta
 
 
+class _Compose2(Function):
+    """Packed gate matrices of a GConvLSTM with two ChebConvs per stack, straight from the per-layer weight stacks
+    (qt_compose2_fwd / _bwd: one launch each way).  Same algebra as compose_chebconvs + the row / column layout of
+    GConvLSTM._assemble, which remain the reference implementation (and the path for other depths).
+    variants: tuple of with_h flags, one output each."""
+
+    @staticmethod
+    def forward(ctx, Px0, Bx0, Px1, Bx1, Ph0, Bh0, Ph1, Bh1, cin_pad, variants):
+        ins = [_c(t.float()) for t in (Px0, Bx0, Px1, Bx1, Ph0, Bh0, Ph1, Bh1)]
+        _lib.require_cuda(ins[0], 'weight stacks')
+        _, K, cin, h = ins[0].shape
+        assert ins[2].shape == (4, K, h, h) and ins[4].shape == (4, K, h, h) and ins[6].shape == (4, K, h, h)
+        K2, ksp = 2 * K - 1, (K + 3) // 4 * 4
+        W1 = ins[0].new_empty(K2 * (cin_pad + h) + ksp, 4 * h) if True in variants else None
+        W0 = ins[0].new_empty(K2 * cin_pad + ksp, 4 * h) if False in variants else None
+        _lib.call('qt_compose2_fwd', *[ptr(t) for t in ins], K, cin, cin_pad, h, ptr(W1), ptr(W0))
+        ctx.save_for_backward(*ins)
+        ctx.cin_pad, ctx.variants = cin_pad, tuple(variants)
+        ctx.set_materialize_grads(False)
+        return tuple(W1 if v else W0 for v in variants)
+
+    @staticmethod
+    def backward(ctx, *gWs):
+        ins = ctx.saved_tensors
+        _, K, cin, h = ins[0].shape
+        g = {v: (_c(gw) if gw is not None else None) for v, gw in zip(ctx.variants, gWs)}
+        if all(v is None for v in g.values()):
+            return (None,) * 10
+        outs = [torch.empty_like(t) for t in ins]
+        _lib.call('qt_compose2_bwd', *[ptr(t) for t in ins], K, cin, ctx.cin_pad, h, ptr(g.get(True)), ptr(g.get(False)),
+                  *[ptr(t) for t in outs])
+        return (*outs, None, None)
+
+
+def compose2_pack(Px, Bx, Ph, Bh, cin_pad, variants):
+    """[W per variant] from the two layers' stacks of the x and h branches: Px = [Px0 (4, K, cin, h), Px1 (4, K, h, h)],
+    Bx = [Bx0, Bx1] (4, h) each, likewise Ph, Bh."""
+    return _Compose2.apply(Px[0], Bx[0], Px[1], Bx[1], Ph[0], Bh[0], Ph[1], Bh[1], cin_pad, tuple(variants))
+
+
 _COMB = {}
 
 

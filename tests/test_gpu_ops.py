@@ -447,3 +447,45 @@ def test_concat_cols_kernel():
     g = torch.randn_like(out)
     ga, gb, gc = torch.autograd.grad(out, [a, b, c], g)
     assert torch.equal(ga, g[:, :4]) and torch.equal(gb, g[:, 4:20]) and torch.equal(gc, g[:, 20:])
+
+
+@pytest.mark.parametrize('cin,in_pad,K', [(4, 4, 3), (5, 8, 3), (4, 4, 2)])
+def test_compose2_kernel_equals_torch_composition(cin, in_pad, K):
+    """qt_compose2_fwd / _bwd (two-layer stacks composed and laid out as the packed gate matrix in one launch) == the torch
+    composition (ops.compose_chebconvs + GConvLSTM._assemble) for both variants: values and every parameter gradient,
+    fp32 tolerance rtol 1e-4 / atol 1e-5 (sums of <= 9 products of 16-term dot products, different summation order)."""
+    from model.model import CONVOLUTION_KWARGS, GConvLSTM
+    from qtmpnn import ops
+    torch.manual_seed(4)
+    old = dict(CONVOLUTION_KWARGS['ChebConv'])
+    CONVOLUTION_KWARGS['ChebConv']['K'] = K
+    try:
+        cell = GConvLSTM(cin, 16, 2, 'ChebConv').to(dev())
+    finally:
+        CONVOLUTION_KWARGS['ChebConv'].update(old)
+    for p in cell.parameters():
+        p.data.normal_(std=0.5)
+    variants = (False, True)
+    ref = cell.pack(in_pad, None, variants)                       # torch ops only
+    params = cell.plan_params()
+    plan = ops.PackPlan(params, lambda T, fill: cell.plan_layout(T, fill, 'c.', in_pad, variants))
+    got = cell.pack_from(plan(), 'c.', in_pad, None, variants)    # gather + compose kernel
+    for r, g in zip(ref, got):
+        assert (r.K, r.Ks) == (g.K, g.Ks) and r.W.shape == g.W.shape
+        close(g.W, r.W, 1e-4, 1e-5)
+
+    def probe(cells):
+        gen = torch.Generator().manual_seed(0)
+        return sum((c.W * torch.randn(c.W.shape, generator=gen).to(c.W.device)).sum() for c in cells)
+    gr = torch.autograd.grad(probe(ref), params, allow_unused=True, retain_graph=True)
+    gg = torch.autograd.grad(probe(got), params, allow_unused=True)
+    for a, b in zip(gr, gg):
+        close(b, a if a is not None else torch.zeros_like(b), 1e-4, 1e-5)      # (the plan hands zeros to unused parameters)
+    # one variant only (the upper encoder layers): the h-branch weights still get their bias-row gradient
+    one = cell.pack_from(plan(), 'c.', in_pad, None, (False,))
+    close(one[0].W, ref[0].W, 1e-4, 1e-5)
+    g1 = torch.autograd.grad(probe(one), params, allow_unused=True)
+    r1 = torch.autograd.grad(probe(ref[:1]), params, allow_unused=True)
+    for a, b in zip(r1, g1):
+        if a is not None:
+            close(b if b is not None else torch.zeros_like(a), a, 1e-4, 1e-5)
