@@ -282,7 +282,7 @@ int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, cons
  * qt_compose2_bwd: gradients of all eight inputs from gW1 / gW0 (either may be NULL). */
 int qt_compose2_fwd(const float* Px0, const float* Bx0, const float* Px1, const float* Bx1, const float* Ph0,
                     const float* Bh0, const float* Ph1, const float* Bh1, int K, int cin, int cin_pad, int h,
-                    float* W1, float* W0, void* stream);
+                    float* W1, float* W0, float* WT1 /* optional transposes, (4h, rows) */, float* WT0, void* stream);
 int qt_compose2_bwd(const float* Px0, const float* Bx0, const float* Px1, const float* Bx1, const float* Ph0,
                     const float* Bh0, const float* Ph1, const float* Bh1, int K, int cin, int cin_pad, int h,
                     const float* gW1, const float* gW0, float* gPx0, float* gBx0, float* gPx1, float* gBx1,

@@ -23,6 +23,8 @@ struct ComposeArgs {
     int K, cin, cin_pad, h;
     float* W1;         // variant with H: ((2K-1)(cin_pad + h) + ksp, 4h), or NULL
     float* W0;         // variant without H: ((2K-1) cin_pad + ksp, 4h), or NULL
+    float* WT1;        // the transposes (4h, rows), optional: what the gate GEMM stages its weight chunk from
+    float* WT0;
     // backward
     const float* gW1;
     const float* gW0;
@@ -67,6 +69,8 @@ __global__ __launch_bounds__(256) void k_compose2_fwd(ComposeArgs A) {
     if (!with_h) idx -= n1;
     const int C = with_h ? C1 : C0;
     float* W = with_h ? A.W1 : A.W0;
+    float* WT = with_h ? A.WT1 : A.WT0;
+    const int rows = K2 * C + ksp;
     const int row = idx / nc, col = idx - row * nc;
     const int g = col / h, p = col - g * h;
     float v = 0.0f;
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(256) void k_compose2_fwd(ComposeArgs A) {
         if (k < K) v = bias_elem(A.x, g, k, p, K, h) + bias_elem(A.hb, g, k, p, K, h);
     }
     W[idx] = v;
+    if (WT) WT[(int64_t)col * rows + row] = v;
 }
 
 // dL/dM[g, k, c, p] of the x branch (both variants) / the h branch, and of the bias rows
@@ -191,11 +196,11 @@ int check(const char* fn, const ComposeArgs& A) {
 
 extern "C" int qt_compose2_fwd(const float* Px0, const float* Bx0, const float* Px1, const float* Bx1, const float* Ph0,
                                const float* Bh0, const float* Ph1, const float* Bh1, int K, int cin, int cin_pad, int h,
-                               float* W1, float* W0, void* stream) {
+                               float* W1, float* W0, float* WT1, float* WT0, void* stream) {
     ComposeArgs A = {};
     A.x = {Px0, Bx0, Px1, Bx1};
     A.hb = {Ph0, Bh0, Ph1, Bh1};
-    A.K = K; A.cin = cin; A.cin_pad = cin_pad; A.h = h; A.W1 = W1; A.W0 = W0;
+    A.K = K; A.cin = cin; A.cin_pad = cin_pad; A.h = h; A.W1 = W1; A.W0 = W0; A.WT1 = W1 ? WT1 : nullptr; A.WT0 = W0 ? WT0 : nullptr;
     if (int rc = check(__func__, A)) return rc;
     QT_ARG(W1 || W0, "no output requested");
     const int K2 = 2 * K - 1, ksp = (K + 3) / 4 * 4, nc = 4 * h;

@@ -281,8 +281,12 @@ class GConvLSTM(nn.Module):
         if L == 2 and wc.is_cuda:           # both branches, both variants: one launch (ops.compose2_pack)
             stacks = [[outs[f'{prefix}{n}{br}{l}'] for l in range(L)] for n, br in (('P', 'x'), ('B', 'x'), ('P', 'h'), ('B', 'h'))]
             Ws = ops.compose2_pack(*stacks, in_pad or self.in_channels, variants)
-            K = stacks[0][0].shape[1]
-            return [PackedCell(W, 2 * K - 1, K, wc, b, ln, ops.GradAcc(), acc_p) for W in Ws]
+            K, nv, cells = stacks[0][0].shape[1], len(variants), []
+            for W, WT in zip(Ws[:nv], Ws[nv:]):
+                acc_w = ops.GradAcc()
+                acc_w.wt['T'] = WT                   # the gate GEMM stages its weight chunk from the transpose
+                cells.append(PackedCell(W, 2 * K - 1, K, wc, b, ln, acc_w, acc_p))
+            return cells
         Px, bx = ops.compose_chebconvs([outs[f'{prefix}Px{l}'] for l in range(L)], [outs[f'{prefix}Bx{l}'] for l in range(L)])
         Ph, bh = ops.compose_chebconvs([outs[f'{prefix}Ph{l}'] for l in range(L)], [outs[f'{prefix}Bh{l}'] for l in range(L)])
         return self._assemble(Px, bx, Ph, bh, wc, b, in_pad, ln, variants, acc_p)

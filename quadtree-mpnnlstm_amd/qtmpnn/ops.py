@@ -462,17 +462,21 @@ class _Compose2(Function):
         K2, ksp = 2 * K - 1, (K + 3) // 4 * 4
         W1 = ins[0].new_empty(K2 * (cin_pad + h) + ksp, 4 * h) if True in variants else None
         W0 = ins[0].new_empty(K2 * cin_pad + ksp, 4 * h) if False in variants else None
-        _lib.call('qt_compose2_fwd', *[ptr(t) for t in ins], K, cin, cin_pad, h, ptr(W1), ptr(W0))
+        WT1 = W1.new_empty(W1.shape[1], W1.shape[0]) if W1 is not None else None
+        WT0 = W0.new_empty(W0.shape[1], W0.shape[0]) if W0 is not None else None
+        _lib.call('qt_compose2_fwd', *[ptr(t) for t in ins], K, cin, cin_pad, h, ptr(W1), ptr(W0), ptr(WT1), ptr(WT0))
         ctx.save_for_backward(*ins)
         ctx.cin_pad, ctx.variants = cin_pad, tuple(variants)
         ctx.set_materialize_grads(False)
-        return tuple(W1 if v else W0 for v in variants)
+        outs = tuple(W1 if v else W0 for v in variants) + tuple(WT1 if v else WT0 for v in variants)
+        ctx.mark_non_differentiable(*outs[len(variants):])
+        return outs
 
     @staticmethod
     def backward(ctx, *gWs):
         ins = ctx.saved_tensors
         _, K, cin, h = ins[0].shape
-        g = {v: (_c(gw) if gw is not None else None) for v, gw in zip(ctx.variants, gWs)}
+        g = {v: (_c(gw) if gw is not None else None) for v, gw in zip(ctx.variants, gWs)}        # (the transposes have none)
         if all(v is None for v in g.values()):
             return (None,) * 10
         outs = [torch.empty_like(t) for t in ins]
@@ -482,7 +486,7 @@ class _Compose2(Function):
 
 
 def compose2_pack(Px, Bx, Ph, Bh, cin_pad, variants):
-    """[W per variant] from the two layers' stacks of the x and h branches: Px = [Px0 (4, K, cin, h), Px1 (4, K, h, h)],
+    """[W per variant] + [W^T per variant] from the two layers' stacks of the x and h branches: Px = [Px0 (4, K, cin, h), Px1 (4, K, h, h)],
     Bx = [Bx0, Bx1] (4, h) each, likewise Ph, Bh."""
     return _Compose2.apply(Px[0], Bx[0], Px[1], Bx[1], Ph[0], Bh[0], Ph[1], Bh[1], cin_pad, tuple(variants))
 
