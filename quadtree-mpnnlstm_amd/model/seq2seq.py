@@ -254,20 +254,35 @@ class Seq2Seq(nn.Module):
         else:
             mesh = self._mesh_from_image(x[..., 0].amax(dim=1), mask, high_interest_region)
             size = mesh.posfeat[:, 2:3]
-        means = ops.pool_image(x.reshape(B, T, n * m, c), mesh, True)                 # (T, N, c)
-        nodefeat = torch.cat([mesh.posfeat[:, :2], size], dim=1)
-        feats = torch.cat([means, nodefeat.unsqueeze(0).expand(T, -1, -1)], dim=-1)
+        fpad = (-(c + 3)) % 4
+        if x.requires_grad or not x.is_cuda:
+            means = ops.pool_image(x.reshape(B, T, n * m, c), mesh, True)                 # (T, N, c)
+            nodefeat = torch.cat([mesh.posfeat[:, :2], size], dim=1)
+            feats = torch.cat([means, nodefeat.unsqueeze(0).expand(T, -1, -1)], dim=-1)
+            feats_in = nn.functional.pad(feats, (0, fpad)) if fpad else feats
+        else:
+            # rows [frame means | position | size | 0-pad] assembled in place: the means land in their columns, one
+            # broadcast copy fills the rest (two concatenations and a pad of the (T, N, c+3) matrix otherwise)
+            feats_in = x.new_empty(T, mesh.N, c + 3 + fpad, dtype=torch.float32)
+            ops.pool_image_into(x.reshape(B, T, n * m, c), mesh, feats_in, 0, True)
+            if size.data_ptr() == mesh.posfeat[:, 2:3].data_ptr():
+                feats_in[:, :, c:c + 3] = mesh.posfeat
+            else:
+                feats_in[:, :, c:c + 2] = mesh.posfeat[:, :2]
+                feats_in[:, :, c + 2:c + 3] = size
+            if fpad:
+                feats_in[:, :, c + 3:] = 0
+            feats = feats_in[:, :, :c + 3]
         self.graph = Graph(None, None)
         self.graph.mapping, self.graph.n_pixels_per_node, self.graph.image_shape = mesh, mesh.npix, (n, m)
-        fpad = (-(c + 3)) % 4
         enc_pack = self.encoder.pack(c + 3 + fpad)     # local: nothing on `self` may keep the autograd graph alive
-        feats_in = nn.functional.pad(feats, (0, fpad)) if fpad else feats
         hidden = cell = None
         for t in range(self.input_timesteps):
             hidden, cell = self.encoder.run(feats_in[t], mesh, None if hidden is None else hidden[-1],
                                             None if cell is None else cell[-1], enc_pack)
         self.graph.hidden, self.graph.cell = hidden, cell            # per-layer lists while the rollout runs
-        self.graph.pyg.x = torch.cat([feats[-1][:, :1], feats[-1][:, -3:]], dim=1)     # x[-1, :, [0,-3,-2,-1]] (:336)
+        last = feats[-1]                                                                # x[-1, :, [0,-3,-2,-1]] (:336)
+        self.graph.pyg.x = last if (c == 1 and last.is_contiguous()) else torch.cat([last[:, :1], last[:, -3:]], dim=1)
 
     # -- decoder + remesh ----------------------------------------------------------------
     def unroll_output(self, unroll_steps, y, concat_layers=None, teacher_forcing_ratio=0.5, mask=None,

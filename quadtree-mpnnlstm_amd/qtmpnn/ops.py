@@ -765,6 +765,22 @@ def pool_image(img, mesh, mean=True):
     return _PoolImage.apply(img, mesh, mean)
 
 
+def pool_image_into(img, mesh, out, coff=0, mean=True):
+    """Node means of img (B, S, n*m, C) written into columns [coff, coff + C) of out (S, N, W) -- data only (no autograd):
+    the encoder's input rows [frame means | position | size] are assembled in place instead of concatenated."""
+    assert not img.requires_grad and out.dim() == 3 and out.is_contiguous()
+    img = img.float()
+    B, S, P, C = img.shape
+    clip_stride = 0
+    if B > 1 and img[0].is_contiguous() and img.stride(0) >= S * P * C:
+        clip_stride = img.stride(0)
+    else:
+        img = _c(img)
+    if mesh.N > 0:
+        _pool_raw(mesh, C, out, out.shape[2], coff, mean, img=img, S=S, img_clip_stride=clip_stride)
+    return out
+
+
 class _Gather(Function):
     """unflatten (model/graph_functions.py:451-458): node values (N, C) -> pixels (B, n*m, C)."""
 
