@@ -264,10 +264,11 @@ int qt_act_bwd(const float* gY, const float* Y, const float* res, int res_stride
 int qt_attn_blocks(int N, int C);
 int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
                 const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
-                float keep, uint32_t seed, float* out, float* stats, void* stream);
+                float keep, uint32_t seed, const uint32_t* seed_dev /* optional device-side step counter mixed into seed */,
+                float* out, float* stats, void* stream);
 int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
                 const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
-                float keep, uint32_t seed, const float* g, const float* stats, float* gproj, float* Dn,
+                float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, const float* stats, float* gproj, float* Dn,
                 float* part, void* stream);
 
 /* ---------------------------------------------------------------- gate-weight packing of two-layer ChebConv stacks

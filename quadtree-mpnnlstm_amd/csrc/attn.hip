@@ -47,7 +47,13 @@ struct AttnArgs {
     float scale;            // 1 / sqrt(real channel count)
     float keep;             // 1 - dropout p (1 = no dropout)
     uint32_t seed;
+    const uint32_t* seed_dev;   // optional step counter on the device, mixed into the seed: a captured launch (fixed `seed`
+                                // argument) then still draws a new dropout mask at every replay
 };
+
+__device__ __forceinline__ uint32_t eff_seed(const AttnArgs& a) {
+    return a.seed_dev ? a.seed ^ (*a.seed_dev * 0x9E3779B9u) : a.seed;
+}
 
 // [angle, dist] of the message j -> i (graph_functions.py:358-370): atan2(xx_j - xx_i, yy_j - yy_i) mod 2pi / 2pi
 __device__ __forceinline__ void edge_attr(const float* xy, int j, int i, float* ang, float* dst) {
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a, float* __restrict_
         const float s = group_sum<LPN>(dot4(q, kj)) * a.scale;
         const float mn = fmaxf(m, s);
         const float r = __expf(m - mn), p = __expf(s - mn);       // m = -inf on the first edge: r = 0
-        const float pd = p * drop_mult(a.seed, i, j, a.keep);
+        const float pd = p * drop_mult(eff_seed(a), i, j, a.keep);
         l = l * r + p;
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc.v[c] = acc.v[c] * r + pd * vj.v[c];
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_target(AttnArgs a, const float
         }
         const float s = group_sum<LPN>(dot4(q, kj)) * a.scale;
         const float alpha = __expf(s - m) * inv;
-        const float t = drop_mult(a.seed, i, j, a.keep) * group_sum<LPN>(dot4(gi, vj));
+        const float t = drop_mult(eff_seed(a), i, j, a.keep) * group_sum<LPN>(dot4(gi, vj));
         D += alpha * t;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
             const float m = stats[2 * i], l = stats[2 * i + 1];
             const float s = group_sum<LPN>(dot4(qi, kj)) * a.scale;
             const float alpha = l > 0.0f ? __expf(s - m) / l : 0.0f;
-            const float d = drop_mult(a.seed, i, (int)j, a.keep);
+            const float d = drop_mult(eff_seed(a), i, (int)j, a.keep);
             const float t = d * group_sum<LPN>(dot4(gi, vj));
             const float ds = alpha * (t - Dn[i]) * a.scale;
 #pragma unroll
@@ -256,9 +262,9 @@ inline bool c_ok(int C) { return C == 4 || C == 8 || C == 16 || C == 32 || C == 
 
 static int fill_args(AttnArgs* a, const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
                      const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
-                     float keep, uint32_t seed) {
+                     float keep, uint32_t seed, const uint32_t* seed_dev) {
     a->rowptr = rowptr; a->col = col; a->xy = xy; a->selfloop = selfloop; a->proj = proj; a->We = We;
-    a->ld = ld; a->C = C; a->Ncap = N; a->n_dev = n_dev; a->scale = 1.0f / sqrtf((float)c_real); a->keep = keep; a->seed = seed;
+    a->ld = ld; a->C = C; a->Ncap = N; a->n_dev = n_dev; a->scale = 1.0f / sqrtf((float)c_real); a->keep = keep; a->seed = seed; a->seed_dev = seed_dev;
     return 0;
 }
 
@@ -270,12 +276,12 @@ extern "C" int qt_attn_blocks(int N, int C) {
 
 extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
                            const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
-                           float keep, uint32_t seed, float* out, float* stats, void* stream) {
+                           float keep, uint32_t seed, const uint32_t* seed_dev, float* out, float* stats, void* stream) {
     QT_ARG(rowptr && col && xy && proj && We && out && stats, "null pointer");
     QT_ARG(c_ok(C) && ld >= 4 * C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
     if (N <= 0) return QT_OK;
     AttnArgs a;
-    fill_args(&a, rowptr, col, xy, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed);
+    fill_args(&a, rowptr, col, xy, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
     const int grid = qt_cdiv((int64_t)N * (C / 4), 256);
     QT_ATTN_DISPATCH(C, k_attn_fwd, grid, stream, a, out, stats);
     QT_LAUNCHED();
@@ -284,13 +290,13 @@ extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const floa
 
 extern "C" int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
                            const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
-                           float keep, uint32_t seed, const float* g, const float* stats, float* gproj, float* Dn,
+                           float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, const float* stats, float* gproj, float* Dn,
                            float* part, void* stream) {
     QT_ARG(rowptr && col && xy && proj && We && g && stats && gproj && Dn && part, "null pointer");
     QT_ARG(c_ok(C) && ld >= 4 * C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
     if (N <= 0) return QT_OK;
     AttnArgs a;
-    fill_args(&a, rowptr, col, xy, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed);
+    fill_args(&a, rowptr, col, xy, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
     const int grid = qt_cdiv((int64_t)N * (C / 4), 256);
     QT_ATTN_DISPATCH(C, k_attn_bwd_target, grid, stream, a, g, stats, gproj, Dn);
     const int gridB = qt_attn_blocks(N, C);

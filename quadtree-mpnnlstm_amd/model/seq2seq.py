@@ -244,6 +244,8 @@ class Seq2Seq(nn.Module):
         x = x.float()
         B, T, n, m, c = x.shape
         self.mask = mask
+        if self.training:
+            ops.advance_dropout_epoch(x.device)        # (a no-op unless an attention convolution with dropout ran before)
         if graph_structure is not None:
             # preset static mesh (:288-294): node size feature = n_pixels_per_node / 4 ("Don't assume 4 !!" in the reference)
             mesh = graph_structure['mapping'].for_batch(B)

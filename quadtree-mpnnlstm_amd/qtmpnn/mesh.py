@@ -89,8 +89,8 @@ class Mesh:
         which the attention kernels recompute [angle, dist] and know which nodes carry a self pair (multi-pixel cells of
         quadtree meshes, get_adj :329-333; pixelwise meshes have none, get_adj_pixelwise)."""
         if 'geom' not in self._ones:
-            scale = torch.tensor([self.m * self.resolution, self.n * self.resolution], device=self.posfeat.device)
-            xy = (self.posfeat[:, :2] * scale).contiguous()
+            # (python scalars travel as kernel arguments: no host-to-device copy, so this also runs inside a graph capture)
+            xy = torch.stack([self.posfeat[:, 0] * (self.m * self.resolution), self.posfeat[:, 1] * (self.n * self.resolution)], dim=1)
             self._ones['geom'] = (xy, None if self.pixelwise else (self.npix > 1).float())
         return self._ones['geom']
 

@@ -508,6 +508,22 @@ def _comb(ka, kb, device):
 
 # ------------------------------------------------------------------------------ TransformerConv attention
 _ATTN_CALLS = [0]
+_ATTN_EPOCH = {}        # device -> int32[1] step counter mixed into every attention-dropout seed on the device
+
+
+def dropout_epoch(device):
+    key = str(device)
+    if key not in _ATTN_EPOCH:
+        _ATTN_EPOCH[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _ATTN_EPOCH[key]
+
+
+def advance_dropout_epoch(device):
+    """Once per training step (Seq2Seq.process_inputs): inside a captured step the launch arguments -- the host-side seeds
+    included -- are frozen, the counter on the device is what makes every replay draw new attention-dropout masks."""
+    ep = _ATTN_EPOCH.get(str(device))
+    if ep is not None:
+        ep.add_(1)
 
 
 class _Attention(Function):
@@ -517,12 +533,13 @@ class _Attention(Function):
     @staticmethod
     def forward(ctx, proj, We, mesh, c_real, keep, seed):
         proj, We = _c(proj.float()), _c(We.float())
+        ctx.epoch = dropout_epoch(proj.device) if keep < 1.0 else None
         N, C = proj.shape[0], proj.shape[1] // 4
         xy, selfpair = mesh.attn_geometry()
         out = proj.new_empty(N, C)
         stats = proj.new_empty(N, 2)
         _lib.call('qt_attn_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(selfpair), ptr(proj), 4 * C, ptr(We), C, c_real,
-                  N, ptr(mesh.n_dev), keep, seed, ptr(out), ptr(stats))
+                  N, ptr(mesh.n_dev), keep, seed, ptr(ctx.epoch), ptr(out), ptr(stats))
         ctx.save_for_backward(proj, We, stats)
         ctx.mesh, ctx.c_real, ctx.keep, ctx.seed = mesh, c_real, keep, seed
         return out
@@ -540,7 +557,8 @@ class _Attention(Function):
         part = proj.new_zeros(nblk, 2 * C)
         if N > 0:
             _lib.call('qt_attn_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(selfpair), ptr(proj), 4 * C, ptr(We), C,
-                      ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(g), ptr(stats), ptr(gproj), ptr(Dn), ptr(part))
+                      ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(ctx.epoch), ptr(g), ptr(stats), ptr(gproj), ptr(Dn),
+                      ptr(part))
         else:
             gproj.zero_()
         gWe = part.sum(0).view(2, C).t().contiguous()

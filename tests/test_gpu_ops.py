@@ -489,3 +489,37 @@ def test_compose2_kernel_equals_torch_composition(cin, in_pad, K):
     for a, b in zip(r1, g1):
         if a is not None:
             close(b if b is not None else torch.zeros_like(a), a, 1e-4, 1e-5)
+
+
+def test_attention_dropout_epoch_counter():
+    """Attention dropout masks come from (host seed, device step counter, edge): the same seed and counter reproduce the
+    forward exactly (the backward relies on that), advancing the counter on the device -- all a hipGraph replay can do --
+    draws a new mask for the forward and the gradient alike; without dropout the counter plays no part."""
+    from qtmpnn import ops
+    mesh, _ = _mesh_64(82, noise=0.0, B=2)
+    torch.manual_seed(9)
+    C = 8
+    proj = torch.randn(mesh.N, 4 * C, device=dev())
+    We = torch.randn(C, 2, device=dev())
+
+    def run(seed):
+        p = proj.clone().requires_grad_(True)
+        out = ops._Attention.apply(p, We, mesh, C, 0.5, seed)
+        g, = torch.autograd.grad(out, p, torch.ones_like(out))
+        return out.detach(), g
+    ep = ops.dropout_epoch(dev())
+    start = int(ep.item())
+    a, ga = run(1234)
+    b, gb = run(1234)
+    assert torch.equal(a, b) and torch.equal(ga, gb)
+    ops.advance_dropout_epoch(dev())
+    assert int(ep.item()) == start + 1
+    c, gc = run(1234)
+    assert not torch.equal(a, c) and not torch.equal(ga, gc)
+    # keep = 1: the counter plays no part
+    d0 = ops._Attention.apply(proj, We, mesh, C, 1.0, 1)
+    ops.advance_dropout_epoch(dev())
+    assert torch.equal(d0, ops._Attention.apply(proj, We, mesh, C, 1.0, 1))
+    # about half of the coefficients survive, scaled by 1 / keep: the mean over many targets stays near the undropped output
+    rel = float((c - d0).abs().mean() / d0.abs().mean())
+    assert 0.05 < rel < 2.0, rel
