@@ -97,21 +97,38 @@ class TransformerConv(nn.Module):
             if lin.bias is not None:
                 nn.init.zeros_(lin.bias)
 
-    def forward(self, x, edge_index, edge_weight=None):
+    def pack(self):
+        """(W, We, accumulator) for one forward pass: the fused projection [q | k | v | skip] with its bias row, the padded
+        edge weight, and the gradient accumulator all uses of this convolution in the pass share (a recurrent cell calls it
+        once per time step: packing per call cost ~40 tiny kernels each time, forward + backward)."""
+        cin, cout = self.in_channels, self.out_channels
+        cin_p, cp = cin + (-cin) % 4, cout + (-cout) % 4
+        blocks = [self.lin_query, self.lin_key, self.lin_value, self.lin_skip]
+        w = torch.cat([nn.functional.pad(l.weight.t(), (0, cp - cout, 0, cin_p - cin)) for l in blocks], dim=1)   # (cin_p, 4 cp)
+        b = torch.cat([nn.functional.pad(l.bias, (0, cp - cout)) for l in blocks]).unsqueeze(0)
+        W = torch.cat([w, nn.functional.pad(b, (0, 0, 0, 3))], dim=0)                   # bias row + 3 zero rows
+        We = nn.functional.pad(self.lin_edge.weight, (0, 0, 0, cp - cout))
+        return PackedConv(W, We, ops.GradAcc())
+
+    def forward(self, x, edge_index, edge_weight=None, packed=None):
         mesh = _need_mesh(edge_index)
         cin, cout = self.in_channels, self.out_channels
         cin_p, cp = cin + (-cin) % 4, cout + (-cout) % 4
         x = x[:, :cin] if x.shape[1] > cin_p else x
         if x.shape[1] < cin_p:
             x = nn.functional.pad(x, (0, cin_p - x.shape[1]))
-        blocks = [self.lin_query, self.lin_key, self.lin_value, self.lin_skip]
-        w = torch.cat([nn.functional.pad(l.weight.t(), (0, cp - cout, 0, cin_p - cin)) for l in blocks], dim=1)   # (cin_p, 4 cp)
-        b = torch.cat([nn.functional.pad(l.bias, (0, cp - cout)) for l in blocks]).unsqueeze(0)
-        W = torch.cat([w, nn.functional.pad(b, (0, 0, 0, 3))], dim=0)                   # bias row + 3 zero rows
-        proj = ops.cheb_poly(x, W, mesh, 1, 1)                                          # one GEMM: [q | k | v | skip]
-        We = nn.functional.pad(self.lin_edge.weight, (0, 0, 0, cp - cout))
-        out = ops.attention(proj, We, mesh, cout, self.dropout, self.training)
+        pc = packed if packed is not None else self.pack()
+        proj = ops.cheb_poly(x, pc.W, mesh, 1, 1, acc=pc.acc if packed is not None else None)     # one GEMM: [q | k | v | skip]
+        out = ops.attention(proj, pc.We, mesh, cout, self.dropout, self.training)
         return out[:, :cout] if cp != cout else out
+
+
+class PackedConv:
+    """Packed weights of one attention convolution for one forward pass."""
+    __slots__ = ('W', 'We', 'acc')
+
+    def __init__(self, W, We, acc):
+        self.W, self.We, self.acc = W, We, acc
 
 
 def _need_mesh(edge_index):
@@ -214,7 +231,12 @@ class GConvLSTM(nn.Module):
             wc = torch.cat([self.w_c_i, self.w_c_f, self.w_c_o], dim=0)
             b = torch.cat([self.b_i, self.b_f, self.b_c, self.b_o], dim=0)
             acc_p = ops.GradAcc()
-            return [PackedCell(None, 0, 0, wc, b, ln, None, acc_p) for _ in variants]
+            convs = {f'{br}_{g}': [c.pack() for c in getattr(self, f'{br}_{g}').convolutions]
+                     for br in ('conv_x', 'conv_h') for g in self.GATES}
+            cells = [PackedCell(None, 0, 0, wc, b, ln, None, acc_p) for _ in variants]
+            for c in cells:
+                c.convs = convs             # the variants share the packed convolutions (and their accumulators)
+            return cells
         Px, bx = self._branch('conv_x')
         Ph, bh = self._branch('conv_h')
         wc = torch.cat([self.w_c_i, self.w_c_f, self.w_c_o], dim=0)
@@ -309,8 +331,12 @@ class GConvLSTM(nn.Module):
         """One cell update with packed weights `pk`; pk.ln = (4, h) LayerNorm parameters fused onto H', C' or None."""
         if pk.W is None:
             Hz = H if H is not None else X.new_zeros(X.shape[0], self.out_channels)     # conv_h(0) is not 0 (biases)
-            G = torch.cat([getattr(self, f'conv_x_{g}')(X, mesh) + getattr(self, f'conv_h_{g}')(Hz, mesh)
-                           for g in self.GATES], dim=1)
+
+            def stack(name, x):
+                for conv, pc in zip(getattr(self, name).convolutions, pk.convs[name] if pk.convs else [None] * self.n_conv_layers):
+                    x = conv(x, mesh, packed=pc) if pc is not None else conv(x, mesh)
+                return x
+            G = torch.cat([stack(f'conv_x_{g}', X) + stack(f'conv_h_{g}', Hz) for g in self.GATES], dim=1)
             return ops.lstm_cell(G, C, pk.wc, pk.b, pk.ln, mesh, pk.acc_p)
         return ops.gate_cell(X, H, pk.W, C, pk.wc, pk.b, pk.ln, mesh, pk.K, pk.Ks, pk.acc_w, pk.acc_p)
 
@@ -323,10 +349,11 @@ class GConvLSTM(nn.Module):
 
 class PackedCell:
     """Packed weights of one GConvLSTM for one forward pass (+ the gradient accumulators of that pass)."""
-    __slots__ = ('W', 'K', 'Ks', 'wc', 'b', 'ln', 'acc_w', 'acc_p')
+    __slots__ = ('W', 'K', 'Ks', 'wc', 'b', 'ln', 'acc_w', 'acc_p', 'convs')
 
     def __init__(self, W, K, Ks, wc, b, ln, acc_w, acc_p):
         self.W, self.K, self.Ks, self.wc, self.b, self.ln, self.acc_w, self.acc_p = W, K, Ks, wc, b, ln, acc_w, acc_p
+        self.convs = None
 
 
 def _not_built(name):
