@@ -262,14 +262,18 @@ int qt_act_bwd(const float* gY, const float* Y, const float* res, int res_stride
  * qt_attn_bwd: g (N, C) -> gproj (N, ld) [dq | dk | dv | g], Dn (N) scratch, part (qt_attn_blocks, 2*C) partials of dWe^T.
  */
 int qt_attn_blocks(int N, int C);
-int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
+/* eattr (E, 2): [angle, dist] of the message col[e] -> row(e) for every stored edge, computed once per mesh by
+ * qt_attn_edge_attrs and passed to qt_attn_fwd / _bwd (NULL there: recomputed from xy inside the edge loops, slower). */
+int qt_attn_edge_attrs(const int32_t* rowptr, const int32_t* col, const float* xy, int N, const int32_t* n_dev,
+                       float* eattr, void* stream);
+int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                 const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
                 float keep, uint32_t seed, const uint32_t* seed_dev /* optional device-side step counter mixed into seed */,
                 float* out, float* stats, void* stream);
-int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
+int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                 const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
-                float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, const float* stats, float* gproj, float* Dn,
-                float* part, void* stream);
+                float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, int ld_g /* row stride of g, 0 = C */,
+                const float* stats, float* gproj, float* Dn, float* part, int accumulate /* add into part */, void* stream);
 
 /* ---------------------------------------------------------------- gate-weight packing of two-layer ChebConv stacks
  * A GraphConv stack applies its ChebConvs with no nonlinearity in between (model/model.py:59-97, :95-96), so the eight

@@ -39,6 +39,7 @@ struct AttnArgs {
     const int32_t* rowptr;
     const int32_t* col;
     const float* xy;        // (N, 2): centroid x, y in edge-attribute units
+    const float* eattr;     // (E, 2) [angle, dist] of the message col[e] -> row(e), or NULL: recomputed from xy per lane
     const float* selfloop;  // (N) > 0 where the node carries a self pair, or NULL
     const float* proj;      // (N, ld): q | k | v | skip, C columns each
     const float* We;        // (C, 2)
@@ -46,6 +47,8 @@ struct AttnArgs {
     const int32_t* n_dev;
     float scale;            // 1 / sqrt(real channel count)
     float keep;             // 1 - dropout p (1 = no dropout)
+    int ld_g;               // backward: row stride of g (a column block of a wider gradient is read in place)
+    int accumulate;         // backward: add the We partials into `part` (several uses of one convolution share the slab)
     uint32_t seed;
     const uint32_t* seed_dev;   // optional step counter on the device, mixed into the seed: a captured launch (fixed `seed`
                                 // argument) then still draws a new dropout mask at every replay
@@ -55,9 +58,8 @@ __device__ __forceinline__ uint32_t eff_seed(const AttnArgs& a) {
     return a.seed_dev ? a.seed ^ (*a.seed_dev * 0x9E3779B9u) : a.seed;
 }
 
-// [angle, dist] of the message j -> i (graph_functions.py:358-370): atan2(xx_j - xx_i, yy_j - yy_i) mod 2pi / 2pi
-__device__ __forceinline__ void edge_attr(const float* xy, int j, int i, float* ang, float* dst) {
-    const float dx = xy[2 * j] - xy[2 * i], dy = xy[2 * j + 1] - xy[2 * i + 1];
+// [angle, dist] of the message j -> i from (dx, dy) = xy_j - xy_i (graph_functions.py:358-370): atan2(dx, dy) mod 2pi / 2pi
+__device__ __forceinline__ void edge_attr_xy(float dx, float dy, float* ang, float* dst) {
     float a = atan2f(dx, dy);
     if (a < 0.0f) a += 6.283185307179586f;
     *ang = a / 6.283185307179586f;
@@ -86,26 +88,61 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a, float* __restrict_
     F4 acc = {{0, 0, 0, 0}};
     const int e0 = a.rowptr[i], e1 = a.rowptr[i + 1];
     const int extra = (a.selfloop && a.selfloop[i] > 0.0f) ? 1 : 0;
-    for (int e = e0; e < e1 + extra; ++e) {
-        const int j = e < e1 ? a.col[e] : i;
-        float ang = 0.0f, dst = 0.0f;
-        if (j != i) edge_attr(a.xy, j, i, &ang, &dst);
-        const float* pj = a.proj + (int64_t)j * a.ld;
-        F4 kj = ld4(pj + a.C + j0), vj = ld4(pj + 2 * a.C + j0);
+    const uint32_t seed = eff_seed(a);
+    const float xi = a.xy[2 * i], yi = a.xy[2 * i + 1];
+    const int eend = e1 + extra;
+    for (int eb = e0; eb < eend; eb += 4) {
+        // the gathers of up to four edges are issued together; the online-softmax updates then run in edge order
+        int jj[4];
+        F4 kk[4], vv[4];
+        float xj[4], yj[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float ee = w0.v[c] * ang + w1.v[c] * dst;
-            kj.v[c] += ee;
-            vj.v[c] += ee;
+        for (int u = 0; u < 4; ++u) {
+            const int e = eb + u;
+            jj[u] = e < e1 ? a.col[e] : (e < eend ? i : -1);
         }
-        const float s = group_sum<LPN>(dot4(q, kj)) * a.scale;
-        const float mn = fmaxf(m, s);
-        const float r = __expf(m - mn), p = __expf(s - mn);       // m = -inf on the first edge: r = 0
-        const float pd = p * drop_mult(eff_seed(a), i, j, a.keep);
-        l = l * r + p;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc.v[c] = acc.v[c] * r + pd * vj.v[c];
-        m = mn;
+        for (int u = 0; u < 4; ++u)
+            if (jj[u] >= 0) {
+                const float* pj = a.proj + (int64_t)jj[u] * a.ld;
+                kk[u] = ld4(pj + a.C + j0);
+                vv[u] = ld4(pj + 2 * a.C + j0);
+                if (a.eattr) {                      // stored per edge: no atan2 / sqrt in the loop (8 lanes repeated them)
+                    const int e = eb + u;
+                    xj[u] = e < e1 ? a.eattr[2 * e] : 0.0f;
+                    yj[u] = e < e1 ? a.eattr[2 * e + 1] : 0.0f;
+                } else {
+                    xj[u] = a.xy[2 * jj[u]];
+                    yj[u] = a.xy[2 * jj[u] + 1];
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (jj[u] < 0) break;                  // (uniform over the node's lane group)
+            const int j = jj[u];
+            float ang = 0.0f, dst = 0.0f;
+            if (a.eattr) {
+                ang = xj[u];
+                dst = yj[u];
+            } else if (j != i) {
+                edge_attr_xy(xj[u] - xi, yj[u] - yi, &ang, &dst);
+            }
+            F4 kj = kk[u], vj = vv[u];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float ee = w0.v[c] * ang + w1.v[c] * dst;
+                kj.v[c] += ee;
+                vj.v[c] += ee;
+            }
+            const float s = group_sum<LPN>(dot4(q, kj)) * a.scale;
+            const float mn = fmaxf(m, s);
+            const float r = __expf(m - mn), p = __expf(s - mn);       // m = -inf on the first edge: r = 0
+            const float pd = p * drop_mult(seed, i, j, a.keep);
+            l = l * r + p;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc.v[c] = acc.v[c] * r + pd * vj.v[c];
+            m = mn;
+        }
     }
     const float inv = l > 0.0f ? 1.0f / l : 0.0f;
     const F4 sk = ld4(pi + 3 * a.C + j0);
@@ -128,7 +165,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_target(AttnArgs a, const float
     if (i >= qt_rows(a.n_dev, a.Ncap)) return;
     const int j0 = (int)(gid % LPN) * 4;
     const float* pi = a.proj + (int64_t)i * a.ld;
-    const F4 q = ld4(pi + j0), gi = ld4(g + (int64_t)i * a.C + j0);
+    const F4 q = ld4(pi + j0), gi = ld4(g + (int64_t)i * a.ld_g + j0);
     const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
     const F4 w1 = {{a.We[2 * j0 + 1], a.We[2 * j0 + 3], a.We[2 * j0 + 5], a.We[2 * j0 + 7]}};
     const float m = stats[2 * i], l = stats[2 * i + 1];
@@ -137,26 +174,60 @@ __global__ __launch_bounds__(256) void k_attn_bwd_target(AttnArgs a, const float
     const int extra = (a.selfloop && a.selfloop[i] > 0.0f) ? 1 : 0;
     float D = 0.0f;
     F4 dq = {{0, 0, 0, 0}}, dqk = {{0, 0, 0, 0}};      // dq = sum alpha t (k+e) ; dqk = sum alpha (k+e)
-    for (int e = e0; e < e1 + extra; ++e) {
-        const int j = e < e1 ? a.col[e] : i;
-        float ang = 0.0f, dst = 0.0f;
-        if (j != i) edge_attr(a.xy, j, i, &ang, &dst);
-        const float* pj = a.proj + (int64_t)j * a.ld;
-        F4 kj = ld4(pj + a.C + j0), vj = ld4(pj + 2 * a.C + j0);
+    const uint32_t seed = eff_seed(a);
+    const float xi = a.xy[2 * i], yi = a.xy[2 * i + 1];
+    const int eend = e1 + extra;
+    for (int eb = e0; eb < eend; eb += 4) {
+        int jj[4];
+        F4 kk[4], vv[4];
+        float xj[4], yj[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float ee = w0.v[c] * ang + w1.v[c] * dst;
-            kj.v[c] += ee;
-            vj.v[c] += ee;
+        for (int u = 0; u < 4; ++u) {
+            const int e = eb + u;
+            jj[u] = e < e1 ? a.col[e] : (e < eend ? i : -1);
         }
-        const float s = group_sum<LPN>(dot4(q, kj)) * a.scale;
-        const float alpha = __expf(s - m) * inv;
-        const float t = drop_mult(eff_seed(a), i, j, a.keep) * group_sum<LPN>(dot4(gi, vj));
-        D += alpha * t;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            dq.v[c] += alpha * t * kj.v[c];
-            dqk.v[c] += alpha * kj.v[c];
+        for (int u = 0; u < 4; ++u)
+            if (jj[u] >= 0) {
+                const float* pj = a.proj + (int64_t)jj[u] * a.ld;
+                kk[u] = ld4(pj + a.C + j0);
+                vv[u] = ld4(pj + 2 * a.C + j0);
+                if (a.eattr) {                      // stored per edge: no atan2 / sqrt in the loop (8 lanes repeated them)
+                    const int e = eb + u;
+                    xj[u] = e < e1 ? a.eattr[2 * e] : 0.0f;
+                    yj[u] = e < e1 ? a.eattr[2 * e + 1] : 0.0f;
+                } else {
+                    xj[u] = a.xy[2 * jj[u]];
+                    yj[u] = a.xy[2 * jj[u] + 1];
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (jj[u] < 0) break;
+            const int j = jj[u];
+            float ang = 0.0f, dst = 0.0f;
+            if (a.eattr) {
+                ang = xj[u];
+                dst = yj[u];
+            } else if (j != i) {
+                edge_attr_xy(xj[u] - xi, yj[u] - yi, &ang, &dst);
+            }
+            F4 kj = kk[u], vj = vv[u];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float ee = w0.v[c] * ang + w1.v[c] * dst;
+                kj.v[c] += ee;
+                vj.v[c] += ee;
+            }
+            const float s = group_sum<LPN>(dot4(q, kj)) * a.scale;
+            const float alpha = __expf(s - m) * inv;
+            const float t = drop_mult(seed, i, j, a.keep) * group_sum<LPN>(dot4(gi, vj));
+            D += alpha * t;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                dq.v[c] += alpha * t * kj.v[c];
+                dqk.v[c] += alpha * kj.v[c];
+            }
         }
     }
     F4 o;
@@ -181,6 +252,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
     float acc[2][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[0][c] = acc[1][c] = 0.0f;
+    const uint32_t seed = eff_seed(a);
     const int64_t stride = (int64_t)gridDim.x * (256 / LPN);
     for (int64_t j = (int64_t)blockIdx.x * (256 / LPN) + threadIdx.x / LPN; j < N; j += stride) {
         const float* pj = a.proj + j * a.ld;
@@ -188,32 +260,71 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
         F4 dk = {{0, 0, 0, 0}}, dv = {{0, 0, 0, 0}};
         const int e0 = a.rowptr[j], e1 = a.rowptr[j + 1];
         const int extra = (a.selfloop && a.selfloop[j] > 0.0f) ? 1 : 0;
-        for (int e = e0; e < e1 + extra; ++e) {
-            const int i = e < e1 ? a.col[e] : (int)j;
-            float ang = 0.0f, dst = 0.0f;
-            if (i != j) edge_attr(a.xy, (int)j, i, &ang, &dst);
-            const float* pi = a.proj + (int64_t)i * a.ld;
-            const F4 qi = ld4(pi + j0), gi = ld4(g + (int64_t)i * a.C + j0);
-            F4 kj = kj0, vj = vj0;
+        const float xj = a.xy[2 * j], yj = a.xy[2 * j + 1];
+        const int eend = e1 + extra;
+        for (int eb = e0; eb < eend; eb += 4) {
+            int ii[4];
+            F4 qq[4], gg[4];
+            float xi[4], yi[4], mi[4], li[4], Di[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float ee = w0.v[c] * ang + w1.v[c] * dst;
-                kj.v[c] += ee;
-                vj.v[c] += ee;
+            for (int u = 0; u < 4; ++u) {
+                const int e = eb + u;
+                ii[u] = e < e1 ? a.col[e] : (e < eend ? (int)j : -1);
             }
-            const float m = stats[2 * i], l = stats[2 * i + 1];
-            const float s = group_sum<LPN>(dot4(qi, kj)) * a.scale;
-            const float alpha = l > 0.0f ? __expf(s - m) / l : 0.0f;
-            const float d = drop_mult(eff_seed(a), i, (int)j, a.keep);
-            const float t = d * group_sum<LPN>(dot4(gi, vj));
-            const float ds = alpha * (t - Dn[i]) * a.scale;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float dkc = ds * qi.v[c], dvc = alpha * d * gi.v[c];
-                dk.v[c] += dkc;
-                dv.v[c] += dvc;
-                acc[0][c] += (dkc + dvc) * ang;      // d We[:, 0]
-                acc[1][c] += (dkc + dvc) * dst;      // d We[:, 1]
+            for (int u = 0; u < 4; ++u)
+                if (ii[u] >= 0) {
+                    const int i = ii[u];
+                    qq[u] = ld4(a.proj + (int64_t)i * a.ld + j0);
+                    gg[u] = ld4(g + (int64_t)i * a.ld_g + j0);
+                    if (a.eattr) {
+                        const int e = eb + u;
+                        xi[u] = e < e1 ? a.eattr[2 * e] : 0.0f;
+                        yi[u] = e < e1 ? a.eattr[2 * e + 1] : 0.0f;
+                    } else {
+                        xi[u] = a.xy[2 * i];
+                        yi[u] = a.xy[2 * i + 1];
+                    }
+                    mi[u] = stats[2 * i];
+                    li[u] = stats[2 * i + 1];
+                    Di[u] = Dn[i];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ii[u] < 0) break;
+                const int i = ii[u];
+                float ang = 0.0f, dst = 0.0f;
+                if (a.eattr) {
+                    // row j stores the attributes of i -> j; the message here runs j -> i: same distance, opposite direction
+                    if (i != j) {
+                        ang = xi[u] + 0.5f;
+                        if (ang >= 1.0f) ang -= 1.0f;
+                        dst = yi[u];
+                    }
+                } else if (i != j) {
+                    edge_attr_xy(xj - xi[u], yj - yi[u], &ang, &dst);
+                }
+                const F4 qi = qq[u], gi = gg[u];
+                F4 kj = kj0, vj = vj0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float ee = w0.v[c] * ang + w1.v[c] * dst;
+                    kj.v[c] += ee;
+                    vj.v[c] += ee;
+                }
+                const float s = group_sum<LPN>(dot4(qi, kj)) * a.scale;
+                const float alpha = li[u] > 0.0f ? __expf(s - mi[u]) / li[u] : 0.0f;
+                const float d = drop_mult(seed, i, (int)j, a.keep);
+                const float t = d * group_sum<LPN>(dot4(gi, vj));
+                const float ds = alpha * (t - Di[u]) * a.scale;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float dkc = ds * qi.v[c], dvc = alpha * d * gi.v[c];
+                    dk.v[c] += dkc;
+                    dv.v[c] += dvc;
+                    acc[0][c] += (dkc + dvc) * ang;      // d We[:, 0]
+                    acc[1][c] += (dkc + dvc) * dst;      // d We[:, 1]
+                }
             }
         }
         float* gp = gproj + j * a.ld;
@@ -242,7 +353,25 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += sm[(w * LPN + (ch >> 2)) * 8 + k * 4 + (ch & 3)];
-        part[(int64_t)blockIdx.x * 2 * a.C + idx] = s;     // layout [k][channel]; the host transposes to (C, 2)
+        float* pp = part + (int64_t)blockIdx.x * 2 * a.C + idx;     // layout [k][channel]; the host transposes to (C, 2)
+        *pp = a.accumulate ? *pp + s : s;
+    }
+}
+
+// [angle, dist] of every stored edge, once per mesh (the convolutions of a cell, forward and backward, and every time step on
+// the same mesh reuse it)
+__global__ void k_attn_edge_attrs(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                  const float* __restrict__ xy, int Ncap, const int32_t* __restrict__ n_dev,
+                                  float* __restrict__ eattr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= qt_rows(n_dev, Ncap)) return;
+    const float xi = xy[2 * i], yi = xy[2 * i + 1];
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+        const int j = col[e];
+        float ang = 0.0f, dst = 0.0f;
+        if (j != i) edge_attr_xy(xy[2 * j] - xi, xy[2 * j + 1] - yi, &ang, &dst);
+        eattr[2 * e] = ang;
+        eattr[2 * e + 1] = dst;
     }
 }
 
@@ -260,10 +389,10 @@ inline bool c_ok(int C) { return C == 4 || C == 8 || C == 16 || C == 32 || C == 
         default: hipLaunchKernelGGL(KERNEL<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;  \
     }
 
-static int fill_args(AttnArgs* a, const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
+static int fill_args(AttnArgs* a, const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                      const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
                      float keep, uint32_t seed, const uint32_t* seed_dev) {
-    a->rowptr = rowptr; a->col = col; a->xy = xy; a->selfloop = selfloop; a->proj = proj; a->We = We;
+    a->rowptr = rowptr; a->col = col; a->xy = xy; a->eattr = eattr; a->selfloop = selfloop; a->proj = proj; a->We = We;
     a->ld = ld; a->C = C; a->Ncap = N; a->n_dev = n_dev; a->scale = 1.0f / sqrtf((float)c_real); a->keep = keep; a->seed = seed; a->seed_dev = seed_dev;
     return 0;
 }
@@ -271,32 +400,48 @@ static int fill_args(AttnArgs* a, const int32_t* rowptr, const int32_t* col, con
 extern "C" int qt_attn_blocks(int N, int C) {
     if (N <= 0 || !c_ok(C)) return 0;
     const int need = qt_cdiv((int64_t)N * (C / 4), 256);
-    return need < 512 ? need : 512;
+#ifndef QT_ATTN_BLOCKS
+#define QT_ATTN_BLOCKS 4096
+#endif
+    return need < QT_ATTN_BLOCKS ? need : QT_ATTN_BLOCKS;     // (512 left two waves per SIMD for a gather-latency-bound sweep)
 }
 
-extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
+extern "C" int qt_attn_edge_attrs(const int32_t* rowptr, const int32_t* col, const float* xy, int N, const int32_t* n_dev,
+                                  float* eattr, void* stream) {
+    QT_ARG(rowptr && col && xy && eattr, "null pointer");
+    if (N <= 0) return QT_OK;
+    hipLaunchKernelGGL(k_attn_edge_attrs, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, xy, N, n_dev, eattr);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                            const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
                            float keep, uint32_t seed, const uint32_t* seed_dev, float* out, float* stats, void* stream) {
     QT_ARG(rowptr && col && xy && proj && We && out && stats, "null pointer");
     QT_ARG(c_ok(C) && ld >= 4 * C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
     if (N <= 0) return QT_OK;
     AttnArgs a;
-    fill_args(&a, rowptr, col, xy, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
+    fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
+    a.ld_g = C; a.accumulate = 0;
     const int grid = qt_cdiv((int64_t)N * (C / 4), 256);
     QT_ATTN_DISPATCH(C, k_attn_fwd, grid, stream, a, out, stats);
     QT_LAUNCHED();
     return QT_OK;
 }
 
-extern "C" int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* selfloop,
+extern "C" int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                            const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
-                           float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, const float* stats, float* gproj, float* Dn,
-                           float* part, void* stream) {
+                           float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, int ld_g, const float* stats, float* gproj,
+                           float* Dn, float* part, int accumulate, void* stream) {
     QT_ARG(rowptr && col && xy && proj && We && g && stats && gproj && Dn && part, "null pointer");
     QT_ARG(c_ok(C) && ld >= 4 * C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
+    if (ld_g == 0) ld_g = C;
+    QT_ARG(ld_g >= C && ld_g % 4 == 0 && ((uintptr_t)g & 15) == 0, "bad g row stride / alignment");
     if (N <= 0) return QT_OK;
     AttnArgs a;
-    fill_args(&a, rowptr, col, xy, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
+    fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
+    a.ld_g = ld_g; a.accumulate = accumulate;
     const int grid = qt_cdiv((int64_t)N * (C / 4), 256);
     QT_ATTN_DISPATCH(C, k_attn_bwd_target, grid, stream, a, g, stats, gproj, Dn);
     const int gridB = qt_attn_blocks(N, C);

@@ -108,7 +108,7 @@ class TransformerConv(nn.Module):
         b = torch.cat([nn.functional.pad(l.bias, (0, cp - cout)) for l in blocks]).unsqueeze(0)
         W = torch.cat([w, nn.functional.pad(b, (0, 0, 0, 3))], dim=0)                   # bias row + 3 zero rows
         We = nn.functional.pad(self.lin_edge.weight, (0, 0, 0, cp - cout))
-        return PackedConv(W, We, ops.GradAcc())
+        return PackedConv(W, We, ops.GradAcc(), ops.GradAcc())
 
     def forward(self, x, edge_index, edge_weight=None, packed=None):
         mesh = _need_mesh(edge_index)
@@ -119,16 +119,16 @@ class TransformerConv(nn.Module):
             x = nn.functional.pad(x, (0, cin_p - x.shape[1]))
         pc = packed if packed is not None else self.pack()
         proj = ops.cheb_poly(x, pc.W, mesh, 1, 1, acc=pc.acc if packed is not None else None)     # one GEMM: [q | k | v | skip]
-        out = ops.attention(proj, pc.We, mesh, cout, self.dropout, self.training)
+        out = ops.attention(proj, pc.We, mesh, cout, self.dropout, self.training, pc.acc_e if packed is not None else None)
         return out[:, :cout] if cp != cout else out
 
 
 class PackedConv:
     """Packed weights of one attention convolution for one forward pass."""
-    __slots__ = ('W', 'We', 'acc')
+    __slots__ = ('W', 'We', 'acc', 'acc_e')
 
-    def __init__(self, W, We, acc):
-        self.W, self.We, self.acc = W, We, acc
+    def __init__(self, W, We, acc, acc_e):
+        self.W, self.We, self.acc, self.acc_e = W, We, acc, acc_e
 
 
 def _need_mesh(edge_index):

@@ -528,48 +528,58 @@ def advance_dropout_epoch(device):
 
 class _Attention(Function):
     """out = edge-softmax attention over the mesh adjacency + skip, from the fused projection proj = [q | k | v | skip]
-    (N, 4C) and the edge-feature weight We (C, 2)  (PyG TransformerConv as configured by model/model.py:51)."""
+    (N, 4C) and the edge-feature weight We (C, 2)  (PyG TransformerConv as configured by model/model.py:51).
+    acc: GradAcc shared by all uses of We in this forward pass (the dWe partials of every use add up in one slab and the
+    pass's last backward reduces it), or None."""
 
     @staticmethod
-    def forward(ctx, proj, We, mesh, c_real, keep, seed):
+    def forward(ctx, proj, We, mesh, c_real, keep, seed, acc):
         proj, We = _c(proj.float()), _c(We.float())
         ctx.epoch = dropout_epoch(proj.device) if keep < 1.0 else None
         N, C = proj.shape[0], proj.shape[1] // 4
-        xy, selfpair = mesh.attn_geometry()
+        xy, selfpair, eattr = mesh.attn_geometry()
         out = proj.new_empty(N, C)
         stats = proj.new_empty(N, 2)
-        _lib.call('qt_attn_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(selfpair), ptr(proj), 4 * C, ptr(We), C, c_real,
+        _lib.call('qt_attn_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(proj), 4 * C, ptr(We), C, c_real,
                   N, ptr(mesh.n_dev), keep, seed, ptr(ctx.epoch), ptr(out), ptr(stats))
         ctx.save_for_backward(proj, We, stats)
-        ctx.mesh, ctx.c_real, ctx.keep, ctx.seed = mesh, c_real, keep, seed
+        ctx.mesh, ctx.c_real, ctx.keep, ctx.seed, ctx.acc = mesh, c_real, keep, seed, acc
+        ctx.use_idx = acc.enter() if acc is not None else 0
         return out
 
     @staticmethod
     def backward(ctx, g):
         proj, We, stats = ctx.saved_tensors
-        mesh = ctx.mesh
+        mesh, acc = ctx.mesh, ctx.acc
         N, C = proj.shape[0], proj.shape[1] // 4
-        xy, selfpair = mesh.attn_geometry()
-        g = _c(g.float())
+        xy, selfpair, eattr = mesh.attn_geometry()
+        g, ld_g = _rows(g.float())                  # a column block of the gates' gradient is read in place
         gproj = torch.empty_like(proj)
         Dn = proj.new_empty(N)
-        nblk = max(_lib.value('qt_attn_blocks', N, C), 1)
-        part = proj.new_zeros(nblk, 2 * C)
+        if acc is None:
+            nblk = max(_lib.value('qt_attn_blocks', N, C), 1)
+            part = proj.new_empty(nblk, 2 * C) if N > 0 else proj.new_zeros(nblk, 2 * C)
+        else:
+            nblk = max(_lib.value('qt_attn_blocks', max(mesh.B * mesh.P, N), C), 1)
+            part = acc.slab(proj, nblk, 2 * C)
         if N > 0:
-            _lib.call('qt_attn_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(selfpair), ptr(proj), 4 * C, ptr(We), C,
-                      ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(ctx.epoch), ptr(g), ptr(stats), ptr(gproj), ptr(Dn),
-                      ptr(part))
+            _lib.call('qt_attn_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(proj), 4 * C, ptr(We), C,
+                      ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(ctx.epoch), ptr(g), ld_g, ptr(stats), ptr(gproj), ptr(Dn),
+                      ptr(part), 0 if acc is None else 1)
         else:
             gproj.zero_()
-        gWe = part.sum(0).view(2, C).t().contiguous()
-        return gproj, gWe, None, None, None, None
+        if acc is not None and not acc.leave(ctx.use_idx):
+            return gproj, None, None, None, None, None, None
+        psum = proj.new_empty(2 * C)
+        _lib.call('qt_colsum', ptr(part), nblk, 2 * C, ptr(psum))
+        return gproj, psum.view(2, C).t().contiguous(), None, None, None, None, None
 
 
-def attention(proj, We, mesh, c_real, dropout_p=0.0, training=False):
+def attention(proj, We, mesh, c_real, dropout_p=0.0, training=False, acc=None):
     keep = 1.0 - dropout_p if (training and dropout_p > 0) else 1.0
     _ATTN_CALLS[0] += 1
     seed = (_ATTN_CALLS[0] * 2654435761 + int(torch.initial_seed())) & 0xFFFFFFFF       # host-side counter: no device sync
-    return _Attention.apply(proj, We, mesh, c_real, keep, seed)
+    return _Attention.apply(proj, We, mesh, c_real, keep, seed, acc)
 
 
 # ------------------------------------------------------------------------------ LSTM cell

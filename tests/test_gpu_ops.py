@@ -504,7 +504,7 @@ def test_attention_dropout_epoch_counter():
 
     def run(seed):
         p = proj.clone().requires_grad_(True)
-        out = ops._Attention.apply(p, We, mesh, C, 0.5, seed)
+        out = ops._Attention.apply(p, We, mesh, C, 0.5, seed, None)
         g, = torch.autograd.grad(out, p, torch.ones_like(out))
         return out.detach(), g
     ep = ops.dropout_epoch(dev())
@@ -517,9 +517,9 @@ def test_attention_dropout_epoch_counter():
     c, gc = run(1234)
     assert not torch.equal(a, c) and not torch.equal(ga, gc)
     # keep = 1: the counter plays no part
-    d0 = ops._Attention.apply(proj, We, mesh, C, 1.0, 1)
+    d0 = ops._Attention.apply(proj, We, mesh, C, 1.0, 1, None)
     ops.advance_dropout_epoch(dev())
-    assert torch.equal(d0, ops._Attention.apply(proj, We, mesh, C, 1.0, 1))
+    assert torch.equal(d0, ops._Attention.apply(proj, We, mesh, C, 1.0, 1, None))
     # about half of the coefficients survive, scaled by 1 / keep: the mean over many targets stays near the undropped output
     rel = float((c - d0).abs().mean() / d0.abs().mean())
     assert 0.05 < rel < 2.0, rel

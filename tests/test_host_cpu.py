@@ -23,6 +23,34 @@ def test_library_exports_every_declared_symbol():
     assert lib.qt_abi_version() == 1
 
 
+def test_ctypes_signatures_match_the_header():
+    """Every binding in qtmpnn._lib lists exactly as many arguments as the header declares, pointer / int / float in the
+    same places (a short list makes ctypes push garbage for the rest: a host-side crash, not an error code)."""
+    from qtmpnn import _lib
+    header = re.sub(r'/\*.*?\*/', ' ', open(os.path.join(ROOT, 'include', 'qtmpnn.h')).read(), flags=re.S)
+    decls = dict(re.findall(r'\b(qt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', header, flags=re.S))
+    kinds = {ctypes.c_void_p: 'p', ctypes.c_int: 'i', ctypes.c_float: 'f', ctypes.c_uint32: 'u', ctypes.c_int64: 'l'}
+    checked = 0
+    for name, sig in _lib._SIGNATURES.items():
+        params = [p.strip() for p in decls[name].split(',')] if decls[name].strip() not in ('', 'void') else []
+        want = ''
+        for p_ in params:
+            if '*' in p_:
+                want += 'p'
+            elif p_.startswith('float'):
+                want += 'f'
+            elif p_.startswith('uint32_t'):
+                want += 'u'
+            elif p_.startswith('int64_t'):
+                want += 'l'
+            else:
+                want += 'i'
+        got = ''.join(kinds[t] for t in sig)
+        assert got == want, f'{name}: binding {got} vs header {want}'
+        checked += 1
+    assert checked >= 35
+
+
 def test_bad_arguments_fail_loudly_without_gpu():
     from qtmpnn import _lib
     lib = _lib.load()
