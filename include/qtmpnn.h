@@ -265,7 +265,7 @@ int qt_attn_blocks(int N, int C);
 /* eattr (E, 2): [angle, dist] of the message col[e] -> row(e) for every stored edge, computed once per mesh by
  * qt_attn_edge_attrs and passed to qt_attn_fwd / _bwd (NULL there: recomputed from xy inside the edge loops, slower). */
 int qt_attn_edge_attrs(const int32_t* rowptr, const int32_t* col, const float* xy, int N, const int32_t* n_dev,
-                       float* eattr, void* stream);
+                       float* eattr, int32_t* rev /* optional (E): position of the transposed entry */, void* stream);
 int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                 const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
                 float keep, uint32_t seed, const uint32_t* seed_dev /* optional device-side step counter mixed into seed */,
@@ -273,7 +273,9 @@ int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, cons
 int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                 const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
                 float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, int ld_g /* row stride of g, 0 = C */,
-                const float* stats, float* gproj, float* Dn, float* part, int accumulate /* add into part */, void* stream);
+                const float* stats, float* gproj, float* Dn, float* part, int accumulate /* add into part */,
+                const int32_t* rev, float* coef /* optional scratch (E + N, 2): the target pass leaves (alpha, alpha t) per edge
+                and the source pass reads them through rev instead of recomputing the scores */, int E, void* stream);
 
 /* ---------------------------------------------------------------- gate-weight packing of two-layer ChebConv stacks
  * A GraphConv stack applies its ChebConvs with no nonlinearity in between (model/model.py:59-97, :95-96), so the eight

@@ -47,6 +47,9 @@ struct AttnArgs {
     const int32_t* n_dev;
     float scale;            // 1 / sqrt(real channel count)
     float keep;             // 1 - dropout p (1 = no dropout)
+    const int32_t* rev;     // (E) position of the transposed entry (row col[e], column row(e)), with coef: see k_attn_bwd_source
+    float* coef;            // (E + N, 2) backward scratch: (alpha, alpha t) of every stored edge, then of the self pairs
+    int E;
     int ld_g;               // backward: row stride of g (a column block of a wider gradient is read in place)
     int accumulate;         // backward: add the We partials into `part` (several uses of one convolution share the slab)
     uint32_t seed;
@@ -222,6 +225,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_target(AttnArgs a, const float
             const float s = group_sum<LPN>(dot4(q, kj)) * a.scale;
             const float alpha = __expf(s - m) * inv;
             const float t = drop_mult(seed, i, j, a.keep) * group_sum<LPN>(dot4(gi, vj));
+            if (a.coef && j0 == 0) {
+                const int64_t slot = eb + u < e1 ? eb + u : (int64_t)a.E + i;
+                a.coef[2 * slot] = alpha;
+                a.coef[2 * slot + 1] = alpha * t;
+            }
             D += alpha * t;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -256,12 +264,64 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
     const int64_t stride = (int64_t)gridDim.x * (256 / LPN);
     for (int64_t j = (int64_t)blockIdx.x * (256 / LPN) + threadIdx.x / LPN; j < N; j += stride) {
         const float* pj = a.proj + j * a.ld;
-        const F4 kj0 = ld4(pj + a.C + j0), vj0 = ld4(pj + 2 * a.C + j0);
         F4 dk = {{0, 0, 0, 0}}, dv = {{0, 0, 0, 0}};
         const int e0 = a.rowptr[j], e1 = a.rowptr[j + 1];
         const int extra = (a.selfloop && a.selfloop[j] > 0.0f) ? 1 : 0;
-        const float xj = a.xy[2 * j], yj = a.xy[2 * j + 1];
         const int eend = e1 + extra;
+        if (a.coef) {
+            // the target pass left (alpha, alpha t) of every edge: no dot products, shuffles or exponentials here, only the
+            // gathers of q_i and g_i; row j stores i -> j, the message j -> i sits at rev[e] (in row i)
+            for (int eb = e0; eb < eend; eb += 4) {
+                int ii[4];
+                F4 qq[4], gg[4];
+                float al[4], at[4], Di[4], ea[4], ed[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = eb + u;
+                    ii[u] = e < e1 ? a.col[e] : (e < eend ? (int)j : -1);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ii[u] >= 0) {
+                        const int i = ii[u], e = eb + u;
+                        const int64_t slot = e < e1 ? a.rev[e] : (int64_t)a.E + j;
+                        qq[u] = ld4(a.proj + (int64_t)i * a.ld + j0);
+                        gg[u] = ld4(g + (int64_t)i * a.ld_g + j0);
+                        al[u] = a.coef[2 * slot];
+                        at[u] = a.coef[2 * slot + 1];
+                        Di[u] = Dn[i];
+                        ea[u] = e < e1 ? a.eattr[2 * e] : 0.0f;
+                        ed[u] = e < e1 ? a.eattr[2 * e + 1] : 0.0f;
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (ii[u] < 0) break;
+                    const int i = ii[u];
+                    float ang = 0.0f, dst = 0.0f;
+                    if (i != j) {
+                        ang = ea[u] + 0.5f;
+                        if (ang >= 1.0f) ang -= 1.0f;
+                        dst = ed[u];
+                    }
+                    const float ds = (at[u] - al[u] * Di[u]) * a.scale;
+                    const float ad = al[u] * drop_mult(seed, i, (int)j, a.keep);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float dkc = ds * qq[u].v[c], dvc = ad * gg[u].v[c];
+                        dk.v[c] += dkc;
+                        dv.v[c] += dvc;
+                        acc[0][c] += (dkc + dvc) * ang;
+                        acc[1][c] += (dkc + dvc) * dst;
+                    }
+                }
+            }
+            float* gpc = gproj + j * a.ld;
+            st4(gpc + a.C + j0, dk);
+            st4(gpc + 2 * a.C + j0, dv);
+            continue;
+        }
+        const F4 kj0 = ld4(pj + a.C + j0), vj0 = ld4(pj + 2 * a.C + j0);
+        const float xj = a.xy[2 * j], yj = a.xy[2 * j + 1];
         for (int eb = e0; eb < eend; eb += 4) {
             int ii[4];
             F4 qq[4], gg[4];
@@ -362,7 +422,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
 // the same mesh reuse it)
 __global__ void k_attn_edge_attrs(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                   const float* __restrict__ xy, int Ncap, const int32_t* __restrict__ n_dev,
-                                  float* __restrict__ eattr) {
+                                  float* __restrict__ eattr, int32_t* __restrict__ rev) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= qt_rows(n_dev, Ncap)) return;
     const float xi = xy[2 * i], yi = xy[2 * i + 1];
@@ -372,6 +432,15 @@ __global__ void k_attn_edge_attrs(const int32_t* __restrict__ rowptr, const int3
         if (j != i) edge_attr_xy(xy[2 * j] - xi, xy[2 * j + 1] - yi, &ang, &dst);
         eattr[2 * e] = ang;
         eattr[2 * e + 1] = dst;
+        if (rev) {                              // the adjacency is symmetric: (j, i) is in row j (itself when absent)
+            int r = e;
+            for (int f = rowptr[j]; f < rowptr[j + 1]; ++f)
+                if (col[f] == i) {
+                    r = f;
+                    break;
+                }
+            rev[e] = r;
+        }
     }
 }
 
@@ -407,10 +476,10 @@ extern "C" int qt_attn_blocks(int N, int C) {
 }
 
 extern "C" int qt_attn_edge_attrs(const int32_t* rowptr, const int32_t* col, const float* xy, int N, const int32_t* n_dev,
-                                  float* eattr, void* stream) {
+                                  float* eattr, int32_t* rev, void* stream) {
     QT_ARG(rowptr && col && xy && eattr, "null pointer");
     if (N <= 0) return QT_OK;
-    hipLaunchKernelGGL(k_attn_edge_attrs, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, xy, N, n_dev, eattr);
+    hipLaunchKernelGGL(k_attn_edge_attrs, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, xy, N, n_dev, eattr, rev);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -423,7 +492,7 @@ extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const floa
     if (N <= 0) return QT_OK;
     AttnArgs a;
     fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
-    a.ld_g = C; a.accumulate = 0;
+    a.ld_g = C; a.accumulate = 0; a.rev = nullptr; a.coef = nullptr; a.E = 0;
     const int grid = qt_cdiv((int64_t)N * (C / 4), 256);
     QT_ATTN_DISPATCH(C, k_attn_fwd, grid, stream, a, out, stats);
     QT_LAUNCHED();
@@ -433,7 +502,7 @@ extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const floa
 extern "C" int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                            const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
                            float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, int ld_g, const float* stats, float* gproj,
-                           float* Dn, float* part, int accumulate, void* stream) {
+                           float* Dn, float* part, int accumulate, const int32_t* rev, float* coef, int E, void* stream) {
     QT_ARG(rowptr && col && xy && proj && We && g && stats && gproj && Dn && part, "null pointer");
     QT_ARG(c_ok(C) && ld >= 4 * C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
     if (ld_g == 0) ld_g = C;
@@ -441,7 +510,8 @@ extern "C" int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const floa
     if (N <= 0) return QT_OK;
     AttnArgs a;
     fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
-    a.ld_g = ld_g; a.accumulate = accumulate;
+    QT_ARG(!coef || (rev && eattr && E >= 0), "coef needs rev, eattr and the edge capacity E");
+    a.ld_g = ld_g; a.accumulate = accumulate; a.rev = rev; a.coef = coef; a.E = E;
     const int grid = qt_cdiv((int64_t)N * (C / 4), 256);
     QT_ATTN_DISPATCH(C, k_attn_bwd_target, grid, stream, a, g, stats, gproj, Dn);
     const int gridB = qt_attn_blocks(N, C);

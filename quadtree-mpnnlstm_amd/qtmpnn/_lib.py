@@ -47,9 +47,9 @@ _SIGNATURES = {
     'qt_concat': [_P, _P, _P, _I, _I, _P, _P, _P],
     'qt_act_bwd': [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P],
     'qt_attn_blocks': [_I, _I],
-    'qt_attn_edge_attrs': [_P, _P, _P, _I, _P, _P, _P],
+    'qt_attn_edge_attrs': [_P, _P, _P, _I, _P, _P, _P, _P],
     'qt_attn_fwd': [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _P, _P],
-    'qt_attn_bwd': [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _I, _P, _P, _P, _P, _I, _P],
+    'qt_attn_bwd': [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
     'qt_compose2_fwd': [_P] * 8 + [_I] * 4 + [_P, _P, _P, _P, _P],
     'qt_compose2_bwd': [_P] * 8 + [_I] * 4 + [_P] * 11,
     'qt_head_fwd': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P],

@@ -85,15 +85,17 @@ class Mesh:
 
     # -- per-node data of the attention convolutions --------------------------------
     def attn_geometry(self):
-        """(xy (N, 2) centroids in edge-attribute units (graph_functions.py:657), selfpair (N) or None, eattr (E, 2)): the
-        per-edge [angle, dist] of the stored edges (computed once per mesh on the device) and which nodes carry a self pair
+        """(xy (N, 2) centroids in edge-attribute units (graph_functions.py:657), selfpair (N) or None, eattr (E, 2), rev (E)): the
+        per-edge [angle, dist] of the stored edges and the position of each edge's transpose (computed once per mesh on the device) and which nodes carry a self pair
         (multi-pixel cells of quadtree meshes, get_adj :329-333; pixelwise meshes have none, get_adj_pixelwise)."""
         if 'geom' not in self._ones:
             # (python scalars travel as kernel arguments: no host-to-device copy, so this also runs inside a graph capture)
             xy = torch.stack([self.posfeat[:, 0] * (self.m * self.resolution), self.posfeat[:, 1] * (self.n * self.resolution)], dim=1)
-            eattr = torch.empty(max(int(self.col.numel()), 1), 2, device=xy.device)
-            _lib.call('qt_attn_edge_attrs', ptr(self.rowptr), ptr(self.col), ptr(xy), self.N, ptr(self.n_dev), ptr(eattr))
-            self._ones['geom'] = (xy, None if self.pixelwise else (self.npix > 1).float(), eattr)
+            ecap = max(int(self.col.numel()), 1)
+            eattr = torch.empty(ecap, 2, device=xy.device)
+            rev = torch.empty(ecap, dtype=torch.int32, device=xy.device)
+            _lib.call('qt_attn_edge_attrs', ptr(self.rowptr), ptr(self.col), ptr(xy), self.N, ptr(self.n_dev), ptr(eattr), ptr(rev))
+            self._ones['geom'] = (xy, None if self.pixelwise else (self.npix > 1).float(), eattr, rev)
         return self._ones['geom']
 
     # -- T_k(L^) 1 for the bias terms of stacked ChebConvs ------------------------

@@ -537,7 +537,7 @@ class _Attention(Function):
         proj, We = _c(proj.float()), _c(We.float())
         ctx.epoch = dropout_epoch(proj.device) if keep < 1.0 else None
         N, C = proj.shape[0], proj.shape[1] // 4
-        xy, selfpair, eattr = mesh.attn_geometry()
+        xy, selfpair, eattr, _ = mesh.attn_geometry()
         out = proj.new_empty(N, C)
         stats = proj.new_empty(N, 2)
         _lib.call('qt_attn_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(proj), 4 * C, ptr(We), C, c_real,
@@ -552,7 +552,8 @@ class _Attention(Function):
         proj, We, stats = ctx.saved_tensors
         mesh, acc = ctx.mesh, ctx.acc
         N, C = proj.shape[0], proj.shape[1] // 4
-        xy, selfpair, eattr = mesh.attn_geometry()
+        xy, selfpair, eattr, rev = mesh.attn_geometry()
+        coef = proj.new_empty(rev.numel() + N, 2)       # (alpha, alpha t) per edge: target pass -> source pass
         g, ld_g = _rows(g.float())                  # a column block of the gates' gradient is read in place
         gproj = torch.empty_like(proj)
         Dn = proj.new_empty(N)
@@ -565,7 +566,7 @@ class _Attention(Function):
         if N > 0:
             _lib.call('qt_attn_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(proj), 4 * C, ptr(We), C,
                       ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(ctx.epoch), ptr(g), ld_g, ptr(stats), ptr(gproj), ptr(Dn),
-                      ptr(part), 0 if acc is None else 1)
+                      ptr(part), 0 if acc is None else 1, ptr(rev), ptr(coef), rev.numel())
         else:
             gproj.zero_()
         if acc is not None and not acc.leave(ctx.use_idx):

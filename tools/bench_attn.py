@@ -21,7 +21,8 @@ tf = lambda a: abs(abs(a - 0.5) - 0.5)
 src = tf(x[..., 0]).amax(dim=1)
 mesh = build_mesh(src=src, thresh=0.15, mask=mask)
 N, E = mesh.N, mesh.E
-xy, selfpair, eattr = mesh.attn_geometry()
+xy, selfpair, eattr, rev = mesh.attn_geometry()
+coef = torch.empty(rev.numel() + N, 2, device=dev)
 print('N', N, 'E', E, 'self pairs', int((selfpair > 0).sum()) if selfpair is not None else 0, 'C', C)
 proj = torch.randn(N, 4 * C, device=dev)
 We = torch.randn(C, 2, device=dev)
@@ -47,7 +48,8 @@ def timeit(fn, reps=20):
 
 for keep in (1.0, 0.9):
     fwd = lambda: _lib.call('qt_attn_fwd', *common, keep, 7, None, ptr(out), ptr(stats))
-    bwd = lambda: _lib.call('qt_attn_bwd', *common, keep, 7, None, ptr(g), 0, ptr(stats), ptr(gproj), ptr(Dn), ptr(part), 0)
+    bwd = lambda: _lib.call('qt_attn_bwd', *common, keep, 7, None, ptr(g), 0, ptr(stats), ptr(gproj), ptr(Dn), ptr(part), 0,
+                              *((ptr(rev), ptr(coef), rev.numel()) if os.environ.get('QT_NO_COEF') != '1' else (None, None, 0)))
     tf_, tb = timeit(fwd), timeit(bwd)
     cf = 4 * (N * 5 * C + N * 2 + 2 * E + N)                     # proj rows + out + stats + CSR
     gf = 4 * ((E + N) * 2 * C + N * 3 * C)                       # k, v per edge; q, skip, out per node
