@@ -211,8 +211,6 @@ class Seq2Seq(nn.Module):
         self.decoder = Decoder(1 + 3, hidden_size, dropout, n_layers=n_layers, concat_layers_dim=1,
                                convolution_type=convolution_type, rnn_type=rnn_type, n_conv_layers=n_conv_layers,
                                binary=binary, dummy=dummy)
-        if remesh_input:
-            raise NotImplementedError('remesh_input=True is a "next" row (SURVEY.md 8(f) row 3)')
         self.input_timesteps, self.output_timesteps, self.n_layers = input_timesteps, output_timesteps, n_layers
         self.hidden_size, self.condition, self.remesh_input, self.debug = hidden_size, condition, remesh_input, debug
         self.convolution_type = convolution_type
@@ -246,6 +244,10 @@ class Seq2Seq(nn.Module):
         self.mask = mask
         if self.training:
             ops.advance_dropout_epoch(x.device)        # (a no-op unless an attention convolution with dropout ran before)
+        if self.remesh_input:
+            if graph_structure is not None or self.thresh == -np.inf:
+                raise NotImplementedError('remesh_input=True is built for data-driven quadtree meshes only')
+            return self._process_inputs_remesh(x, mask, high_interest_region)
         if graph_structure is not None:
             # preset static mesh (:288-294): node size feature = n_pixels_per_node / 4 ("Don't assume 4 !!" in the reference)
             mesh = graph_structure['mapping'].for_batch(B)
@@ -285,6 +287,40 @@ class Seq2Seq(nn.Module):
         self.graph.hidden, self.graph.cell = hidden, cell            # per-layer lists while the rollout runs
         last = feats[-1]                                                                # x[-1, :, [0,-3,-2,-1]] (:336)
         self.graph.pyg.x = last if (c == 1 and last.is_contiguous()) else torch.cat([last[:, :1], last[:, -3:]], dim=1)
+
+    def _process_inputs_remesh(self, x, mask, hir):
+        """remesh_input=True (model/seq2seq.py:266-276, 312, 323-324, do_remesh_input :493-527): the mesh of encoder step t
+        comes from input frame t alone, and after every step the state moves to the mesh of frame t + 1 -- also after the
+        last one, so x must carry input_timesteps + 1 frames (with fewer the reference fails at x[[t + 1]]; so does this)."""
+        B, T, n, m, c = x.shape
+        if T <= self.input_timesteps:
+            raise IndexError(f'index {self.input_timesteps} is out of bounds for dimension 0 with size {T} '
+                             '(remesh_input=True reads frame t + 1 after every encoder step, model/seq2seq.py:324)')
+        fpad = (-(c + 3)) % 4
+        L, h = self.n_layers, self.hidden_size
+        enc_pack = self.encoder.pack(c + 3 + fpad)
+
+        def frame_rows(t, mesh):                 # [frame means | position | size | 0-pad] of frame t on `mesh`
+            f = x.new_empty(1, mesh.N, c + 3 + fpad, dtype=torch.float32)
+            ops.pool_image_into(x[:, t:t + 1].reshape(B, 1, n * m, c), mesh, f, 0, True)
+            f[0, :, c:c + 3] = mesh.posfeat
+            if fpad:
+                f[0, :, c + 3:] = 0
+            return f[0]
+        mesh = self._mesh_from_image(x[:, 0, ..., 0], mask, hir)
+        rows = frame_rows(0, mesh)
+        hidden = cell = None
+        for t in range(self.input_timesteps):
+            hidden, cell = self.encoder.run(rows, mesh, None if hidden is None else hidden[-1],
+                                            None if cell is None else cell[-1], enc_pack)
+            new = self._mesh_from_image(x[:, t + 1, ..., 0], mask, hir)
+            parts = ops.remesh_transfer([*hidden, *cell], mesh, new, [h] * (2 * L))
+            hidden, cell = list(parts[:L]), list(parts[L:])
+            mesh, rows = new, frame_rows(t + 1, new)
+        self.graph = Graph(None, None)
+        self.graph.mapping, self.graph.n_pixels_per_node, self.graph.image_shape = mesh, mesh.npix, (n, m)
+        self.graph.hidden, self.graph.cell = hidden, cell
+        self.graph.pyg.x = rows if (c == 1 and fpad == 0) else torch.cat([rows[:, :1], rows[:, c:c + 3]], dim=1)
 
     # -- decoder + remesh ----------------------------------------------------------------
     def unroll_output(self, unroll_steps, y, concat_layers=None, teacher_forcing_ratio=0.5, mask=None,

@@ -326,7 +326,7 @@ def rollout_fixed_mesh(name, x, y, concat, mask, hidden, n_layers, n_conv, t_in,
     model.train()
     xt, yt, ct = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(concat)
     gs, extra = None, {}
-    if static is not None and static[1] == 'homogeneous':
+    if static is not None and isinstance(static[1], str) and static[1] == 'homogeneous':
         # uniform preset mesh, fully masked cells removed (graph_functions.py:707-737); partly masked cells keep ALL their pixels
         gs = RG.create_static_homogeneous_graph(x.shape[1:3], static[0], mask, use_edge_attrs=False)
         mp = gs['mapping'].numpy()
@@ -420,6 +420,19 @@ def rollout_variants():
     loss = torch.nn.BCELoss()(y_hat[:, ~mk], yt[:, ~mk])
     loss.backward()
     dump('binary', model, outs, loss)
+
+    # remesh_input=True (seq2seq.py:266-276, 323-324, 493-527): every encoder step on the mesh of ITS frame; x carries
+    # input_timesteps + 1 frames because the reference re-meshes to frame t + 1 after the last step too
+    model = RS.Seq2Seq(hidden_size=8, dropout=0.0, thresh=0.1, input_timesteps=3, input_features=4, output_timesteps=4,
+                       n_layers=1, n_conv_layers=2, convolution_type='ChebConv', remesh_input=True)
+    randomize(model, 83, scale=0.08, bscale=0.02)
+    model.train()
+    x4 = np.concatenate([x, y[:1]], axis=0)
+    outs, maps = model(torch.from_numpy(x4), yt, ct, teacher_forcing_ratio=0, mask=mask)
+    y_hat = torch.stack([RG.unflatten(outs[i], maps[i], (64, 64), mask) for i in range(4)])
+    loss = torch.nn.MSELoss()(y_hat[:, ~mk], yt[:, ~mk])
+    loss.backward()
+    dump('remesh_input', model, outs, loss, dict(x=x4))
 
     # truncated BPTT with truncated_backprop = 2 (mpnnlstm.py:281-315): every chunk re-encodes, zeroes the gradients
     # and unrolls its own steps from the encoder state; only the last chunk's gradient reaches optimizer.step()

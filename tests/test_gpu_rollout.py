@@ -372,6 +372,30 @@ def test_binary_head_golden():
     _check_grads(model, g)
 
 
+def test_remesh_input_golden():
+    """remesh_input=True -- every encoder step runs on the mesh of its own input frame and the state moves
+    to the next frame's mesh after each step (x carries input_timesteps + 1 frames, as the reference's indexing demands)."""
+    from model.mpnnlstm import masked_mse
+    from model.seq2seq import Seq2Seq
+    g = golden('variant_remesh_input.npz')
+    model = Seq2Seq(hidden_size=8, dropout=0.0, thresh=0.1, input_timesteps=3, input_features=4, output_timesteps=4,
+                    n_layers=1, n_conv_layers=2, convolution_type='ChebConv', remesh_input=True)
+    load_state(model, g, 'w/')
+    model.to(dev())
+    x, y, concat = (torch.from_numpy(g[k]).to(dev()) for k in ('x', 'y', 'concat'))
+    assert x.shape[0] == 4
+    outs, meshes = model(x, y, concat, teacher_forcing_ratio=0, mask=g['mask'])
+    for i, o in enumerate(outs):
+        assert o.shape[0] == g[f'out_{i}'].shape[0], f'mesh size of step {i}'
+        close(o, g[f'out_{i}'], msg=f'step {i}')
+    loss = masked_mse(outs, meshes, y, g['mask'])
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    loss.backward()
+    _check_grads(model, g)
+    with pytest.raises(IndexError):          # the reference reads x[[t + 1]] after the last encoder step
+        model(x[:3], y, concat, teacher_forcing_ratio=0, mask=g['mask'])
+
+
 def test_truncated_bptt_golden():
     """the reference's truncated-BPTT chunk loop with truncated_backprop = 2."""
     from model.mpnnlstm import NextFramePredictorS2S
