@@ -155,6 +155,11 @@ class Mesh:
         mp[lab[ok], torch.nonzero(ok).flatten()] = 1.0
         return mp
 
+    def reshape(self, *shape):
+        """`mapping.reshape(-1, *image_shape)` of the reference's notebooks (notebooks/create_mesh.ipynb): one image-shaped
+        0/1 plane per node, from the dense form."""
+        return self.to_dense().reshape(*shape)
+
 
 def spmm(mesh, x, alpha, p, beta, q, gamma, out, C):
     _lib.call('qt_spmm', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), mesh.N, ptr(mesh.n_dev), C, ptr(x), alpha,

@@ -108,3 +108,27 @@ def test_full_size_properties():
     src = torch.repeat_interleave(torch.arange(mesh.N, device=dev()), rp[1:] - rp[:-1])
     deg = torch.zeros(mesh.N, device=dev()).index_add_(0, src, mesh.w[:mesh.E])
     close(mesh.dis, deg.rsqrt(), rtol=1e-5)
+
+
+def test_dense_mapping_compatibility():
+    """the Mesh stands in for the reference's dense (N, P) `mapping` where its tooling touches it --
+    `.to_dense()`, `.reshape(-1, *image_shape)` (notebooks/create_mesh.ipynb), and `flatten` / `unflatten` with a mask
+    (ice_results.py:116-118): dense-matrix flatten == the kernel path."""
+    from model.graph_functions import flatten, unflatten
+    g = np.load(os.path.join(GOLDEN, 'graph_96_ice_masked.npz'), allow_pickle=False)
+    mesh = mesh_from_golden_graph(g)
+    dense = mesh.to_dense()
+    lab = torch.from_numpy(g['labels'].reshape(-1)).to(dev())
+    assert dense.shape == (mesh.N, lab.numel())
+    assert torch.equal(dense.sum(0), (lab >= 0).float()) and torch.equal(dense.sum(1), mesh.npix)
+    planes = mesh.reshape(-1, *g['labels'].shape)
+    assert planes.shape == (mesh.N, *g['labels'].shape) and torch.equal(planes.reshape(mesh.N, -1), dense)
+    torch.manual_seed(0)
+    img = torch.rand(3, *g['labels'].shape, 2, device=dev())
+    mask = g['mask'] if 'mask' in g.files else None
+    flat = flatten(img, mesh, mesh.npix, mask)                                   # (3, N, 2) node means
+    want = torch.einsum('np,spc->snc', dense, img.reshape(3, -1, 2)) / mesh.npix.view(1, -1, 1)
+    close(flat, want, atol=1e-5)
+    back = unflatten(flat, mesh, g['labels'].shape, mask)
+    inside = (lab >= 0).view(*g['labels'].shape)
+    close(back[:, inside], torch.einsum('np,snc->spc', dense, flat).reshape(3, *g['labels'].shape, 2)[:, inside], atol=1e-6)
