@@ -225,6 +225,17 @@ int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_gh, const f
                 int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
                 void* stream);
 
+/* qt_lstm_bwd with the data gradient of the gate GEMM as its second half (hidden 8 / 16): a workgroup computes the gG rows of
+ * its 128 nodes, writes them (the weight gradient reads them later) and multiplies them from LDS with W^T:
+ * out planes (Kb, N, Cb) [+ outb (Kb, N, Cbb)] = gG (N, 4h) @ Wrows^T, Wrows = the first Kb (Cb + Cbb) rows of the forward
+ * weight (row k (Cb + Cbb) + c, 4h columns), Kb (Cb + Cbb) <= 128.  Same planes, bit for bit, as qt_lstm_bwd + qt_dense2.
+ * part: (qt_lstm_dgrad_blocks(N), 11 h) partial sums as in qt_lstm_bwd (one row per 128-node workgroup). */
+int qt_lstm_dgrad_blocks(int N);
+int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,
+                      const float* gates, const float* Cprev, int ld_c, const float* wc, const float* ln,
+                      int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
+                      const float* Wrows, int Kb, int Cb, int Cbb, float* out, float* outb, void* stream);
+
 /* decoder head input, model/seq2seq.py:160-165: Z (N, hp) = [relu(LayerNorm_o(O)) | concat | 0...], hp >= h+1.
  * Zb != NULL: the same row as two matrices, Z (N, h) and Zb (N, hp - h).  O rows have stride ld_o floats (0 = h): the raw
  * output gate may be read in place from the saved gate activations, gates[:, 3h:4h]. */

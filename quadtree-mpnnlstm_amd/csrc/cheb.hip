@@ -840,6 +840,139 @@ constexpr int WGRAD_ROWS = 512;
 #endif
 constexpr int WGRAD_GROUP_ROWS = QT_WG_ROWS;
 
+
+// ---- cell backward fused into the data-gradient GEMM of the gate weights (hidden 8 / 16).
+// gG = d loss / d gate pre-activations comes out of the cell backward (k_lstm_bwd's arithmetic, qt_cell.h) and is at once
+// the left operand of  gT = gG W^T  (K = 4h reduction, all output planes in this workgroup's 32 NT columns).  Here a
+// workgroup computes the gG rows of its 128 nodes into LDS (and to global memory: the deferred weight gradient reads them),
+// then feeds the MFMA loop from LDS: the (N, 4h) matrix is not read back from memory and one launch per use is gone.
+// Same operand order as k_gemm_fwd on the stored gG: bit-identical planes.
+struct DgradCellArgs {
+    const float *gO, *gHn, *gCn, *gates, *Cprev, *wc, *ln;
+    int ld_go, ld_gh, ld_gc, ld_c, h;
+    float *gG, *gCprev, *part;
+    int accumulate;
+    const float* BT;        // (NB, 4h): rows k*C + c of the forward weight (= the transposed right operand)
+    int M, NB, Kb, Cb, Cbb;
+    float *out, *outb;
+    const int32_t* n_dev;
+};
+
+template <int NT, int LPN>
+__global__ __launch_bounds__(256, 2) void k_dgrad_cell(DgradCellArgs g) {
+    using namespace qtcell;
+    constexpr int BNT = 32 * NT, K = 16 * LPN, PITCH = K + 4, RP = 256 / LPN;
+    __shared__ __attribute__((aligned(16))) float Bt[BNT * PITCH];
+    __shared__ __attribute__((aligned(16))) float As[128 * (PITCH > 64 ? PITCH : 64)];
+    __shared__ float sm[4 * LPN * 11 * 4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l32 = lane & 31, half = lane >> 5;
+    const int64_t i0 = (int64_t)blockIdx.x * BM;
+    const int64_t rows = qt_rows(g.n_dev, g.M);
+    const int h = g.h;
+    // W chunk (all of it: K = 4h fits one pass) -> LDS; independent of the cell phase below
+    for (int e = t; e < BNT * (K / 4); e += 256) {
+        const int c = e / (K / 4), kq = e - c * (K / 4);
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < g.NB) w = *reinterpret_cast<const float4*>(g.BT + (int64_t)c * K + 4 * kq);
+        *reinterpret_cast<float4*>(&Bt[c * PITCH + 4 * kq]) = w;
+    }
+    // cell backward of this workgroup's rows (a workgroup past the valid rows contributes zeros to the parameter partials)
+    {
+        const int j0 = (t % LPN) * 4;
+        const F4 wci = ld4(g.wc + j0), wcf = ld4(g.wc + h + j0), wco = ld4(g.wc + 2 * h + j0);
+        F4 gam_h = {{1, 1, 1, 1}}, gam_c = {{1, 1, 1, 1}};
+        if (g.ln) {
+            gam_h = ld4(g.ln + j0);
+            gam_c = ld4(g.ln + 2 * h + j0);
+        }
+        float acc[11][4];
+#pragma unroll
+        for (int a = 0; a < 11; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[a][k] = 0.0f;
+#pragma unroll
+        for (int r0 = 0; r0 < BM; r0 += RP) {
+            const int r = r0 + t / LPN;
+            const int64_t node = i0 + r;
+            const bool ok = node < rows;
+            const F4 z = {{0, 0, 0, 0}};
+            F4 I = z, F = z, T = z, Og = z, cp = z, gyh = z, gyc = z, go_in = z;
+            if (ok) {
+                const float* gs = g.gates + node * 4 * h + j0;
+                I = ld4(gs); F = ld4(gs + h); T = ld4(gs + 2 * h); Og = ld4(gs + 3 * h);
+                if (g.Cprev) cp = ld4(g.Cprev + node * g.ld_c + j0);
+                if (g.gHn) gyh = ld4(g.gHn + node * g.ld_gh + j0);
+                if (g.gCn) gyc = ld4(g.gCn + node * g.ld_gc + j0);
+                if (g.gO) go_in = ld4(g.gO + node * g.ld_go + j0);
+            }
+            const CellBwdOut o = cell_backward<LPN>(I, F, T, Og, cp, gyh, gyc, go_in, wci, wcf, wco, gam_h, gam_c,
+                                                    g.ln != nullptr, h, acc);
+            float* as = As + r * PITCH + j0;
+            st4(as, o.ggi); st4(as + h, o.ggf); st4(as + 2 * h, o.ggc); st4(as + 3 * h, o.ggo);
+            if (ok) {
+                float* gg = g.gG + node * 4 * h + j0;
+                st4(gg, o.ggi); st4(gg + h, o.ggf); st4(gg + 2 * h, o.ggc); st4(gg + 3 * h, o.ggo);
+                if (g.gCprev) st4(g.gCprev + node * h + j0, o.gcp);
+            }
+        }
+        block_param_reduce<LPN, 11>(acc, h, sm, g.part + (int64_t)blockIdx.x * 11 * h, g.accumulate);
+    }
+    __syncthreads();                                 // Bt, As complete
+    if (i0 >= rows) return;
+    f32x16 acc2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[nt][r] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < K / 8; ++j) {
+        const float4 a = *reinterpret_cast<const float4*>(&As[(wave * 32 + l32) * PITCH + 8 * j + 4 * half]);
+        float4 bq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            bq[nt] = *reinterpret_cast<const float4*>(&Bt[(nt * 32 + l32) * PITCH + 8 * j + 4 * half]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[nt].x, acc2[nt], 0, 0, 0);
+            acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[nt].y, acc2[nt], 0, 0, 0);
+            acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[nt].z, acc2[nt], 0, 0, 0);
+            acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[nt].w, acc2[nt], 0, 0, 0);
+        }
+    }
+    // epilogue as in k_gemm_fwd: the tile goes through LDS (As is free now) so that rows leave as float4 pieces
+    float* Cs = As;
+#pragma unroll
+    for (int h2 = 0; h2 < (NT + 1) / 2; ++h2) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int nt = 2 * h2 + u;
+            if (nt < NT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + u * 32 + l32] = acc2[nt][r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < BM * 16 / 256; ++u) {
+            const int e = t + 256 * u;
+            const int row = e >> 4, c4 = (e & 15) * 4;
+            const int64_t i = i0 + row;
+            const int j = h2 * 64 + c4;
+            if (i >= rows || j >= g.NB) continue;
+            const float4 v = *reinterpret_cast<const float4*>(&Cs[row * 64 + c4]);
+            const int ct = g.Cb + g.Cbb;
+            const int pl = j / ct, ch = j - pl * ct;
+            if (ch < g.Cb)
+                *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+            else
+                *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + i * g.Cbb + (ch - g.Cb)) = v;
+        }
+    }
+}
+
 }  // namespace
 
 // shared argument checks / operand setup of the node-feature operand
@@ -978,6 +1111,38 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
                         int res_stride, const float* drop, float* out, void* stream) {
     return qt_dense2(a0, 0, a_rest, nullptr, 0, nullptr, Ka, Ca, 0, W, nullptr, S, Ks, Ws, Kb, Cb, 0, N, n_dev, act, res, res_stride, drop, out,
                      nullptr, stream);
+}
+
+extern "C" int qt_lstm_dgrad_blocks(int N) { return N <= 0 ? 0 : qt_cdiv(N, BM); }
+
+extern "C" int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,
+                                 const float* gates, const float* Cprev, int ld_c, const float* wc, const float* ln, int N,
+                                 const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
+                                 const float* Wrows, int Kb, int Cb, int Cbb, float* out, float* outb, void* stream) {
+    QT_ARG(gates && wc && gG && part && Wrows && out, "null pointer");
+    QT_ARG(h == 8 || h == 16, "fused for hidden sizes 8 and 16 (others: qt_lstm_bwd + qt_dense2)");
+    QT_ARG(Kb >= 1 && Cb >= 4 && Cb % 4 == 0 && Cbb >= 0 && Cbb % 4 == 0 && (Cbb == 0 || outb), "bad output planes");
+    const int NB = Kb * (Cb + Cbb);
+    QT_ARG(NB <= 128, "the output planes must fit one 128-column tile");
+    QT_ARG((!gHn || ld_gh >= h) && (!gCn || ld_gc >= h) && (!gO || ld_go >= h) && ld_gh % 4 == 0 && ld_gc % 4 == 0 &&
+               ld_go % 4 == 0 && ld_c % 4 == 0 && (!Cprev || ld_c >= h), "bad row stride");
+    QT_ARG((((uintptr_t)Wrows | (uintptr_t)gates | (uintptr_t)gG | (uintptr_t)out | (uintptr_t)outb) & 15) == 0, "operands must be 16-byte aligned");
+    if (N <= 0) return QT_OK;
+    DgradCellArgs g = {};
+    g.gO = gO; g.gHn = gHn; g.gCn = gCn; g.gates = gates; g.Cprev = Cprev; g.wc = wc; g.ln = ln;
+    g.ld_go = ld_go; g.ld_gh = ld_gh; g.ld_gc = ld_gc; g.ld_c = ld_c; g.h = h;
+    g.gG = gG; g.gCprev = gCprev; g.part = part; g.accumulate = accumulate;
+    g.BT = Wrows; g.M = N; g.NB = NB; g.Kb = Kb; g.Cb = Cb; g.Cbb = Cbb; g.out = out; g.outb = outb; g.n_dev = n_dev;
+    const dim3 grid(qt_cdiv(N, BM));
+    if (h == 16) {
+        if (NB <= 64) hipLaunchKernelGGL((k_dgrad_cell<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((k_dgrad_cell<4, 4>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    } else {
+        if (NB <= 64) hipLaunchKernelGGL((k_dgrad_cell<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((k_dgrad_cell<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    }
+    QT_LAUNCHED();
+    return QT_OK;
 }
 
 extern "C" int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb,

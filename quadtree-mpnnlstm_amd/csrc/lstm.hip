@@ -37,36 +37,6 @@ __global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, c
     st4(gs + 3 * h, Og);
 }
 
-// reduce NACC*4 per-thread accumulators over the workgroup; lane group layout as above
-template <int LPN, int NACC>
-__device__ __forceinline__ void block_param_reduce(float (&acc)[NACC][4], int h, float* sm, float* part_row, int accumulate) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int a = 0; a < NACC; ++a)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float v = acc[a][k];
-#pragma unroll
-            for (int d = LPN; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
-            acc[a][k] = v;
-        }
-    if (lane < LPN) {
-#pragma unroll
-        for (int a = 0; a < NACC; ++a)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sm[(wave * LPN + lane) * NACC * 4 + a * 4 + k] = acc[a][k];
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < NACC * h; idx += 256) {
-        const int a = idx / h, j = idx % h;
-        const int li = j >> 2, k = j & 3;
-        float s = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) s += sm[(w * LPN + li) * NACC * 4 + a * 4 + k];
-        part_row[idx] = accumulate ? part_row[idx] + s : s;
-    }
-}
-
 template <int LPN>
 __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, const float* __restrict__ gHn,
                                                   const float* __restrict__ gCn, const float* __restrict__ gates,
@@ -96,50 +66,13 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ gO, 
         const F4 I = ld4(gs), F = ld4(gs + h), T = ld4(gs + 2 * h), Og = ld4(gs + 3 * h);
         F4 cp = {{0, 0, 0, 0}};
         if (Cprev) cp = ld4(Cprev + node * ld_c + j0);
-        F4 Cr, Hr, tc;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            Cr.v[k] = cell_craw(F.v[k], cp.v[k], I.v[k], T.v[k]);        // not saved by the forward: same fma, same bits
-            tc.v[k] = tanhf(Cr.v[k]);
-            Hr.v[k] = Og.v[k] * tc.v[k];
-        }
         F4 gyh = {{0, 0, 0, 0}}, gyc = {{0, 0, 0, 0}};      // an output nobody used has no gradient
         if (gHn) gyh = ld4(gHn + node * ld_gh + j0);
         if (gCn) gyc = ld4(gCn + node * ld_gc + j0);
-        F4 xh = {{0, 0, 0, 0}}, xc = {{0, 0, 0, 0}};
-        F4 gHr = gyh, gCr = gyc;
-        if (ln) {
-            float rh, rc;
-            layer_norm<LPN>(Hr, h, &xh, &rh);
-            layer_norm<LPN>(Cr, h, &xc, &rc);
-            gHr = layer_norm_bwd<LPN>(gyh, gam_h, xh, rh, h);
-            gCr = layer_norm_bwd<LPN>(gyc, gam_c, xc, rc, h);
-        }
         F4 go_in = {{0, 0, 0, 0}};
         if (gO) go_in = ld4(gO + node * ld_go + j0);
-        F4 ggi, ggf, ggc, ggo, gcp;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            acc[7][k] += gyh.v[k] * xh.v[k];
-            acc[8][k] += gyh.v[k];
-            acc[9][k] += gyc.v[k] * xc.v[k];
-            acc[10][k] += gyc.v[k];
-            const float gOt = go_in.v[k] + gHr.v[k] * tc.v[k];
-            float gc_ = gCr.v[k] + gHr.v[k] * Og.v[k] * (1.0f - tc.v[k] * tc.v[k]);
-            ggo.v[k] = gOt * Og.v[k] * (1.0f - Og.v[k]);
-            gc_ += ggo.v[k] * wco.v[k];
-            ggi.v[k] = gc_ * T.v[k] * I.v[k] * (1.0f - I.v[k]);
-            ggf.v[k] = gc_ * cp.v[k] * F.v[k] * (1.0f - F.v[k]);
-            ggc.v[k] = gc_ * I.v[k] * (1.0f - T.v[k] * T.v[k]);
-            gcp.v[k] = gc_ * F.v[k] + ggi.v[k] * wci.v[k] + ggf.v[k] * wcf.v[k];
-            acc[0][k] += ggi.v[k] * cp.v[k];
-            acc[1][k] += ggf.v[k] * cp.v[k];
-            acc[2][k] += ggo.v[k] * Cr.v[k];
-            acc[3][k] += ggi.v[k];
-            acc[4][k] += ggf.v[k];
-            acc[5][k] += ggc.v[k];
-            acc[6][k] += ggo.v[k];
-        }
+        const CellBwdOut r = cell_backward<LPN>(I, F, T, Og, cp, gyh, gyc, go_in, wci, wcf, wco, gam_h, gam_c, ln != nullptr, h, acc);
+        const F4 &ggi = r.ggi, &ggf = r.ggf, &ggc = r.ggc, &ggo = r.ggo, &gcp = r.gcp;
         float* gg = gG + node * 4 * h + j0;
         st4(gg, ggi);
         st4(gg + h, ggf);

@@ -105,4 +105,86 @@ __device__ __forceinline__ CellOut cell_forward(const F4& gi, const F4& gf, cons
     return r;
 }
 
+// Backward of one cell update for 4 hidden units of a node (lane group as in cell_forward).  acc[11][4] collects this
+// thread's parameter-gradient terms: w_c i, f, o | b i, f, c, o | LayerNorm gamma_h, beta_h, gamma_c, beta_c.
+struct CellBwdOut {
+    F4 ggi, ggf, ggc, ggo, gcp;
+};
+template <int LPN>
+__device__ __forceinline__ CellBwdOut cell_backward(const F4& I, const F4& F, const F4& T, const F4& Og, const F4& cp,
+                                                    const F4& gyh, const F4& gyc, const F4& go_in, const F4& wci,
+                                                    const F4& wcf, const F4& wco, const F4& gam_h, const F4& gam_c,
+                                                    bool has_ln, int h, float (&acc)[11][4]) {
+    F4 Cr, Hr, tc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        Cr.v[k] = cell_craw(F.v[k], cp.v[k], I.v[k], T.v[k]);        // not saved by the forward: same fma, same bits
+        tc.v[k] = tanhf(Cr.v[k]);
+        Hr.v[k] = Og.v[k] * tc.v[k];
+    }
+    F4 xh = {{0, 0, 0, 0}}, xc = {{0, 0, 0, 0}};
+    F4 gHr = gyh, gCr = gyc;
+    if (has_ln) {
+        float rh, rc;
+        layer_norm<LPN>(Hr, h, &xh, &rh);
+        layer_norm<LPN>(Cr, h, &xc, &rc);
+        gHr = layer_norm_bwd<LPN>(gyh, gam_h, xh, rh, h);
+        gCr = layer_norm_bwd<LPN>(gyc, gam_c, xc, rc, h);
+    }
+    CellBwdOut o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        acc[7][k] += gyh.v[k] * xh.v[k];
+        acc[8][k] += gyh.v[k];
+        acc[9][k] += gyc.v[k] * xc.v[k];
+        acc[10][k] += gyc.v[k];
+        const float gOt = go_in.v[k] + gHr.v[k] * tc.v[k];
+        float gc_ = gCr.v[k] + gHr.v[k] * Og.v[k] * (1.0f - tc.v[k] * tc.v[k]);
+        o.ggo.v[k] = gOt * Og.v[k] * (1.0f - Og.v[k]);
+        gc_ += o.ggo.v[k] * wco.v[k];
+        o.ggi.v[k] = gc_ * T.v[k] * I.v[k] * (1.0f - I.v[k]);
+        o.ggf.v[k] = gc_ * cp.v[k] * F.v[k] * (1.0f - F.v[k]);
+        o.ggc.v[k] = gc_ * I.v[k] * (1.0f - T.v[k] * T.v[k]);
+        o.gcp.v[k] = gc_ * F.v[k] + o.ggi.v[k] * wci.v[k] + o.ggf.v[k] * wcf.v[k];
+        acc[0][k] += o.ggi.v[k] * cp.v[k];
+        acc[1][k] += o.ggf.v[k] * cp.v[k];
+        acc[2][k] += o.ggo.v[k] * Cr.v[k];
+        acc[3][k] += o.ggi.v[k];
+        acc[4][k] += o.ggf.v[k];
+        acc[5][k] += o.ggc.v[k];
+        acc[6][k] += o.ggo.v[k];
+    }
+    return o;
+}
+
+// reduce NACC*4 per-thread accumulators over a 256-thread workgroup into part_row[NACC * h]; sm: 4 * LPN * NACC * 4 floats
+template <int LPN, int NACC>
+__device__ __forceinline__ void block_param_reduce(float (&acc)[NACC][4], int h, float* sm, float* part_row, int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = acc[a][k];
+#pragma unroll
+            for (int d = LPN; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+            acc[a][k] = v;
+        }
+    if (lane < LPN) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sm[(wave * LPN + lane) * NACC * 4 + a * 4 + k] = acc[a][k];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NACC * h; idx += 256) {
+        const int a = idx / h, j = idx % h;
+        const int li = j >> 2, k = j & 3;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += sm[(w * LPN + li) * NACC * 4 + a * 4 + k];
+        part_row[idx] = accumulate ? part_row[idx] + s : s;
+    }
+}
+
 }  // namespace qtcell

@@ -50,12 +50,14 @@ _SIGNATURES = {
     'qt_attn_edge_attrs': [_P, _P, _P, _I, _P, _P, _P, _P],
     'qt_attn_fwd': [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _P, _P],
     'qt_attn_bwd': [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    'qt_lstm_dgrad_blocks': [_I],
+    'qt_lstm_bwd_dgrad': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P],
     'qt_compose2_fwd': [_P] * 8 + [_I] * 4 + [_P, _P, _P, _P, _P],
     'qt_compose2_bwd': [_P] * 8 + [_I] * 4 + [_P] * 11,
     'qt_head_fwd': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P],
     'qt_head_bwd': [_P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
 }
-_PLAIN = {'qt_abi_version', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_attn_blocks'}  # return a value, not an error code
+_PLAIN = {'qt_abi_version', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_lstm_dgrad_blocks', 'qt_attn_blocks'}  # return a value, not an error code
 
 _lib = None
 

@@ -2,6 +2,8 @@
 
 Every op runs on the GPU through libqtmpnn_hip.so; there is no CPU fallback.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -251,7 +253,28 @@ def _w_t(W, acc):
     return Wt
 
 
-def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW):
+def _dgrad_weight(W, K, Cs, live, acc):
+    """(Wb, skinny): the rows of W that multiply the column parts `live` of [T_0 .. T_{K-1}] -- the data gradient is
+    G @ Wb^T, and the GEMM stages (Wb^T)^T = Wb's own rows: no transposed copy at all (except for <= 16 output columns,
+    which the skinny VALU kernel reads as a plain (Co, K Cl) matrix: then Wb is that transpose)."""
+    C, Co = sum(Cs), W.shape[1]
+    Cl = [Cs[i] for i in live]
+    skinny = K * sum(Cl) <= 16
+    key = f'wb{live[0]}{len(live)}{int(skinny)}'
+    Wb = acc.wt.get(key) if acc is not None else None
+    if Wb is None:
+        Wb = W[:K * C]
+        if len(live) < len(Cs):
+            lo = sum(Cs[:live[0]])
+            Wb = Wb.view(K, C, Co)[:, lo:lo + Cs[live[0]]].reshape(-1, Co)     # shared by every use in this pass
+        if skinny:
+            Wb = Wb.t().contiguous()
+        if acc is not None:
+            acc.wt[key] = Wb
+    return Wb, skinny
+
+
+def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, gTs_pre=None):
     """(gZ parts, gW) of Y = [T_0 .. T_{K-1} | S] W from G = dL/dY (N, Co)."""
     N = Zs[0].shape[0]
     Cs = [Z.shape[1] for Z in Zs]
@@ -264,26 +287,16 @@ def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW):
         # only the column parts whose input wants a gradient are propagated (the encoder's X is data: the K-1 Clenshaw
         # launches of its cells then carry H's 16 channels alone, and the data-gradient GEMM is narrower)
         live = [i for i, f in enumerate(need) if f]
-        # the data gradient multiplies by W^T, and the GEMM stages (W^T)^T = W's own rows: no transposed copy at all
-        # (except for <= 16 output columns, which the skinny VALU kernel reads as a plain (Co, K Cl) matrix)
         Cl = [Cs[i] for i in live]
-        skinny = K * sum(Cl) <= 16
-        key = f'wb{live[0]}{len(live)}{int(skinny)}'
-        Wb = acc.wt.get(key) if acc is not None else None
-        if Wb is None:
-            Wb = W[:K * C]
-            if len(live) < len(Zs):
-                lo = sum(Cs[:live[0]])
-                Wb = Wb.view(K, C, Co)[:, lo:lo + Cs[live[0]]].reshape(-1, Co)     # shared by every use in this pass
-            if skinny:
-                Wb = Wb.t().contiguous()
-            if acc is not None:
-                acc.wt[key] = Wb
-        gTs = [Zs[0].new_empty(K, N, c) for c in Cl]
-        _lib.call('qt_dense2', ptr(G), 0, None, None, 0, None, 1, Co, 0, ptr(Wb) if skinny else None,
-                  None if skinny else ptr(Wb), None, 0, None, K, Cl[0],
-                  Cl[1] if len(Cl) > 1 else 0, N, ptr(mesh.n_dev), ACT_NONE, None, 0, None, ptr(gTs[0]),
-                  ptr(gTs[1]) if len(Cl) > 1 else None)
+        if gTs_pre is not None:
+            gTs = gTs_pre                      # already computed together with G (qt_lstm_bwd_dgrad)
+        else:
+            Wb, skinny = _dgrad_weight(W, K, Cs, live, acc)
+            gTs = [Zs[0].new_empty(K, N, c) for c in Cl]
+            _lib.call('qt_dense2', ptr(G), 0, None, None, 0, None, 1, Co, 0, ptr(Wb) if skinny else None,
+                      None if skinny else ptr(Wb), None, 0, None, K, Cl[0],
+                      Cl[1] if len(Cl) > 1 else 0, N, ptr(mesh.n_dev), ACT_NONE, None, 0, None, ptr(gTs[0]),
+                      ptr(gTs[1]) if len(Cl) > 1 else None)
         # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
         for k in range(K - 2, 0, -1):
             spmm2(mesh, [g[k + 1] for g in gTs], 2.0, [g[k] for g in gTs], 1.0,
@@ -611,20 +624,30 @@ class _LstmCell(Function):
         return (*_lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, ctx.mesh, ctx.acc, ctx.use_idx), None, None)
 
 
-def _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, mesh, acc, use_idx):
-    """(gG, gCprev, g_wc, g_b, g_ln) of the cell; the parameter gradients are None until the pass's last backward."""
+def _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, mesh, acc, use_idx, dgrad=None):
+    """(gG, gCprev, g_wc, g_b, g_ln) of the cell; the parameter gradients are None until the pass's last backward.
+    dgrad = (Wrows, K, [part widths], [plane tensors (K, N, c)]): the data gradient of the gate GEMM, gG @ Wrows^T, is
+    computed by the same launch (qt_lstm_bwd_dgrad) into the given planes."""
     N, h = gates.shape[0], gates.shape[1] // 4
     (gHn, ld_gh), (gCn, ld_gc) = _rows(gHn), _rows(gCn)
     (gO, ld_go), (Cprev, ld_c) = _rows(gO), _rows(Cprev)
     gG = torch.empty_like(gates)
     gCp = gates.new_empty(N, h) if Cprev is not None else None
+    rows_of = lambda n: max(_lib.value('qt_lstm_bwd_blocks', n, h), _lib.value('qt_lstm_dgrad_blocks', n), 1)
     if acc is None:
-        nblk = max(_lib.value('qt_lstm_bwd_blocks', N, h), 1)
-        part = gates.new_empty(nblk, 11 * h)
+        nblk = rows_of(N)
+        part = gates.new_empty(nblk, 11 * h) if dgrad is None else gates.new_zeros(nblk, 11 * h)
     else:
-        nblk = max(_lib.value('qt_lstm_bwd_blocks', mesh.B * mesh.P, h), 1)
+        nblk = rows_of(max(mesh.B * mesh.P, N))      # one slab for every use of the pass, whichever kernel serves it
         part = acc.slab(gates, nblk, 11 * h)
-    if N > 0:
+    if N > 0 and dgrad is not None:
+        Wrows, K, Cl, planes = dgrad
+        _lib.call('qt_lstm_bwd_dgrad', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Cprev), ld_c,
+                  ptr(wc), ptr(ln), N, ptr(mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part), 0 if acc is None else 1,
+                  ptr(Wrows), K, Cl[0], Cl[1] if len(Cl) > 1 else 0, ptr(planes[0]), ptr(planes[1]) if len(Cl) > 1 else None)
+    elif N > 0:
+        if acc is None and nblk > _lib.value('qt_lstm_bwd_blocks', N, h):
+            part.zero_()
         _lib.call('qt_lstm_bwd', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Cprev),
                   ld_c, ptr(wc), ptr(ln), N, ptr(mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part), 0 if acc is None else 1)
     if acc is not None and not acc.leave(use_idx):
@@ -674,9 +697,20 @@ class _GateCell(Function):
         saved = ctx.saved_tensors
         Zs, TZs = list(saved[:nz]), list(saved[nz:2 * nz])
         W, gates, Cprev, wc, ln = saved[2 * nz:]
-        gG, gCp, gwc, gb, gln = _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, ctx.mesh, ctx.acc_p, ctx.use_p)
-        gZs, gW = _cheb_backward(Zs, TZs, W, gG, ctx.mesh, ctx.K, ctx.Ks, ctx.acc_w, ctx.use_w,
-                                 list(ctx.needs_input_grad[:nz]), ctx.needs_input_grad[2])
+        need = list(ctx.needs_input_grad[:nz])
+        K, N, h = ctx.K, gates.shape[0], gates.shape[1] // 4
+        Cs = [Z.shape[1] for Z in Zs]
+        live = [i for i, f in enumerate(need) if f]
+        NB = K * sum(Cs[i] for i in live)
+        dgrad = planes = None
+        if N > 0 and live and h in (8, 16) and 16 < NB <= 128 and os.environ.get('QT_NO_DGRAD_FUSION') != '1':
+            # the cell backward and the data gradient of the gate GEMM in one launch: gG feeds the MFMA loop from LDS
+            Wb, _ = _dgrad_weight(W, K, Cs, live, ctx.acc_w)
+            planes = [Zs[0].new_empty(K, N, Cs[i]) for i in live]
+            dgrad = (Wb, K, [Cs[i] for i in live], planes)
+        gG, gCp, gwc, gb, gln = _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, ctx.mesh, ctx.acc_p, ctx.use_p, dgrad)
+        gZs, gW = _cheb_backward(Zs, TZs, W, gG, ctx.mesh, K, ctx.Ks, ctx.acc_w, ctx.use_w, need, ctx.needs_input_grad[2],
+                                 gTs_pre=planes)
         gZa = gZs[0] if gZs is not None else None
         gZb = gZs[1] if gZs is not None and nz > 1 else None
         return gZa, gZb, gW, gCp, gwc, gb, gln, None, None, None, None, None

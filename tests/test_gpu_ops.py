@@ -413,8 +413,22 @@ def test_fused_gate_cell_equals_gemm_then_cell(with_c, h):
         grads = torch.autograd.grad(outs, ins, gs)
         return [o.detach() for o in outs] + list(grads)
 
-    for a, r in zip(run(True), run(False)):
-        assert torch.equal(a, r)
+    import os
+    names = ['O', 'H', 'C'] + [n for n, t in zip(('gZ', 'gW', 'gCp', 'gwc', 'gb', 'gln'), (Z, W, Cp, wc, b, ln)) if t is not None]
+    os.environ['QT_NO_DGRAD_FUSION'] = '1'            # backward as qt_lstm_bwd + qt_dense2: everything bit for bit
+    try:
+        for a, r, n in zip(run(True), run(False), names):
+            assert torch.equal(a, r), n
+    finally:
+        del os.environ['QT_NO_DGRAD_FUSION']
+    # default backward: the cell backward and the data gradient in one launch (qt_lstm_bwd_dgrad, h = 8 / 16).  Node-sized
+    # results stay bit-identical; the parameter partials are summed per 128-node workgroup instead of per grid-stride
+    # sweep, so the cell's parameter gradients agree to fp32 rounding only.
+    for a, r, n in zip(run(True), run(False), names):
+        if n in ('gwc', 'gb', 'gln'):
+            close(a, r, 1e-4, 1e-4 * float(r.abs().max()), msg=n)
+        else:
+            assert torch.equal(a, r), n
 
 
 def test_spmm_two_row_strided_parts_equal_one_matrix():
