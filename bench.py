@@ -50,7 +50,9 @@ def make_predictor(device, capturable=False):
     torch.manual_seed(1)
     nfp = NextFramePredictorS2S(thresh=THRESH, input_features=1, input_timesteps=T_IN, output_timesteps=T_OUT,
                                 device=device, model_kwargs=dict(hidden_size=HIDDEN, dropout=DROPOUT, n_layers=N_LAYERS))
-    nfp.initiate_training(lr=LR, lr_decay=0.95, capturable=capturable)
+    # QT_BENCH_LR=0 freezes the model (diagnostics: the meshes of the decoder then stay the same over a run, which makes
+    # A/B comparisons of kernels independent of the training trajectory); the bench itself always trains at LR
+    nfp.initiate_training(lr=float(os.environ.get('QT_BENCH_LR', LR)), lr_decay=0.95, capturable=capturable)
     return nfp
 
 

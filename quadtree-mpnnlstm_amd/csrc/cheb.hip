@@ -870,6 +870,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_cell(DgradCellArgs g) {
     const int64_t i0 = (int64_t)blockIdx.x * BM;
     const int64_t rows = qt_rows(g.n_dev, g.M);
     const int h = g.h;
+    if (i0 >= rows) return;        // past the valid rows: nothing to add to the partials (the slab rows start at zero)
     // W chunk (all of it: K = 4h fits one pass) -> LDS; independent of the cell phase below
     for (int e = t; e < BNT * (K / 4); e += 256) {
         const int c = e / (K / 4), kq = e - c * (K / 4);
@@ -877,7 +878,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_cell(DgradCellArgs g) {
         if (c < g.NB) w = *reinterpret_cast<const float4*>(g.BT + (int64_t)c * K + 4 * kq);
         *reinterpret_cast<float4*>(&Bt[c * PITCH + 4 * kq]) = w;
     }
-    // cell backward of this workgroup's rows (a workgroup past the valid rows contributes zeros to the parameter partials)
+    // cell backward of this workgroup's rows (rows past the valid count contribute zeros)
     {
         const int j0 = (t % LPN) * 4;
         const F4 wci = ld4(g.wc + j0), wcf = ld4(g.wc + h + j0), wco = ld4(g.wc + 2 * h + j0);
@@ -919,7 +920,6 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_cell(DgradCellArgs g) {
         block_param_reduce<LPN, 11>(acc, h, sm, g.part + (int64_t)blockIdx.x * 11 * h, g.accumulate);
     }
     __syncthreads();                                 // Bt, As complete
-    if (i0 >= rows) return;
     f32x16 acc2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
