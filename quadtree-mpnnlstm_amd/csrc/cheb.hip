@@ -1134,11 +1134,14 @@ extern "C" int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, i
     g.gG = gG; g.gCprev = gCprev; g.part = part; g.accumulate = accumulate;
     g.BT = Wrows; g.M = N; g.NB = NB; g.Kb = Kb; g.Cb = Cb; g.Cbb = Cbb; g.out = out; g.outb = outb; g.n_dev = n_dev;
     const dim3 grid(qt_cdiv(N, BM));
+    // 32-column MFMA tiles: as many as the output planes need (K' C = 80 or 96 columns take three, not four)
     if (h == 16) {
         if (NB <= 64) hipLaunchKernelGGL((k_dgrad_cell<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        else if (NB <= 96) hipLaunchKernelGGL((k_dgrad_cell<3, 4>), grid, dim3(256), 0, (hipStream_t)stream, g);
         else hipLaunchKernelGGL((k_dgrad_cell<4, 4>), grid, dim3(256), 0, (hipStream_t)stream, g);
     } else {
         if (NB <= 64) hipLaunchKernelGGL((k_dgrad_cell<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        else if (NB <= 96) hipLaunchKernelGGL((k_dgrad_cell<3, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
         else hipLaunchKernelGGL((k_dgrad_cell<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
     }
     QT_LAUNCHED();
