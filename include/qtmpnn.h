@@ -288,21 +288,27 @@ int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, cons
                 const int32_t* rev, float* coef /* optional scratch (E + N, 2): the target pass leaves (alpha, alpha t) per edge
                 and the source pass reads them through rev instead of recomputing the scores */, int E, void* stream);
 
-/* ---------------------------------------------------------------- gate-weight packing of two-layer ChebConv stacks
+/* ---------------------------------------------------------------- gate-weight packing of stacked ChebConvs
  * A GraphConv stack applies its ChebConvs with no nonlinearity in between (model/model.py:59-97, :95-96), so the eight
- * stacks of a GConvLSTM (model/model.py:263-463) with TWO layers each are one Chebyshev series of order 2K-1 in weight
- * space: M[k] = sum_{a,b} (delta(a+b, k) + delta(|a-b|, k)) / 2 * W0[a] W1[b].  The entries write that series straight into
- * the packed gate matrix qt_dense_lstm multiplies with: rows k*C + c for Z = [X (cin_pad) | H (h)], then pad4(K) bias rows
- * (the first layer's bias through the second layer, orders 0..K-1, + the second layer's bias at order 0, x and h branches
- * summed); columns gate-major i, f, c, o.
- *   P?0 (4, K, in, h): first-layer lins^T per gate (in = cin for x, h for h); P?1 (4, K, h, h); B?? (4, h).
- *   W1: variant with H, ((2K-1)(cin_pad + h) + pad4(K), 4h); W0: without H, ((2K-1) cin_pad + pad4(K), 4h); either may be NULL.
- * qt_compose2_bwd: gradients of all eight inputs from gW1 / gW0 (either may be NULL). */
+ * stacks of a GConvLSTM (model/model.py:263-463) are Chebyshev series in weight space, composed layer by layer:
+ *   M[k] = sum_{a,b} (delta(a+b, k) + delta(|a-b|, k)) / 2 * P[a] W[b],   orders Ka + K - 1.
+ * qt_compose_step: one branch, natural layout -- series P0 (4, Ka, in, h) with bias series B0 (4, Kb0, h) through the layer
+ *   P1 (4, K, h, h), B1 (4, h) -> P (4, Ka + K - 1, in, h), B (4, Kb0 + K - 1, h) (the layer's bias joins order 0).
+ * qt_compose2: the LAST product of both branches (x: in = cin, h: in = h), written straight into the packed gate matrix
+ *   qt_dense_lstm multiplies with: rows k*C + c for Z = [X (cin_pad) | H (h)], then pad4(Kb0 + K - 1) bias rows (x and h
+ *   branches summed); columns gate-major i, f, c, o.  W1: variant with H, ((Ka+K-1)(cin_pad + h) + pad4(..), 4h); W0: without
+ *   H; WT1 / WT0: their transposes; any of them may be NULL.  Two layers per stack: Ka = K, Kb0 = 1, no step.
+ * The _bwd entries return the gradients of all inputs (compose2: from gW1 / gW0, either may be NULL). */
+int qt_compose_step_fwd(const float* P0, const float* B0, const float* P1, const float* B1, int Ka, int Kb0, int K, int in,
+                        int h, float* P, float* B, void* stream);
+int qt_compose_step_bwd(const float* P0, const float* B0, const float* P1, const float* B1, int Ka, int Kb0, int K, int in,
+                        int h, const float* gP, const float* gB, float* gP0, float* gB0, float* gP1, float* gB1,
+                        void* stream);
 int qt_compose2_fwd(const float* Px0, const float* Bx0, const float* Px1, const float* Bx1, const float* Ph0,
-                    const float* Bh0, const float* Ph1, const float* Bh1, int K, int cin, int cin_pad, int h,
+                    const float* Bh0, const float* Ph1, const float* Bh1, int Ka, int Kb0, int K, int cin, int cin_pad, int h,
                     float* W1, float* W0, float* WT1 /* optional transposes, (4h, rows) */, float* WT0, void* stream);
 int qt_compose2_bwd(const float* Px0, const float* Bx0, const float* Px1, const float* Bx1, const float* Ph0,
-                    const float* Bh0, const float* Ph1, const float* Bh1, int K, int cin, int cin_pad, int h,
+                    const float* Bh0, const float* Ph1, const float* Bh1, int Ka, int Kb0, int K, int cin, int cin_pad, int h,
                     const float* gW1, const float* gW0, float* gPx0, float* gBx0, float* gPx1, float* gBx1,
                     float* gPh0, float* gBh0, float* gPh1, float* gBh1, void* stream);
 

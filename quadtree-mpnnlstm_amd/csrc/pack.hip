@@ -1,28 +1,30 @@
-// Gate-weight packing of a GConvLSTM whose eight GraphConv stacks hold TWO ChebConvs each (model/model.py:59-97, no
-// nonlinearity in between, :95-96): the stacks are composed in weight space into one Chebyshev series of order 2K-1,
-//   T_a T_b = (T_{a+b} + T_|a-b|) / 2   =>   M[k] = sum_{a,b} cf(k,a,b) W0[a] W1[b],
-// and written straight into the packed gate matrix W ((2K-1) C + pad4(K), 4h) that k_gemm_fwd multiplies [T_k(L^) Z | T_k(L^) 1]
-// with (Z = [X | H], columns = gate-major i, f, c, o).  The first layer's bias rides through the second layer as a
-// series of its own (orders 0 .. K-1) and lands in the bias rows next to the second layer's bias.
+// Gate-weight packing of a GConvLSTM whose eight GraphConv stacks hold SEVERAL ChebConvs each (model/model.py:59-97, no
+// nonlinearity in between, :95-96): the stacks are composed in weight space into one Chebyshev series,
+//   T_a T_b = (T_{a+b} + T_|a-b|) / 2   =>   M[k] = sum_{a,b} cf(k,a,b) P[a] W[b],
+// layer by layer.  k_compose_step does one such product for one branch in the natural layout (series (4, Ka, in, h) times
+// layer (4, K, h, h) -> series (4, Ka + K - 1, in, h), with the bias series riding along); k_compose2 does the LAST product
+// of both branches and writes it straight into the packed gate matrix W (K' C + pad4(bias orders), 4h) that k_gemm_fwd
+// multiplies [T_k(L^) Z | T_k(L^) 1] with (Z = [X | H], columns gate-major i, f, c, o).  Two layers per stack (the
+// reference's default) are one k_compose2 launch; L layers are L - 2 steps per branch and one k_compose2.
 //
-// Parameter-sized work (a few thousand outputs of a few hundred FMAs): one launch forward, one backward, instead of the
-// ~110 bmm / pad / cat / slice kernels the same algebra costs through torch ops and their autograd (0.3 ms per step).
+// Parameter-sized work (a few thousand outputs of a few hundred FMAs): one launch forward, one backward per product,
+// instead of the ~110 bmm / pad / cat / slice kernels the same algebra costs through torch ops and their autograd.
 #include "qt_common.h"
 
 namespace {
 
 struct Branch {
-    const float* P0;   // (4, K, in, h)   first-layer lins^T per gate
-    const float* B0;   // (4, h)
-    const float* P1;   // (4, K, h, h)    second layer
+    const float* P0;   // (4, Ka, in, h)   series so far (first layer: lins^T per gate, Ka = K)
+    const float* B0;   // (4, Kb0, h)      its bias series (first layer: Kb0 = 1)
+    const float* P1;   // (4, K, h, h)     next layer
     const float* B1;   // (4, h)
 };
 
 struct ComposeArgs {
     Branch x, hb;
-    int K, cin, cin_pad, h;
-    float* W1;         // variant with H: ((2K-1)(cin_pad + h) + ksp, 4h), or NULL
-    float* W0;         // variant without H: ((2K-1) cin_pad + ksp, 4h), or NULL
+    int Ka, Kb0, K, cin, cin_pad, h;
+    float* W1;         // variant with H: (K2 (cin_pad + h) + ksp, 4h), or NULL
+    float* W0;         // variant without H: (K2 cin_pad + ksp, 4h), or NULL
     float* WT1;        // the transposes (4h, rows), optional: what the gate GEMM stages its weight chunk from
     float* WT0;
     // backward
@@ -31,18 +33,28 @@ struct ComposeArgs {
     float *gxP0, *gxB0, *gxP1, *gxB1, *ghP0, *ghB0, *ghP1, *ghB1;
 };
 
+struct StepArgs {      // one branch, natural layout
+    Branch b;
+    int Ka, Kb0, K, in, h;
+    float* P;          // (4, Ka + K - 1, in, h)
+    float* B;          // (4, Kb0 + K - 1, h)
+    const float* gP;
+    const float* gB;
+    float *gP0, *gB0, *gP1, *gB1;
+};
+
 __device__ __forceinline__ float cf(int k, int a, int b) {
     return 0.5f * (float)((a + b == k) + ((a > b ? a - b : b - a) == k));
 }
 
 // M[g, k, c, p] of one branch
-__device__ float series_elem(const Branch& br, int g, int k, int c, int p, int in, int K, int h) {
+__device__ float series_elem(const Branch& br, int g, int k, int c, int p, int in, int Ka, int K, int h) {
     float s = 0.0f;
-    for (int a = 0; a < K; ++a)
+    for (int a = 0; a < Ka; ++a)
         for (int b = 0; b < K; ++b) {
             const float f = cf(k, a, b);
             if (f == 0.0f) continue;
-            const float* r0 = br.P0 + ((int64_t)(g * K + a) * in + c) * h;
+            const float* r0 = br.P0 + ((int64_t)(g * Ka + a) * in + c) * h;
             const float* r1 = br.P1 + (int64_t)(g * K + b) * h * h + p;
             float d = 0.0f;
             for (int o = 0; o < h; ++o) d = fmaf(r0[o], r1[(int64_t)o * h], d);
@@ -51,16 +63,24 @@ __device__ float series_elem(const Branch& br, int g, int k, int c, int p, int i
     return s;
 }
 
-// bias series order k (< K) of one branch: B0 through W1[k], plus B1 at order 0
-__device__ float bias_elem(const Branch& br, int g, int k, int p, int K, int h) {
-    const float* r1 = br.P1 + (int64_t)(g * K + k) * h * h + p;
-    float d = 0.0f;
-    for (int o = 0; o < h; ++o) d = fmaf(br.B0[g * h + o], r1[(int64_t)o * h], d);
-    return k == 0 ? d + br.B1[g * h + p] : d;
+// bias series order k (< Kb0 + K - 1) of one branch: the bias series so far through the layer, plus its bias at order 0
+__device__ float bias_elem(const Branch& br, int g, int k, int p, int Kb0, int K, int h) {
+    float s = 0.0f;
+    for (int a = 0; a < Kb0; ++a)
+        for (int b = 0; b < K; ++b) {
+            const float f = cf(k, a, b);
+            if (f == 0.0f) continue;
+            const float* r0 = br.B0 + (int64_t)(g * Kb0 + a) * h;
+            const float* r1 = br.P1 + (int64_t)(g * K + b) * h * h + p;
+            float d = 0.0f;
+            for (int o = 0; o < h; ++o) d = fmaf(r0[o], r1[(int64_t)o * h], d);
+            s = fmaf(f, d, s);
+        }
+    return k == 0 ? s + br.B1[g * h + p] : s;
 }
 
 __global__ __launch_bounds__(256) void k_compose2_fwd(ComposeArgs A) {
-    const int K = A.K, K2 = 2 * K - 1, h = A.h, nc = 4 * h, ksp = (K + 3) / 4 * 4;
+    const int K = A.K, K2 = A.Ka + K - 1, Kbo = A.Kb0 + K - 1, h = A.h, nc = 4 * h, ksp = (Kbo + 3) / 4 * 4;
     const int C1 = A.cin_pad + h, C0 = A.cin_pad;
     const int n1 = A.W1 ? (K2 * C1 + ksp) * nc : 0, n0 = A.W0 ? (K2 * C0 + ksp) * nc : 0;
     int idx = blockIdx.x * 256 + threadIdx.x;
@@ -77,53 +97,69 @@ __global__ __launch_bounds__(256) void k_compose2_fwd(ComposeArgs A) {
     if (row < K2 * C) {
         const int k = row / C, c = row - k * C;
         if (c < A.cin)
-            v = series_elem(A.x, g, k, c, p, A.cin, K, h);
+            v = series_elem(A.x, g, k, c, p, A.cin, A.Ka, K, h);
         else if (c >= A.cin_pad)
-            v = series_elem(A.hb, g, k, c - A.cin_pad, p, h, K, h);
+            v = series_elem(A.hb, g, k, c - A.cin_pad, p, h, A.Ka, K, h);
     } else {
         const int k = row - K2 * C;
-        if (k < K) v = bias_elem(A.x, g, k, p, K, h) + bias_elem(A.hb, g, k, p, K, h);
+        if (k < Kbo) v = bias_elem(A.x, g, k, p, A.Kb0, K, h) + bias_elem(A.hb, g, k, p, A.Kb0, K, h);
     }
     W[idx] = v;
     if (WT) WT[(int64_t)col * rows + row] = v;
 }
 
-// dL/dM[g, k, c, p] of the x branch (both variants) / the h branch, and of the bias rows
-__device__ __forceinline__ float gw_x(const ComposeArgs& A, int k, int c, int col) {
-    const int nc = 4 * A.h;
-    float v = 0.0f;
-    if (A.gW1) v += A.gW1[(int64_t)(k * (A.cin_pad + A.h) + c) * nc + col];
-    if (A.gW0) v += A.gW0[(int64_t)(k * A.cin_pad + c) * nc + col];
-    return v;
-}
-__device__ __forceinline__ float gw_h(const ComposeArgs& A, int k, int c, int col) {
-    return A.gW1 ? A.gW1[(int64_t)(k * (A.cin_pad + A.h) + A.cin_pad + c) * (4 * A.h) + col] : 0.0f;
-}
-__device__ __forceinline__ float gw_b(const ComposeArgs& A, int k, int col) {
-    const int nc = 4 * A.h, K2 = 2 * A.K - 1;
-    float v = 0.0f;
-    if (A.gW1) v += A.gW1[(int64_t)(K2 * (A.cin_pad + A.h) + k) * nc + col];
-    if (A.gW0) v += A.gW0[(int64_t)(K2 * A.cin_pad + k) * nc + col];
-    return v;
+__global__ __launch_bounds__(256) void k_compose_step_fwd(StepArgs A) {
+    const int K2 = A.Ka + A.K - 1, Kbo = A.Kb0 + A.K - 1, h = A.h;
+    const int nP = 4 * K2 * A.in * h, nB = 4 * Kbo * h;
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < nP) {
+        const int p = idx % h, c = (idx / h) % A.in, k = (idx / (h * A.in)) % K2, g = idx / (h * A.in * K2);
+        A.P[idx] = series_elem(A.b, g, k, c, p, A.in, A.Ka, A.K, h);
+        return;
+    }
+    idx -= nP;
+    if (idx < nB) {
+        const int p = idx % h, k = (idx / h) % Kbo, g = idx / (h * Kbo);
+        A.B[idx] = bias_elem(A.b, g, k, p, A.Kb0, A.K, h);
+    }
 }
 
-template <bool HB>
-__device__ __forceinline__ float gw_m(const ComposeArgs& A, int k, int c, int col) {
-    return HB ? gw_h(A, k, c, col) : gw_x(A, k, c, col);
-}
+// dL/dM[g, k, c, p] and dL/dbias-series[k, g, p] as the two output layouts hold them
+struct PackedGrad {            // packed gate matrices (both variants summed)
+    const float *gW1, *gW0;
+    int cin_pad, h, K2;
+    bool hb;
+    __device__ __forceinline__ float gm(int k, int c, int g, int p) const {
+        const int nc = 4 * h, col = g * h + p;
+        if (hb) return gW1 ? gW1[(int64_t)(k * (cin_pad + h) + cin_pad + c) * nc + col] : 0.0f;
+        float v = 0.0f;
+        if (gW1) v += gW1[(int64_t)(k * (cin_pad + h) + c) * nc + col];
+        if (gW0) v += gW0[(int64_t)(k * cin_pad + c) * nc + col];
+        return v;
+    }
+    __device__ __forceinline__ float gb(int k, int g, int p) const {
+        const int nc = 4 * h, col = g * h + p;
+        float v = 0.0f;
+        if (gW1) v += gW1[(int64_t)(K2 * (cin_pad + h) + k) * nc + col];
+        if (gW0) v += gW0[(int64_t)(K2 * cin_pad + k) * nc + col];
+        return v;
+    }
+};
+struct NaturalGrad {           // (4, K2, in, h) and (4, Kbo, h)
+    const float *gP, *gB;
+    int in, h, K2, Kbo;
+    __device__ __forceinline__ float gm(int k, int c, int g, int p) const { return gP[((int64_t)(g * K2 + k) * in + c) * h + p]; }
+    __device__ __forceinline__ float gb(int k, int g, int p) const { return gB[(int64_t)(g * Kbo + k) * h + p]; }
+};
 
-template <bool HB>
-__device__ void branch_bwd(const ComposeArgs& A, int idx) {
-    const Branch& br = HB ? A.hb : A.x;
-    const int K = A.K, K2 = 2 * K - 1, h = A.h;
-    const int in = HB ? h : A.cin;
-    float* gP0 = HB ? A.ghP0 : A.gxP0;
-    float* gB0 = HB ? A.ghB0 : A.gxB0;
-    float* gP1 = HB ? A.ghP1 : A.gxP1;
-    float* gB1 = HB ? A.ghB1 : A.gxB1;
-    const int nP0 = 4 * K * in * h, nP1 = 4 * K * h * h, nB = 4 * h;
+// gradient element `idx` of one branch's four inputs, laid out [gP0 | gP1 | gB0 | gB1]
+template <class G>
+__device__ void branch_bwd(const Branch& br, const G& gr, int Ka, int Kb0, int K, int in, int h, float* gP0, float* gB0,
+                           float* gP1, float* gB1, int idx) {
+    const int K2 = Ka + K - 1, Kbo = Kb0 + K - 1;
+    const int nP0 = 4 * Ka * in * h, nP1 = 4 * K * h * h, nB0 = 4 * Kb0 * h, nB1 = 4 * h;
     if (idx < nP0) {                         // gP0[g, a, c, o] = sum_{b, k} cf sum_p gM[g, k, c, p] P1[g, b, o, p]
-        const int o = idx % h, c = (idx / h) % in, a = (idx / (h * in)) % K, g = idx / (h * in * K);
+        const int o = idx % h, c = (idx / h) % in, a = (idx / (h * in)) % Ka, g = idx / (h * in * Ka);
         float s = 0.0f;
         for (int b = 0; b < K; ++b)
             for (int k = 0; k < K2; ++k) {
@@ -131,62 +167,87 @@ __device__ void branch_bwd(const ComposeArgs& A, int idx) {
                 if (f == 0.0f) continue;
                 const float* r1 = br.P1 + ((int64_t)(g * K + b) * h + o) * h;
                 float d = 0.0f;
-                for (int p = 0; p < h; ++p) d = fmaf(gw_m<HB>(A, k, c, g * h + p), r1[p], d);
+                for (int p = 0; p < h; ++p) d = fmaf(gr.gm(k, c, g, p), r1[p], d);
                 s = fmaf(f, d, s);
             }
         gP0[idx] = s;
         return;
     }
     idx -= nP0;
-    if (idx < nP1) {                         // gP1[g, b, o, p] = sum_{a, k} cf sum_c P0[g, a, c, o] gM[g, k, c, p] + B0[g, o] gBias[b, g, p]
+    if (idx < nP1) {           // gP1[g, b, o, p] = sum_{a, k} cf (sum_c P0[g, a, c, o] gM[g, k, c, p]) + sum_{a, k} cf B0[g, a, o] gBias[k, g, p]
         const int p = idx % h, o = (idx / h) % h, b = (idx / (h * h)) % K, g = idx / (h * h * K);
         float s = 0.0f;
-        for (int a = 0; a < K; ++a)
+        for (int a = 0; a < Ka; ++a)
             for (int k = 0; k < K2; ++k) {
                 const float f = cf(k, a, b);
                 if (f == 0.0f) continue;
-                const float* r0 = br.P0 + (int64_t)(g * K + a) * in * h + o;
+                const float* r0 = br.P0 + (int64_t)(g * Ka + a) * in * h + o;
                 float d = 0.0f;
-                for (int c = 0; c < in; ++c) d = fmaf(r0[(int64_t)c * h], gw_m<HB>(A, k, c, g * h + p), d);
+                for (int c = 0; c < in; ++c) d = fmaf(r0[(int64_t)c * h], gr.gm(k, c, g, p), d);
                 s = fmaf(f, d, s);
             }
-        gP1[idx] = fmaf(br.B0[g * h + o], gw_b(A, b, g * h + p), s);
+        for (int a = 0; a < Kb0; ++a)
+            for (int k = 0; k < Kbo; ++k) {
+                const float f = cf(k, a, b);
+                if (f != 0.0f) s = fmaf(f * br.B0[(int64_t)(g * Kb0 + a) * h + o], gr.gb(k, g, p), s);
+            }
+        gP1[idx] = s;
         return;
     }
     idx -= nP1;
-    if (idx < nB) {                          // gB0[g, o] = sum_{k < K, p} gBias[k, g, p] P1[g, k, o, p]
-        const int o = idx % h, g = idx / h;
+    if (idx < nB0) {                         // gB0[g, a, o] = sum_{b, k} cf sum_p gBias[k, g, p] P1[g, b, o, p]
+        const int o = idx % h, a = (idx / h) % Kb0, g = idx / (h * Kb0);
         float s = 0.0f;
-        for (int k = 0; k < K; ++k) {
-            const float* r1 = br.P1 + ((int64_t)(g * K + k) * h + o) * h;
-            for (int p = 0; p < h; ++p) s = fmaf(gw_b(A, k, g * h + p), r1[p], s);
-        }
+        for (int b = 0; b < K; ++b)
+            for (int k = 0; k < Kbo; ++k) {
+                const float f = cf(k, a, b);
+                if (f == 0.0f) continue;
+                const float* r1 = br.P1 + ((int64_t)(g * K + b) * h + o) * h;
+                float d = 0.0f;
+                for (int p = 0; p < h; ++p) d = fmaf(gr.gb(k, g, p), r1[p], d);
+                s = fmaf(f, d, s);
+            }
         gB0[idx] = s;
         return;
     }
-    idx -= nB;
-    if (idx < nB) gB1[idx] = gw_b(A, 0, idx);
+    idx -= nB0;
+    if (idx < nB1) gB1[idx] = gr.gb(0, idx / h, idx % h);
+}
+
+__device__ __forceinline__ int branch_count(int Ka, int Kb0, int K, int in, int h) {
+    return 4 * Ka * in * h + 4 * K * h * h + 4 * Kb0 * h + 4 * h;
 }
 
 __global__ __launch_bounds__(256) void k_compose2_bwd(ComposeArgs A) {
-    const int K = A.K, h = A.h;
-    const int nx = 4 * K * A.cin * h + 4 * K * h * h + 8 * h, nh = 8 * K * h * h + 8 * h;
+    const int nx = branch_count(A.Ka, A.Kb0, A.K, A.cin, A.h), nh = branch_count(A.Ka, A.Kb0, A.K, A.h, A.h);
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < nx)
-        branch_bwd<false>(A, idx);
-    else if (idx < nx + nh)
-        branch_bwd<true>(A, idx - nx);
+    PackedGrad gr = {A.gW1, A.gW0, A.cin_pad, A.h, A.Ka + A.K - 1, false};
+    if (idx < nx) {
+        branch_bwd(A.x, gr, A.Ka, A.Kb0, A.K, A.cin, A.h, A.gxP0, A.gxB0, A.gxP1, A.gxB1, idx);
+    } else if (idx < nx + nh) {
+        gr.hb = true;
+        branch_bwd(A.hb, gr, A.Ka, A.Kb0, A.K, A.h, A.h, A.ghP0, A.ghB0, A.ghP1, A.ghB1, idx - nx);
+    }
 }
 
-int check(const char* fn, const ComposeArgs& A) {
-    const Branch* b[2] = {&A.x, &A.hb};
-    for (int i = 0; i < 2; ++i)
-        if (!b[i]->P0 || !b[i]->B0 || !b[i]->P1 || !b[i]->B1) {
-            qt_set_error("%s: null weight pointer", fn);
-            return QT_E_ARG;
-        }
-    if (A.K < 1 || A.K > 8 || A.h < 1 || A.cin < 1 || A.cin_pad < A.cin || A.cin_pad % 4 || A.h % 4) {
-        qt_set_error("%s: bad sizes (K in 1..8, cin <= cin_pad, cin_pad and h multiples of 4)", fn);
+__global__ __launch_bounds__(256) void k_compose_step_bwd(StepArgs A) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= branch_count(A.Ka, A.Kb0, A.K, A.in, A.h)) return;
+    const NaturalGrad gr = {A.gP, A.gB, A.in, A.h, A.Ka + A.K - 1, A.Kb0 + A.K - 1};
+    branch_bwd(A.b, gr, A.Ka, A.Kb0, A.K, A.in, A.h, A.gP0, A.gB0, A.gP1, A.gB1, idx);
+}
+
+int check_branch(const char* fn, const Branch& b) {
+    if (!b.P0 || !b.B0 || !b.P1 || !b.B1) {
+        qt_set_error("%s: null weight pointer", fn);
+        return QT_E_ARG;
+    }
+    return QT_OK;
+}
+
+int check_sizes(const char* fn, int Ka, int Kb0, int K, int in, int h) {
+    if (Ka < 1 || Ka > 32 || Kb0 < 1 || Kb0 > Ka || K < 1 || K > 8 || in < 1 || h < 4 || h % 4) {
+        qt_set_error("%s: bad sizes (Ka in 1..32, Kb0 in 1..Ka, K in 1..8, h a multiple of 4)", fn);
         return QT_E_ARG;
     }
     return QT_OK;
@@ -195,15 +256,19 @@ int check(const char* fn, const ComposeArgs& A) {
 }  // namespace
 
 extern "C" int qt_compose2_fwd(const float* Px0, const float* Bx0, const float* Px1, const float* Bx1, const float* Ph0,
-                               const float* Bh0, const float* Ph1, const float* Bh1, int K, int cin, int cin_pad, int h,
-                               float* W1, float* W0, float* WT1, float* WT0, void* stream) {
+                               const float* Bh0, const float* Ph1, const float* Bh1, int Ka, int Kb0, int K, int cin,
+                               int cin_pad, int h, float* W1, float* W0, float* WT1, float* WT0, void* stream) {
     ComposeArgs A = {};
     A.x = {Px0, Bx0, Px1, Bx1};
     A.hb = {Ph0, Bh0, Ph1, Bh1};
-    A.K = K; A.cin = cin; A.cin_pad = cin_pad; A.h = h; A.W1 = W1; A.W0 = W0; A.WT1 = W1 ? WT1 : nullptr; A.WT0 = W0 ? WT0 : nullptr;
-    if (int rc = check(__func__, A)) return rc;
+    A.Ka = Ka; A.Kb0 = Kb0; A.K = K; A.cin = cin; A.cin_pad = cin_pad; A.h = h;
+    A.W1 = W1; A.W0 = W0; A.WT1 = W1 ? WT1 : nullptr; A.WT0 = W0 ? WT0 : nullptr;
+    if (int rc = check_branch(__func__, A.x)) return rc;
+    if (int rc = check_branch(__func__, A.hb)) return rc;
+    if (int rc = check_sizes(__func__, Ka, Kb0, K, cin, h)) return rc;
+    QT_ARG(cin_pad >= cin && cin_pad % 4 == 0, "cin_pad must be a multiple of 4 and >= cin");
     QT_ARG(W1 || W0, "no output requested");
-    const int K2 = 2 * K - 1, ksp = (K + 3) / 4 * 4, nc = 4 * h;
+    const int K2 = Ka + K - 1, ksp = (Kb0 + K - 1 + 3) / 4 * 4, nc = 4 * h;
     const int64_t n = (W1 ? (int64_t)(K2 * (cin_pad + h) + ksp) * nc : 0) + (W0 ? (int64_t)(K2 * cin_pad + ksp) * nc : 0);
     hipLaunchKernelGGL(k_compose2_fwd, dim3(qt_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, A);
     QT_LAUNCHED();
@@ -211,20 +276,53 @@ extern "C" int qt_compose2_fwd(const float* Px0, const float* Bx0, const float* 
 }
 
 extern "C" int qt_compose2_bwd(const float* Px0, const float* Bx0, const float* Px1, const float* Bx1, const float* Ph0,
-                               const float* Bh0, const float* Ph1, const float* Bh1, int K, int cin, int cin_pad, int h,
-                               const float* gW1, const float* gW0, float* gPx0, float* gBx0, float* gPx1, float* gBx1,
-                               float* gPh0, float* gBh0, float* gPh1, float* gBh1, void* stream) {
+                               const float* Bh0, const float* Ph1, const float* Bh1, int Ka, int Kb0, int K, int cin,
+                               int cin_pad, int h, const float* gW1, const float* gW0, float* gPx0, float* gBx0,
+                               float* gPx1, float* gBx1, float* gPh0, float* gBh0, float* gPh1, float* gBh1, void* stream) {
     ComposeArgs A = {};
     A.x = {Px0, Bx0, Px1, Bx1};
     A.hb = {Ph0, Bh0, Ph1, Bh1};
-    A.K = K; A.cin = cin; A.cin_pad = cin_pad; A.h = h; A.gW1 = gW1; A.gW0 = gW0;
+    A.Ka = Ka; A.Kb0 = Kb0; A.K = K; A.cin = cin; A.cin_pad = cin_pad; A.h = h; A.gW1 = gW1; A.gW0 = gW0;
     A.gxP0 = gPx0; A.gxB0 = gBx0; A.gxP1 = gPx1; A.gxB1 = gBx1;
     A.ghP0 = gPh0; A.ghB0 = gBh0; A.ghP1 = gPh1; A.ghB1 = gBh1;
-    if (int rc = check(__func__, A)) return rc;
+    if (int rc = check_branch(__func__, A.x)) return rc;
+    if (int rc = check_branch(__func__, A.hb)) return rc;
+    if (int rc = check_sizes(__func__, Ka, Kb0, K, cin, h)) return rc;
+    QT_ARG(cin_pad >= cin && cin_pad % 4 == 0, "cin_pad must be a multiple of 4 and >= cin");
     QT_ARG(gW1 || gW0, "no gradient given");
     QT_ARG(gPx0 && gBx0 && gPx1 && gBx1 && gPh0 && gBh0 && gPh1 && gBh1, "null gradient pointer");
-    const int64_t n = (int64_t)4 * K * cin * h + (int64_t)12 * K * h * h + 16 * h;
+    const int64_t n = (int64_t)4 * Ka * (cin + h) * h + (int64_t)8 * K * h * h + (int64_t)8 * Kb0 * h + 8 * h;
     hipLaunchKernelGGL(k_compose2_bwd, dim3(qt_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_compose_step_fwd(const float* P0, const float* B0, const float* P1, const float* B1, int Ka, int Kb0, int K,
+                                   int in, int h, float* P, float* B, void* stream) {
+    StepArgs A = {};
+    A.b = {P0, B0, P1, B1};
+    A.Ka = Ka; A.Kb0 = Kb0; A.K = K; A.in = in; A.h = h; A.P = P; A.B = B;
+    if (int rc = check_branch(__func__, A.b)) return rc;
+    if (int rc = check_sizes(__func__, Ka, Kb0, K, in, h)) return rc;
+    QT_ARG(P && B, "null output pointer");
+    const int64_t n = (int64_t)4 * (Ka + K - 1) * in * h + (int64_t)4 * (Kb0 + K - 1) * h;
+    hipLaunchKernelGGL(k_compose_step_fwd, dim3(qt_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_compose_step_bwd(const float* P0, const float* B0, const float* P1, const float* B1, int Ka, int Kb0, int K,
+                                   int in, int h, const float* gP, const float* gB, float* gP0, float* gB0, float* gP1,
+                                   float* gB1, void* stream) {
+    StepArgs A = {};
+    A.b = {P0, B0, P1, B1};
+    A.Ka = Ka; A.Kb0 = Kb0; A.K = K; A.in = in; A.h = h; A.gP = gP; A.gB = gB;
+    A.gP0 = gP0; A.gB0 = gB0; A.gP1 = gP1; A.gB1 = gB1;
+    if (int rc = check_branch(__func__, A.b)) return rc;
+    if (int rc = check_sizes(__func__, Ka, Kb0, K, in, h)) return rc;
+    QT_ARG(gP && gB && gP0 && gB0 && gP1 && gB1, "null gradient pointer");
+    const int64_t n = (int64_t)4 * Ka * in * h + (int64_t)4 * K * h * h + (int64_t)4 * Kb0 * h + 4 * h;
+    hipLaunchKernelGGL(k_compose_step_bwd, dim3(qt_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, A);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -300,14 +300,14 @@ class GConvLSTM(nn.Module):
         if L == 1:
             K = len(self.conv_x_i.convolutions[0].lins)
             return [PackedCell(outs[f'{prefix}W{int(v)}'], K, 1, wc, b, ln, ops.GradAcc(), acc_p) for v in variants]
-        if L == 2 and wc.is_cuda:           # both branches, both variants: one launch (ops.compose2_pack)
+        if wc.is_cuda:           # composition and layout on the device: one launch per product (ops.compose_pack)
             stacks = [[outs[f'{prefix}{n}{br}{l}'] for l in range(L)] for n, br in (('P', 'x'), ('B', 'x'), ('P', 'h'), ('B', 'h'))]
-            Ws = ops.compose2_pack(*stacks, in_pad or self.in_channels, variants)
-            K, nv, cells = stacks[0][0].shape[1], len(variants), []
-            for W, WT in zip(Ws[:nv], Ws[nv:]):
+            Ws, WTs, Kc, Ksc = ops.compose_pack(*stacks, in_pad or self.in_channels, variants)
+            cells = []
+            for W, WT in zip(Ws, WTs):
                 acc_w = ops.GradAcc()
                 acc_w.wt['T'] = WT                   # the gate GEMM stages its weight chunk from the transpose
-                cells.append(PackedCell(W, 2 * K - 1, K, wc, b, ln, acc_w, acc_p))
+                cells.append(PackedCell(W, Kc, Ksc, wc, b, ln, acc_w, acc_p))
             return cells
         Px, bx = ops.compose_chebconvs([outs[f'{prefix}Px{l}'] for l in range(L)], [outs[f'{prefix}Bx{l}'] for l in range(L)])
         Ph, bh = ops.compose_chebconvs([outs[f'{prefix}Ph{l}'] for l in range(L)], [outs[f'{prefix}Bh{l}'] for l in range(L)])

@@ -52,8 +52,10 @@ _SIGNATURES = {
     'qt_attn_bwd': [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
     'qt_lstm_dgrad_blocks': [_I],
     'qt_lstm_bwd_dgrad': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P],
-    'qt_compose2_fwd': [_P] * 8 + [_I] * 4 + [_P, _P, _P, _P, _P],
-    'qt_compose2_bwd': [_P] * 8 + [_I] * 4 + [_P] * 11,
+    'qt_compose_step_fwd': [_P] * 4 + [_I] * 5 + [_P] * 3,
+    'qt_compose_step_bwd': [_P] * 4 + [_I] * 5 + [_P] * 7,
+    'qt_compose2_fwd': [_P] * 8 + [_I] * 6 + [_P, _P, _P, _P, _P],
+    'qt_compose2_bwd': [_P] * 8 + [_I] * 6 + [_P] * 11,
     'qt_head_fwd': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P],
     'qt_head_bwd': [_P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
 }

@@ -460,26 +460,62 @@ def compose_chebconvs(weights, biases):
     return P, beta
 
 
+def _series3(B):
+    return B.unsqueeze(1) if B.dim() == 2 else B          # a layer's bias (4, h) is a one-order bias series
+
+
+class _ComposeStep(Function):
+    """Series (P0 (4, Ka, in, h), bias series B0 (4, Kb0, h)) through the layer (P1 (4, K, h, h), B1 (4, h)): one product of
+    the weight-space composition, natural layout (qt_compose_step_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, P0, B0, P1, B1):
+        ins = [_c(P0.float()), _c(_series3(B0).float()), _c(P1.float()), _c(B1.float())]
+        _lib.require_cuda(ins[0], 'weight stacks')
+        _, Ka, cin, h = ins[0].shape
+        Kb0, K = ins[1].shape[1], ins[2].shape[1]
+        P = ins[0].new_empty(4, Ka + K - 1, cin, h)
+        B = ins[0].new_empty(4, Kb0 + K - 1, h)
+        _lib.call('qt_compose_step_fwd', *[ptr(t) for t in ins], Ka, Kb0, K, cin, h, ptr(P), ptr(B))
+        ctx.save_for_backward(*ins)
+        ctx.b0_shape = B0.shape
+        return P, B
+
+    @staticmethod
+    def backward(ctx, gP, gB):
+        ins = ctx.saved_tensors
+        _, Ka, cin, h = ins[0].shape
+        Kb0, K = ins[1].shape[1], ins[2].shape[1]
+        gP = _c(gP) if gP is not None else torch.zeros(4, Ka + K - 1, cin, h, device=ins[0].device)
+        gB = _c(gB) if gB is not None else torch.zeros(4, Kb0 + K - 1, h, device=ins[0].device)
+        outs = [torch.empty_like(t) for t in ins]
+        _lib.call('qt_compose_step_bwd', *[ptr(t) for t in ins], Ka, Kb0, K, cin, h, ptr(gP), ptr(gB), *[ptr(t) for t in outs])
+        outs[1] = outs[1].view(ctx.b0_shape)
+        return tuple(outs)
+
+
 class _Compose2(Function):
-    """Packed gate matrices of a GConvLSTM with two ChebConvs per stack, straight from the per-layer weight stacks
-    (qt_compose2_fwd / _bwd: one launch each way).  Same algebra as compose_chebconvs + the row / column layout of
-    GConvLSTM._assemble, which remain the reference implementation (and the path for other depths).
-    variants: tuple of with_h flags, one output each."""
+    """Packed gate matrices of a GConvLSTM from the (folded) series of its x and h branches and their LAST layers, straight
+    into the layout the gate GEMM multiplies with (qt_compose2_fwd / _bwd: one launch each way).  Same algebra as
+    compose_chebconvs + the row / column layout of GConvLSTM._assemble, which remain the reference implementation.
+    variants: tuple of with_h flags; returns W per variant, then W^T per variant."""
 
     @staticmethod
     def forward(ctx, Px0, Bx0, Px1, Bx1, Ph0, Bh0, Ph1, Bh1, cin_pad, variants):
-        ins = [_c(t.float()) for t in (Px0, Bx0, Px1, Bx1, Ph0, Bh0, Ph1, Bh1)]
+        ins = [_c(t.float()) for t in (Px0, _series3(Bx0), Px1, Bx1, Ph0, _series3(Bh0), Ph1, Bh1)]
         _lib.require_cuda(ins[0], 'weight stacks')
-        _, K, cin, h = ins[0].shape
-        assert ins[2].shape == (4, K, h, h) and ins[4].shape == (4, K, h, h) and ins[6].shape == (4, K, h, h)
-        K2, ksp = 2 * K - 1, (K + 3) // 4 * 4
+        _, Ka, cin, h = ins[0].shape
+        Kb0, K = ins[1].shape[1], ins[2].shape[1]
+        assert ins[2].shape == (4, K, h, h) and ins[4].shape == (4, Ka, h, h) and ins[6].shape == (4, K, h, h)
+        assert ins[5].shape[1] == Kb0
+        K2, ksp = Ka + K - 1, (Kb0 + K - 1 + 3) // 4 * 4
         W1 = ins[0].new_empty(K2 * (cin_pad + h) + ksp, 4 * h) if True in variants else None
         W0 = ins[0].new_empty(K2 * cin_pad + ksp, 4 * h) if False in variants else None
         WT1 = W1.new_empty(W1.shape[1], W1.shape[0]) if W1 is not None else None
         WT0 = W0.new_empty(W0.shape[1], W0.shape[0]) if W0 is not None else None
-        _lib.call('qt_compose2_fwd', *[ptr(t) for t in ins], K, cin, cin_pad, h, ptr(W1), ptr(W0), ptr(WT1), ptr(WT0))
+        _lib.call('qt_compose2_fwd', *[ptr(t) for t in ins], Ka, Kb0, K, cin, cin_pad, h, ptr(W1), ptr(W0), ptr(WT1), ptr(WT0))
         ctx.save_for_backward(*ins)
-        ctx.cin_pad, ctx.variants = cin_pad, tuple(variants)
+        ctx.cin_pad, ctx.variants, ctx.b_shapes = cin_pad, tuple(variants), (Bx0.shape, Bh0.shape)
         ctx.set_materialize_grads(False)
         outs = tuple(W1 if v else W0 for v in variants) + tuple(WT1 if v else WT0 for v in variants)
         ctx.mark_non_differentiable(*outs[len(variants):])
@@ -488,20 +524,32 @@ class _Compose2(Function):
     @staticmethod
     def backward(ctx, *gWs):
         ins = ctx.saved_tensors
-        _, K, cin, h = ins[0].shape
+        _, Ka, cin, h = ins[0].shape
+        Kb0, K = ins[1].shape[1], ins[2].shape[1]
         g = {v: (_c(gw) if gw is not None else None) for v, gw in zip(ctx.variants, gWs)}        # (the transposes have none)
         if all(v is None for v in g.values()):
             return (None,) * 10
         outs = [torch.empty_like(t) for t in ins]
-        _lib.call('qt_compose2_bwd', *[ptr(t) for t in ins], K, cin, ctx.cin_pad, h, ptr(g.get(True)), ptr(g.get(False)),
+        _lib.call('qt_compose2_bwd', *[ptr(t) for t in ins], Ka, Kb0, K, cin, ctx.cin_pad, h, ptr(g.get(True)), ptr(g.get(False)),
                   *[ptr(t) for t in outs])
+        outs[1], outs[5] = outs[1].view(ctx.b_shapes[0]), outs[5].view(ctx.b_shapes[1])
         return (*outs, None, None)
 
 
-def compose2_pack(Px, Bx, Ph, Bh, cin_pad, variants):
-    """[W per variant] + [W^T per variant] from the two layers' stacks of the x and h branches: Px = [Px0 (4, K, cin, h), Px1 (4, K, h, h)],
-    Bx = [Bx0, Bx1] (4, h) each, likewise Ph, Bh."""
-    return _Compose2.apply(Px[0], Bx[0], Px[1], Bx[1], Ph[0], Bh[0], Ph[1], Bh[1], cin_pad, tuple(variants))
+def compose_pack(Px, Bx, Ph, Bh, cin_pad, variants):
+    """([W per variant], [W^T per variant], K', Ks) from the per-layer stacks of the x and h branches (L >= 2 layers each):
+    Px[l] (4, K, in_l, h), Bx[l] (4, h), likewise Ph, Bh.  Layers 0 .. L-2 fold into one series per branch
+    (qt_compose_step), the last product lands in the packed layout (qt_compose2)."""
+    def fold(Ps, Bs):
+        P, B = Ps[0], Bs[0]
+        for Wl, bl in zip(Ps[1:-1], Bs[1:-1]):
+            P, B = _ComposeStep.apply(P, B, Wl, bl)
+        return P, B
+    (Pxf, Bxf), (Phf, Bhf) = fold(Px, Bx), fold(Ph, Bh)
+    outs = _Compose2.apply(Pxf, Bxf, Px[-1], Bx[-1], Phf, Bhf, Ph[-1], Bh[-1], cin_pad, tuple(variants))
+    nv = len(variants)
+    K = Px[-1].shape[1]
+    return outs[:nv], outs[nv:], Pxf.shape[1] + K - 1, _series3(Bxf).shape[1] + K - 1
 
 
 _COMB = {}

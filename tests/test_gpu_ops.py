@@ -463,10 +463,11 @@ def test_concat_cols_kernel():
     assert torch.equal(ga, g[:, :4]) and torch.equal(gb, g[:, 4:20]) and torch.equal(gc, g[:, 20:])
 
 
-@pytest.mark.parametrize('cin,in_pad,K', [(4, 4, 3), (5, 8, 3), (4, 4, 2)])
-def test_compose2_kernel_equals_torch_composition(cin, in_pad, K):
-    """qt_compose2_fwd / _bwd (two-layer stacks composed and laid out as the packed gate matrix in one launch) == the torch
-    composition (ops.compose_chebconvs + GConvLSTM._assemble) for both variants: values and every parameter gradient,
+@pytest.mark.parametrize('cin,in_pad,K,L', [(4, 4, 3, 2), (5, 8, 3, 2), (4, 4, 2, 2), (8, 8, 3, 3), (5, 8, 2, 4)])
+def test_compose2_kernel_equals_torch_composition(cin, in_pad, K, L):
+    """qt_compose_step / qt_compose2 (L-layer stacks composed in weight space, the last product laid out as the packed gate
+    matrix: one launch per product) == the torch composition (ops.compose_chebconvs + GConvLSTM._assemble) for both
+    variants: values and every parameter gradient,
     fp32 tolerance rtol 1e-4 / atol 1e-5 (sums of <= 9 products of 16-term dot products, different summation order)."""
     from model.model import CONVOLUTION_KWARGS, GConvLSTM
     from qtmpnn import ops
@@ -474,7 +475,7 @@ def test_compose2_kernel_equals_torch_composition(cin, in_pad, K):
     old = dict(CONVOLUTION_KWARGS['ChebConv'])
     CONVOLUTION_KWARGS['ChebConv']['K'] = K
     try:
-        cell = GConvLSTM(cin, 16, 2, 'ChebConv').to(dev())
+        cell = GConvLSTM(cin, 16, L, 'ChebConv').to(dev())
     finally:
         CONVOLUTION_KWARGS['ChebConv'].update(old)
     for p in cell.parameters():
