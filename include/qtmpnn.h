@@ -125,11 +125,12 @@ int qt_pool(const float* img, int S, int64_t img_clip_stride /* floats between c
 
 /* qt_pool's mesh -> mesh transfer with the source node values given as up to 8 matrices side by side (host arrays of nparts
  * device pointers, widths and row strides, all multiples of 4): the state [out | H_0 .. | C_0 ..] is transferred across a
- * re-mesh (model/seq2seq.py:440-442, 474-477) without being concatenated first.  out: dense (N, sum widths). */
+ * re-mesh (model/seq2seq.py:440-442, 474-477) without being concatenated first.  The result is written as nout dense
+ * matrices (N, out_widths[i]) side by side (same total width): every consumer of a state part then reads dense rows. */
 int qt_remesh(const float* const* src_parts, const int* widths, const int* lds, int nparts,
               const int32_t* src_labels, const float* src_npix, int src_inv, const int32_t* labels, const uint8_t* level,
-              const float* npix, int mean, int B, int n, int m, int N, const int32_t* cell, const int32_t* n_dev, float* out,
-              void* stream);
+              const float* npix, int mean, int B, int n, int m, int N, const int32_t* cell, const int32_t* n_dev,
+              float* const* out_parts, const int* out_widths, int nout, void* stream);
 
 /* masked MSE, model/mpnnlstm.py:243-246: partial[b*ntile + tile] = sum over the tile's unmasked pixels of
  * (out[labels[p]] - y[p])^2 ; y (B, n*m).  Pixels with label < 0 are the masked ones. */

@@ -29,6 +29,8 @@ struct PoolArgs {
     int B, n, m, N;
     float* out;
     int out_stride, out_coff;
+    float* opart[8];         // mesh -> mesh: the result as up to 8 dense matrices side by side (widths as float4 prefix
+    int opart_w[8], opart_end[8], noparts;   // opart_end), so that every consumer reads dense rows; 0: one matrix `out`
     int tiles_r, tiles_c;
     const int32_t* cell;     // (N, 4) r, c, size, clip: given -> nodes up to 4x4 pixels go through k_pool_nodes
     const int32_t* n_dev;
@@ -47,6 +49,15 @@ __device__ __forceinline__ const float* src_chunk(const PoolArgs& a, int64_t sl,
     int s = 0;
     while (ch >= a.part_end[s]) ++s;
     return a.part[s] + sl * a.part_ld[s] + (ch - (s ? a.part_end[s - 1] : 0)) * 4;
+}
+
+// address of channel chunk `ch` of output node `node` (step s)
+template <int VEC>
+__device__ __forceinline__ float* dst_chunk(const PoolArgs& a, int s, int64_t node, int ch) {
+    if (VEC == 1 || a.noparts == 0) return a.out + ((int64_t)s * a.N + node) * a.out_stride + a.out_coff + ch * VEC;
+    int o = 0;
+    while (ch >= a.opart_end[o]) ++o;
+    return a.opart[o] + node * a.opart_w[o] + (ch - (o ? a.opart_end[o - 1] : 0)) * 4;
 }
 
 template <int VEC>
@@ -119,7 +130,6 @@ __global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
     const int total = (a.src_labels ? 1 : a.S) * nch;
     for (int it = blockIdx.y; it < total; it += gridDim.y) {
         const int s = it / nch, ch = it % nch;
-        float* outp = a.out + (int64_t)s * a.N * a.out_stride + a.out_coff + ch * VEC;
         Vec<VEC> val[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const unsigned lv = (lv_pack[q >> 2] >> (8 * (q & 3))) & 0xff;
-            if (lab[q] >= 0 && lv == 0) vstore<VEC>(outp + (int64_t)lab[q] * a.out_stride, val[q], 1.0f);
+            if (lab[q] >= 0 && lv == 0) vstore<VEC>(dst_chunk<VEC>(a, s, lab[q], ch), val[q], 1.0f);
         }
         // 2x2 and 4x4 sums in registers
         Vec<VEC> s2;
@@ -164,10 +174,10 @@ __global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
                 }
                 const unsigned lv = (lv_pack[2 * i2] >> (8 * (2 * j2))) & 0xff;
                 if (lab[q0] >= 0 && lv == 1)
-                    vstore<VEC>(outp + (int64_t)lab[q0] * a.out_stride, s1, a.mean ? 1.0f / a.npix[lab[q0]] : 1.0f);
+                    vstore<VEC>(dst_chunk<VEC>(a, s, lab[q0], ch), s1, a.mean ? 1.0f / a.npix[lab[q0]] : 1.0f);
             }
         if (lab[0] >= 0 && (lv_pack[0] & 0xff) == 2)
-            vstore<VEC>(outp + (int64_t)lab[0] * a.out_stride, s2, a.mean ? 1.0f / a.npix[lab[0]] : 1.0f);
+            vstore<VEC>(dst_chunk<VEC>(a, s, lab[0], ch), s2, a.mean ? 1.0f / a.npix[lab[0]] : 1.0f);
 
         if (any_big) {
             // LDS pyramid: level 2 (16x16) -> 3 (8x8) -> 4 (4x4) -> 5 (2x2) -> 6 (1)
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
                         const int64_t p = (int64_t)r * a.m + c;
                         const int lb = lab_img[p];
                         if (lb >= 0 && lvl_img[p] == L)
-                            vstore<VEC>(outp + (int64_t)lb * a.out_stride, acc, a.mean ? 1.0f / a.npix[lb] : 1.0f);
+                            vstore<VEC>(dst_chunk<VEC>(a, s, lb, ch), acc, a.mean ? 1.0f / a.npix[lb] : 1.0f);
                     }
                 }
                 __syncthreads();
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
                 for (int k = 0; k < VEC; ++k) acc.v[k] += x.v[k];
             }
         }
-    vstore<VEC>(a.out + (int64_t)s * a.N * a.out_stride + i * a.out_stride + a.out_coff + ch * VEC, acc,
+    vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), acc,
                 a.mean ? 1.0f / a.npix[i] : 1.0f);
 }
 
@@ -375,8 +385,9 @@ extern "C" int qt_pool(const float* img, int S, int64_t img_clip_stride, const f
 extern "C" int qt_remesh(const float* const* src_parts, const int* widths, const int* lds, int nparts,
                          const int32_t* src_labels, const float* src_npix, int src_inv, const int32_t* labels,
                          const uint8_t* level, const float* npix, int mean, int B, int n, int m, int N, const int32_t* cell,
-                         const int32_t* n_dev, float* out, void* stream) {
-    QT_ARG(src_parts && widths && lds && nparts >= 1 && nparts <= 8 && src_labels && labels && level && out && B > 0, "bad arguments");
+                         const int32_t* n_dev, float* const* out_parts, const int* out_widths, int nout, void* stream) {
+    QT_ARG(src_parts && widths && lds && nparts >= 1 && nparts <= 8 && src_labels && labels && level && B > 0, "bad arguments");
+    QT_ARG(out_parts && out_widths && nout >= 1 && nout <= 8, "bad output parts");
     QT_ARG(!mean || npix, "mean pooling needs npix");
     QT_ARG(!src_inv || src_npix, "src_inv needs src_npix");
     PoolArgs a = {};
@@ -394,7 +405,19 @@ extern "C" int qt_remesh(const float* const* src_parts, const int* widths, const
     if (N <= 0) return QT_OK;
     a.img = nullptr; a.S = 1; a.img_clip_stride = 0; a.src_val = src_parts[0]; a.src_labels = src_labels; a.src_npix = src_npix;
     a.src_inv = src_inv; a.C = 4 * c4; a.labels = labels; a.level = level; a.npix = npix; a.mean = mean;
-    a.B = B; a.n = n; a.m = m; a.N = N; a.out = out; a.out_stride = 4 * c4; a.out_coff = 0;
+    int o4 = 0;
+    for (int i = 0; i < nout; ++i) {
+        QT_ARG(out_parts[i] && out_widths[i] > 0 && out_widths[i] % 4 == 0 && ((uintptr_t)out_parts[i] & 15) == 0,
+               "output parts must be 16-byte aligned with widths that are multiples of 4");
+        a.opart[i] = out_parts[i];
+        a.opart_w[i] = out_widths[i];
+        o4 += out_widths[i] / 4;
+        a.opart_end[i] = o4;
+    }
+    for (int i = nout; i < 8; ++i) { a.opart[i] = nullptr; a.opart_w[i] = 0; a.opart_end[i] = o4; }
+    QT_ARG(o4 == c4, "the output parts must add up to the source width");
+    a.noparts = nout > 1 ? nout : 0;
+    a.B = B; a.n = n; a.m = m; a.N = N; a.out = out_parts[0]; a.out_stride = 4 * c4; a.out_coff = 0;
     a.tiles_r = qt_cdiv(n, 64); a.tiles_c = qt_cdiv(m, 64);
     return pool_launch(a, true, cell, n_dev, (hipStream_t)stream);
 }

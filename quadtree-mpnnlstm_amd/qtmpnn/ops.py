@@ -919,44 +919,48 @@ def gather_pixels(val, mesh):
     return _Gather.apply(val, mesh)
 
 
-def _remesh_raw(dst, src, parts, out, src_inv, mean):
-    """out (dst.N, sum widths) = per-node reduction over dst's pixels of [parts...][src.labels[p]] (qt_remesh)."""
+def _remesh_raw(dst, src, parts, outs, src_inv, mean):
+    """outs (dense (dst.N, w) matrices, side by side) = per-node reduction over dst's pixels of [parts...][src.labels[p]]
+    (qt_remesh)."""
     import ctypes
-    n = len(parts)
+    n, no = len(parts), len(outs)
     ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in parts])
     widths = (ctypes.c_int * n)(*[t.shape[1] for t in parts])
     lds = (ctypes.c_int * n)(*[_ld(t) for t in parts])
+    optrs = (ctypes.c_void_p * no)(*[t.data_ptr() for t in outs])
+    owidths = (ctypes.c_int * no)(*[t.shape[1] for t in outs])
     _lib.call('qt_remesh', ptrs, widths, lds, n, ptr(src.labels), ptr(src.npix), int(src_inv), ptr(dst.labels), ptr(dst.level),
-              ptr(dst.npix), int(mean), dst.B, dst.n, dst.m, dst.N, ptr(dst.cell), ptr(dst.n_dev), ptr(out))
+              ptr(dst.npix), int(mean), dst.B, dst.n, dst.m, dst.N, ptr(dst.cell), ptr(dst.n_dev), optrs, owidths, no)
 
 
 class _Remesh(Function):
     """State transfer between meshes: new node = mean over its pixels of the old node value (unflatten + flatten of
     model/seq2seq.py:440-442, 474-477 fused; no image is materialised).  The state is given as up to 8 matrices side by
-    side (row-strided column views welcome) and comes back as column views of ONE transferred matrix, split by
-    `out_widths`: neither the forward nor the backward concatenates anything."""
+    side (row-strided column views welcome) and comes back as dense matrices split by `out_widths` (gradients likewise):
+    neither direction concatenates anything, and every consumer of a state part reads dense rows (as 64-byte column slices
+    of one 272-byte-pitch matrix the same parts cost the gate kernels 5 % more)."""
 
     @staticmethod
     def forward(ctx, old, new, out_widths, *vals):
         parts = [_rows(v.float())[0] for v in vals]
         C = sum(t.shape[1] for t in parts)
         assert sum(out_widths) == C and len(parts) <= 8 and len(out_widths) <= 8
-        out = parts[0].new_empty(new.N, C)
+        outs = [parts[0].new_empty(new.N, w) for w in out_widths]
         if new.N > 0:
-            _remesh_raw(new, old, parts, out, False, True)
+            _remesh_raw(new, old, parts, outs, False, True)
         ctx.old, ctx.new, ctx.in_widths, ctx.out_widths = old, new, [t.shape[1] for t in parts], out_widths
         ctx.set_materialize_grads(False)
-        return tuple(out.split(list(out_widths), dim=1))
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gs):
         old, new = ctx.old, ctx.new
         ref = next(g for g in gs if g is not None)
         parts = [_rows(g)[0] if g is not None else ref.new_zeros(new.N, w) for g, w in zip(gs, ctx.out_widths)]
-        gval = ref.new_empty(old.N, sum(ctx.in_widths))
+        gvals = [ref.new_empty(old.N, w) for w in ctx.in_widths]
         if old.N > 0:
-            _remesh_raw(old, new, parts, gval, True, False)
-        return (None, None, None, *gval.split(ctx.in_widths, dim=1))
+            _remesh_raw(old, new, parts, gvals, True, False)
+        return (None, None, None, *gvals)
 
 
 def remesh_transfer(vals, old, new, out_widths=None):
