@@ -148,10 +148,12 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ gZ, 
 __global__ void k_act_bwd(const float* __restrict__ gY, const float* __restrict__ Y, const float* __restrict__ res, int rs,
                           const float* __restrict__ drop, int act, int Ncap, const int32_t* __restrict__ n_dev, int Co,
                           float* __restrict__ G, float* __restrict__ gres) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row = idx / Co;
-    if (row >= qt_rows(n_dev, Ncap)) return;
-    const int c = (int)(idx - row * Co);
+    // 32-bit thread index and division (the launcher checks N * Co < 2^31): a 64-bit division by a run-time value is a
+    // ~100-instruction routine per thread
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned row = idx / (unsigned)Co;
+    if ((int)row >= qt_rows(n_dev, Ncap)) return;
+    const int c = (int)(idx - row * (unsigned)Co);
     const float g = gY[idx], y = Y[idx];
     float o;
     if (act == QT_ACT_RELU) {
@@ -173,10 +175,10 @@ struct ConcatArgs {
     int nsrc, C4;
 };
 __global__ void k_concat(ConcatArgs a, int Ncap, const int32_t* __restrict__ n_dev, float* __restrict__ out) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row = idx / a.C4;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;          // (N * C4 < 2^31 checked by the launcher)
+    const int64_t row = idx / (unsigned)a.C4;
     if (row >= qt_rows(n_dev, Ncap)) return;
-    const int q = (int)(idx - row * a.C4);
+    const int q = (int)(idx - (unsigned)row * (unsigned)a.C4);
     int s = 0;
     while (q >= a.c4_end[s]) ++s;
     const int q0 = s ? a.c4_end[s - 1] : 0;
@@ -279,6 +281,7 @@ extern "C" int qt_act_bwd(const float* gY, const float* Y, const float* res, int
                           const int32_t* n_dev, int Co, float* G, float* gres, void* stream) {
     QT_ARG(gY && Y && G && Co >= 1, "null pointer");
     QT_ARG(act == QT_ACT_RELU || (act == QT_ACT_TANH_RES && res && res_stride >= 1 && res_stride <= Co), "bad activation arguments");
+    QT_ARG((int64_t)N * Co + 256 < ((int64_t)1 << 31), "N * Co too large for 32-bit thread indices");
     if (N <= 0) return QT_OK;
     hipLaunchKernelGGL(k_act_bwd, dim3(qt_cdiv((int64_t)N * Co, 256)), dim3(256), 0, (hipStream_t)stream, gY, Y, res, res_stride,
                        drop, act, N, n_dev, Co, G, gres);
@@ -302,6 +305,7 @@ extern "C" int qt_concat(const float* const* srcs, const int* widths, const int*
     for (int i = nsrc; i < 8; ++i) { a.src[i] = nullptr; a.ld[i] = 0; a.c4_end[i] = c4; }
     a.nsrc = nsrc;
     a.C4 = c4;
+    QT_ARG((int64_t)N * c4 + 256 < ((int64_t)1 << 31), "N * C too large for 32-bit thread indices");
     if (N <= 0) return QT_OK;
     hipLaunchKernelGGL(k_concat, dim3(qt_cdiv((int64_t)N * c4, 256)), dim3(256), 0, (hipStream_t)stream, a, N, n_dev, out);
     QT_LAUNCHED();

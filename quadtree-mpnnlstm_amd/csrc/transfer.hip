@@ -224,10 +224,12 @@ template <int VEC>
 __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
     const int nch = a.C / VEC;
     const int per = (a.src_labels ? 1 : a.S) * nch;
-    const int64_t idx = (int64_t)blockIdx.x * QT_NODES_BS + threadIdx.x;
-    const int64_t i = idx / per;
+    // 32-bit thread index and division (pool_launch checks N * per < 2^31): the 64-bit division by a run-time value that
+    // stood here is a ~100-instruction routine per thread
+    const unsigned idx = blockIdx.x * QT_NODES_BS + threadIdx.x;
+    const int64_t i = idx / (unsigned)per;
     if (i >= qt_rows(a.n_dev, a.N)) return;
-    const int rem = (int)(idx - i * per);
+    const int rem = (int)(idx - (unsigned)i * (unsigned)per);
     const int s = rem / nch, ch = rem - s * nch;
     const int4 cl = reinterpret_cast<const int4*>(a.cell)[i];
     if (cl.z > 4) return;
@@ -264,8 +266,15 @@ __global__ void k_gather(const float* __restrict__ val, int C, const int32_t* __
     const int nch = C / VEC;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total * nch) return;
-    const int64_t p = idx / nch;
-    const int ch = (int)(idx % nch);
+    int64_t p;
+    int ch;
+    if (total * nch < ((int64_t)1 << 31)) {          // 32-bit division whenever the index fits (uniform branch)
+        p = (unsigned)idx / (unsigned)nch;
+        ch = (int)((unsigned)idx - (unsigned)p * (unsigned)nch);
+    } else {
+        p = idx / nch;
+        ch = (int)(idx % nch);
+    }
     const int lab = labels[p];
     Vec<VEC> x;
 #pragma unroll
@@ -305,10 +314,10 @@ __global__ __launch_bounds__(256) void k_sse(const float* __restrict__ out, int 
 __global__ void k_sse_bwd(const float* __restrict__ out, int out_stride, const float* __restrict__ npix,
                           const float* __restrict__ sy, const float* __restrict__ g, int Ncap, const int32_t* __restrict__ n_dev,
                           int W, float* __restrict__ gout) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t i = idx / W;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;          // (N * W < 2^31 checked by the launcher)
+    const int64_t i = idx / (unsigned)W;
     if (i >= qt_rows(n_dev, Ncap)) return;
-    gout[idx] = (idx - i * W) == 0 ? 2.0f * g[0] * (npix[i] * out[i * out_stride] - sy[i]) : 0.0f;
+    gout[idx] = (idx - (unsigned)i * (unsigned)W) == 0 ? 2.0f * g[0] * (npix[i] * out[i * out_stride] - sy[i]) : 0.0f;
 }
 
 }  // namespace
@@ -316,6 +325,7 @@ __global__ void k_sse_bwd(const float* __restrict__ out, int out_stride, const f
 extern "C" int qt_sse_bwd(const float* out, int out_stride, const float* npix, const float* sy, const float* g, int N,
                           const int32_t* n_dev, int W, float* gout, void* stream) {
     QT_ARG(out && npix && sy && g && gout && W >= 1 && out_stride >= 1, "bad arguments");
+    QT_ARG((int64_t)N * W + 256 < ((int64_t)1 << 31), "N * W too large for 32-bit thread indices");
     if (N <= 0) return QT_OK;
     hipLaunchKernelGGL(k_sse_bwd, dim3(qt_cdiv((int64_t)N * W, 256)), dim3(256), 0, (hipStream_t)stream, out, out_stride, npix,
                        sy, g, N, n_dev, W, gout);
@@ -327,6 +337,10 @@ static int pool_launch(PoolArgs& a, bool v4, const int32_t* cell, const int32_t*
     const int total = a.S * (v4 ? a.C / 4 : a.C);
     a.cell = cell; a.n_dev = n_dev; a.big_only = cell != nullptr;
     if (cell) {
+        if ((int64_t)a.N * total + QT_NODES_BS >= ((int64_t)1 << 31)) {
+            qt_set_error("%s: N * channels too large for 32-bit thread indices", __func__);
+            return QT_E_ARG;
+        }
         const int grid = qt_cdiv((int64_t)a.N * total, QT_NODES_BS);
         if (v4)
             hipLaunchKernelGGL(k_pool_nodes<4>, dim3(grid), dim3(QT_NODES_BS), 0, stream, a);
