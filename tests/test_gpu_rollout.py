@@ -167,6 +167,47 @@ def test_graphed_step_matches_eager_steps():
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
 
 
+def test_graphed_transformerconv_step_matches_eager_steps():
+    """a training step with convolution_type='TransformerConv' captures into a hipGraph (edge attributes
+    built once per mesh on the device, weights packed once per pass) and replays to the eager losses; with attention
+    dropout on, replays draw new masks (the losses of two replays on the same batch differ), eager or graphed."""
+    from model.mpnnlstm import NextFramePredictorS2S
+    from qtmpnn import synthetic
+    x, y = synthetic.make_batch(1, 0, 2, 3, 3, n_digits=1, pixel_noise=0.02)
+    x2, y2 = synthetic.make_batch(1, 50, 2, 3, 3, n_digits=1, pixel_noise=0.02)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    mask = np.zeros((64, 64), dtype=bool)
+    concat = torch.zeros(2, 3, 64, 64, 1, device=dev())
+
+    def fresh(lr):
+        torch.manual_seed(5)
+        nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=3, output_timesteps=3, device=dev(),
+                                    model_kwargs=dict(hidden_size=8, dropout=0.0, n_layers=1, n_conv_layers=2,
+                                                      convolution_type='TransformerConv'))
+        nfp.initiate_training(lr=lr, lr_decay=0.95, capturable=True)
+        nfp.model.static_shapes = True
+        return nfp
+    from model.model import CONVOLUTION_KWARGS
+    old = dict(CONVOLUTION_KWARGS['TransformerConv'])
+    try:
+        CONVOLUTION_KWARGS['TransformerConv']['dropout'] = 0.0
+        eager, graphed = fresh(1e-3), fresh(1e-3)
+        for _ in range(2):
+            eager.train_step(t(x), t(y), concat, mask)
+        step = graphed.make_graphed_step(t(x), t(y), concat, mask, warmup=2)
+        for a, b in ((x2, y2), (x, y)):
+            le, lg = float(eager.train_step(t(a), t(b), concat, mask)), float(step(t(a), t(b), concat))
+            assert np.isfinite(le) and abs(le - lg) <= 1e-5 * abs(le), (le, lg)
+        # attention dropout: a frozen model (lr = 0) replayed twice on the same batch sees two different masks
+        CONVOLUTION_KWARGS['TransformerConv']['dropout'] = 0.3
+        drop = fresh(0.0)
+        step = drop.make_graphed_step(t(x), t(y), concat, mask, warmup=2)
+        l1, l2 = float(step(t(x), t(y), concat)), float(step(t(x), t(y), concat))
+        assert np.isfinite(l1) and np.isfinite(l2) and l1 != l2, (l1, l2)
+    finally:
+        CONVOLUTION_KWARGS['TransformerConv'].update(old)
+
+
 def test_graph_replay_gradients_bit_identical_to_eager():
     """Forward + loss + backward captured in a hipGraph and replayed on NEW inputs gives bit-identical loss and
     gradients to the eager launches (same weights): the capture contains every kernel of the path."""

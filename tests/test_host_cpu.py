@@ -57,6 +57,18 @@ def test_bad_arguments_fail_loudly_without_gpu():
     rc = lib.qt_spmm(None, None, None, 4, None, 4, None, 1.0, None, 0.0, None, 0.0, None, None)
     assert rc == -1 and b'qt_spmm' in lib.qt_last_error()
     assert lib.qt_lstm_fwd(None, None, 0, None, None, None, 1, None, 16, None, None, None, None, None) == -1
+    # every entry point refuses NULL / inconsistent arguments with an error code and a message naming itself -- no launch
+    null_calls = {
+        'qt_lstm_bwd_dgrad': (None, 0, None, 0, None, 0, None, None, 0, None, None, 4, None, 16, None, None, None, 0, None, 3, 16, 0, None, None, None),
+        'qt_compose2_fwd': (None,) * 8 + (3, 1, 3, 4, 4, 16, None, None, None, None, None),
+        'qt_compose_step_fwd': (None,) * 4 + (3, 1, 3, 4, 16, None, None, None),
+        'qt_remesh': (None, None, None, 0, None, None, 0, None, None, None, 1, 1, 64, 64, 4, None, None, None, None, 0, None),
+        'qt_attn_fwd': (None,) * 6 + (0, None, 8, 8, 4, None, 1.0, 0, None, None, None, None),
+        'qt_dense2': (None, 0, None, None, 0, None, 1, 4, 0, None, None, None, 0, None, 1, 4, 0, 4, None, 0, None, 0, None, None, None, None),
+    }
+    for name, args in null_calls.items():
+        assert getattr(lib, name)(*args) == -1, name
+        assert name.encode() in lib.qt_last_error(), (name, lib.qt_last_error())
 
 
 def test_product_path_refuses_cpu_tensors():
