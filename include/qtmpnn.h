@@ -137,6 +137,17 @@ int qt_remesh(const float* const* src_parts, const int* widths, const int* lds, 
 int qt_sse(const float* out, int out_stride, const int32_t* labels, const float* y, int64_t y_clip_stride,
            int B, int n, int m, float* partial /* B*ceil(P/1024) */, void* stream);
 
+/* The same for all output steps of a rollout at once (up to 16 per call; host arrays of nseg device pointers / sizes, one
+ * mesh per step): partial (nseg, B*ceil(P/1024)) and, for the backward, sys[z] (N_z) = per-node sum of the target over
+ * the node's pixels.  y: step z of clip b starts at y + z*y_step_stride + b*y_clip_stride.  qt_sse_rollout_bwd writes every
+ * step's gradient rows (as qt_sse_bwd). */
+int qt_sse_rollout(int nseg, const float* const* outs, const int* out_strides, const int32_t* const* labels,
+                   const uint8_t* const* levels, const int* Ns, float* const* sys, const float* y, int64_t y_clip_stride,
+                   int64_t y_step_stride, int B, int n, int m, float* partial, void* stream);
+int qt_sse_rollout_bwd(int nseg, const float* const* outs, const int* out_strides, const float* const* npixs,
+                       const float* const* sys, const int* Ns, const int32_t* const* n_devs, const float* g, int W,
+                       float* const* gouts, void* stream);
+
 /* gradient of the qt_sse partial sums with respect to the node values, written as full rows of width W (column 0 carries
  * the value, the rest zeros): gout[i, 0] = 2 * g[0] * (npix[i] * out[i * out_stride] - sy[i]), sy = per-node sum of y. */
 int qt_sse_bwd(const float* out, int out_stride, const float* npix, const float* sy, const float* g, int N,

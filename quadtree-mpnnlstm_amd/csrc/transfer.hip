@@ -79,11 +79,10 @@ __device__ __forceinline__ void vstore(float* p, const Vec<VEC>& r, float scale)
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
-    __shared__ float pyr[(256 + 64 + 16 + 4 + 1) * VEC];
+__device__ __forceinline__ void tile_body(const PoolArgs& a, int bx, int by, int ny, float* pyr) {
     const int t = threadIdx.x;
     const int tiles = a.tiles_r * a.tiles_c;
-    const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int b = bx / tiles, tile = bx % tiles;
     const int R0 = (tile / a.tiles_c) * 64, C0 = (tile % a.tiles_c) * 64;
     const int br = t >> 4, bc = t & 15;
     const int64_t P = (int64_t)a.n * a.m;
@@ -128,7 +127,7 @@ __global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
 
     const int nch = a.C / VEC;
     const int total = (a.src_labels ? 1 : a.S) * nch;
-    for (int it = blockIdx.y; it < total; it += gridDim.y) {
+    for (int it = by; it < total; it += ny) {
         const int s = it / nch, ch = it % nch;
         Vec<VEC> val[16];
 #pragma unroll
@@ -211,6 +210,38 @@ __global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
             }
         }
     }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
+    __shared__ float pyr[(256 + 64 + 16 + 4 + 1) * VEC];
+    tile_body<VEC>(a, blockIdx.x, blockIdx.y, gridDim.y, pyr);
+}
+
+// The loss of a rollout touches every output step once, after the last step: the per-step launches (squared error, per-node
+// sum of the target for the gradient, the gradient itself) become one launch each over up to 16 steps, each step with its
+// own mesh (pointer tables in the kernel arguments).
+struct LossSeg {
+    const float* out[16];         // node values of the step (column 0 of rows of out_stride floats)
+    const int32_t* labels[16];
+    const uint8_t* level[16];
+    const float* npix[16];
+    const int32_t* n_dev[16];
+    float* sy[16];                // per-node sum of the target over the node's pixels
+    float* gout[16];
+    int out_stride[16], N[16];
+};
+
+__global__ __launch_bounds__(256) void k_pool_targets(PoolArgs a, LossSeg sg, int64_t y_step_stride) {
+    __shared__ float pyr[256 + 64 + 16 + 4 + 1];
+    const int z = blockIdx.z;
+    a.img = a.img + z * y_step_stride;
+    a.labels = sg.labels[z];
+    a.level = sg.level[z];
+    a.npix = sg.npix[z];
+    a.N = sg.N[z];
+    a.out = sg.sy[z];
+    tile_body<1>(a, blockIdx.x, 0, 1, pyr);
 }
 
 // Node-centric transfer for nodes of 1x1 .. 4x4 pixels: thread = (node, float4 chunk of its row), chunk fastest, so the
@@ -311,6 +342,44 @@ __global__ __launch_bounds__(256) void k_sse(const float* __restrict__ out, int 
     if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+__global__ __launch_bounds__(256) void k_sse_multi(LossSeg sg, const float* __restrict__ y, int64_t y_clip_stride,
+                                                   int64_t y_step_stride, int64_t P, int B, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, z = blockIdx.z;
+    const float* out = sg.out[z];
+    const int32_t* labels = sg.labels[z];
+    const int os = sg.out_stride[z];
+    const float* yz = y + z * y_step_stride + b * y_clip_stride;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t p = (int64_t)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (p < P) {
+            const int lab = labels[b * P + p];
+            if (lab >= 0) {
+                const float d = out[(int64_t)lab * os] - yz[p];
+                acc += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[((int64_t)z * B + b) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void k_sse_bwd_multi(LossSeg sg, const float* __restrict__ g, int W) {
+    const int z = blockIdx.y;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = idx / (unsigned)W;
+    if (i >= qt_rows(sg.n_dev[z], sg.N[z])) return;
+    const float* out = sg.out[z];
+    sg.gout[z][idx] = (idx - (unsigned)i * (unsigned)W) == 0
+                          ? 2.0f * g[0] * (sg.npix[z][i] * out[i * sg.out_stride[z]] - sg.sy[z][i]) : 0.0f;
+}
+
 __global__ void k_sse_bwd(const float* __restrict__ out, int out_stride, const float* __restrict__ npix,
                           const float* __restrict__ sy, const float* __restrict__ g, int Ncap, const int32_t* __restrict__ n_dev,
                           int W, float* __restrict__ gout) {
@@ -329,6 +398,48 @@ extern "C" int qt_sse_bwd(const float* out, int out_stride, const float* npix, c
     if (N <= 0) return QT_OK;
     hipLaunchKernelGGL(k_sse_bwd, dim3(qt_cdiv((int64_t)N * W, 256)), dim3(256), 0, (hipStream_t)stream, out, out_stride, npix,
                        sy, g, N, n_dev, W, gout);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_sse_rollout(int nseg, const float* const* outs, const int* out_strides, const int32_t* const* labels,
+                              const uint8_t* const* levels, const int* Ns, float* const* sys, const float* y,
+                              int64_t y_clip_stride, int64_t y_step_stride, int B, int n, int m, float* partial, void* stream) {
+    QT_ARG(nseg >= 1 && nseg <= 16 && outs && out_strides && labels && levels && Ns && sys && y && partial && B > 0, "bad arguments");
+    LossSeg sg = {};
+    for (int z = 0; z < nseg; ++z) {
+        QT_ARG(outs[z] && labels[z] && levels[z] && sys[z] && out_strides[z] >= 1, "null segment pointer");
+        sg.out[z] = outs[z]; sg.out_stride[z] = out_strides[z]; sg.labels[z] = labels[z]; sg.level[z] = levels[z];
+        sg.N[z] = Ns[z]; sg.sy[z] = sys[z];
+    }
+    const int64_t P = (int64_t)n * m;
+    hipLaunchKernelGGL(k_sse_multi, dim3(qt_cdiv(P, 1024), B, nseg), dim3(256), 0, (hipStream_t)stream, sg, y, y_clip_stride,
+                       y_step_stride, P, B, partial);
+    QT_LAUNCHED();
+    PoolArgs a = {};
+    a.img = y; a.S = 1; a.img_clip_stride = y_clip_stride; a.C = 1; a.mean = 0; a.B = B; a.n = n; a.m = m;
+    a.out_stride = 1; a.out_coff = 0; a.tiles_r = qt_cdiv(n, 64); a.tiles_c = qt_cdiv(m, 64);
+    hipLaunchKernelGGL(k_pool_targets, dim3(B * a.tiles_r * a.tiles_c, 1, nseg), dim3(256), 0, (hipStream_t)stream, a, sg,
+                       y_step_stride);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_sse_rollout_bwd(int nseg, const float* const* outs, const int* out_strides, const float* const* npixs,
+                                  const float* const* sys, const int* Ns, const int32_t* const* n_devs, const float* g, int W,
+                                  float* const* gouts, void* stream) {
+    QT_ARG(nseg >= 1 && nseg <= 16 && outs && out_strides && npixs && sys && Ns && n_devs && g && gouts && W >= 1, "bad arguments");
+    LossSeg sg = {};
+    int nmax = 0;
+    for (int z = 0; z < nseg; ++z) {
+        QT_ARG(outs[z] && npixs[z] && sys[z] && gouts[z] && out_strides[z] >= 1, "null segment pointer");
+        sg.out[z] = outs[z]; sg.out_stride[z] = out_strides[z]; sg.npix[z] = npixs[z]; sg.sy[z] = (float*)sys[z];
+        sg.N[z] = Ns[z]; sg.n_dev[z] = n_devs[z]; sg.gout[z] = gouts[z];
+        nmax = Ns[z] > nmax ? Ns[z] : nmax;
+    }
+    QT_ARG((int64_t)nmax * W + 256 < ((int64_t)1 << 31), "N * W too large for 32-bit thread indices");
+    if (nmax <= 0) return QT_OK;
+    hipLaunchKernelGGL(k_sse_bwd_multi, dim3(qt_cdiv((int64_t)nmax * W, 256), nseg), dim3(256), 0, (hipStream_t)stream, sg, g, W);
     QT_LAUNCHED();
     return QT_OK;
 }

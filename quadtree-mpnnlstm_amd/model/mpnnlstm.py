@@ -46,8 +46,10 @@ def masked_mse(outputs, meshes, y, mask=None, binary=False):
         keep = torch.ones(mesh0.n, mesh0.m, dtype=torch.bool) if mask is None else ~torch.as_tensor(np.asarray(mask, dtype=bool))
         return torch.nn.functional.binary_cross_entropy(y_hat[:, :, keep], y.to(y_hat.device)[:, :, keep])
     y = y.to(outputs[0].device)
-    parts = [ops.step_sse_partials(out, y[:, t], mesh) for t, (out, mesh) in enumerate(zip(outputs, meshes))]
-    return torch.cat(parts).sum() / float(mesh0.B * len(outputs) * n_valid)        # one reduction for all steps
+    part = ops.rollout_sse_partials(outputs, y, meshes) if y.shape[1] == len(outputs) else None     # all steps in one launch
+    if part is None:
+        part = torch.cat([ops.step_sse_partials(out, y[:, t], mesh) for t, (out, mesh) in enumerate(zip(outputs, meshes))])
+    return part.sum() / float(mesh0.B * len(outputs) * n_valid)        # one reduction for all steps
 
 
 class NextFramePredictorS2S:

@@ -27,6 +27,8 @@ _SIGNATURES = {
     'qt_edges_norm': [_P, _P, _P, _P, _I, _P, _P, _P],
     'qt_gather': [_P, _I, _P, _P, _L, _P, _P],
     'qt_pool': [_P, _I, _L, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],
+    'qt_sse_rollout': [_I, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64, _I, _I, _I, _P, _P],
+    'qt_sse_rollout_bwd': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     'qt_remesh': [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     'qt_sse': [_P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
     'qt_spmm': [_P, _P, _P, _I, _P, _I, _P, _F, _P, _F, _P, _F, _P, _P],

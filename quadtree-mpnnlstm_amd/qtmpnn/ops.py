@@ -1062,6 +1062,77 @@ class _StepSSE(Function):
         return gout, None, None
 
 
+def _full_rows(out):
+    """`out` (N, 1) as the contiguous matrix whose column 0 it is (the head's 4-wide output), if it is such a view."""
+    base = out._base
+    if (base is not None and base.dim() == 2 and out.dim() == 2 and out.shape[1] == 1 and base.is_contiguous()
+            and base.shape[0] == out.shape[0] and out.storage_offset() == base.storage_offset()
+            and out.stride(0) == base.shape[1] and base.dtype == torch.float32):
+        return base
+    return out
+
+
+class _RolloutSSE(Function):
+    """_StepSSE for all output steps of a rollout in one launch per kernel (qt_sse_rollout / _bwd): the loss touches every
+    step once, after the last one, so the 3 x T_out small launches (squared error, per-node target sums for the gradient,
+    the gradient rows) become 3 per 16 steps.  y: (B, T, P) contiguous fp32; outs[t]: contiguous (N_t, W) matrices whose
+    column 0 is the prediction."""
+
+    @staticmethod
+    def forward(ctx, y, meshes, *outs):
+        import ctypes
+        B, T, P = y.shape
+        m0 = meshes[0]
+        nt = -(P // -1024)
+        part = outs[0].new_empty(T, B * nt)
+        sys_ = [o.new_empty(ms.N) for o, ms in zip(outs, meshes)]
+        vp, ip = ctypes.c_void_p, ctypes.c_int
+        for z0 in range(0, T, 16):
+            sl = slice(z0, min(z0 + 16, T))
+            n = sl.stop - sl.start
+            _lib.call('qt_sse_rollout', n, (vp * n)(*[o.data_ptr() for o in outs[sl]]), (ip * n)(*[o.stride(0) for o in outs[sl]]),
+                      (vp * n)(*[ms.labels.data_ptr() for ms in meshes[sl]]), (vp * n)(*[ms.level.data_ptr() for ms in meshes[sl]]),
+                      (ip * n)(*[ms.N for ms in meshes[sl]]), (vp * n)(*[t.data_ptr() for t in sys_[sl]]),
+                      y.data_ptr() + 4 * z0 * P, T * P, P, B, m0.n, m0.m, ptr(part[z0:]))
+        ctx.save_for_backward(*outs, *sys_)
+        ctx.meshes = meshes
+        return part
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        meshes = ctx.meshes
+        T = len(meshes)
+        outs, sys_ = ctx.saved_tensors[:T], ctx.saved_tensors[T:]
+        gouts = [torch.empty_like(o) for o in outs]
+        g1 = g.reshape(-1)[:1].contiguous()      # every partial has the same upstream gradient (they are only ever summed)
+        vp, ip = ctypes.c_void_p, ctypes.c_int
+        W = outs[0].shape[1]
+        for z0 in range(0, T, 16):
+            sl = slice(z0, min(z0 + 16, T))
+            n = sl.stop - sl.start
+            _lib.call('qt_sse_rollout_bwd', n, (vp * n)(*[o.data_ptr() for o in outs[sl]]), (ip * n)(*[o.stride(0) for o in outs[sl]]),
+                      (vp * n)(*[ms.npix.data_ptr() for ms in meshes[sl]]), (vp * n)(*[t.data_ptr() for t in sys_[sl]]),
+                      (ip * n)(*[ms.N for ms in meshes[sl]]), (vp * n)(*[ms.n_dev.data_ptr() if ms.n_dev is not None else None for ms in meshes[sl]]),
+                      ptr(g1), W, (vp * n)(*[t.data_ptr() for t in gouts[sl]]))
+        return (None, None, *gouts)
+
+
+def rollout_sse_partials(outputs, y, meshes):
+    """Partial sums of the squared error of every output step (their total is the MSE numerator), or None when the steps
+    cannot share the launches (masked-per-pixel preset meshes, odd layouts): the caller then goes step by step."""
+    if not outputs or any(ms.loss_mask is not None or ms.N == 0 for ms in meshes):
+        return None
+    outs = [_full_rows(o) for o in outputs]
+    W = outs[0].shape[1]
+    if any(o.dtype != torch.float32 or not o.is_contiguous() or o.shape[1] != W or not o.is_cuda for o in outs):
+        return None
+    B, T = meshes[0].B, len(outs)
+    if y.dtype != torch.float32 or not y.is_contiguous() or y.numel() != B * T * meshes[0].P:
+        return None
+    return _RolloutSSE.apply(y.view(B, T, meshes[0].P), tuple(meshes), *outs)
+
+
 def step_sse_partials(out, y, mesh):
     """`out` (N, 1); when it is column 0 of a wider contiguous matrix (the head's 4-wide output) the op runs on that
     matrix, so the gradient is written once as full rows instead of slice_backward's zero-fill + copy."""
