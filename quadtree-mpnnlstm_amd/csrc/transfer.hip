@@ -268,6 +268,19 @@ __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
     Vec<VEC> acc;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc.v[k] = 0.0f;
+    if (cl.z == 1 && a.src_labels) {
+        // a single-pixel node (almost all of them on noisy frames) owns its pixel: straight-line code, no pixel loop, no
+        // label check, and its pixel count is 1 (no npix load for the mean)
+        const int sl = a.src_labels[base + (int64_t)cl.x * a.m + cl.y];
+        if (sl >= 0) {
+            const Vec<VEC> x = vload<VEC>(src_chunk<VEC>(a, sl, ch));
+            const float sc = a.src_inv ? 1.0f / a.src_npix[sl] : 1.0f;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc.v[k] = x.v[k] * sc;
+        }
+        vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), acc, 1.0f);
+        return;
+    }
     for (int dr = 0; dr < cl.z; ++dr)
         for (int dc = 0; dc < cl.z; ++dc) {
             const int r = cl.x + dr, c = cl.y + dc;
