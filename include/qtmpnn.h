@@ -73,7 +73,9 @@ int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_offsets /* ex
                        int32_t* labels /* (B,n,m) */, const uint8_t* level, int32_t* cell /* (Nmax,4) */,
                        int32_t* node_off /* (B+1) */,
                        float size_norm, float* feat /* (Nmax,3) or NULL */, float* npix /* (Nmax) or NULL: the
-                       qt_node_features outputs, written by the same pass */, void* stream);
+                       qt_node_features outputs, written by the same pass */,
+                       int raw_counts /* != 0: cnt_offsets is stage 1's cnt itself (B*nbase <= 1024 counts), scanned by
+                       every workgroup in LDS: no qt_scan_i32 launch in between (static capacities) */, void* stream);
 
 /* exclusive scan: out[0]=0, out[i+1]=sum(in[0..i]); len+1 outputs.  tmp: (len/1024+2) int32. */
 int qt_scan_i32(const int32_t* in, int32_t* out, int64_t len, int32_t* tmp, void* stream);
@@ -89,14 +91,15 @@ int qt_node_features(const int32_t* cell, int N, const int32_t* n_dev, int n, in
  * get_adj + dist, model/graph_functions.py:261-363, and the ChebConv normalisation that PyG
  * recomputes in every conv call (torch_geometric ChebConv.__norm__, restated in oracle/).
  * qt_edges_count: distinct neighbours per (node, side) -> cnt4, plus the total of every 1024-thread workgroup -> sums
- *   (nblk = qt_edges_blocks(N) entries; cnt4 holds nblk*1024 ints).  qt_scan_top(sums, nblk) turns them into offsets.
+ *   (nblk = qt_edges_blocks(N) entries; cnt4 holds nblk*1024 ints); qt_edges_fill adds up the totals before its workgroup
+ *   itself.
  * qt_edges_fill: rowptr (N+1), col, w = centroid distance * resolution, and dis[i] = 1/sqrt(sum of row i's weights).
  * qt_edges_norm: nrm[e] = -dis_i w_e dis_j.
  */
 int qt_edges_blocks(int N);
 int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, const int32_t* n_dev, int n, int m,
                    int32_t* cnt4, int32_t* sums /* nblk+1 */, void* stream);
-int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* cnt4, const int32_t* sums /* scanned */,
+int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* cnt4, const int32_t* sums /* as counted */,
                   int N, const int32_t* n_dev, int n, int m, float resolution,
                   int32_t* rowptr /* N+1 */, int32_t* col, float* w, float* dis /* N */, void* stream);
 int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, const float* dis, int N,

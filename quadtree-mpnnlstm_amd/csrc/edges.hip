@@ -77,8 +77,14 @@ __global__ __launch_bounds__(ET) void k_edges_fill(const int32_t* __restrict__ l
     const int idx = blockIdx.x * ET + threadIdx.x;
     const int N = qt_rows(n_dev, Ncap);
     const int mine = idx < 4 * Ncap ? cnt4[idx] : 0;
+    // offset of this workgroup = the totals of the workgroups before it (`sums` as qt_edges_count left it: a few hundred
+    // entries, one strided pass -- the separate single-workgroup scan launch is gone)
+    int before = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += ET) before += sums[j];
+    int offset;
+    qt_block_excl_scan(before, red, &offset);
     int total;
-    int e = sums[blockIdx.x] + qt_block_excl_scan(mine, red, &total);
+    int e = offset + qt_block_excl_scan(mine, red, &total);
     const int node = idx >> 2;
     if ((idx & 3) == 0 && node <= Ncap) rowptr[node] = e;       // rows N .. Ncap all point at the end (empty rows)
     float wsum = 0.0f;

@@ -204,11 +204,32 @@ __device__ __forceinline__ void node_features(int4 cl, int i, int n, int m, floa
     npix[i] = np_;
 }
 
-__global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const int32_t* __restrict__ offs,
+__global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const int32_t* __restrict__ offs_in, int raw,
                                   int B, int n, int m, int MS, int nbj, int nbase,
                                   int32_t* __restrict__ labels, const uint8_t* __restrict__ level,
                                   int32_t* __restrict__ cell, int32_t* __restrict__ node_off, float size_norm,
                                   float* __restrict__ feat, float* __restrict__ npix) {
+    // raw != 0: offs_in holds the per-cell leaf COUNTS (stage 1's output) and every workgroup scans the B * nbase <= 1024 of
+    // them itself in LDS -- the separate scan launch between the two stages is gone (static capacities: nobody on the host
+    // needs the total)
+    __shared__ int soffs[1025];
+    __shared__ int red[8];
+    const int32_t* offs = offs_in;
+    if (raw) {
+        const int len = B * nbase;
+        int carry = 0;
+        for (int c0 = 0; c0 < len; c0 += 256) {
+            const int i = c0 + (int)threadIdx.x;
+            const int vv = i < len ? offs_in[i] : 0;
+            int total;
+            const int ex = qt_block_excl_scan_256(vv, red, &total);
+            if (i < len) soffs[i] = carry + ex;
+            carry += total;
+        }
+        if (threadIdx.x == 0) soffs[len] = carry;
+        __syncthreads();
+        offs = soffs;
+    }
     const int64_t P = (int64_t)n * m;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx <= B) node_off[idx] = offs[idx * nbase];
@@ -356,13 +377,14 @@ extern "C" int qt_quadtree_stage1(const float* src, int src_rows, int src_cols, 
 
 extern "C" int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_offsets, int B, int n, int m,
                                   int max_size, int32_t* labels, const uint8_t* level, int32_t* cell,
-                                  int32_t* node_off, float size_norm, float* feat, float* npix, void* stream) {
+                                  int32_t* node_off, float size_norm, float* feat, float* npix, int raw_counts, void* stream) {
     QT_ARG(local_id && cnt_offsets && labels && level && cell && node_off, "null pointer");
     QT_ARG((feat == nullptr) == (npix == nullptr), "give both feat and npix or neither");
     const int nbi = qt_cdiv(n, max_size), nbj = qt_cdiv(m, max_size);
+    QT_ARG(!raw_counts || (int64_t)B * nbi * nbj <= 1024, "raw_counts: at most 1024 base cells (scan them with qt_scan_i32 instead)");
     const int64_t total = (int64_t)B * n * m;
     hipLaunchKernelGGL(k_quadtree_stage3, dim3(qt_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, local_id,
-                       cnt_offsets, B, n, m, max_size, nbj, nbi * nbj, labels, level, cell, node_off, size_norm, feat, npix);
+                       cnt_offsets, raw_counts, B, n, m, max_size, nbj, nbi * nbj, labels, level, cell, node_off, size_norm, feat, npix);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -6,6 +6,7 @@ model/seq2seq.py:297-304).  Everything is built by the HIP kernels of libqtmpnn_
 only host read-back is the node count N (one sync per mesh).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -230,7 +231,9 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
         _lib.call('qt_quadtree_stage1', None, 0, 0, ptr(nodeval), nodeval.stride(0) if nodeval.numel() > 1 else 1,
                   ptr(old.labels), B, n, m, max_size,
                   float(thresh), CONDITIONS.index(condition), ptr(mk), ptr(hr), ptr(local_id), ptr(level), ptr(cnt))
-    _lib.call('qt_scan_i32', ptr(cnt), ptr(offs), B * nbase, ptr(tmp))
+    fused_scan = static and B * nbase <= 1024 and os.environ.get('QT_NO_FUSED_SCAN') != '1'   # stage 3 scans the counts itself
+    if not fused_scan:
+        _lib.call('qt_scan_i32', ptr(cnt), ptr(offs), B * nbase, ptr(tmp))
     N = B * n * m if static else int(offs[-1].item())     # dynamic mode: the one host sync of a mesh build
 
     ms = Mesh()
@@ -245,8 +248,8 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     ms.posfeat = torch.empty(N, 3, device=device)
     ms.npix = torch.empty(N, device=device)
     size_norm = size_norm if size_norm is not None else (max_size / 2) ** 2
-    _lib.call('qt_quadtree_stage3', ptr(local_id), ptr(offs), B, n, m, max_size, ptr(ms.labels), ptr(level),
-              ptr(ms.cell), ptr(ms.node_off), float(size_norm), ptr(ms.posfeat), ptr(ms.npix))
+    _lib.call('qt_quadtree_stage3', ptr(local_id), ptr(cnt if fused_scan else offs), B, n, m, max_size, ptr(ms.labels), ptr(level),
+              ptr(ms.cell), ptr(ms.node_off), float(size_norm), ptr(ms.posfeat), ptr(ms.npix), int(fused_scan))
     nd = None
     if static:
         ms.n_dev = ms.node_off[B:]                # view of the last entry = N
@@ -275,7 +278,6 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
     cnt4 = torch.empty(nblk * 1024, **i32)
     sums = torch.empty(nblk + 1, **i32)
     _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4), ptr(sums))
-    _lib.call('qt_scan_top', ptr(sums), nblk)
     emax = 4 * B * n * m                          # every directed edge owns >= 1 of the 4*P pixel adjacencies
     ms.col = torch.empty(emax, **i32)
     ms.w = torch.empty(emax, device=device)
