@@ -260,7 +260,7 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
 
 def _finish_mesh(ms, device, size_norm, resolution, nd):
     """CSR adjacency (and, when size_norm is given, the node features) of a mesh whose labels / level / cell / node_off
-    are in place: count -> scan of the per-workgroup totals -> fill (+ degree) -> normalise, four launches."""
+    are in place: count -> fill (+ degree) -> normalise, three launches."""
     N, n, m, B = ms.N, ms.n, ms.m, ms.B
     i32 = dict(dtype=torch.int32, device=device)
     if size_norm is not None:
