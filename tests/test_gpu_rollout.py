@@ -499,3 +499,41 @@ def test_train_loop_with_graph_replay_matches_eager_loop():
     # (capacity-sized launches sum some reductions in another order than exact-size ones: 1e-4-level drift after 8 updates)
     for a, b in zip(tr_g + te_g, tr_e + te_e):
         assert abs(a - b) <= 1e-3 * abs(b) + 1e-7, (tr_g, tr_e, te_g, te_e)
+
+
+def test_graphed_step_odd_shape_with_mask():
+    """Static capacities + hipGraph on a frame that is neither square nor a multiple of the 64-pixel base cell, with a land
+    mask and 3 clips: the replayed step gives the eager step's loss and weights (exercises the fused mesh-build scans, the
+    dense multi-part re-mesh transfer, the fused cell backward and the rollout-wide loss away from the bench shape)."""
+    from model.mpnnlstm import NextFramePredictorS2S
+    rng = np.random.default_rng(11)
+    n, m, B, T = 40, 72, 3, 3
+    mask = np.zeros((n, m), dtype=bool)
+    mask[5:14, 50:66] = True
+    mask[30:, :9] = True
+
+    def clips(seed):
+        r = np.random.default_rng(seed)
+        f = r.random((B, 2 * T, n, m, 1)).astype(np.float32)
+        f = (f > 0.93).astype(np.float32) * r.random((B, 2 * T, n, m, 1)).astype(np.float32)     # sparse blobs: mixed cell sizes
+        return f[:, :T], f[:, T:]
+    (x, y), (x2, y2) = clips(1), clips(2)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    concat = torch.from_numpy(rng.random((B, T, n, m, 1)).astype(np.float32) * 0.1).to(dev())
+
+    def fresh():
+        torch.manual_seed(7)
+        nfp = NextFramePredictorS2S(thresh=0.2, input_features=1, input_timesteps=T, output_timesteps=T, device=dev(),
+                                    model_kwargs=dict(hidden_size=16, dropout=0.0, n_layers=2))
+        nfp.initiate_training(lr=1e-3, lr_decay=0.95, capturable=True)
+        nfp.model.static_shapes = True
+        return nfp
+    eager, graphed = fresh(), fresh()
+    for _ in range(2):
+        eager.train_step(t(x), t(y), concat, mask)
+    step = graphed.make_graphed_step(t(x), t(y), concat, mask, warmup=2)
+    for a, b in ((x2, y2), (x, y)):
+        le, lg = float(eager.train_step(t(a), t(b), concat, mask)), float(step(t(a), t(b), concat))
+        assert np.isfinite(le) and abs(le - lg) <= 1e-6 * abs(le), (le, lg)
+    for (k, p), (_, q) in zip(eager.model.named_parameters(), graphed.model.named_parameters()):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
