@@ -110,6 +110,27 @@ class TransformerConv(nn.Module):
         We = nn.functional.pad(self.lin_edge.weight, (0, 0, 0, cp - cout))
         return PackedConv(W, We, ops.GradAcc(), ops.GradAcc())
 
+    @staticmethod
+    def pack_many(convs):
+        """[PackedConv] for a list of convolutions, one batched packing per (in, out) shape: the same matrices as pack()."""
+        out = [None] * len(convs)
+        groups = {}
+        for i, c in enumerate(convs):
+            groups.setdefault((c.in_channels, c.out_channels), []).append(i)
+        for (cin, cout), idxs in groups.items():
+            cin_p, cp = cin + (-cin) % 4, cout + (-cout) % 4
+            cs = [convs[i] for i in idxs]
+            blocks = [[c.lin_query, c.lin_key, c.lin_value, c.lin_skip] for c in cs]
+            w = torch.stack([l.weight for b4 in blocks for l in b4]).view(len(cs), 4, cout, cin)          # (G, 4, cout, cin)
+            w = nn.functional.pad(w.permute(0, 3, 1, 2), (0, cp - cout, 0, 0, 0, cin_p - cin))             # (G, cin_p, 4, cp)
+            b = torch.stack([l.bias for b4 in blocks for l in b4]).view(len(cs), 1, 4, cout)
+            b = nn.functional.pad(b, (0, cp - cout, 0, 0, 0, 3))                                            # bias row + 3 zero rows
+            W = torch.cat([w, b], dim=1).reshape(len(cs), cin_p + 4, 4 * cp)
+            We = nn.functional.pad(torch.stack([c.lin_edge.weight for c in cs]), (0, 0, 0, cp - cout))     # (G, cp, 2)
+            for i, Wk, Wek in zip(idxs, W.unbind(0), We.unbind(0)):          # (unbind: one stack in the backward)
+                out[i] = PackedConv(Wk, Wek, ops.GradAcc(), ops.GradAcc())
+        return out
+
     def forward(self, x, edge_index, edge_weight=None, packed=None):
         mesh = _need_mesh(edge_index)
         cin, cout = self.in_channels, self.out_channels
@@ -231,8 +252,17 @@ class GConvLSTM(nn.Module):
             wc = torch.cat([self.w_c_i, self.w_c_f, self.w_c_o], dim=0)
             b = torch.cat([self.b_i, self.b_f, self.b_c, self.b_o], dim=0)
             acc_p = ops.GradAcc()
-            convs = {f'{br}_{g}': [c.pack() for c in getattr(self, f'{br}_{g}').convolutions]
-                     for br in ('conv_x', 'conv_h') for g in self.GATES}
+            names = [f'{br}_{g}' for br in ('conv_x', 'conv_h') for g in self.GATES]
+            if isinstance(self.conv_x_i.convolutions[0], TransformerConv):
+                # all convolutions of one shape are packed together: a handful of stack / pad / cat launches per shape
+                # instead of a dozen per convolution (24+ convolutions per cell)
+                flat = [(n, l, c) for n in names for l, c in enumerate(getattr(self, n).convolutions)]
+                packed = TransformerConv.pack_many([c for _, _, c in flat])
+                convs = {n: [None] * self.n_conv_layers for n in names}
+                for (n, l, _), pc in zip(flat, packed):
+                    convs[n][l] = pc
+            else:
+                convs = {n: [c.pack() for c in getattr(self, n).convolutions] for n in names}
             cells = [PackedCell(None, 0, 0, wc, b, ln, None, acc_p) for _ in variants]
             for c in cells:
                 c.convs = convs             # the variants share the packed convolutions (and their accumulators)
