@@ -77,12 +77,25 @@ __device__ __forceinline__ float drop_mult(uint32_t seed, int i, int j, float ke
     return ((h >> 8) * (1.0f / 16777216.0f)) < keep ? 1.0f / keep : 0.0f;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with a private L2: XCD x gets the contiguous node range
+// [x * chunk, (x + 1) * chunk) (chunk from the VALID rows), so a node's neighbours -- close in the mesh's node order -- sit in
+// the L2 that gathers them (the same mapping as k_spmm).  Returns the node-group index of this workgroup or -1.
+__device__ __forceinline__ int xcd_block(int rows, int nodes_per_block) {
+    const int nblk = (rows + nodes_per_block - 1) / nodes_per_block;
+    const int chunk = (nblk + 7) >> 3;
+    const int bid = blockIdx.x;
+    if ((bid >> 3) >= chunk) return -1;
+    return (bid & 7) * chunk + (bid >> 3);
+}
+
 template <int LPN>
 __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a, float* __restrict__ out, float* __restrict__ stats) {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int i = (int)(gid / LPN);
-    if (i >= qt_rows(a.n_dev, a.Ncap)) return;
-    const int j0 = (int)(gid % LPN) * 4;
+    const int rows = qt_rows(a.n_dev, a.Ncap);
+    const int blk = xcd_block(rows, 256 / LPN);
+    if (blk < 0) return;
+    const int i = blk * (256 / LPN) + (int)threadIdx.x / LPN;
+    if (i >= rows) return;
+    const int j0 = ((int)threadIdx.x % LPN) * 4;
     const float* pi = a.proj + (int64_t)i * a.ld;
     const F4 q = ld4(pi + j0);
     const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
@@ -163,10 +176,12 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a, float* __restrict_
 template <int LPN>
 __global__ __launch_bounds__(256) void k_attn_bwd_target(AttnArgs a, const float* __restrict__ g, const float* __restrict__ stats,
                                                          float* __restrict__ gproj, float* __restrict__ Dn) {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int i = (int)(gid / LPN);
-    if (i >= qt_rows(a.n_dev, a.Ncap)) return;
-    const int j0 = (int)(gid % LPN) * 4;
+    const int rows = qt_rows(a.n_dev, a.Ncap);
+    const int blk = xcd_block(rows, 256 / LPN);
+    if (blk < 0) return;
+    const int i = blk * (256 / LPN) + (int)threadIdx.x / LPN;
+    if (i >= rows) return;
+    const int j0 = ((int)threadIdx.x % LPN) * 4;
     const float* pi = a.proj + (int64_t)i * a.ld;
     const F4 q = ld4(pi + j0), gi = ld4(g + (int64_t)i * a.ld_g + j0);
     const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
@@ -261,8 +276,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[0][c] = acc[1][c] = 0.0f;
     const uint32_t seed = eff_seed(a);
-    const int64_t stride = (int64_t)gridDim.x * (256 / LPN);
-    for (int64_t j = (int64_t)blockIdx.x * (256 / LPN) + threadIdx.x / LPN; j < N; j += stride) {
+    // XCD x sweeps the contiguous eighth [x * per, (x + 1) * per) of the nodes with its share of the workgroups
+    const bool split = gridDim.x >= 8;                      // (a handful of workgroups: plain sweep)
+    const int xcd = split ? blockIdx.x & 7 : 0, wg = split ? blockIdx.x >> 3 : blockIdx.x;
+    const int nwg = split ? (gridDim.x + 7 - xcd) >> 3 : gridDim.x;
+    const int64_t per = split ? ((int64_t)N + 7) >> 3 : N;
+    const int64_t jlo = xcd * per, jhi = jlo + per < N ? jlo + per : N;
+    const int64_t stride = (int64_t)nwg * (256 / LPN);
+    for (int64_t j = jlo + (int64_t)wg * (256 / LPN) + threadIdx.x / LPN; j < jhi; j += stride) {
         const float* pj = a.proj + j * a.ld;
         F4 dk = {{0, 0, 0, 0}}, dv = {{0, 0, 0, 0}};
         const int e0 = a.rowptr[j], e1 = a.rowptr[j + 1];
@@ -493,7 +514,7 @@ extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const floa
     AttnArgs a;
     fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
     a.ld_g = C; a.accumulate = 0; a.rev = nullptr; a.coef = nullptr; a.E = 0;
-    const int grid = qt_cdiv((int64_t)N * (C / 4), 256);
+    const int grid = (qt_cdiv((int64_t)N * (C / 4), 256) + 7) & ~7;      // whole rounds over the 8 XCDs (xcd_block)
     QT_ATTN_DISPATCH(C, k_attn_fwd, grid, stream, a, out, stats);
     QT_LAUNCHED();
     return QT_OK;
@@ -512,7 +533,7 @@ extern "C" int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const floa
     fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
     QT_ARG(!coef || (rev && eattr && E >= 0), "coef needs rev, eattr and the edge capacity E");
     a.ld_g = ld_g; a.accumulate = accumulate; a.rev = rev; a.coef = coef; a.E = E;
-    const int grid = qt_cdiv((int64_t)N * (C / 4), 256);
+    const int grid = (qt_cdiv((int64_t)N * (C / 4), 256) + 7) & ~7;
     QT_ATTN_DISPATCH(C, k_attn_bwd_target, grid, stream, a, g, stats, gproj, Dn);
     const int gridB = qt_attn_blocks(N, C);
     QT_ATTN_DISPATCH(C, k_attn_bwd_source, gridB, stream, a, g, stats, Dn, gproj, part);
