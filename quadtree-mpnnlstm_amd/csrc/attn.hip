@@ -88,12 +88,15 @@ __device__ __forceinline__ int xcd_block(int rows, int nodes_per_block) {
     return (bid & 7) * chunk + (bid >> 3);
 }
 
+#ifndef QT_ATTN_BS
+#define QT_ATTN_BS 64      // one wave per workgroup (forward 32.4 -> 31.0 us at the cfg4 shapes; 128: 31.3)
+#endif
 template <int LPN>
-__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a, float* __restrict__ out, float* __restrict__ stats) {
+__global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __restrict__ out, float* __restrict__ stats) {
     const int rows = qt_rows(a.n_dev, a.Ncap);
-    const int blk = xcd_block(rows, 256 / LPN);
+    const int blk = xcd_block(rows, QT_ATTN_BS / LPN);
     if (blk < 0) return;
-    const int i = blk * (256 / LPN) + (int)threadIdx.x / LPN;
+    const int i = blk * (QT_ATTN_BS / LPN) + (int)threadIdx.x / LPN;
     if (i >= rows) return;
     const int j0 = ((int)threadIdx.x % LPN) * 4;
     const float* pi = a.proj + (int64_t)i * a.ld;
@@ -174,12 +177,12 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a, float* __restrict_
 
 // pass A: per target i -- D_i = sum_e alpha_e t_e (t_e = d_e g_i.(v_j + e)), dq_i = scale * sum_e alpha_e (t_e - D_i)(k_j + e)
 template <int LPN>
-__global__ __launch_bounds__(256) void k_attn_bwd_target(AttnArgs a, const float* __restrict__ g, const float* __restrict__ stats,
+__global__ __launch_bounds__(QT_ATTN_BS) void k_attn_bwd_target(AttnArgs a, const float* __restrict__ g, const float* __restrict__ stats,
                                                          float* __restrict__ gproj, float* __restrict__ Dn) {
     const int rows = qt_rows(a.n_dev, a.Ncap);
-    const int blk = xcd_block(rows, 256 / LPN);
+    const int blk = xcd_block(rows, QT_ATTN_BS / LPN);
     if (blk < 0) return;
-    const int i = blk * (256 / LPN) + (int)threadIdx.x / LPN;
+    const int i = blk * (QT_ATTN_BS / LPN) + (int)threadIdx.x / LPN;
     if (i >= rows) return;
     const int j0 = ((int)threadIdx.x % LPN) * 4;
     const float* pi = a.proj + (int64_t)i * a.ld;
@@ -469,15 +472,17 @@ inline bool c_ok(int C) { return C == 4 || C == 8 || C == 16 || C == 32 || C == 
 
 }  // namespace
 
-#define QT_ATTN_DISPATCH(C, KERNEL, grid, stream, ...)                                                               \
+#define QT_ATTN_DISPATCH_BS(C, KERNEL, grid, BS, stream, ...)                                                               \
     switch ((C) / 4) {                                                                                               \
-        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;    \
-        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;    \
-        case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;    \
-        case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;    \
-        case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;  \
-        default: hipLaunchKernelGGL(KERNEL<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;  \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(grid), dim3(BS), 0, (hipStream_t)stream, __VA_ARGS__); break;    \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(BS), 0, (hipStream_t)stream, __VA_ARGS__); break;    \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(grid), dim3(BS), 0, (hipStream_t)stream, __VA_ARGS__); break;    \
+        case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(grid), dim3(BS), 0, (hipStream_t)stream, __VA_ARGS__); break;    \
+        case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(grid), dim3(BS), 0, (hipStream_t)stream, __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL(KERNEL<32>, dim3(grid), dim3(BS), 0, (hipStream_t)stream, __VA_ARGS__); break;  \
     }
+
+#define QT_ATTN_DISPATCH(C, KERNEL, grid, stream, ...) QT_ATTN_DISPATCH_BS(C, KERNEL, grid, 256, stream, __VA_ARGS__)
 
 static int fill_args(AttnArgs* a, const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                      const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
@@ -514,8 +519,8 @@ extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const floa
     AttnArgs a;
     fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
     a.ld_g = C; a.accumulate = 0; a.rev = nullptr; a.coef = nullptr; a.E = 0;
-    const int grid = (qt_cdiv((int64_t)N * (C / 4), 256) + 7) & ~7;      // whole rounds over the 8 XCDs (xcd_block)
-    QT_ATTN_DISPATCH(C, k_attn_fwd, grid, stream, a, out, stats);
+    const int grid = (qt_cdiv((int64_t)N * (C / 4), QT_ATTN_BS) + 7) & ~7;      // whole rounds over the 8 XCDs (xcd_block)
+    QT_ATTN_DISPATCH_BS(C, k_attn_fwd, grid, QT_ATTN_BS, stream, a, out, stats);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -533,8 +538,8 @@ extern "C" int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const floa
     fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
     QT_ARG(!coef || (rev && eattr && E >= 0), "coef needs rev, eattr and the edge capacity E");
     a.ld_g = ld_g; a.accumulate = accumulate; a.rev = rev; a.coef = coef; a.E = E;
-    const int grid = (qt_cdiv((int64_t)N * (C / 4), 256) + 7) & ~7;
-    QT_ATTN_DISPATCH(C, k_attn_bwd_target, grid, stream, a, g, stats, gproj, Dn);
+    const int grid = (qt_cdiv((int64_t)N * (C / 4), QT_ATTN_BS) + 7) & ~7;
+    QT_ATTN_DISPATCH_BS(C, k_attn_bwd_target, grid, QT_ATTN_BS, stream, a, g, stats, gproj, Dn);
     const int gridB = qt_attn_blocks(N, C);
     QT_ATTN_DISPATCH(C, k_attn_bwd_source, gridB, stream, a, g, stats, Dn, gproj, part);
     QT_LAUNCHED();
