@@ -103,7 +103,9 @@ int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* cnt
                   int N, const int32_t* n_dev, int n, int m, float resolution,
                   int32_t* rowptr /* N+1 */, int32_t* col, float* w, float* dis /* N */, void* stream);
 int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, const float* dis, int N,
-                  const int32_t* n_dev, float* nrm, void* stream);
+                  const int32_t* n_dev, float* nrm, int32_t* ell /* optional (N, 8): the first four edges of every row
+                  again as [col x4 | nrm bits x4] (an unused slot = the row itself with weight 0; a complemented last column
+                  flags more than four edges): qt_spmm2 then reaches its gathers without the row pointer */, void* stream);
 
 /* ---------------------------------------------------------------- mesh <-> image transfers
  * flatten / unflatten, model/graph_functions.py:391-419, 451-458, by labels instead of the dense
@@ -171,7 +173,8 @@ int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, 
 int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, const int32_t* n_dev,
              int Ca, const float* xa, int ldxa, const float* pa, int ldpa, const float* qa, int ldqa, float* outa,
              int Cb, const float* xb, int ldxb, const float* pb, int ldpb, const float* qb, int ldqb, float* outb,
-             float alpha, float beta, float gamma, void* stream);   /* ld*: row strides in floats, 0 = dense; out rows are dense */
+             float alpha, float beta, float gamma, const int32_t* ell /* optional, from qt_edges_norm */,
+             void* stream);   /* ld*: row strides in floats, 0 = dense; out rows are dense */
 
 /* qt_dense: out planes = act( [A planes | S] @ [W ; Ws] ), the gate GEMM.
  *   A: Ka planes, plane k at a0 (k == 0) or a_rest + (k-1)*N*Ca, each (N, Ca)   (T_0 = Z stays in the caller's tensor)

@@ -29,7 +29,8 @@ template <int VEC, int RPT, int EPT>
 #define QT_SPMM_BS 64      // one wave per workgroup: 11.08 ms per training step against 11.12 (128) and 11.18 (256)
 #endif
 __global__ __launch_bounds__(QT_SPMM_BS) void k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                              const float* __restrict__ nrm, int Ncap, const int32_t* __restrict__ n_dev,
+                                              const float* __restrict__ nrm, const int4* __restrict__ ell, int Ncap,
+                                              const int32_t* __restrict__ n_dev,
                                               SpmmPart pa, SpmmPart pb, int nblk_a,     // workgroups [nblk_a, ..) do part b
                                               float alpha, float beta, float gamma) {
     const bool second = (int)blockIdx.x >= nblk_a;
@@ -64,14 +65,40 @@ __global__ __launch_bounds__(QT_SPMM_BS) void k_spmm(const int32_t* __restrict__
         row[u] = rp * RPT + u;
         const bool ok = row[u] < rows;
         if (!ok) row[u] = rows - 1;                // duplicate of a valid row; its result is not stored
-        e0[u] = ok ? rowptr[row[u]] : 0;
-        e1[u] = ok ? rowptr[row[u] + 1] : 0;
+        e0[u] = (ok && !(VEC == 4 && ell)) ? rowptr[row[u]] : 0;
+        e1[u] = (ok && !(VEC == 4 && ell)) ? rowptr[row[u] + 1] : 0;
     }
     float acc[RPT][VEC];
 #pragma unroll
     for (int u = 0; u < RPT; ++u)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[u][k] = 0.0f;
+    if constexpr (VEC == 4) {
+        if (ell) {
+            // the first four edges of a row come as two 16-byte vectors (qt_edges_norm): no row pointer on the way to the
+            // gathers, fully regular index loads; only rows flagged with more than four edges go on to the CSR loop below
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) {
+                int4 c4 = ell[2 * row[u]];
+                const int4 wb = ell[2 * row[u] + 1];
+                const bool more4 = c4.w < 0;
+                if (more4) c4.w = ~c4.w;
+                const float4 f0 = *reinterpret_cast<const float4*>(x + (int64_t)c4.x * ldx + ch);
+                const float4 f1 = *reinterpret_cast<const float4*>(x + (int64_t)c4.y * ldx + ch);
+                const float4 f2 = *reinterpret_cast<const float4*>(x + (int64_t)c4.z * ldx + ch);
+                const float4 f3 = *reinterpret_cast<const float4*>(x + (int64_t)c4.w * ldx + ch);
+                const float w0 = __int_as_float(wb.x), w1 = __int_as_float(wb.y), w2 = __int_as_float(wb.z), w3 = __int_as_float(wb.w);
+                acc[u][0] += w0 * f0.x; acc[u][1] += w0 * f0.y; acc[u][2] += w0 * f0.z; acc[u][3] += w0 * f0.w;
+                acc[u][0] += w1 * f1.x; acc[u][1] += w1 * f1.y; acc[u][2] += w1 * f1.z; acc[u][3] += w1 * f1.w;
+                acc[u][0] += w2 * f2.x; acc[u][1] += w2 * f2.y; acc[u][2] += w2 * f2.z; acc[u][3] += w2 * f2.w;
+                acc[u][0] += w3 * f3.x; acc[u][1] += w3 * f3.y; acc[u][2] += w3 * f3.z; acc[u][3] += w3 * f3.w;
+                if (more4 && rp * RPT + u < rows) {
+                    e0[u] = rowptr[row[u]] + 4;
+                    e1[u] = rowptr[row[u] + 1];
+                }
+            }
+        }
+    }
     // 4 edges per trip: the index/weight loads, then the neighbour gathers, are independent and stay in flight together
     // (quadtree rows have ~4 neighbours, so most rows finish in the first trip, which is issued for all RPT rows at once).
     // Tried and rejected (round 1): staging each 64-row run of the reversed-Morton node order in LDS so that the ~87 %
@@ -1015,7 +1042,7 @@ static int spmm_part(SpmmPart* P, int* nblk, int N, int C, const float* x, int l
 extern "C" int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* nrm, int N, const int32_t* n_dev, int Ca,
                         const float* xa, int ldxa, const float* pa, int ldpa, const float* qa, int ldqa, float* outa, int Cb,
                         const float* xb, int ldxb, const float* pb, int ldpb, const float* qb, int ldqb, float* outb,
-                        float alpha, float beta, float gamma, void* stream) {
+                        float alpha, float beta, float gamma, const int32_t* ell, void* stream) {
     QT_ARG((ldxa | ldpa | ldqa | ldxb | ldpb | ldqb) % 4 == 0, "row strides must be multiples of 4");
     QT_ARG(rowptr && col && nrm && xa && outa && Ca > 0 && Ca % 4 == 0 && Cb >= 0 && Cb % 4 == 0, "bad arguments");
     QT_ARG(Cb == 0 || (xb && outb && (pb != nullptr) == (pa != nullptr) && (qb != nullptr) == (qa != nullptr)),
@@ -1023,7 +1050,7 @@ extern "C" int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* 
     QT_ARG(xa != outa && (Cb == 0 || xb != outb), "out must not alias x");
     QT_ARG((int64_t)N * max(Ca, Cb) / 4 + 2048 < (int64_t)1 << 31, "N * C too large for 32-bit thread indices");
     QT_ARG((((uintptr_t)xa | (uintptr_t)outa | (uintptr_t)pa | (uintptr_t)qa | (uintptr_t)xb | (uintptr_t)outb | (uintptr_t)pb |
-             (uintptr_t)qb) & 15) == 0, "operands must be 16-byte aligned");
+             (uintptr_t)qb | (uintptr_t)ell) & 15) == 0, "operands must be 16-byte aligned");
     if (N <= 0) return QT_OK;
     SpmmPart A, B = {};
     int na = 0, nb = 0;
@@ -1034,9 +1061,9 @@ extern "C" int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* 
 #define QT_EPT8_MAXC 20
 #endif
     if (max(Ca, Cb) <= QT_EPT8_MAXC)
-        hipLaunchKernelGGL((k_spmm<4, 1, 8>), dim3(na + nb), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, na, alpha, beta, gamma);
+        hipLaunchKernelGGL((k_spmm<4, 1, 8>), dim3(na + nb), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, reinterpret_cast<const int4*>(ell), N, n_dev, A, B, na, alpha, beta, gamma);
     else
-        hipLaunchKernelGGL((k_spmm<4, 1, 4>), dim3(na + nb), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, na, alpha, beta, gamma);
+        hipLaunchKernelGGL((k_spmm<4, 1, 4>), dim3(na + nb), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, reinterpret_cast<const int4*>(ell), N, n_dev, A, B, na, alpha, beta, gamma);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -1048,7 +1075,7 @@ extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* n
     QT_ARG(x != out, "out must not alias x");
     if (N <= 0) return QT_OK;
     const bool v4 = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)p | (uintptr_t)q) % 16) == 0);
-    if (v4) return qt_spmm2(rowptr, col, nrm, N, n_dev, C, x, 0, p, 0, q, 0, out, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, alpha, beta, gamma, stream);
+    if (v4) return qt_spmm2(rowptr, col, nrm, N, n_dev, C, x, 0, p, 0, q, 0, out, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, alpha, beta, gamma, nullptr, stream);
     // scalar rows (C not a multiple of 4): one float per thread
     SpmmPart A, B = {};
     A.x = x; A.p = p; A.q = q; A.out = out; A.C = C; A.ldx = A.ldp = A.ldq = C; A.xcd_chunk = 0;
@@ -1056,7 +1083,7 @@ extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* n
     // Edges per trip: a trip is two dependent loads (col/nrm, then the x rows), and the few rows with many neighbours
     // (a 4x4 cell next to 1x1 cells has 16) set the length of the whole launch.  8 per trip: 6.6 -> 4.5 us at C = 4,
     // 9.3 -> 7.5 us at C = 16 (N = 1.2e5, inside a hipGraph); wider rows are bandwidth bound and prefer fewer registers.
-    hipLaunchKernelGGL((k_spmm<1, 1, 8>), dim3(grid), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, N, n_dev, A, B, grid, alpha, beta, gamma);
+    hipLaunchKernelGGL((k_spmm<1, 1, 8>), dim3(grid), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, (const int4*)nullptr, N, n_dev, A, B, grid, alpha, beta, gamma);
     QT_LAUNCHED();
     return QT_OK;
 }

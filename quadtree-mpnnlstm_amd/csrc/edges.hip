@@ -117,11 +117,28 @@ __global__ __launch_bounds__(ET) void k_edges_fill(const int32_t* __restrict__ l
 
 __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
                             const float* __restrict__ dis, int Ncap, const int32_t* __restrict__ n_dev,
-                            float* __restrict__ nrm) {
+                            float* __restrict__ nrm, int4* __restrict__ ell) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= qt_rows(n_dev, Ncap)) return;
     const float di = dis[i];
-    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) nrm[e] = -(di * w[e] * dis[col[e]]);
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    int c4[4] = {i, i, i, i};              // (an unused slot re-reads the row itself with weight 0)
+    float w4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int e = e0; e < e1; ++e) {
+        const float v = -(di * w[e] * dis[col[e]]);
+        nrm[e] = v;
+        if (e - e0 < 4) {
+            c4[e - e0] = col[e];
+            w4[e - e0] = v;
+        }
+    }
+    if (ell) {
+        // the first four edges of every row again, as two 16-byte vectors per row: k_spmm reads them without the row pointer
+        // (most quadtree rows have exactly four neighbours); a negative (complemented) last column flags more edges in the CSR
+        if (e1 - e0 > 4) c4[3] = ~c4[3];
+        ell[2 * (int64_t)i] = make_int4(c4[0], c4[1], c4[2], c4[3]);
+        ell[2 * (int64_t)i + 1] = make_int4(__float_as_int(w4[0]), __float_as_int(w4[1]), __float_as_int(w4[2]), __float_as_int(w4[3]));
+    }
 }
 
 }  // namespace
@@ -150,10 +167,12 @@ extern "C" int qt_edges_fill(const int32_t* labels, const int32_t* cell, const i
 }
 
 extern "C" int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, const float* dis, int N,
-                             const int32_t* n_dev, float* nrm, void* stream) {
+                             const int32_t* n_dev, float* nrm, int32_t* ell, void* stream) {
     QT_ARG(rowptr && col && w && dis && nrm, "null pointer");
+    QT_ARG(((uintptr_t)ell & 15) == 0, "ell must be 16-byte aligned");
     if (N <= 0) return QT_OK;
-    hipLaunchKernelGGL(k_edges_nrm, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, w, dis, N, n_dev, nrm);
+    hipLaunchKernelGGL(k_edges_nrm, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, w, dis, N, n_dev, nrm,
+                       reinterpret_cast<int4*>(ell));
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -24,7 +24,7 @@ _SIGNATURES = {
     'qt_scan_top': [_P, _I, _P],
     'qt_edges_count': [_P, _P, _I, _P, _I, _I, _P, _P, _P],
     'qt_edges_fill': [_P, _P, _P, _P, _I, _P, _I, _I, _F, _P, _P, _P, _P, _P],
-    'qt_edges_norm': [_P, _P, _P, _P, _I, _P, _P, _P],
+    'qt_edges_norm': [_P, _P, _P, _P, _I, _P, _P, _P, _P],
     'qt_gather': [_P, _I, _P, _P, _L, _P, _P],
     'qt_pool': [_P, _I, _L, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],
     'qt_sse_rollout': [_I, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64, _I, _I, _I, _P, _P],
@@ -33,7 +33,7 @@ _SIGNATURES = {
     'qt_sse': [_P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
     'qt_spmm': [_P, _P, _P, _I, _P, _I, _P, _F, _P, _F, _P, _F, _P, _P],
     'qt_dense2': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P],
-    'qt_spmm2': [_P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _F, _F, _F, _P],
+    'qt_spmm2': [_P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _F, _F, _F, _P, _P],
     'qt_dense': [_P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P],
     'qt_wgrad_blocks': [_I],
     'qt_wgrad': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P],

@@ -49,6 +49,7 @@ class Mesh:
         self._ones = {}
         self._E = None
         self.n_dev = None        # device int32[1] with the valid node count when N is a capacity (static mode)
+        self.ell = None          # (N, 8) int32: [col x4 | nrm bits x4] of the first four edges of every row
         self.pixelwise = False   # every unmasked pixel is a node (thresh = -inf); unflatten then NaN-fills the mask
         self.recipe = None       # arguments that rebuild a data-independent mesh for another batch size
         self.loss_mask = None    # (n, m) u8 when the labels do not encode the mask (homogeneous preset mesh): the loss
@@ -182,7 +183,8 @@ def spmm2(mesh, xs, alpha, ps, beta, qs, gamma, outs):
             args += [xs[i].shape[1], x, ldx, p, ldp, q, ldq, ptr(outs[i])]
         else:
             args += [0, None, 0, None, 0, None, 0, None]
-    _lib.call('qt_spmm2', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), mesh.N, ptr(mesh.n_dev), *args, alpha, beta, gamma)
+    ell = ptr(mesh.ell) if os.environ.get('QT_SPMM_NO_ELL') != '1' else None
+    _lib.call('qt_spmm2', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), mesh.N, ptr(mesh.n_dev), *args, alpha, beta, gamma, ell)
 
 
 def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition='max_larger_than', mask=None,
@@ -284,7 +286,8 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
     ms.nrm = torch.empty(emax, device=device)
     _lib.call('qt_edges_fill', ptr(ms.labels), ptr(ms.cell), ptr(cnt4), ptr(sums), N, nd, n, m, float(resolution),
               ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis))
-    _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm))
+    ms.ell = torch.empty(N, 8, **i32)             # first four edges per row as two 16-byte vectors (k_spmm's fast path)
+    _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm), ptr(ms.ell))
 
 
 def build_homogeneous_mesh(n, m, max_size, mask, B=1, device=None, resolution=0.25):
