@@ -73,6 +73,22 @@ __global__ __launch_bounds__(QT_SPMM_BS) void k_spmm(const int32_t* __restrict__
     for (int u = 0; u < RPT; ++u)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[u][k] = 0.0f;
+    // the addends are requested now, together with the index loads, not after the gather loop: one dependent memory phase
+    // less at the end of every launch (each thread reads its own p / q element before it writes out: aliasing is fine)
+    float pv[RPT][VEC], qv[RPT][VEC];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        if constexpr (VEC == 4) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (p) a = *reinterpret_cast<const float4*>(p + row[u] * P.ldp + ch);
+            if (q) b = *reinterpret_cast<const float4*>(q + row[u] * P.ldq + ch);
+            pv[u][0] = a.x; pv[u][1] = a.y; pv[u][2] = a.z; pv[u][3] = a.w;
+            qv[u][0] = b.x; qv[u][1] = b.y; qv[u][2] = b.z; qv[u][3] = b.w;
+        } else {
+            pv[u][0] = p ? p[row[u] * P.ldp + ch] : 0.0f;
+            qv[u][0] = q ? q[row[u] * P.ldq + ch] : 0.0f;
+        }
+    }
     if constexpr (VEC == 4) {
         if (ell) {
             // the first four edges of a row come as two 16-byte vectors (qt_edges_norm): no row pointer on the way to the
@@ -173,8 +189,8 @@ __global__ __launch_bounds__(QT_SPMM_BS) void k_spmm(const int32_t* __restrict__
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             r[k] = alpha * acc[u][k];
-            if (p) r[k] += beta * p[row[u] * P.ldp + ch + k];
-            if (q) r[k] += gamma * q[row[u] * P.ldq + ch + k];
+            if (p) r[k] += beta * pv[u][k];
+            if (q) r[k] += gamma * qv[u][k];
         }
         if constexpr (VEC == 4) {
             *reinterpret_cast<float4*>(out + o) = make_float4(r[0], r[1], r[2], r[3]);
