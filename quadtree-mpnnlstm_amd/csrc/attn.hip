@@ -101,6 +101,7 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __re
     const int j0 = ((int)threadIdx.x % LPN) * 4;
     const float* pi = a.proj + (int64_t)i * a.ld;
     const F4 q = ld4(pi + j0);
+    const F4 sk = ld4(pi + 3 * a.C + j0);          // (requested now, not after the edge loop: no dependent load at the end)
     const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
     const F4 w1 = {{a.We[2 * j0 + 1], a.We[2 * j0 + 3], a.We[2 * j0 + 5], a.We[2 * j0 + 7]}};
     float m = -INFINITY, l = 0.0f;
@@ -164,7 +165,6 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __re
         }
     }
     const float inv = l > 0.0f ? 1.0f / l : 0.0f;
-    const F4 sk = ld4(pi + 3 * a.C + j0);
     F4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) o.v[c] = acc.v[c] * inv + sk.v[c];

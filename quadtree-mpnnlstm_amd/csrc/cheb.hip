@@ -320,6 +320,18 @@ __global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : QT_GEMM_OCC) void
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    // fused cell: this thread's previous cell states (one node per epilogue pass) are requested now, before the MFMA loop,
+    // so the epilogue does not start with a dependent memory round trip
+    constexpr int NPASS = CELL != 0 ? BM / (256 / (CELL != 0 ? CELL : 1)) : 1;
+    float4 cpre[NPASS];
+    if constexpr (CELL != 0) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int64_t node = i0 + ps * (256 / CELL) + t / CELL;
+            cpre[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (node < rows && g.Cprev) cpre[ps] = *reinterpret_cast<const float4*>(g.Cprev + node * g.ld_c + (t % CELL) * 4);
+        }
+    }
     for (int k0 = 0; k0 < g.K; k0 += KWT) {
         const int kn = min(KWT, g.K - k0);           // multiple of 4
         __syncthreads();                              // table ready / previous pass done with Bs
@@ -410,8 +422,8 @@ __global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : QT_GEMM_OCC) void
             const bool ok = node < rows;
             const float* cs = Cs + row * CP + j0;
             const F4 gi = ld4(cs), gf = ld4(cs + h), gc = ld4(cs + 2 * h), go = ld4(cs + 3 * h);
-            F4 cp = {{0, 0, 0, 0}};
-            if (ok && g.Cprev) cp = ld4(g.Cprev + node * g.ld_c + j0);
+            const float4 c4 = cpre[r0 / RP];
+            const F4 cp = {{c4.x, c4.y, c4.z, c4.w}};
             const CellOut r = cell_forward<lpn>(gi, gf, gc, go, cp, g.wc, g.bias, g.ln, h, j0);
             if (ok) {
                 if (g.O) st4(g.O + node * h + j0, r.Og);

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
         vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), acc, 1.0f);
         return;
     }
+    const float oscale = a.mean ? 1.0f / a.npix[i] : 1.0f;      // (requested before the pixel loop, not after it)
     for (int dr = 0; dr < cl.z; ++dr)
         for (int dc = 0; dc < cl.z; ++dc) {
             const int r = cl.x + dr, c = cl.y + dc;
@@ -300,8 +301,7 @@ __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
                 for (int k = 0; k < VEC; ++k) acc.v[k] += x.v[k];
             }
         }
-    vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), acc,
-                a.mean ? 1.0f / a.npix[i] : 1.0f);
+    vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), acc, oscale);
 }
 
 template <int VEC>
