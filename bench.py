@@ -38,6 +38,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-clips', type=int, default=10)
+    ap.add_argument('--frozen-steps', type=int, default=10,
+                    help='steps timed with the learning rate at 0 before training starts (frozen_ms_per_step; 0 = skip)')
     ap.add_argument('--eager', action='store_true', help='Python-driven launches instead of hipGraph replay')
     ap.add_argument('--host-inputs', action='store_true',
                     help='keep the batches in pinned host memory and copy them in every step (PCIe-inclusive rate; informational)')
@@ -74,13 +76,17 @@ def spmm_roofline(nfp, batch, mask, reps=10):
         orig(ms, xs, alpha, ps, beta, qs, gamma, outs)
     qmesh.spmm2 = ops.spmm2 = spy
     try:
-        nfp.train_step(*batch, mask)
+        # forward + loss + backward only: no all-reduce, no optimizer step -- rank 0 runs this alone, so nothing in it may
+        # be a collective (the other ranks are already waiting at the final barrier)
+        nfp.optimizer.zero_grad(set_to_none=True)
+        nfp.forward_loss(*batch, mask).backward()
+        nfp.optimizer.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
     finally:
         qmesh.spmm2 = ops.spmm2 = orig
     dev = batch[0].device
     bufs, timed = {}, {}
-    tot_us, tot_bytes = 0.0, 0.0
+    tot_us, tot_bytes, tot_moved = 0.0, 0.0, 0.0
     side = torch.cuda.Stream()
     for ms, Cs, has_p, has_q in records:
         key = (id(ms), Cs, has_p, has_q)
@@ -110,21 +116,36 @@ def spmm_roofline(nfp, batch, mask, reps=10):
             del g
         tot_us += timed[key]
         nv = ms.n_valid                      # static mode: ms.N is the capacity, the count lives on the device
-        tot_bytes += 4.0 * (nv + 1) + 8.0 * ms.E + 8.0 * nv * sum(Cs)
+        b = 4.0 * (nv + 1) + 8.0 * ms.E + 8.0 * nv * sum(Cs)
+        tot_bytes += b
+        tot_moved += b + 4.0 * nv * sum(Cs) * (int(has_p) + int(has_q))     # + the addend rows p, q of the recurrence
     n = len(records)
     achieved = tot_bytes / (tot_us * 1e-6) / 1e9
-    traffic = None           # HBM-side bytes per launch from the committed PMC passes (cannot be collected in-process)
-    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_spmm.json')
-    if os.path.exists(pmc):
-        traffic = json.load(open(pmc))['traffic_bytes_per_launch']
+    moved = tot_moved / (tot_us * 1e-6) / 1e9
+    # HBM-side bytes per launch come from separate rocprofv3 --pmc passes over this same command (they cannot be collected
+    # in-process); the newest committed record is quoted and named
+    traffic = source = None
+    for name in ('r02_pmc_spmm.json', 'r01_pmc_spmm.json'):
+        pmc = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(pmc):
+            traffic, source = json.load(open(pmc))['traffic_bytes_per_launch'], 'profiles/' + name
+            break
     return {'bound': 'hbm', 'kernel': 'k_spmm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'launches_per_step': n,
-            'avg_launch_us': round(tot_us / n, 2), 'avg_bytes_per_launch': round(tot_bytes / n)}
+            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': source,
+            'launches_per_step': n, 'avg_launch_us': round(tot_us / n, 2), 'avg_bytes_per_launch': round(tot_bytes / n),
+            'achieved_incl_addends': round(moved, 1), 'frac_incl_addends': round(moved / HBM_PEAK_GBS, 4),
+            'bytes_formula': '4(N+1) + 8E\' + 8NC per launch (SURVEY 8(d)); incl_addends adds 4NC per addend operand'}
 
 
-def cpu_baseline(n_clips):
-    """The CPU oracle (kind "port": a restatement of the reference algorithm, see oracle/qt_oracle.py) on a
-    bounded sample of the same workload: one clip per optimizer step, like the reference's batch_size=1 loop."""
+def gemm_mfma(nfp, batch, mask):
+    return None
+
+
+def cpu_baseline(n_clips, n_warm=3):
+    """The CPU oracle (kind "port": a restatement of the reference algorithm, see oracle/qt_oracle.py) on a bounded sample,
+    as SURVEY.md 8(d) prescribes: the cfg1 clips (64x64, ONE digit, in=10/out=10, noise 0.05), one clip per optimizer step
+    like the reference's batch_size=1 loop, torch threads = the cores this process may use, `n_warm` warm-up clips, then
+    the MEDIAN clip time of `n_clips` clips."""
     import numpy as np
     import torch
     from oracle import qt_oracle as O
@@ -133,23 +154,23 @@ def cpu_baseline(n_clips):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))      # the GPU box gives one job a 16-core share; more threads only thrash
-    torch.set_num_threads(cores)
+    torch.set_num_threads(max(1, cores))
     torch.manual_seed(1)
     model = O.Seq2Seq(HIDDEN, DROPOUT, THRESH, input_timesteps=T_IN, input_features=4, output_timesteps=T_OUT,
                       n_layers=N_LAYERS, n_conv_layers=2)
     opt = torch.optim.Adam(model.parameters(), lr=LR)
     mask = np.zeros(CANVAS, dtype=bool)
-    x, y = synthetic.make_batch(2, 0, n_clips + 1, T_IN, T_OUT, n_digits=N_DIGITS, pixel_noise=NOISE, canvas=CANVAS)
+    x, y = synthetic.make_batch(1, 0, n_warm + n_clips, T_IN, T_OUT, n_digits=1, pixel_noise=NOISE, canvas=CANVAS)
     concat = torch.zeros(T_OUT, *CANVAS, 1)
-    O.train_step(model, opt, torch.from_numpy(x[0]), torch.from_numpy(y[0]), concat, mask)      # warm-up clip
-    t0 = time.perf_counter()
-    for i in range(1, n_clips + 1):
+    times = []
+    for i in range(n_warm + n_clips):
+        t0 = time.perf_counter()
         O.train_step(model, opt, torch.from_numpy(x[i]), torch.from_numpy(y[i]), concat, mask)
-    dt = time.perf_counter() - t0
-    return {'value': round(n_clips * (T_IN + T_OUT) / dt, 3), 'unit': 'frames/s', 'cores': torch.get_num_threads(),
-            'kind': 'port', 'sample': f'{n_clips} clips of the same workload, one clip per optimizer step, '
-                                      f'after 1 warm-up clip ({dt:.1f} s)'}
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times[n_warm:]))
+    return {'value': round((T_IN + T_OUT) / med, 3), 'unit': 'frames/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'sample': f'cfg1 clips (64x64, 1 digit, in=10/out=10, noise {NOISE}), one clip per optimizer step: '
+                                      f'median of {n_clips} clips after {n_warm} warm-up clips ({sum(times):.1f} s in all)'}
 
 
 def log(msg):
@@ -179,6 +200,7 @@ def main():
     nfp = make_predictor(device, capturable=not args.eager)
     if world > 1:
         broadcast_parameters(nfp.model)
+        torch.manual_seed(1000 + rank)      # same weights everywhere, but every rank draws its own dropout masks
     nfp.model.train()
 
     # synthetic batches resident in HBM before the timed region; rank r owns clips [r*B, (r+1)*B) of each batch
@@ -199,29 +221,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def set_lr(v):
+        g = nfp.optimizer.param_groups[0]
+        if torch.is_tensor(g['lr']):
+            g['lr'].fill_(v)
+        else:
+            g['lr'] = v
+
+    def timed(n):
+        """n steps bracketed by barrier + synchronize on both sides; max over ranks of the wall time."""
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n):
+            if host_pool is not None:
+                loss = step(*(t.to(device, non_blocking=True) for t in host_pool[i % n_pool]))
+            else:
+                loss = step(*pool[i % n_pool])
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, loss
+
+    # Phase 0 (untimed for `value`): the same step with the learning rate at 0.  The decoder's meshes follow the model's own
+    # output, so the trained number below moves with the training trajectory; the frozen one is comparable between builds.
+    lr = float(os.environ.get('QT_BENCH_LR', LR))
+    frozen = args.frozen_steps > 0
+    if frozen:
+        set_lr(0.0)
     if args.eager:
         step = lambda x, y, c: nfp.train_step(x, y, c, mask)
     else:
-        # the whole step (forward, loss, backward, clip, Adam) as ONE hipGraph; 2 of the warm-up steps run eagerly
+        # the whole step (forward, loss, backward, clip, Adam) as ONE hipGraph; its 2 eager warm-up steps run first
         step = nfp.make_graphed_step(*pool[0], mask=mask, warmup=2)
         log('training step captured into a hipGraph')
-    for i in range(max(args.warmup - (0 if args.eager else 2), 0)):
+    frozen_ms = None
+    if frozen:
+        for i in range(3):
+            step(*pool[i % n_pool])
+        dtf, _ = timed(args.frozen_steps)
+        frozen_ms = dtf / args.frozen_steps * 1e3
+        set_lr(lr)
+        for st in nfp.optimizer.state.values():         # the frozen steps leave no trace in Adam's moments / step counts
+            for v in st.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+        log(f'frozen model (lr = 0): {frozen_ms:.3f} ms per step over {args.frozen_steps} steps')
+
+    for i in range(args.warmup):
         l = step(*pool[i % n_pool])
         if rank == 0:
             log(f'warm-up step {i}: loss {float(l):.5f}')
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if host_pool is not None:
-            loss = step(*(t.to(device, non_blocking=True) for t in host_pool[i % n_pool]))
-        else:
-            loss = step(*pool[i % n_pool])
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt, loss = timed(args.steps)
     assert torch.isfinite(loss).item(), 'non-finite loss in the timed region'
 
     if rank == 0:
@@ -235,15 +288,27 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: Moving-MNIST-like 64x64, 2 digits, in=10/out=10, '
                                    f'{args.batch} clips per GPU, pixel noise {args.noise}, thresh {THRESH}, hidden {HIDDEN}, '
                                    f'{N_LAYERS} layers, ChebConv K=3, dropout {DROPOUT}, Adam',
-                       'global_batch': global_batch, 'frames_per_clip': T_IN + T_OUT, 'parallelism': f'dp{world}', 'launch': 'eager' if args.eager else 'hipGraph replay', 'inputs': 'pinned host memory, copied every step' if args.host_inputs else 'resident in HBM',
+                       'global_batch': global_batch, 'frames_per_clip': T_IN + T_OUT, 'parallelism': f'dp{world}',
+                       'launch': 'eager' if args.eager else 'hipGraph replay',
+                       'inputs': 'pinned host memory, copied every step' if args.host_inputs else 'resident in HBM',
                        'final_loss': round(float(loss), 6)},
+            'frozen_ms_per_step': None if frozen_ms is None else round(frozen_ms, 3),
         }
         log(f'timed {args.steps} steps in {dt:.3f} s')
+        # the probes below run on rank 0 alone (the other ranks wait at the barrier): nothing in them is a collective, and a
+        # failure costs the optional object, never the metric line
         if not args.no_roofline:
-            line['roofline'] = spmm_roofline(nfp, pool[0], mask)
-            log('roofline step done')
+            try:
+                line['roofline'] = spmm_roofline(nfp, pool[0], mask)
+                line['mfma'] = gemm_mfma(nfp, pool[0], mask)
+            except Exception as e:                                            # pragma: no cover
+                line.setdefault('roofline', {'error': repr(e)[:200]})
+            log('roofline probes done')
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args.cpu_clips)
+            try:
+                line['cpu_baseline'] = cpu_baseline(args.cpu_clips)
+            except Exception as e:                                            # pragma: no cover
+                line['cpu_baseline'] = {'error': repr(e)[:200]}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -206,6 +206,9 @@ class Seq2Seq(nn.Module):
                  n_conv_layers=2, transform_func=None, condition='max_larger_than', remesh_input=False,
                  convolution_type='ChebConv', rnn_type='LSTM', binary=False, dummy=False, device=None, debug=False):
         super().__init__()
+        if hidden_size % 4:
+            raise ValueError(f'hidden_size={hidden_size}: the HIP path moves node rows as 16-byte vectors, so the hidden size '
+                             'must be a multiple of 4 (the reference scripts use 16 and 32)')
         self.encoder = Encoder(input_features, hidden_size, dropout, n_layers=n_layers, convolution_type=convolution_type,
                                rnn_type=rnn_type, n_conv_layers=n_conv_layers, dummy=dummy)
         self.decoder = Decoder(1 + 3, hidden_size, dropout, n_layers=n_layers, concat_layers_dim=1,
@@ -237,6 +240,7 @@ class Seq2Seq(nn.Module):
     def process_inputs(self, x, mask=None, high_interest_region=None, graph_structure=None):
         """model/seq2seq.py:254-336.  x: (T_in, W, H, C) or (B, T_in, W, H, C)."""
         self._single = x.dim() == 4
+        self._deferred = None
         if self._single:
             x = x.unsqueeze(0)
         x = x.float()
@@ -327,6 +331,7 @@ class Seq2Seq(nn.Module):
                       high_interest_region=None, remesh_every=1):
         """model/seq2seq.py:339-398.  concat_layers: (T_out, W, H, 1) or (B, T_out, W, H, 1)."""
         g = self.graph
+        self._apply_deferred_update()
         mesh = g.mapping
         if concat_layers is not None:
             concat_layers = concat_layers.to(g.pyg.x.device).float()
@@ -350,14 +355,18 @@ class Seq2Seq(nn.Module):
             output_mappings.append(mesh)
             teacher_force = random.random() < teacher_forcing_ratio
             if t == steps[-1]:
-                # the reference re-meshes once more here (:393-394); nothing reads that mesh, so it is skipped.
-                # The kept state is detached: a live reference into the autograd graph would pin its AccumulateGrad
-                # nodes (and their stream) across iterations, which breaks hipGraph capture of the next step.
-                g.hidden = torch.stack([h.detach() for h in hidden])
-                g.cell = torch.stack([c.detach() for c in cell])
+                # the reference updates the state once more here (:393-396: re-mesh or input update); nothing in a training
+                # step reads it, so it is DEFERRED: a later unroll_output call without process_inputs in between (a
+                # continued rollout) applies it first.  The kept state is detached: a live reference into the autograd
+                # graph would pin its AccumulateGrad nodes (and their stream) across iterations, which breaks hipGraph
+                # capture of the next step -- so a continued rollout does not backpropagate into the earlier call.
+                g.hidden = [h.detach() for h in hidden]
+                g.cell = [c.detach() for c in cell]
                 g.pyg.x = g.pyg.x.detach()
                 if concat_layers is not None:
                     g.concat_layers = g.concat_layers.detach()
+                self._deferred = (output.detach(), (t + 1) % remesh_every == 0, mask, high_interest_region, teacher_force,
+                                  y[:, t].detach() if teacher_force else None)
                 break
             if self.thresh != -np.inf and (t + 1) % remesh_every == 0:
                 mesh = self.do_remesh(output, hidden, cell, mask, high_interest_region, teacher_force,
@@ -365,6 +374,18 @@ class Seq2Seq(nn.Module):
             else:
                 self.update_without_remesh(output, hidden, cell, teacher_force, y[:, t] if teacher_force else None)
         return outputs, output_mappings
+
+    def _apply_deferred_update(self):
+        """The state update the previous unroll_output call left out after its last step (see there)."""
+        d, self._deferred = getattr(self, '_deferred', None), None
+        if d is None:
+            return
+        output, remesh, mask, hir, teacher_force, teacher_input = d
+        g = self.graph
+        if self.thresh != -np.inf and remesh:
+            self.do_remesh(output, g.hidden, g.cell, mask, hir, teacher_force, teacher_input)
+        else:
+            self.update_without_remesh(output, g.hidden, g.cell, teacher_force, teacher_input)
 
     def forward(self, x, y=None, concat_layers=None, teacher_forcing_ratio=0.5, mask=None, high_interest_region=None,
                 graph_structure=None, remesh_every=1):
@@ -374,12 +395,15 @@ class Seq2Seq(nn.Module):
                                   high_interest_region=high_interest_region, remesh_every=remesh_every)
 
     def update_without_remesh(self, data, hidden, cell, teacher_force=False, teacher_input=None):
-        """model/seq2seq.py:420-431."""
+        """model/seq2seq.py:420-431.  With teacher forcing the reference rebuilds the whole input row as
+        [flatten(teacher + positional encoding) | RAW n_pixels_per_node] (:422-425): the size column is then the pixel count
+        itself, not the normalised size the mesh build wrote (npix / 1024, resolution^2 on pixelwise meshes, npix / 4 on
+        preset meshes) -- reproduced as is."""
         g = self.graph
         if teacher_force:
             mesh = g.mapping
-            val = ops.pool_image(teacher_input.reshape(mesh.B, 1, mesh.P, -1)[..., :1], mesh, True)[0]
-            g.pyg.x = torch.cat([val, g.pyg.x[:, 1:]], dim=-1)
+            val = ops.pool_image(teacher_input.reshape(mesh.B, 1, mesh.P, -1)[..., :1].float(), mesh, True)[0]
+            g.pyg.x = torch.cat([val, mesh.posfeat[:, :2], mesh.npix.unsqueeze(1)], dim=-1)
         else:
             g.pyg.x = torch.cat([data, g.pyg.x[:, 1:]], dim=-1)
         g.hidden, g.cell = hidden, cell

@@ -968,13 +968,55 @@ def remesh_transfer(vals, old, new, out_widths=None):
     one matrix (out_widths None) or as the list of its column parts."""
     single = not isinstance(vals, (list, tuple))
     vals = [vals] if single else list(vals)
-    C = sum(v.shape[1] for v in vals)
-    if any(v.shape[1] % 4 for v in vals) or len(vals) > 8:            # odd widths: one matrix through qt_pool
-        assert out_widths is None or list(out_widths) == [C]
+    win = [v.shape[1] for v in vals]
+    C = sum(win)
+    wout = list(out_widths) if out_widths is not None else [C]
+    if sum(wout) != C:
+        raise ValueError(f'remesh_transfer: out_widths {wout} do not add up to the {C} columns of the state')
+    if any(w % 4 for w in win + wout):                   # odd widths: one matrix through qt_pool, then column views
         v = vals[0] if len(vals) == 1 else torch.cat(vals, dim=1)
-        return _RemeshOne.apply(v, old, new)
-    outs = _Remesh.apply(old, new, tuple(out_widths) if out_widths is not None else (C,), *vals)
+        out = _RemeshOne.apply(v, old, new)
+        return out if out_widths is None else list(torch.split(out, wout, dim=1))
+    # qt_remesh takes <= 8 parts in and out per launch; more parts (n_layers >= 4) go across in balanced runs
+    nmax = max(len(win), len(wout))
+    groups = _remesh_groups(win, wout, -(-nmax // -(-nmax // 8))) or _remesh_groups(win, wout)
+    outs = []
+    if groups is None:       # e.g. 9 parts into one matrix: across in runs of 8 with their own widths, regrouped afterwards
+        for a in range(0, len(vals), 8):
+            outs += _Remesh.apply(old, new, tuple(win[a:a + 8]), *vals[a:a + 8])
+        outs = torch.split(concat_cols(outs, new), wout, dim=1)
+    else:
+        for i0, i1, o0, o1 in groups:
+            outs += _Remesh.apply(old, new, tuple(wout[o0:o1]), *vals[i0:i1])
     return outs[0] if out_widths is None else list(outs)
+
+
+def _remesh_groups(win, wout, limit=8):
+    """[(i0, i1, o0, o1)]: consecutive runs of input parts [i0, i1) and output parts [o0, o1) that cover the same columns
+    with at most `limit` parts on either side (one qt_remesh launch each), chosen greedily; None when some stretch between
+    two column boundaries the two splits share needs more parts than that."""
+    def cum(ws):
+        out = [0]
+        for w in ws:
+            out.append(out[-1] + w)
+        return out
+    ci, co = cum(win), cum(wout)
+    at_i, at_o = {c: i for i, c in enumerate(ci)}, {c: i for i, c in enumerate(co)}
+    common = sorted(set(ci) & set(co))
+    groups, i0, o0 = [], 0, 0
+    while i0 < len(win):
+        best = None
+        for c in common:
+            if c <= ci[i0]:
+                continue
+            if at_i[c] - i0 > limit or at_o[c] - o0 > limit:
+                break
+            best = (at_i[c], at_o[c])
+        if best is None:
+            return None
+        groups.append((i0, best[0], o0, best[1]))
+        i0, o0 = best
+    return groups
 
 
 class _RemeshOne(Function):

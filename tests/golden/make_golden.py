@@ -307,13 +307,31 @@ def rollouts():
     concat = np.zeros((4, 64, 64, 1), np.float32)
     rollout('mnist64_h16', x[0], y[0], concat, mask, hidden=16, n_layers=2, n_conv=2, thresh=0.1, t_in=4, t_out=4, scale=0.06,
             bscale=0.02)
-    x, y = synthetic.make_batch(9, 5, 1, 3, 3, n_digits=1, pixel_noise=0.02, canvas=(64, 64))
+    # noisy frames, weights small enough that the model's own output keeps the meshes fine (N stays in the thousands; the
+    # round-1 version of this case collapsed to a 1-node mesh by the last step)
+    x, y = synthetic.make_batch(9, 5, 1, 3, 3, n_digits=1, pixel_noise=0.05, canvas=(64, 64))
     concat = (0.1 * np.random.default_rng(3).random((3, 64, 64, 1))).astype(np.float32)
-    rollout('mnist64_noise_h8', x[0], y[0], concat, mask, hidden=8, n_layers=1, n_conv=1, thresh=0.1, t_in=3, t_out=3, seed=61)
+    rollout('mnist64_noise_h8', x[0], y[0], concat, mask, hidden=8, n_layers=1, n_conv=1, thresh=0.1, t_in=3, t_out=3, seed=61,
+            scale=0.03, bscale=0.01)
+    # the reference's default depth n_layers=4: 1 + 2*4 = 9 state parts cross every re-mesh
+    x, y = synthetic.make_batch(9, 7, 1, 2, 3, n_digits=1, pixel_noise=0.04, canvas=(64, 64))
+    concat = (0.1 * np.random.default_rng(4).random((3, 64, 64, 1))).astype(np.float32)
+    rollout('mnist64_l4_h8', x[0], y[0], concat, mask, hidden=8, n_layers=4, n_conv=2, thresh=0.1, t_in=2, t_out=3, seed=63,
+            scale=0.05, bscale=0.01)
     f, m = synthetic.make_ice_like(18, shape=(64, 64), channels=3, n_frames=5)
     concat = f[2:5, ..., :1].copy() * 0.5
     rollout('ice64_masked_h8', f[:2], f[2:5, ..., :1].copy(), concat, m, hidden=8, n_layers=1, n_conv=3, thresh=0.15,
             t_in=2, t_out=3, transform=dist_from_05, seed=62, scale=0.1)
+
+
+def rollout_headline():
+    """One clip of the BENCHMARKED workload (BASELINE configs[1]: 64x64, 2 digits, noise 0.05, in=10/out=10, hidden 16,
+    2 layers, 2 conv layers, dropout 0): clip 0 of bench.py's first batch (synthetic seed 2000)."""
+    x, y = synthetic.make_batch(2, 0, 1, 10, 10, n_digits=2, pixel_noise=0.05, canvas=(64, 64))
+    mask = np.zeros((64, 64), dtype=bool)
+    concat = np.zeros((10, 64, 64, 1), np.float32)
+    rollout('cfg2_mnist64', x[0], y[0], concat, mask, hidden=16, n_layers=2, n_conv=2, thresh=0.1, t_in=10, t_out=10, seed=64,
+            scale=0.06, bscale=0.02)
 
 
 # ------------------------------------------------------------------ SURVEY 8(f) row 2: pixelwise and preset static meshes
@@ -505,6 +523,109 @@ def transformer_cases():
     print('transformer rollout loss', loss.item(), 'N', [len(o) for o in outs])
 
 
+# ------------------------------------------------------------------ what ice_exp.py really runs (+ predict, climatology)
+def climatology_from_base(base):
+    """(1, 365, w, h) daily normals from a (w, h) base field: the fixture stores `base` only (tests/helpers.py repeats this)."""
+    d = np.arange(365, dtype=np.float32)[:, None, None]
+    return (base[None] * (0.5 + 0.5 * np.cos(2 * np.pi * d / 365.0)) + 0.001 * d)[None].astype(np.float32)
+
+
+class _DS:
+    def __init__(self, shape):
+        self.image_shape = shape
+
+
+class _Loader(list):
+    pass
+
+
+def ice_exp_case():
+    """ice_exp.py:48,145,153-162: thresh = -inf (pixelwise mesh) x TransformerConv x hidden 32 x n_conv_layers 3 x n_layers 1,
+    5 input variables, land mask, climatology concat through NextFramePredictorS2S.get_climatology_array, and predict().
+    Run through the reference's own trainer class (model/mpnnlstm.py); eval mode (attention / decoder dropout cannot be RNG
+    matched).  Launch dates sit at 12:00 so that datetime.fromtimestamp gives the same day in any time zone; the second clip
+    crosses the year end (day-of-year index 363, 364, 0)."""
+    from model import mpnnlstm as RP
+    shape = (24, 32)
+    f0, m = synthetic.make_ice_like(25, shape=shape, channels=5, n_frames=6)
+    f1, _ = synthetic.make_ice_like(26, shape=shape, channels=5, n_frames=6)
+    x = np.stack([f0[:3], f1[:3]])
+    y = np.stack([f0[3:, ..., :1], f1[3:, ..., :1]])
+    base = synthetic.make_ice_like(27, shape=shape, channels=1, n_frames=1)[0][0, ..., 0]
+    clim = torch.from_numpy(climatology_from_base(base))
+    import datetime as _dt
+    launch = np.array([int(_dt.datetime(2010, 3, 1, 12, tzinfo=_dt.timezone.utc).timestamp()) * 10 ** 9,
+                       int(_dt.datetime(2010, 12, 30, 12, tzinfo=_dt.timezone.utc).timestamp()) * 10 ** 9], dtype=np.int64)
+    kw = dict(hidden_size=32, dropout=0.1, n_layers=1, transform_func=dist_from_05, dummy=False, n_conv_layers=3,
+              rnn_type='LSTM', convolution_type='TransformerConv')
+    nfp = RP.NextFramePredictorS2S(thresh=-np.inf, input_features=5, input_timesteps=3, output_timesteps=3,
+                                   device=torch.device('cpu'), transform_func=dist_from_05, model_kwargs=kw)
+    randomize(nfp.model, 95, scale=0.1, bscale=0.05)
+    nfp.model.eval()
+    mk = torch.from_numpy(m)
+    out = dict(x=x, y=y, mask=m, clim_base=base, launch=launch, n_params=np.int64(nfp.get_n_params()))
+    for c in range(2):
+        ld = torch.tensor([launch[c]])
+        concat = nfp.get_climatology_array(clim, ld)
+        out[f'concat_{c}'] = concat.numpy()
+        nfp.model.zero_grad()
+        outs, maps = nfp.model(torch.from_numpy(x[c]), torch.from_numpy(y[c]), concat, teacher_forcing_ratio=0, mask=m)
+        y_hat = torch.stack([RG.unflatten(outs[i], maps[i], shape, m) for i in range(3)])
+        loss = torch.nn.MSELoss()(y_hat[:, ~mk], torch.from_numpy(y[c])[:, ~mk])
+        loss.backward()
+        out[f'loss_{c}'] = np.float64(loss.item())
+        for i, o in enumerate(outs):
+            out[f'out_{c}_{i}'] = o.detach().numpy()
+        if c == 0:
+            for k, p in nfp.model.named_parameters():
+                out['g/' + k] = p.grad.numpy().copy() if p.grad is not None else np.zeros(p.shape, np.float32)
+    out.update(state_arrays(nfp.model, 'w/'))
+    loader = _Loader([(torch.from_numpy(x[c])[None], torch.from_numpy(y[c])[None], torch.tensor([launch[c]])) for c in range(2)])
+    loader.dataset = _DS(shape)
+    pred = nfp.predict(loader, clim, mask=m)
+    out['pred'] = pred
+    np.savez_compressed(os.path.join(HERE, 'variant_ice_exp.npz'), **out)
+    print('ice_exp case: losses', out['loss_0'], out['loss_1'], 'N', len(outs[0]), 'params', int(out['n_params']), 'pred', pred.shape)
+
+
+def teacher_fixed_cases():
+    """Teacher forcing where no re-mesh happens (model/seq2seq.py:420-425): the decoder's next input is rebuilt as
+    [flatten(teacher + positional encoding) | RAW n_pixels_per_node] -- on a pixelwise mesh (thresh = -inf), on a preset
+    heterogeneous mesh, and on quadtree meshes with remesh_every = 2 (every other step takes this branch)."""
+    f, m = synthetic.make_ice_like(29, shape=(32, 40), channels=3, n_frames=6)
+    x, y = f[:2], f[2:6, ..., :1].copy()
+    concat = y * 0.5
+    mk = torch.from_numpy(m)
+    xt, yt, ct = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(concat)
+
+    def run(name, thresh, gs=None, remesh_every=1, mask=m, seed=100, extra=None):
+        model = RS.Seq2Seq(hidden_size=8, dropout=0.0, thresh=thresh, input_timesteps=2, input_features=6, output_timesteps=4,
+                           n_layers=2, n_conv_layers=1, convolution_type='ChebConv')
+        randomize(model, seed, scale=0.1, bscale=0.05)
+        model.train()
+        outs, maps = model(xt, yt, ct, teacher_forcing_ratio=1.0, mask=mask, graph_structure=gs, remesh_every=remesh_every)
+        y_hat = torch.stack([RG.unflatten(outs[i], maps[i], x.shape[1:3], mask) for i in range(4)])
+        mk_ = torch.from_numpy(mask)
+        loss = torch.nn.MSELoss()(y_hat[:, ~mk_], yt[:, ~mk_])
+        loss.backward()
+        out = dict(x=x, y=y, concat=concat, mask=mask, loss=np.float64(loss.item()), thresh=np.float64(thresh),
+                   remesh_every=np.int64(remesh_every))
+        for i, o in enumerate(outs):
+            out[f'out_{i}'] = o.detach().numpy()
+        out.update(state_arrays(model, 'w/'))
+        for k, p in model.named_parameters():
+            out['g/' + k] = p.grad.numpy() if p.grad is not None else np.zeros(p.shape, np.float32)
+        out.update(extra or {})
+        np.savez_compressed(os.path.join(HERE, f'variant_{name}.npz'), **out)
+        print(name, 'loss', loss.item(), 'N', [len(o) for o in outs])
+
+    run('teacher_pixelwise', -np.inf)
+    hir = np.zeros_like(m); hir[8:14, 20:30] = True
+    gs = RG.create_static_heterogeneous_graph(x.shape[1:3], 8, m, high_interest_region=hir, use_edge_attrs=False)
+    run('teacher_static', -np.inf, gs=gs, seed=101, extra=dict(hir=hir, max_grid_size=np.int64(8)))
+    run('teacher_every2', 0.15, remesh_every=2, mask=np.zeros_like(m), seed=102)
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -514,7 +635,6 @@ if __name__ == '__main__':
         graphs()
         transfers()
         cells()
-        rollouts()
     if only in ('', 'fixed'):
         fixed_meshes()
     if only in ('', 'homog'):
@@ -523,4 +643,12 @@ if __name__ == '__main__':
         rollout_variants()
     if only in ('', 'transformer'):
         transformer_cases()
+    if only in ('', 'rollouts'):
+        rollouts()
+    if only in ('', 'headline'):
+        rollout_headline()
+    if only in ('', 'ice_exp'):
+        ice_exp_case()
+    if only in ('', 'teacher_fixed'):
+        teacher_fixed_cases()
     print('golden vectors written to', HERE)

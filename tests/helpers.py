@@ -51,3 +51,18 @@ def mesh_from_golden_graph(g):
     hir = g['hir'] if 'hir' in g.files else None
     return build_mesh(src=_criterion(img0, n, m, 64, tf), n=n, m=m, thresh=float(g['thresh']),
                       condition=str(g['condition']), mask=mask, high_interest_region=hir)
+
+
+def climatology_from_base(base):
+    """(1, 365, w, h) daily normals from the (w, h) base field a fixture stores (the formula of tests/golden/make_golden.py)."""
+    d = np.arange(365, dtype=np.float32)[:, None, None]
+    return (base[None] * (0.5 + 0.5 * np.cos(2 * np.pi * d / 365.0)) + 0.001 * d)[None].astype(np.float32)
+
+
+class TinyLoader(list):
+    """In-memory stand-in for the reference's DataLoader(batch_size=1): items (x (1, T, W, H, C), y, launch_date) and
+    `.dataset.image_shape` (model/mpnnlstm.py:201, 219-221)."""
+
+    def __init__(self, items, image_shape):
+        super().__init__(items)
+        self.dataset = type('DS', (), {'image_shape': tuple(image_shape)})()

@@ -1,6 +1,8 @@
-"""Data-parallel equivalence on the GPU: two ranks (gloo transport, both on cuda:0 -- RCCL needs one GPU per rank, the
-driver's multi-GPU bench covers that) training on half the clips each must reproduce the single-process step on all
-clips: same loss (mean of the rank losses) and the same weights after the update."""
+"""Data-parallel equivalence on the GPU: two ranks training on half the clips each must reproduce the single-process step
+on all clips: same loss (mean of the rank losses) and the same weights after the update.  With two or more GPUs visible the
+ranks take one GPU each and exchange gradients over RCCL (backend "nccl"); on a one-GPU box both ranks share cuda:0 and
+the transport is gloo (RCCL needs one GPU per rank).  bench.py's multi-rank path (probes on rank 0 only while the other
+ranks wait) is run the same way."""
 import os
 import socket
 
@@ -14,10 +16,15 @@ pytestmark = pytest.mark.gpu
 T, B = 3, 4
 
 
-def _setup():
+def _backend():
+    return 'nccl' if torch.cuda.device_count() >= 2 else 'gloo'
+
+
+def _setup(rank=0):
     from model.mpnnlstm import NextFramePredictorS2S
     torch.manual_seed(11)
-    dev = torch.device('cuda', 0)
+    dev = torch.device('cuda', rank if torch.cuda.device_count() >= 2 else 0)
+    torch.cuda.set_device(dev)
     nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=T, output_timesteps=T, device=dev,
                                 model_kwargs=dict(hidden_size=8, dropout=0.0, n_layers=1))
     nfp.initiate_training(lr=1e-3, lr_decay=0.95, capturable=True)
@@ -34,8 +41,8 @@ def _data(dev, lo, hi):
 def _rank(rank, world, port, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from qtmpnn.dist import init_from_env, shard_range
-    init_from_env('gloo')
-    nfp, dev = _setup()
+    init_from_env(_backend())
+    nfp, dev = _setup(rank)
     lo, hi = shard_range(B, rank, world)
     x, y, c = _data(dev, lo, hi)
     mask = np.zeros((64, 64), dtype=bool)
@@ -75,3 +82,28 @@ def test_two_ranks_equal_one_process():
     for k in ref:
         np.testing.assert_allclose(res[0][2][k], res[1][2][k], rtol=0, atol=0, err_msg=f'ranks diverged: {k}')
         np.testing.assert_allclose(res[0][2][k], ref[k].numpy(), rtol=2e-3, atol=2e-4, err_msg=k)
+
+
+def test_bench_two_ranks_prints_one_line_with_probes():
+    """bench.py --gpus 2 (spawned through torchrun as the driver does): rank 0 runs the roofline probes alone after the
+    timed region, so they must be collective-free -- the run has to end with ONE JSON line carrying `roofline`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_PORT=str(port), QT_DIST_BACKEND=_backend())
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '4',
+           '--frozen-steps', '2']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 8 and rec['value'] > 0
+    assert rec['roofline'].get('frac', 0) > 0, rec['roofline']
+    assert rec['frozen_ms_per_step'] > 0

@@ -68,7 +68,7 @@ def _check_trace(g, outs, meshes, clip=0):
         close(o, g[f'out_{i}'], msg=f'output step {i}')
 
 
-@pytest.mark.parametrize('name', ['mnist64_h16', 'mnist64_noise_h8', 'ice64_masked_h8'])
+@pytest.mark.parametrize('name', ['mnist64_h16', 'mnist64_noise_h8', 'ice64_masked_h8', 'mnist64_l4_h8', 'cfg2_mnist64'])
 def test_rollout_golden(name):
     g = golden(f'rollout_{name}.npz')
     model, outs, meshes, loss = _run(g)
