@@ -144,8 +144,10 @@ def gemm_mfma(nfp, batch, mask):
 def cpu_baseline(n_clips, n_warm=3):
     """The CPU oracle (kind "port": a restatement of the reference algorithm, see oracle/qt_oracle.py) on a bounded sample,
     as SURVEY.md 8(d) prescribes: the cfg1 clips (64x64, ONE digit, in=10/out=10, noise 0.05), one clip per optimizer step
-    like the reference's batch_size=1 loop, torch threads = the cores this process may use, `n_warm` warm-up clips, then
-    the MEDIAN clip time of `n_clips` clips."""
+    like the reference's batch_size=1 loop, `n_warm` warm-up clips, then the MEDIAN clip time of `n_clips` clips.  Threads =
+    the cores this process may use, at most 16: a one-GPU job owns a 16-core share of the box, and with one thread per
+    visible core (128+) the small per-node tensor ops only thrash (measured: > 40 s per clip instead of ~1.5 s);
+    `cores` reports the thread count actually used."""
     import numpy as np
     import torch
     from oracle import qt_oracle as O
@@ -154,7 +156,7 @@ def cpu_baseline(n_clips, n_warm=3):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    torch.set_num_threads(max(1, cores))
+    torch.set_num_threads(max(1, min(cores, 16)))
     torch.manual_seed(1)
     model = O.Seq2Seq(HIDDEN, DROPOUT, THRESH, input_timesteps=T_IN, input_features=4, output_timesteps=T_OUT,
                       n_layers=N_LAYERS, n_conv_layers=2)
@@ -167,6 +169,10 @@ def cpu_baseline(n_clips, n_warm=3):
         t0 = time.perf_counter()
         O.train_step(model, opt, torch.from_numpy(x[i]), torch.from_numpy(y[i]), concat, mask)
         times.append(time.perf_counter() - t0)
+        log(f'cpu baseline clip {i + 1}/{n_warm + n_clips}: {times[-1]:.2f} s')
+        if sum(times) > 120 and i >= n_warm + 2:          # bounded sample: never more than ~2 minutes of CPU work
+            break
+    n_clips = len(times) - n_warm
     med = float(np.median(times[n_warm:]))
     return {'value': round((T_IN + T_OUT) / med, 3), 'unit': 'frames/s', 'cores': torch.get_num_threads(),
             'kind': 'port', 'sample': f'cfg1 clips (64x64, 1 digit, in=10/out=10, noise {NOISE}), one clip per optimizer step: '
@@ -270,6 +276,19 @@ def main():
                     v.zero_()
         log(f'frozen model (lr = 0): {frozen_ms:.3f} ms per step over {args.frozen_steps} steps')
 
+    # Kernel probes (rank 0 alone, collective-free; the other ranks wait at the next barrier).  They run on the model as
+    # initialised -- before any training step -- so the launch mix they time is the same in every build.
+    probes = {}
+    if rank == 0 and not args.no_roofline:
+        try:
+            probes['roofline'] = spmm_roofline(nfp, pool[0], mask)
+            m = gemm_mfma(nfp, pool[0], mask)
+            if m is not None:
+                probes['mfma'] = m
+        except Exception as e:                                            # pragma: no cover
+            probes.setdefault('roofline', {'error': repr(e)[:200]})
+        log('roofline probes done')
+
     for i in range(args.warmup):
         l = step(*pool[i % n_pool])
         if rank == 0:
@@ -295,15 +314,7 @@ def main():
             'frozen_ms_per_step': None if frozen_ms is None else round(frozen_ms, 3),
         }
         log(f'timed {args.steps} steps in {dt:.3f} s')
-        # the probes below run on rank 0 alone (the other ranks wait at the barrier): nothing in them is a collective, and a
-        # failure costs the optional object, never the metric line
-        if not args.no_roofline:
-            try:
-                line['roofline'] = spmm_roofline(nfp, pool[0], mask)
-                line['mfma'] = gemm_mfma(nfp, pool[0], mask)
-            except Exception as e:                                            # pragma: no cover
-                line.setdefault('roofline', {'error': repr(e)[:200]})
-            log('roofline probes done')
+        line.update(probes)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(args.cpu_clips)

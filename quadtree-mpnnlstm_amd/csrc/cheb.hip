@@ -479,6 +479,186 @@ __global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : QT_GEMM_OCC) void
     QT_STAMP(5);
 }
 
+// ---- persistent gate GEMM + LSTM cell (hidden 8 / 16): one 512-thread workgroup per CU, W staged ONCE, no workgroup barrier
+// after that.  The unit of work is a WAVE's 32 node rows x all 4h gate columns: the wave streams its A quads global -> VGPR
+// through a 4-deep ring that already holds the next unit's first quads when the current unit's epilogue starts, runs the
+// MFMA chain, parks the accumulators in its OWN staging rows in LDS and computes the cell for those 32 nodes itself (h / 4
+// lanes per node, as k_gemm_fwd's fused epilogue: same arithmetic in the same order, bit-identical results).  Two waves
+// share a SIMD, so one wave's epilogue (VALU, LDS, stores) runs beside the other's MFMA chain.  Against the one-tile
+// workgroups of k_gemm_fwd<2, 128, 4> this removes the per-tile W staging (4 us of 21 at the bench shape), the four
+// workgroup barriers per tile, and the serial memory -> MFMA -> store phases of a tile.
+// Work split: workgroup b owns the contiguous units [U b / G, U (b + 1) / G) of the U = ceil(rows / 32) units (valid rows
+// read on the device), its wave w takes every 8th of them.
+constexpr int GATE_P_MAXK = 256, GATE_P_MAXPITCH = GATE_P_MAXK + 8;
+#ifndef QT_GATE_STAGGER
+#define QT_GATE_STAGGER 0
+#endif
+template <int NT, int LPN, int R>
+__global__ __launch_bounds__(512, 2) void k_gate_cell_p(GemmArgs g, int pitch) {
+    using namespace qtcell;
+    constexpr int BNT = 32 * NT, h = 4 * LPN, CP = 5 * h, NPW = 64 / LPN, NPASS = 32 / NPW;
+    static_assert(4 * h == BNT, "the gate columns fill the MFMA tiles exactly");
+    // static LDS (a single workgroup may declare up to 160 KiB on gfx950; dynamic LDS beyond 64 KiB was refused at launch)
+    __shared__ __attribute__((aligned(16))) float Bt[BNT * GATE_P_MAXPITCH];   // W^T: [BNT][pitch], pitch / 4 odd -> conflict-free ds_read_b128
+    __shared__ __attribute__((aligned(16))) float Cst[8 * 32 * CP];
+    __shared__ const float* qptr[MAXQ];
+    __shared__ int qstr[MAXQ];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l32 = lane & 31, half = lane >> 5;
+    float* Cs = Cst + wave * (32 * CP);                 // this wave's staging rows
+    const int rows = qt_rows(g.n_dev, g.M);
+    const int nunits = (rows + 31) >> 5;
+    const int u0 = (int)((int64_t)nunits * blockIdx.x / gridDim.x), u1 = (int)((int64_t)nunits * (blockIdx.x + 1) / gridDim.x);
+    if (u0 >= u1) return;
+    QT_STAMP(0);
+    const int nquad = g.K >> 2;
+    build_quad_table(g.A, qptr, qstr, nquad);
+    if (g.BT) {
+        for (int e = t; e < BNT * nquad; e += 512) {
+            const int c = e / nquad, kq = e - c * nquad;
+            *reinterpret_cast<float4*>(&Bt[c * pitch + 4 * kq]) = *reinterpret_cast<const float4*>(g.BT + (int64_t)c * g.K + 4 * kq);
+        }
+    } else {
+        for (int e = t; e < g.K * (BNT / 4); e += 512) {
+            const int kb = e / (BNT / 4), jq = (e % (BNT / 4)) * 4;
+            const float4 w = *reinterpret_cast<const float4*>(g.B + (int64_t)kb * BNT + jq);
+            Bt[(jq + 0) * pitch + kb] = w.x;
+            Bt[(jq + 1) * pitch + kb] = w.y;
+            Bt[(jq + 2) * pitch + kb] = w.z;
+            Bt[(jq + 3) * pitch + kb] = w.w;
+        }
+    }
+    if (g.K & 4)                                          // an odd quad count: the last k-group's upper half reads zeros
+        for (int c = t; c < BNT; c += 512) *reinterpret_cast<float4*>(&Bt[c * pitch + g.K]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();                                      // the only workgroup barrier
+    QT_STAMP(1);
+    int unit = u0 + wave;
+    if (unit >= u1) return;
+    const int nj = (g.K + 7) >> 3;
+    // Every A load is UNCONDITIONAL (row and quad clamped to valid ones, the value zeroed by a select): a load inside a
+    // branch makes hipcc's s_waitcnt bookkeeping fall back to draining the whole queue at the next use, which serialised
+    // the stream (41 us per launch at the bench shape, whatever the ring depth).
+    const int64_t last_row = rows - 1;
+    auto ldq = [&](int64_t row, bool ok, int j) {
+        const int q = 2 * j + half;
+        const bool use = ok && q < nquad;
+        const int qc = q < nquad ? q : 0;
+        const float4 r = gload4(qptr[qc] + (row <= last_row ? row : last_row) * qstr[qc]);
+        return make_float4(use ? r.x : 0.f, use ? r.y : 0.f, use ? r.z : 0.f, use ? r.w : 0.f);
+    };
+    int64_t my_row = (int64_t)unit * 32 + l32;
+    bool row_ok = my_row < rows;
+    // The A operand is streamed once and shared with no other wave: it goes global -> VGPR, and what bounds the stream is the
+    // bytes a CU keeps in flight (8 waves x 4 quads of 1 KiB = 32 KiB ran at 2.5 TB/s).  R > 0: the ring holds a WHOLE unit
+    // (nj <= R steps, the j loop fully unrolled so that ring[j] is a fixed register): step j consumes ring[j] and at once
+    // requests the next unit's quad j into it, so a wave always has ~nj KiB in flight, across the epilogue too.
+    // R == 0 (any nj): the 4-deep rotating ring of k_gemm_fwd.
+    float4 ring[R > 0 ? R : 4];
+#pragma unroll
+    for (int j = 0; j < (R > 0 ? R : 4); ++j) ring[j] = ldq(my_row, row_ok, j);
+    const int nl = lane / LPN, j0 = (lane - nl * LPN) * 4;
+    const CellParams cpar = cell_params(g.wc, g.bias, g.ln, h, j0);      // in registers for the whole launch
+    // Stagger: the two waves of a SIMD (w and w + 4) run the same program; started together they sit in their MFMA chains
+    // together (matrix pipe shared: 2 x 6.7k cycles) and then in their epilogues together (VALU issue shared: the cell's
+    // sigmoids / tanhs are ~6k cycles per unit) -- in-kernel stamps showed 7.7 + 7.5 us per unit that way.  Waves 4..7 start
+    // half a unit late, so one wave's epilogue runs beside the other's MFMA chain.
+    if (wave >= 4) {
+#pragma unroll 1
+        for (int i = 0; i < QT_GATE_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);       // 64 x 64 clocks per trip
+    }
+    while (true) {
+        // this unit's previous cell states (one node per epilogue pass and lane group): requested before the MFMA chain
+        float4 cpre[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int64_t node = (int64_t)unit * 32 + ps * NPW + nl;
+            cpre[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (node < rows && g.Cprev) cpre[ps] = *reinterpret_cast<const float4*>(g.Cprev + node * g.ld_c + j0);
+        }
+        const int nxt = unit + 8;
+        const bool has_next = nxt < u1;
+        const int64_t nrow = (int64_t)nxt * 32 + l32;
+        const bool nok = has_next && nrow < rows;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+        auto step = [&](const float4& a, int j) {
+            float4 bq[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                bq[nt] = *reinterpret_cast<const float4*>(&Bt[(nt * 32 + l32) * pitch + 8 * j + 4 * half]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#ifdef QT_EXP_NOMFMA
+                acc[nt][0] += a.x * bq[nt].x + a.y * bq[nt].y + a.z * bq[nt].z + a.w * bq[nt].w;
+#else
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[nt].x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[nt].y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[nt].z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[nt].w, acc[nt], 0, 0, 0);
+#endif
+            }
+        };
+        if constexpr (R > 0) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {     // nj == R (the host picks the instance): straight-line code, no branch
+                const float4 a = ring[j];
+                ring[j] = ldq(nrow, nok, j);
+                step(a, j);
+            }
+        } else {
+            for (int j = 0; j < nj; ++j) {
+                const float4 a = ring[0];
+                ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3];
+                ring[3] = ldq(my_row, row_ok, j + 4);
+                step(a, j);
+            }
+            // the next unit's first quads fly during this unit's epilogue
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ring[j] = ldq(nrow, nok, j);
+        }
+        // epilogue: accumulator columns -> this wave's staging rows -> h / 4 lanes per node
+        if (unit == u0) QT_STAMP(2);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * half) * CP + u * 32 + l32] = acc[u][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = ps * NPW + nl;
+            const int64_t node = (int64_t)unit * 32 + row;
+            const float* cs = Cs + row * CP + j0;
+            const F4 gi = ld4(cs), gf = ld4(cs + h), gc = ld4(cs + 2 * h), go = ld4(cs + 3 * h);
+            const F4 cp = {{cpre[ps].x, cpre[ps].y, cpre[ps].z, cpre[ps].w}};
+#ifdef QT_EXP_NOCELL
+            CellOut r;
+            r.I = gi; r.F = gf; r.T = gc; r.Og = go; r.hn = cp; r.cn = cp;
+#else
+            const CellOut r = cell_forward<LPN>(gi, gf, gc, go, cp, cpar, h);
+#endif
+            if (node < rows) {
+                if (g.O) st4(g.O + node * h + j0, r.Og);
+                st4(g.Hn + node * h + j0, r.hn);
+                st4(g.Cn + node * h + j0, r.cn);
+                float* gs = g.gates + node * 4 * h + j0;
+                st4(gs, r.I);
+                st4(gs + h, r.F);
+                st4(gs + 2 * h, r.T);
+                st4(gs + 3 * h, r.Og);
+            }
+        }
+        if (unit == u0) QT_STAMP(3);
+        if (!has_next) break;
+        unit = nxt; my_row = nrow; row_ok = nok;
+    }
+    QT_STAMP(4);
+}
+
 // ---- skinny shapes: few output columns (the decoder head: 16 or 4) or a short reduction (its data gradients: K = 16 or 4).
 // The MFMA kernel's fixed costs (W staging, barriers, the LDS round trip of the epilogue: ~15 us) dwarf such a product; here a
 // wave owns 64 rows x 4 output columns, reads its A quads straight from global memory and the matching 4 x 4 block of W
@@ -1221,6 +1401,35 @@ extern "C" int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, con
     g.row0_step = 0; g.n_dev = n_dev; g.accumulate = 0;
     g.Cprev = Cprev; g.wc = wc; g.bias = b; g.ln = ln; g.ld_c = ld_c; g.h = h;
     g.O = O; g.Hn = Hn; g.Cn = Cn; g.gates = gates;
+#ifdef QT_GEMM_TIMING
+    g.dbg = g_dbg;
+#endif
+    // hidden 8 / 16 with the whole W^T in LDS: the persistent wave-centric kernel (one workgroup per CU)
+    static const bool persistent = getenv("QT_GATE_CELL_TILED") == nullptr;
+    if (persistent && (h == 8 || h == 16) && g.K <= GATE_P_MAXK) {
+        const int pitch = g.K + (((g.K >> 2) & 1) ? 8 : 4);                 // pitch / 4 odd
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+            if (n_cu <= 0) n_cu = 256;
+        }
+        const dim3 pgrid(min(n_cu, qt_cdiv(N, 32)), 1, 1);
+        const int nj = (g.K + 7) >> 3;
+#define QT_GATE_P(NT_, LPN_)                                                                                              \
+        do {                                                                                                              \
+            if (nj == 8) hipLaunchKernelGGL((k_gate_cell_p<NT_, LPN_, 8>), pgrid, dim3(512), 0, (hipStream_t)stream, g, pitch);       \
+            else if (nj == 11) hipLaunchKernelGGL((k_gate_cell_p<NT_, LPN_, 11>), pgrid, dim3(512), 0, (hipStream_t)stream, g, pitch); \
+            else if (nj == 13) hipLaunchKernelGGL((k_gate_cell_p<NT_, LPN_, 13>), pgrid, dim3(512), 0, (hipStream_t)stream, g, pitch); \
+            else hipLaunchKernelGGL((k_gate_cell_p<NT_, LPN_, 0>), pgrid, dim3(512), 0, (hipStream_t)stream, g, pitch);               \
+        } while (0)
+        if (h == 16) QT_GATE_P(2, 4);
+        else QT_GATE_P(1, 2);
+#undef QT_GATE_P
+        QT_LAUNCHED();
+        return QT_OK;
+    }
     const dim3 grid(qt_cdiv(N, BM), 1, 1);
     if (h == 32)
         hipLaunchKernelGGL((k_gemm_fwd<4, 64, 8>), grid, dim3(256), 0, (hipStream_t)stream, g);

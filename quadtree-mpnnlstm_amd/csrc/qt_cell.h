@@ -7,7 +7,21 @@ namespace qtcell {
 
 constexpr float LN_EPS = 1e-5f;
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Branch-free gate nonlinearities on the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each).  The libm forms
+// (expf + IEEE division, tanhf with its range branches) cost ~25-40 instructions per value: 80 values per node made the
+// cell ~10 us of pure VALU issue per launch at the bench shape, as much as the gate GEMM's MFMA time, and the branches
+// kept the scheduler from placing that arithmetic beside the MFMAs.  Error: sigmoid <= 3 ulp; tanh <= 2e-7 absolute
+// (<= 8 ulp; |x| < 1/8 takes the odd series, where the quotient form would lose relative accuracy by cancellation).
+// Forward and backward call the SAME functions, so recomputed values carry the same bits.
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+    const float ax = fabsf(x), x2 = x * x;
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * ax));
+    const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, -17.0f / 315.0f, 2.0f / 15.0f), -1.0f / 3.0f), 1.0f);
+    return copysignf(ax < 0.125f ? small : big, x);
+}
 
 template <int LPN>
 __device__ __forceinline__ float group_sum(float v) {
@@ -71,38 +85,62 @@ __device__ __forceinline__ float cell_craw(float F, float cp, float I, float T) 
 struct CellOut {
     F4 I, F, T, Og, Cr, hn, cn;
 };
+// The cell's parameters for this lane's 4 hidden units, loaded once (a persistent kernel keeps them in registers: a load in
+// the epilogue would make the wave wait for every older load in its queue, the prefetched operand stream included).
+struct CellParams {
+    F4 wci, wcf, wco, bi, bf, bc, bo, gh, bh, gcn, bcn;
+    bool has_ln;
+};
+__device__ __forceinline__ CellParams cell_params(const float* __restrict__ wc, const float* __restrict__ b,
+                                                  const float* __restrict__ ln, int h, int j0) {
+    CellParams p;
+    p.wci = ld4(wc + j0); p.wcf = ld4(wc + h + j0); p.wco = ld4(wc + 2 * h + j0);
+    p.bi = ld4(b + j0); p.bf = ld4(b + h + j0); p.bc = ld4(b + 2 * h + j0); p.bo = ld4(b + 3 * h + j0);
+    p.has_ln = ln != nullptr;
+    const F4 one = {{1, 1, 1, 1}}, zero = {{0, 0, 0, 0}};
+    p.gh = p.gcn = one;
+    p.bh = p.bcn = zero;
+    if (ln) {
+        p.gh = ld4(ln + j0); p.bh = ld4(ln + h + j0); p.gcn = ld4(ln + 2 * h + j0); p.bcn = ld4(ln + 3 * h + j0);
+    }
+    return p;
+}
+
 template <int LPN>
 __device__ __forceinline__ CellOut cell_forward(const F4& gi, const F4& gf, const F4& gc, const F4& go, const F4& cp,
-                                                const float* __restrict__ wc, const float* __restrict__ b,
-                                                const float* __restrict__ ln, int h, int j0) {
-    const F4 wci = ld4(wc + j0), wcf = ld4(wc + h + j0), wco = ld4(wc + 2 * h + j0);
-    const F4 bi = ld4(b + j0), bf = ld4(b + h + j0), bc = ld4(b + 2 * h + j0), bo = ld4(b + 3 * h + j0);
+                                                const CellParams& P, int h) {
     CellOut r;
     F4 Hr;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        r.I.v[k] = sigmoidf_(gi.v[k] + wci.v[k] * cp.v[k] + bi.v[k]);
-        r.F.v[k] = sigmoidf_(gf.v[k] + wcf.v[k] * cp.v[k] + bf.v[k]);
-        r.T.v[k] = tanhf(gc.v[k] + bc.v[k]);
+        r.I.v[k] = sigmoidf_(gi.v[k] + P.wci.v[k] * cp.v[k] + P.bi.v[k]);
+        r.F.v[k] = sigmoidf_(gf.v[k] + P.wcf.v[k] * cp.v[k] + P.bf.v[k]);
+        r.T.v[k] = tanhf_(gc.v[k] + P.bc.v[k]);
         r.Cr.v[k] = cell_craw(r.F.v[k], cp.v[k], r.I.v[k], r.T.v[k]);
-        r.Og.v[k] = sigmoidf_(go.v[k] + wco.v[k] * r.Cr.v[k] + bo.v[k]);
-        Hr.v[k] = r.Og.v[k] * tanhf(r.Cr.v[k]);
+        r.Og.v[k] = sigmoidf_(go.v[k] + P.wco.v[k] * r.Cr.v[k] + P.bo.v[k]);
+        Hr.v[k] = r.Og.v[k] * tanhf_(r.Cr.v[k]);
     }
     r.hn = Hr;
     r.cn = r.Cr;
-    if (ln) {
+    if (P.has_ln) {
         F4 xh, xc;
         float rh, rc;
         layer_norm<LPN>(Hr, h, &xh, &rh);
         layer_norm<LPN>(r.Cr, h, &xc, &rc);
-        const F4 gh = ld4(ln + j0), bh = ld4(ln + h + j0), gcn = ld4(ln + 2 * h + j0), bcn = ld4(ln + 3 * h + j0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            r.hn.v[k] = gh.v[k] * xh.v[k] + bh.v[k];
-            r.cn.v[k] = gcn.v[k] * xc.v[k] + bcn.v[k];
+            r.hn.v[k] = P.gh.v[k] * xh.v[k] + P.bh.v[k];
+            r.cn.v[k] = P.gcn.v[k] * xc.v[k] + P.bcn.v[k];
         }
     }
     return r;
+}
+
+template <int LPN>
+__device__ __forceinline__ CellOut cell_forward(const F4& gi, const F4& gf, const F4& gc, const F4& go, const F4& cp,
+                                                const float* __restrict__ wc, const float* __restrict__ b,
+                                                const float* __restrict__ ln, int h, int j0) {
+    return cell_forward<LPN>(gi, gf, gc, go, cp, cell_params(wc, b, ln, h, j0), h);
 }
 
 // Backward of one cell update for 4 hidden units of a node (lane group as in cell_forward).  acc[11][4] collects this
@@ -119,7 +157,7 @@ __device__ __forceinline__ CellBwdOut cell_backward(const F4& I, const F4& F, co
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         Cr.v[k] = cell_craw(F.v[k], cp.v[k], I.v[k], T.v[k]);        // not saved by the forward: same fma, same bits
-        tc.v[k] = tanhf(Cr.v[k]);
+        tc.v[k] = tanhf_(Cr.v[k]);
         Hr.v[k] = Og.v[k] * tc.v[k];
     }
     F4 xh = {{0, 0, 0, 0}}, xc = {{0, 0, 0, 0}};
