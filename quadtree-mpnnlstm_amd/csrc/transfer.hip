@@ -282,24 +282,53 @@ __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
         return;
     }
     const float oscale = a.mean ? 1.0f / a.npix[i] : 1.0f;      // (requested before the pixel loop, not after it)
+    if (a.src_labels) {
+        // 2x2 and 4x4 nodes, mesh -> mesh: FOUR pixels per trip, their label loads together and then their row gathers
+        // together (two dependent memory phases per trip).  The pixel-by-pixel loop that stood here walked three dependent
+        // loads per pixel -- 12 phases for a 2x2 node, 48 for a 4x4 one -- and although such nodes are a few per cent of a
+        // noisy frame's mesh, a quarter of the waves holds one: those waves were the tail that set the launch time.
+        const int z = cl.z;                           // 2 or 4 (3 never occurs: cells are powers of two)
+        for (int dr = 0; dr < z; dr += (z == 2 ? 2 : 1)) {
+            int sl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = cl.x + dr + (z == 2 ? (q >> 1) : 0), c = cl.y + (z == 2 ? (q & 1) : q);
+                sl[q] = -1;
+                if (r < a.n && c < a.m) {
+                    const int64_t p = base + (int64_t)r * a.m + c;
+                    const int own = a.labels[p], s_ = a.src_labels[p];       // independent loads
+                    sl[q] = own == (int)i ? s_ : -1;
+                }
+            }
+            Vec<VEC> x[4];
+            float sc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) x[q].v[k] = 0.0f;
+                sc[q] = 1.0f;
+                if (sl[q] >= 0) {
+                    x[q] = vload<VEC>(src_chunk<VEC>(a, sl[q], ch));
+                    if (a.src_inv) sc[q] = 1.0f / a.src_npix[sl[q]];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc.v[k] += x[q].v[k] * sc[q];
+        }
+        vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), acc, oscale);
+        return;
+    }
     for (int dr = 0; dr < cl.z; ++dr)
         for (int dc = 0; dc < cl.z; ++dc) {
             const int r = cl.x + dr, c = cl.y + dc;
             if (r >= a.n || c >= a.m) continue;
             const int64_t p = (int64_t)r * a.m + c;
             if (cl.z > 1 && a.labels[base + p] != (int)i) continue;      // (a single-pixel node owns its pixel)
-            if (a.src_labels) {
-                const int sl = a.src_labels[base + p];
-                if (sl < 0) continue;
-                const Vec<VEC> x = vload<VEC>(src_chunk<VEC>(a, sl, ch));
-                const float sc = a.src_inv ? 1.0f / a.src_npix[sl] : 1.0f;
+            const Vec<VEC> x = vload<VEC>(a.img + (int64_t)cl.w * a.img_clip_stride + ((int64_t)s * P + p) * a.C + ch * VEC);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) acc.v[k] += x.v[k] * sc;
-            } else {
-                const Vec<VEC> x = vload<VEC>(a.img + (int64_t)cl.w * a.img_clip_stride + ((int64_t)s * P + p) * a.C + ch * VEC);
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc.v[k] += x.v[k];
-            }
+            for (int k = 0; k < VEC; ++k) acc.v[k] += x.v[k];
         }
     vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), acc, oscale);
 }
