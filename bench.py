@@ -78,9 +78,9 @@ def spmm_roofline(nfp, batch, mask, reps=10):
     try:
         # forward + loss + backward only: no all-reduce, no optimizer step -- rank 0 runs this alone, so nothing in it may
         # be a collective (the other ranks are already waiting at the final barrier)
-        nfp.optimizer.zero_grad(set_to_none=True)
+        nfp.zero_grad()
         nfp.forward_loss(*batch, mask).backward()
-        nfp.optimizer.zero_grad(set_to_none=True)
+        nfp.zero_grad()
         torch.cuda.synchronize()
     finally:
         qmesh.spmm2 = ops.spmm2 = orig

@@ -18,6 +18,7 @@ from model.seq2seq import Seq2Seq
 from model.utils import add_positional_encoding, get_n_params, int_to_datetime
 from qtmpnn import ops
 from qtmpnn.dist import allreduce_gradients
+from qtmpnn.flat import flat_params
 
 try:                                        # pragma: no cover - optional dependency
     from torch.utils.tensorboard import SummaryWriter
@@ -104,7 +105,15 @@ class NextFramePredictorS2S:
         # fused: one multi-tensor kernel for all 238 parameter tensors (the default per-tensor path costs ~1000 tiny
         # launches per step once the step counters live on the device)
         fused = self.device is not None and torch.device(self.device).type == 'cuda'
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, capturable=capturable, fused=fused or None)
+        # Plain ChebConv models on the GPU: every parameter is a view of one flat buffer and the backward pass returns one
+        # flat gradient vector (qtmpnn.flat), so the optimizer sees ONE tensor -- Adam is elementwise, and the clipping norm is
+        # the norm of all gradients either way, so the update is the reference's; only the launch count differs (1 fused-Adam
+        # kernel instead of 16, no per-tensor clipping kernels, the all-reduce without a gather copy).
+        self.flat = None
+        if fused and self.model.encoder.plannable and self.model.decoder.plannable:
+            self.flat = flat_params(self.model)
+        opt_params = [self.flat.param] if self.flat is not None else self.model.parameters()
+        self.optimizer = torch.optim.Adam(opt_params, lr=lr, capturable=capturable, fused=fused or None)
         self.scheduler = StepLR(self.optimizer, step_size=3, gamma=lr_decay)
         self.writer = SummaryWriter('runs/' + self.experiment_name + '_' + datetime.datetime.now().strftime('%Y%m%d_%H_%M_%S'))
         self.test_loss, self.train_loss = [], []
@@ -116,17 +125,46 @@ class NextFramePredictorS2S:
                                    high_interest_region=high_interest_region, graph_structure=graph_structure)
         return masked_mse(y_hat, meshes, y, mask, self.binary)
 
+    def zero_grad(self):
+        """Drop all gradients (set to None, like optimizer.zero_grad(set_to_none=True) on the reference's per-tensor optimizer)."""
+        if getattr(self, 'flat', None) is not None:
+            self.flat.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+
+    def _grads_ready(self, world=1, group=None):
+        """After backward: average the gradients over the ranks (ONE all-reduce of one flat tensor) and hand them to the
+        optimizer.  Returns the tensors clip_grad_norm_ has to see."""
+        if self.flat is None:
+            params = list(self.model.parameters())
+            if world > 1:
+                allreduce_gradients(params, group)
+            return params
+        if not self.flat.intact(self.model):
+            raise RuntimeError('the model parameters were moved or replaced after initiate_training(): call it again')
+        g = self.flat.grad_vector()
+        if g is None:                          # gradients that did not come from the model-wide packing gather: by copy
+            g = self.flat.gather_grads()
+        if world > 1:
+            torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=group)
+            g.mul_(1.0 / world)
+        self.flat.param.grad = g
+        return [self.flat.param]
+
+    def _world(self):
+        d = torch.distributed
+        if self.process_group is not None:
+            return d.get_world_size(self.process_group)
+        return d.get_world_size() if d.is_available() and d.is_initialized() else 1
+
     def train_step(self, x, y, concat_layers=None, mask=None, high_interest_region=None, graph_structure=None,
                    max_norm=10.0):
         """zero_grad -> forward -> masked MSE -> backward -> [all-reduce] -> clip_grad_norm_(10) -> Adam
         (mpnnlstm.py:229-257).  x: (T_in, W, H, C) or (B, T_in, W, H, C).  Returns the loss tensor."""
-        self.optimizer.zero_grad(set_to_none=True)
+        self.zero_grad()
         loss = self.forward_loss(x, y, concat_layers, mask, high_interest_region, graph_structure)
         loss.backward()
-        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
-                                               and torch.distributed.get_world_size() > 1):
-            allreduce_gradients(self.model.parameters(), self.process_group)
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=max_norm)
+        torch.nn.utils.clip_grad_norm_(self._grads_ready(self._world(), self.process_group), max_norm=max_norm)
         self.optimizer.step()
         return loss.detach()
 
@@ -141,7 +179,7 @@ class NextFramePredictorS2S:
         while step < self.output_timesteps:
             step = min(step + truncated_backprop, self.output_timesteps + 1)
             steps = range(step - truncated_backprop, step)
-            self.optimizer.zero_grad(set_to_none=True)
+            self.zero_grad()
             self.model.process_inputs(x, mask=mask, high_interest_region=high_interest_region, graph_structure=graph_structure)
             y_hat, meshes = self.model.unroll_output(steps, y, concat_layers=concat_layers, teacher_forcing_ratio=0, mask=mask,
                                                      high_interest_region=high_interest_region, remesh_every=1)
@@ -170,18 +208,17 @@ class NextFramePredictorS2S:
             lr = self.optimizer.param_groups[0]['lr']
             assert not self.optimizer.state, 'make_graphed_step must be called before the first optimizer step'
             self.initiate_training(float(lr), self.scheduler.gamma, capturable=True)
-        params = [p for p in self.model.parameters()]
         sx, sy = x.clone(), y.clone()
         sc = concat_layers.clone() if concat_layers is not None else None
 
         def fwd_bwd():
-            self.optimizer.zero_grad(set_to_none=True)
+            self.zero_grad()
             loss = self.forward_loss(sx, sy, sc, mask, high_interest_region, graph_structure)
             loss.backward()
             return loss.detach()
 
-        def update():
-            torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+        def update(clip_params):
+            torch.nn.utils.clip_grad_norm_(clip_params, max_norm=max_norm)
             self.optimizer.step()
 
         side = torch.cuda.Stream()
@@ -189,30 +226,40 @@ class NextFramePredictorS2S:
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self.last_warmup_loss = fwd_bwd()        # (a real training step on this batch)
-                if multi:
-                    allreduce_gradients(params, self.process_group)
-                update()
+                update(self._grads_ready(world, self.process_group))
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        self.optimizer.zero_grad(set_to_none=True)
+        self.zero_grad()
         # thread_local: other threads (the RCCL watchdog under torch.distributed) may issue HIP calls meanwhile
         with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
             static_loss = fwd_bwd()
             if multi:
-                flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+                # the graph ends with the gradients in ONE flat buffer: the packing gather's own output on the flat path
+                # (no copy), a concatenation otherwise
+                if self.flat is not None:
+                    flat = self.flat.grad_vector()
+                    flat = flat if flat is not None else self.flat.gather_grads()
+                else:
+                    params = list(self.model.parameters())
+                    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
             else:
-                update()
+                update(self._grads_ready())
         self._graph = graph
         graph2 = None
         if multi:
-            off = 0
-            for p in params:                              # gradients become views of the flat buffer: no unpack copies
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
+            if self.flat is not None:
+                self.flat.param.grad = flat
+                clip_params = [self.flat.param]
+            else:
+                off = 0
+                for p in params:                          # gradients become views of the flat buffer: no unpack copies
+                    p.grad = flat[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+                clip_params = params
             graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph2, stream=side, capture_error_mode='thread_local'):
                 flat.mul_(1.0 / world)
-                update()
+                update(clip_params)
 
         def step(x, y, concat_layers=None):
             sx.copy_(x)
@@ -253,6 +300,7 @@ class NextFramePredictorS2S:
                 if truncate:
                     loss = self.truncated_backward(x, y, concat, mask, high_interest_region, graph_structure,
                                                    truncated_backprop)[-1]
+                    self._grads_ready(self._world(), self.process_group)
                     self.optimizer.step()                 # no gradient clipping in this branch (:311 is commented out)
                 elif use_graph:
                     key = (tuple(x.shape), tuple(y.shape), None if concat is None else tuple(concat.shape))

@@ -12,6 +12,7 @@ import torch.nn as nn
 from model.graph_functions import Graph, _criterion
 from model.model import CONVOLUTION_KWARGS, GConvLSTM, _conv_class
 from qtmpnn import ops
+from qtmpnn.flat import flat_params
 from qtmpnn.mesh import build_mesh, build_pixel_mesh
 
 
@@ -37,37 +38,49 @@ class Encoder(nn.Module):
         self.norm_h = nn.LayerNorm(hidden_size)
         self.norm_c = nn.LayerNorm(hidden_size)
 
+    @property
+    def plannable(self):
+        return all(r.plannable for r in self.rnns)
+
     def pack(self, in_pad):
         """Per-forward weight packing: layer 0 with and without a hidden state, upper layers without."""
-        if all(r.plannable for r in self.rnns):
+        if self.plannable:
             return self._pack_planned(in_pad)
         ln = _ln_params(self.norm_h, self.norm_c)
         first, cont = self.rnns[0].pack(in_pad, ln, (False, True))
         return dict(first=first, cont=cont, upper=[r.pack(None, ln, (False,))[0] for r in self.rnns[1:]])
 
+    def plan_spec(self, in_pad):
+        """(params, layout, finish) of the encoder's weight packing as ONE parameter gather (ops.PackPlan): `layout` maps
+        stand-ins of the parameters to the packed matrices, `finish(outs)` turns the gathered matrices into the pack."""
+        params = [p for r in self.rnns for p in r.plan_params()] + [self.norm_h.weight, self.norm_h.bias,
+                                                                    self.norm_c.weight, self.norm_c.bias]
+        counts = [len(r.plan_params()) for r in self.rnns]
+
+        def layout(T, fill):
+            out, o = {}, 0
+            for i, (r, n) in enumerate(zip(self.rnns, counts)):
+                out.update(r.plan_layout(T[o:o + n], fill, f'r{i}.', in_pad if i == 0 else None,
+                                         (False, True) if i == 0 else (False,)))
+                o += n
+            out['ln'] = torch.stack(T[o:o + 4])
+            return out
+
+        def finish(outs):
+            ln = outs['ln']
+            first, cont = self.rnns[0].pack_from(outs, 'r0.', in_pad, ln, (False, True))
+            return dict(first=first, cont=cont,
+                        upper=[r.pack_from(outs, f'r{i + 1}.', None, ln, (False,))[0] for i, r in enumerate(self.rnns[1:])])
+        return params, layout, finish
+
     def _pack_planned(self, in_pad):
         """The same through ONE parameter gather for the whole encoder (ops.PackPlan, cached per input width)."""
         plans = self.__dict__.setdefault('_plans', {})
         key = (in_pad, self.norm_h.weight.device)
-        params = [p for r in self.rnns for p in r.plan_params()] + [self.norm_h.weight, self.norm_h.bias,
-                                                                    self.norm_c.weight, self.norm_c.bias]
+        params, layout, finish = self.plan_spec(in_pad)
         if key not in plans or not plans[key].same_params(params):       # (a re-assigned Parameter invalidates the plan)
-            counts = [len(r.plan_params()) for r in self.rnns]
-
-            def layout(T, fill):
-                out, o = {}, 0
-                for i, (r, n) in enumerate(zip(self.rnns, counts)):
-                    out.update(r.plan_layout(T[o:o + n], fill, f'r{i}.', in_pad if i == 0 else None,
-                                             (False, True) if i == 0 else (False,)))
-                    o += n
-                out['ln'] = torch.stack(T[o:o + 4])
-                return out
             plans[key] = ops.PackPlan(params, layout)
-        outs = plans[key]()
-        ln = outs['ln']
-        first, cont = self.rnns[0].pack_from(outs, 'r0.', in_pad, ln, (False, True))
-        return dict(first=first, cont=cont,
-                    upper=[r.pack_from(outs, f'r{i + 1}.', None, ln, (False,))[0] for i, r in enumerate(self.rnns[1:])])
+        return finish(plans[key]())
 
     def run(self, X, mesh, H, C, pk):
         """One encoder step on packed weights; returns per-layer lists (no stacking on the hot path)."""
@@ -116,8 +129,7 @@ class Decoder(nn.Module):
         return self.hidden_size + 4          # [relu(norm_o(O)) | concat | 0 0 0] keeps rows 16-byte aligned
 
     def pack(self, in_pad):
-        from model.model import ChebConv
-        if all(r.plannable for r in self.rnns) and type(self.fc_out1) is ChebConv and type(self.fc_out2) is ChebConv:
+        if self.plannable:
             return self._pack_planned(in_pad)
         ln = _ln_params(self.norm_h, self.norm_c)
         series = hasattr(self.fc_out1, 'packed')
@@ -126,36 +138,48 @@ class Decoder(nn.Module):
                     fc1=self.fc_out1.packed(self.head_width, self.hidden_size) if series else None, acc1=ops.GradAcc(),
                     fc2=self.fc_out2.packed(self.hidden_size, 4) if series else None, acc2=ops.GradAcc())
 
+    @property
+    def plannable(self):
+        from model.model import ChebConv
+        return all(r.plannable for r in self.rnns) and type(self.fc_out1) is ChebConv and type(self.fc_out2) is ChebConv
+
+    def plan_spec(self, in_pad):
+        """(params, layout, finish) of the decoder's weight packing as one parameter gather (see Encoder.plan_spec)."""
+        params = ([p for r in self.rnns for p in r.plan_params()] + self.fc_out1.plan_params() + self.fc_out2.plan_params()
+                  + [self.norm_h.weight, self.norm_h.bias, self.norm_c.weight, self.norm_c.bias,
+                     self.norm_o.weight, self.norm_o.bias])
+        counts = [len(r.plan_params()) for r in self.rnns]
+        n1, n2 = len(self.fc_out1.plan_params()), len(self.fc_out2.plan_params())
+
+        def layout(T, fill):
+            out, o = {}, 0
+            for i, (r, n) in enumerate(zip(self.rnns, counts)):
+                out.update(r.plan_layout(T[o:o + n], fill, f'r{i}.', in_pad if i == 0 else None, (True,)))
+                o += n
+            out['fc1'] = self.fc_out1.plan_layout(T[o:o + n1], fill, self.head_width, self.hidden_size)
+            o += n1
+            out['fc2'] = self.fc_out2.plan_layout(T[o:o + n2], fill, self.hidden_size, 4)
+            o += n2
+            out['ln'] = torch.stack(T[o:o + 4])
+            out['ln_o'] = torch.stack(T[o + 4:o + 6])
+            return out
+
+        def finish(outs):
+            ln = outs['ln']
+            return dict(ln_o=outs['ln_o'], acc_o=ops.GradAcc(),
+                        rnns=[r.pack_from(outs, f'r{i}.', in_pad if i == 0 else None, ln, (True,))[0]
+                              for i, r in enumerate(self.rnns)],
+                        fc1=outs['fc1'], acc1=ops.GradAcc(), fc2=outs['fc2'], acc2=ops.GradAcc())
+        return params, layout, finish
+
     def _pack_planned(self, in_pad):
         """The same through ONE parameter gather for the whole decoder (ops.PackPlan, cached per input width)."""
         plans = self.__dict__.setdefault('_plans', {})
         key = (in_pad, self.norm_h.weight.device)
-        params = ([p for r in self.rnns for p in r.plan_params()] + self.fc_out1.plan_params() + self.fc_out2.plan_params()
-                  + [self.norm_h.weight, self.norm_h.bias, self.norm_c.weight, self.norm_c.bias,
-                     self.norm_o.weight, self.norm_o.bias])
+        params, layout, finish = self.plan_spec(in_pad)
         if key not in plans or not plans[key].same_params(params):
-            counts = [len(r.plan_params()) for r in self.rnns]
-            n1, n2 = len(self.fc_out1.plan_params()), len(self.fc_out2.plan_params())
-
-            def layout(T, fill):
-                out, o = {}, 0
-                for i, (r, n) in enumerate(zip(self.rnns, counts)):
-                    out.update(r.plan_layout(T[o:o + n], fill, f'r{i}.', in_pad if i == 0 else None, (True,)))
-                    o += n
-                out['fc1'] = self.fc_out1.plan_layout(T[o:o + n1], fill, self.head_width, self.hidden_size)
-                o += n1
-                out['fc2'] = self.fc_out2.plan_layout(T[o:o + n2], fill, self.hidden_size, 4)
-                o += n2
-                out['ln'] = torch.stack(T[o:o + 4])
-                out['ln_o'] = torch.stack(T[o + 4:o + 6])
-                return out
             plans[key] = ops.PackPlan(params, layout)
-        outs = plans[key]()
-        ln = outs['ln']
-        return dict(ln_o=outs['ln_o'], acc_o=ops.GradAcc(),
-                    rnns=[r.pack_from(outs, f'r{i}.', in_pad if i == 0 else None, ln, (True,))[0]
-                          for i, r in enumerate(self.rnns)],
-                    fc1=outs['fc1'], acc1=ops.GradAcc(), fc2=outs['fc2'], acc2=ops.GradAcc())
+        return finish(plans[key]())
 
     def dropout_masks(self, steps, rows, device):
         """Inverted-dropout multipliers for `steps` decoder steps at once (one RNG launch instead of one per step);
@@ -222,6 +246,32 @@ class Seq2Seq(nn.Module):
         self.max_grid_size = 64                      # image_to_graph default, never overridden (graph_functions.py:590)
         self.static_shapes = False                   # True: worst-case capacities + device-side node counts (hipGraph)
 
+    # -- weight packing -----------------------------------------------------------------
+    def _packs(self, enc_in_pad):
+        """(encoder pack, decoder pack) of this forward pass.  Plain ChebConv models pack BOTH through one parameter gather
+        (ops.PackPlan over all parameters in module order): its backward hands every parameter a view of ONE gradient
+        vector, so the trainer's all-reduce, clip and Adam run on a single flat tensor (qtmpnn.flat)."""
+        if not (self.encoder.plannable and self.decoder.plannable):
+            return self.encoder.pack(enc_in_pad), None          # the decoder packs itself when the rollout starts
+        params = list(self.parameters())
+        fp = flat_params(self) if params[0].is_cuda else None
+        plans = self.__dict__.setdefault('_plans', {})
+        key = (enc_in_pad, params[0].device)
+        ep, el, ef = self.encoder.plan_spec(enc_in_pad)
+        dp, dl, df = self.decoder.plan_spec(4)
+        if key not in plans or not plans[key].same_params(params) or plans[key].flat is not fp:
+            pos = {id(p): i for i, p in enumerate(params)}
+            ei, di = [pos[id(p)] for p in ep], [pos[id(p)] for p in dp]
+
+            def layout(T, fill):
+                out = {'e.' + k: v for k, v in el([T[i] for i in ei], fill).items()}
+                out.update({'d.' + k: v for k, v in dl([T[i] for i in di], fill).items()})
+                return out
+            plans[key] = ops.PackPlan(params, layout, flat=fp)
+        outs = plans[key]()
+        return (ef({k[2:]: v for k, v in outs.items() if k.startswith('e.')}),
+                df({k[2:]: v for k, v in outs.items() if k.startswith('d.')}))
+
     # -- mesh helpers -----------------------------------------------------------------
     def _mesh_from_image(self, img0, mask, hir):
         B, n, m = img0.shape
@@ -283,7 +333,7 @@ class Seq2Seq(nn.Module):
             feats = feats_in[:, :, :c + 3]
         self.graph = Graph(None, None)
         self.graph.mapping, self.graph.n_pixels_per_node, self.graph.image_shape = mesh, mesh.npix, (n, m)
-        enc_pack = self.encoder.pack(c + 3 + fpad)     # local: nothing on `self` may keep the autograd graph alive
+        enc_pack, self._dec_pack = self._packs(c + 3 + fpad)     # (the decoder pack waits for unroll_output)
         hidden = cell = None
         for t in range(self.input_timesteps):
             hidden, cell = self.encoder.run(feats_in[t], mesh, None if hidden is None else hidden[-1],
@@ -302,7 +352,7 @@ class Seq2Seq(nn.Module):
                              '(remesh_input=True reads frame t + 1 after every encoder step, model/seq2seq.py:324)')
         fpad = (-(c + 3)) % 4
         L, h = self.n_layers, self.hidden_size
-        enc_pack = self.encoder.pack(c + 3 + fpad)
+        enc_pack, self._dec_pack = self._packs(c + 3 + fpad)
 
         def frame_rows(t, mesh):                 # [frame means | position | size | 0-pad] of frame t on `mesh`
             f = x.new_empty(1, mesh.N, c + 3 + fpad, dtype=torch.float32)
@@ -339,7 +389,11 @@ class Seq2Seq(nn.Module):
                 concat_layers = concat_layers.unsqueeze(0)
         if y is not None and y.dim() == 4:
             y = y.unsqueeze(0)
-        dec_pack = self.decoder.pack(4)
+        # packed together with the encoder by this forward pass's process_inputs; taken once: nothing on `self` may keep
+        # the autograd graph alive beyond the pass (a continued unroll packs the decoder on its own)
+        dec_pack, self._dec_pack = getattr(self, '_dec_pack', None), None
+        if dec_pack is None:
+            dec_pack = self.decoder.pack(4)
         outputs, output_mappings = [], []
         steps = list(unroll_steps)
         drops = self.decoder.dropout_masks(len(steps), mesh.B * mesh.P, g.pyg.x.device)

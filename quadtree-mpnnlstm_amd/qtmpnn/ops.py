@@ -100,8 +100,11 @@ class PackPlan:
     the transposed gather, whose result is handed to autograd as per-parameter views (no stack / unbind / slice
     backward / AccumulateGrad copies: ~200 tiny kernels per training step with per-tensor torch ops)."""
 
-    def __init__(self, params, layout):
+    def __init__(self, params, layout, flat=None):
         self.params = list(params)
+        # flat: qtmpnn.flat.FlatParams whose parameter list is exactly `params` -- the gather then reads the shared buffer
+        # (no concatenation) and its backward's gradient vector is the model's flat gradient
+        self.flat = flat
         dev = self.params[0].device
         sizes = [p.numel() for p in self.params]
         offs = [0]
@@ -151,7 +154,10 @@ class PackPlan:
 class _PackGather(Function):
     @staticmethod
     def forward(ctx, plan, *params):
-        flat = torch.cat([p.reshape(-1) for p in params] + [plan.zero1])
+        if plan.flat is not None and plan.flat.intact():
+            flat = plan.flat.buffer                 # parameters are views of it, element n_flat is the zero slot
+        else:
+            flat = torch.cat([p.reshape(-1) for p in params] + [plan.zero1])
         out = flat[plan.src[0]]
         if plan.two_src:
             out = out + flat[plan.src[1]]
@@ -169,6 +175,8 @@ class _PackGather(Function):
         gflat = gcat[plan.inv[0]]
         if plan.two_inv:
             gflat = gflat + gcat[plan.inv[1]]
+        if plan.flat is not None:
+            plan.flat.last_grad = gflat
         return (None, *[gflat[a:b].view(p.shape) for a, b, p in zip(plan.offs[:-1], plan.offs[1:], plan.params)])
 
 

@@ -167,6 +167,9 @@ def test_baseline_mnist64_configs_train(cfg):
     eager, graphed = fresh(), fresh()
     assert eager.get_n_params() == 34513
     le = [float(eager.train_step(xt, yt, ct, mask)) for _ in range(5)]
+    # the flat path is live: one optimizer tensor, and every parameter's gradient is a view of the backward's one vector
+    assert eager.flat is not None and len(eager.optimizer.param_groups[0]['params']) == 1
+    assert eager.flat.grad_vector() is not None and eager.flat.param.grad.data_ptr() == eager.flat.grad_vector().data_ptr()
     step = graphed.make_graphed_step(xt, yt, ct, mask=mask, warmup=2)
     lg = [float(step(xt, yt, ct)) for _ in range(3)]
     assert np.isfinite(le).all() and le[-1] < le[0], le

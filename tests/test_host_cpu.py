@@ -217,3 +217,42 @@ def test_pack_plan_equals_per_tensor_packing(n_conv):
         p.data.normal_()
     plan = ops.PackPlan(conv.plan_params(), lambda T, fill: {'w': conv.plan_layout(T, fill, 20, 16)})
     assert torch.equal(plan()['w'], conv.packed(20, 16))
+
+
+def test_flat_params_views_and_single_tensor_update_equal_per_tensor_update():
+    """qtmpnn.flat.FlatParams (CPU, plain torch): every parameter becomes a view of one buffer without changing values, keys
+    or shapes; load_state_dict keeps the views; clip_grad_norm_ + Adam on the ONE flat tensor give the same weights as the
+    reference's per-tensor clip + Adam (mpnnlstm.py:251-257)."""
+    import copy
+    import torch
+    from qtmpnn.flat import FlatParams, flat_params
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.LayerNorm(7), torch.nn.Linear(7, 3))
+    ref = copy.deepcopy(net)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    fp = flat_params(net)
+    assert isinstance(fp, FlatParams) and fp.intact(net) and flat_params(net) is fp
+    assert fp.n == sum(p.numel() for p in net.parameters()) and float(fp.buffer[fp.n:].abs().sum()) == 0.0
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k])
+    net.load_state_dict({k: v + 1.0 for k, v in before.items()})
+    assert fp.intact(net) and torch.equal(fp.param.detach()[:35], (before['0.weight'] + 1.0).reshape(-1))
+    net.load_state_dict(before)
+    x = torch.randn(11, 5)
+    opt_f = torch.optim.Adam([fp.param], lr=0.05)
+    opt_r = torch.optim.Adam(ref.parameters(), lr=0.05)
+    for _ in range(3):
+        fp.zero_grad()
+        (net(x) ** 2).sum().backward()
+        assert fp.grad_vector() is None                # plain autograd gradients are separate tensors: gathered by copy
+        fp.param.grad = fp.gather_grads()
+        torch.nn.utils.clip_grad_norm_([fp.param], 1.0)
+        opt_f.step()
+        opt_r.zero_grad()
+        (ref(x) ** 2).sum().backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        opt_r.step()
+    for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), k
+    moved = copy.deepcopy(net)                          # a copy owns separate tensors: its own FlatParams is made on demand
+    assert not fp.intact(moved) and flat_params(moved) is not fp
