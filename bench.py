@@ -137,8 +137,63 @@ def spmm_roofline(nfp, batch, mask, reps=10):
             'bytes_formula': '4(N+1) + 8E\' + 8NC per launch (SURVEY 8(d)); incl_addends adds 4NC per addend operand'}
 
 
-def gemm_mfma(nfp, batch, mask):
-    return None
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= the fp32 vector rate)
+
+
+def gemm_mfma(nfp, batch, mask, reps=20):
+    """MFMA utilisation of the gate GEMM (north_star): the encoder's layer-0 launch of this workload -- qt_dense_lstm on
+    Z = [X (4) | H (16)], K' = 5 Chebyshev planes + bias rows -> (N x 104)(104 x 64) + the fused LSTM cell -- re-issued `reps`
+    times from a hipGraph on the input mesh of the batch, timed with HIP events on the replay stream.  achieved = 2 N K 4h
+    flops / launch time against the dense fp32-MFMA peak.  The counter view of the same launch (SQ_VALU_MFMA_BUSY_CYCLES per
+    SIMD-cycle, wave stall breakdown) is a separate rocprofv3 --pmc pass: profiles/r02_pmc_gemm.json."""
+    import torch
+    from qtmpnn import _lib
+    from qtmpnn._lib import ptr
+    x = batch[0]
+    dev = x.device
+    nfp.model.eval()
+    with torch.no_grad():
+        mesh = nfp.model._mesh_from_image(x[..., 0].amax(dim=1), mask, None)
+    nfp.model.train()
+    N, h, K, Ca, Cab = mesh.N, HIDDEN, 5, 4, HIDDEN
+    nv = mesh.n_valid
+    Kt = K * (Ca + Cab) + 4
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    X, H, TX, TH = rnd(N, Ca), rnd(N, Cab), rnd(K - 1, N, Ca), rnd(K - 1, N, Cab)
+    S = mesh.cheb_ones(3)
+    W = 0.1 * rnd(Kt, 4 * h)
+    WT = W.t().contiguous()
+    Cp, wc, b, ln = rnd(N, h), 0.1 * rnd(3, h), 0.1 * rnd(4, h), rnd(4, h)
+    Hn, Cn, gates = (torch.empty(N, w, device=dev) for w in (h, h, 4 * h))
+    fn = lambda: _lib.call('qt_dense_lstm', ptr(X), Ca, ptr(TX), ptr(H), Cab, ptr(TH), K, Ca, Cab, ptr(W), ptr(WT), ptr(S), 4,
+                           ptr(W[K * (Ca + Cab):]), h, N, ptr(mesh.n_dev), ptr(Cp), h, ptr(wc), ptr(b), ptr(ln), None, ptr(Hn),
+                           ptr(Cn), ptr(gates))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=side, capture_error_mode='thread_local'):
+        for _ in range(reps):
+            fn()
+    gr.replay()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    gr.replay()
+    e.record()
+    e.synchronize()
+    us = a.elapsed_time(e) * 1e3 / reps
+    tflops = 2.0 * nv * Kt * 4 * h / us / 1e6
+    rec = {'kernel': 'k_gate_cell_p (qt_dense_lstm: gate GEMM + LSTM cell)', 'shape': f'({nv} x {Kt})({Kt} x {4 * h})',
+           'launch_us': round(us, 2), 'achieved_tflops': round(tflops, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+           'frac': round(tflops / MFMA_F32_PEAK_TFLOPS, 3),
+           'hbm_gbs': round(4.0 * nv * (Kt + 7 * h) / us / 1e3, 1)}
+    pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_gemm.json')
+    if os.path.exists(pmc):
+        rec['counters'] = {k: v for k, v in json.load(open(pmc)).items() if k in ('mfma_busy_frac', 'wave_stall_frac', 'source')}
+    return rec
 
 
 def cpu_baseline(n_clips, n_warm=3):

@@ -254,6 +254,21 @@ int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, int ld_gh, c
                       int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
                       const float* Wrows, int Kb, int Cb, int Cbb, float* out, float* outb, void* stream);
 
+/* The whole backward pass of one gate-cell use (hidden 8 / 16) in one persistent launch: qt_lstm_bwd's cell backward, the data
+ * gradient of qt_lstm_bwd_dgrad (same planes) AND the weight gradient gW = [T_0 .. T_{K-1} | S]^T gG of the forward
+ * operand (a0 .. S as in qt_dense_lstm), K (Ca + Cab) + Ks <= 128 rows.  gG itself is never written.  slab: (nslab >=
+ * qt_lstm_fused_blocks(), Kt, 4h), zeroed by the caller before the first use of the weight in a pass: every launch ADDS the partial
+ * weight gradient of workgroup b to slab[b]; qt_colsum over the slabs gives gW (fixed order: reproducible).  part: as
+ * qt_lstm_bwd_dgrad, one row per workgroup.  Replaces (model/model.py:394-424 backward) k_lstm_bwd + two GEMMs. */
+int qt_num_cus(void);
+int qt_lstm_fused_blocks(void);
+int qt_lstm_bwd_fused(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,
+                      const float* gates, const float* Cprev, int ld_c, const float* wc, const float* ln,
+                      int N, const int32_t* n_dev, int h, float* gCprev, float* part, int accumulate,
+                      const float* Wrows, int Kb, int Cb, int Cbb, float* out, float* outb,
+                      const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb,
+                      int Ka, int Ca, int Cab, const float* S, int Ks, float* slab, int nslab, void* stream);
+
 /* decoder head input, model/seq2seq.py:160-165: Z (N, hp) = [relu(LayerNorm_o(O)) | concat | 0...], hp >= h+1.
  * Zb != NULL: the same row as two matrices, Z (N, h) and Zb (N, hp - h).  O rows have stride ld_o floats (0 = h): the raw
  * output gate may be read in place from the saved gate activations, gates[:, 3h:4h]. */

@@ -1208,6 +1208,265 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_cell(DgradCellArgs g) {
     }
 }
 
+// ---- the whole backward pass of one gate-cell use in ONE persistent launch (hidden 8 / 16): cell backward, the data gradient
+// gT = gG W^T AND the weight gradient gW = [T_0 .. T_{K-1} | S]^T gG.  The gate gradients gG (N, 4h) never exist in memory:
+// a workgroup (one per CU, 512 threads) walks its share of the 128-row tiles, computes a tile's gG rows into LDS, feeds both
+// MFMA products from there and keeps its partial gW (<= 128 x 64) in accumulator registers across all its tiles -- one slab
+// per workgroup at the end, summed over the workgroups (and over the uses of the weight in the pass) by qt_colsum, in a
+// fixed order.  Against qt_lstm_bwd_dgrad + the deferred qt_wgrad_group this drops the gG round trip (31 MB written and
+// read back per use at the bench shape) and the separate weight-gradient launches, and the weight gradient's left operand
+// is read while it is still warm from nothing -- it is read once either way -- but beside the cell's own traffic.
+//   per tile:  TZ tile (128 x K) global -> LDS, row major (8 float4 in flight per thread)
+//              cell backward of the 128 nodes (h / 4 lanes per node, k_lstm_bwd's arithmetic) -> gG tile in LDS, gCprev
+//              barrier
+//              wave w: weight-gradient tile (i block w & 3, j block w >> 2): 64 x mfma_32x32x2 over the 128 rows
+//                      data-gradient tiles of row group w & 3 (column tiles split between waves 0-3 and 4-7)
+//              barrier; data-gradient tiles -> LDS (over the TZ tile) -> row-contiguous float4 stores; barrier
+struct CellBwdFusedArgs {
+    DgradCellArgs d;          // cell operands, gCprev, part, BT = Wrows, NB, Kb, Cb, Cbb, out, outb, M (capacity), n_dev; gG unused
+    PlaneSrc A;               // [T_0 .. T_{K-1} | S] of the forward pass
+    int Kt;                   // rows of W: K * C + padded bias rows (<= 128)
+    float* slab;              // (gridDim.x, Kt, 4h): this launch ADDS its partial weight gradients (zeroed by the caller)
+};
+
+template <int LPN, int NW, int NACC>
+__device__ __forceinline__ void block_param_reduce_n(float (&acc)[NACC][4], int h, float* sm, float* part_row, int accumulate) {
+    using namespace qtcell;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = acc[a][k];
+#pragma unroll
+            for (int d = LPN; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+            acc[a][k] = v;
+        }
+    if (lane < LPN) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sm[(wave * LPN + lane) * NACC * 4 + a * 4 + k] = acc[a][k];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NACC * h; idx += 64 * NW) {
+        const int a = idx / h, j = idx % h;
+        const int li = j >> 2, k = j & 3;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += sm[(w * LPN + li) * NACC * 4 + a * 4 + k];
+        part_row[idx] = accumulate ? part_row[idx] + s : s;
+    }
+}
+
+// TR = rows per tile (threads = 4 TR): 64 -> two 256-thread workgroups per CU whose phases (loads + cell arithmetic / MFMA /
+// stores) drift apart and overlap; 128 -> one 512-thread workgroup per CU (every phase of the CU in lockstep: 71 us per launch
+// at the bench shape against 68 us for the separate launches it replaces).
+template <int NT, int LPN, int TR>
+__global__ __launch_bounds__(4 * TR, 2) void k_cell_bwd_fused(CellBwdFusedArgs f) {
+    using namespace qtcell;
+    const DgradCellArgs& g = f.d;
+    constexpr int h = 4 * LPN, G4 = 4 * h, GP = G4 + 4, TP = 128, NJB = G4 / 32, NTA = (NT + 1) / 2;
+    constexpr int NTHR = 4 * TR, NWAVE = NTHR / 64, NRG = TR / 32;            // waves = 2 NRG: (row group, column-tile half)
+    constexpr int NWT = (4 * NJB + NWAVE - 1) / NWAVE;                        // weight-gradient tiles per wave
+    constexpr int RSTEP = NTHR / 32, NU = TR / RSTEP;                         // TZ quads per thread (8)
+    __shared__ __attribute__((aligned(16))) float TZt[TR * TP];       // TZ tile [row][k]; later the data-gradient staging tile
+    __shared__ __attribute__((aligned(16))) float Gt[TR * GP];        // gG tile [row][4h]
+    __shared__ __attribute__((aligned(16))) float Bt[32 * NT * GP];   // Wrows [column][4h]
+    __shared__ const float* qptr[MAXQ];
+    __shared__ int qstr[MAXQ];
+    __shared__ float sm[NWAVE * LPN * 11 * 4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l32 = lane & 31, half = lane >> 5;
+    const int rows = qt_rows(g.n_dev, g.M);
+    const int ntiles = (rows + TR - 1) / TR;
+    const int t0 = (int)((int64_t)ntiles * blockIdx.x / gridDim.x), t1 = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
+    float* part_row = g.part + (int64_t)blockIdx.x * 11 * h;
+    if (t0 >= t1) {                 // no tile for this workgroup: its slab rows keep what they hold (the launch only adds)
+        if (!g.accumulate)
+            for (int idx = t; idx < 11 * h; idx += NTHR) part_row[idx] = 0.0f;
+        return;
+    }
+    const int nquad = f.Kt >> 2;
+    for (int Q = t; Q < nquad; Q += NTHR) {              // (build_quad_table strides by 256 threads)
+        const PlaneSrc& A = f.A;
+        const int ct = A.Ca + A.Cab;
+        const int k = 4 * Q, kc = A.Ka * ct;
+        if (k < kc) {
+            const int pl = k / ct, c = k - pl * ct;
+            if (c < A.Ca) {
+                qptr[Q] = (pl == 0 ? A.a0 : A.a_rest + (int64_t)(pl - 1) * A.N * A.Ca) + c;
+                qstr[Q] = pl == 0 ? A.lda0 : A.Ca;
+            } else {
+                qptr[Q] = (pl == 0 ? A.a0b : A.a_restb + (int64_t)(pl - 1) * A.N * A.Cab) + (c - A.Ca);
+                qstr[Q] = pl == 0 ? A.lda0b : A.Cab;
+            }
+        } else {
+            qptr[Q] = A.S + (k - kc);
+            qstr[Q] = A.Ks;
+        }
+    }
+    for (int e = t; e < 32 * NT * (G4 / 4); e += NTHR) {
+        const int c = e / (G4 / 4), kq = e - c * (G4 / 4);
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < g.NB) w = *reinterpret_cast<const float4*>(g.BT + (int64_t)c * G4 + 4 * kq);
+        *reinterpret_cast<float4*>(&Bt[c * GP + 4 * kq]) = w;
+    }
+    const int j0 = (t % LPN) * 4;
+    float pacc[11][4];
+#pragma unroll
+    for (int a = 0; a < 11; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pacc[a][k] = 0.0f;
+    f32x16 accw[NWT];               // this wave's tiles of the partial weight gradient
+#pragma unroll
+    for (int v = 0; v < NWT; ++v)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accw[v][r] = 0.0f;
+    const int rg = wave % NRG, own = wave / NRG;
+    __syncthreads();                // quad table, Bt
+
+    const int Qq = t & 31, rb = t >> 5;
+    const bool qok = Qq < nquad;
+    const float* qp = qptr[qok ? Qq : 0];
+    const int qs = qstr[qok ? Qq : 0];
+    const int crow = t / LPN;
+    float4 tz[NU];
+    auto load_tz = [&](int tile) {
+        const int64_t i0 = (int64_t)tile * TR;
+        // thread (Q = t & 31, row = (t >> 5) + RSTEP u); quads beyond K and rows beyond the valid count are zeros (the capacity
+        // rows of a static-mode operand hold garbage); the loads themselves are unconditional (clamped addresses)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int64_t row = i0 + rb + RSTEP * u;
+            const bool ok = qok && row < rows;
+            const float4 v = gload4(qp + (row < rows ? row : (int64_t)rows - 1) * qs);
+            tz[u] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+    };
+    load_tz(t0);
+    for (int tile = t0; tile < t1; ++tile) {
+        const int64_t i0 = (int64_t)tile * TR;
+        // (1) cell backward of the TR nodes (LPN lanes each) -> gG tile; the TZ quads (requested one tile ahead) -> LDS while
+        // the cell operands are on their way
+        {
+            const int64_t node = i0 + crow;
+            const bool act = t < TR * LPN, ok = act && node < rows;
+            const F4 z = {{0, 0, 0, 0}};
+            F4 I = z, F = z, T = z, Og = z, cp = z, gyh = z, gyc = z, go_in = z;
+            if (ok) {
+                const float* gs = g.gates + node * 4 * h + j0;
+                I = ld4(gs); F = ld4(gs + h); T = ld4(gs + 2 * h); Og = ld4(gs + 3 * h);
+                if (g.Cprev) cp = ld4(g.Cprev + node * g.ld_c + j0);
+                if (g.gHn) gyh = ld4(g.gHn + node * g.ld_gh + j0);
+                if (g.gCn) gyc = ld4(g.gCn + node * g.ld_gc + j0);
+                if (g.gO) go_in = ld4(g.gO + node * g.ld_go + j0);
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) *reinterpret_cast<float4*>(&TZt[(rb + RSTEP * u) * TP + 4 * Qq]) = tz[u];
+            if (act) {
+                const F4 wci = ld4(g.wc + j0), wcf = ld4(g.wc + h + j0), wco = ld4(g.wc + 2 * h + j0);
+                F4 gam_h = {{1, 1, 1, 1}}, gam_c = {{1, 1, 1, 1}};
+                if (g.ln) {
+                    gam_h = ld4(g.ln + j0);
+                    gam_c = ld4(g.ln + 2 * h + j0);
+                }
+                const CellBwdOut o = cell_backward<LPN>(I, F, T, Og, cp, gyh, gyc, go_in, wci, wcf, wco, gam_h, gam_c,
+                                                        g.ln != nullptr, h, pacc);
+                float* as = Gt + crow * GP + j0;
+                st4(as, o.ggi); st4(as + h, o.ggf); st4(as + 2 * h, o.ggc); st4(as + 3 * h, o.ggo);
+                if (ok && g.gCprev) st4(g.gCprev + node * h + j0, o.gcp);
+            }
+        }
+        __syncthreads();            // TZt, Gt complete
+        if (tile + 1 < t1) load_tz(tile + 1);          // in flight during the MFMA phase
+        // (2) weight gradient: rows 2 s + half of the tile are the two k slots of step s; the operands of the next 4 steps
+        // are read from LDS before the current 4 MFMAs issue
+#pragma unroll
+        for (int v = 0; v < NWT; ++v) {
+            const int tau = wave + NWAVE * v, ib = tau & 3, jb = tau >> 2;
+            if (jb < NJB) {
+                const float* ap = TZt + half * TP + 32 * ib + l32;
+                const float* bp = Gt + half * GP + 32 * jb + l32;
+                float av[4], bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { av[q] = ap[2 * q * TP]; bv[q] = bp[2 * q * GP]; }
+#pragma unroll 1
+                for (int s0 = 0; s0 < TR / 2; s0 += 4) {
+                    float an[4], bn[4];
+                    const int sn = s0 + 4 < TR / 2 ? s0 + 4 : s0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { an[q] = ap[2 * (sn + q) * TP]; bn[q] = bp[2 * (sn + q) * GP]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) accw[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], accw[v], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { av[q] = an[q]; bv[q] = bn[q]; }
+                }
+            }
+        }
+        // (3) data gradient of row group rg, one column tile per pass: the first half of the waves takes tile 2 ps, the second
+        // half tile 2 ps + 1; the tile goes through LDS (over the TZ tile, once every wave is done with it) so that rows leave
+        // as float4 pieces
+        float* Cs = TZt;
+#pragma unroll
+        for (int ps = 0; ps < NTA; ++ps) {
+            const int nt = 2 * ps + own;
+            f32x16 acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
+            if (nt < NT) {
+#pragma unroll
+                for (int j = 0; j < G4 / 8; ++j) {
+                    const float4 a = *reinterpret_cast<const float4*>(&Gt[(rg * 32 + l32) * GP + 8 * j + 4 * half]);
+                    const float4 b = *reinterpret_cast<const float4*>(&Bt[(nt * 32 + l32) * GP + 8 * j + 4 * half]);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc2, 0, 0, 0);
+                }
+            }
+            __syncthreads();        // pass 0: every wave is done with the TZ tile; later passes: the stores have read the staging tile
+            if (nt < NT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cs[(rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + own * 32 + l32] = acc2[r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = t + NTHR * u;
+                const int row = e >> 4, c4 = (e & 15) * 4;
+                const int64_t i = i0 + row;
+                const int j = ps * 64 + c4;
+                if (i < rows && j < g.NB) {
+                    const float4 v = *reinterpret_cast<const float4*>(&Cs[row * 64 + c4]);
+                    const int ct = g.Cb + g.Cbb;
+                    const int pl = j / ct, ch = j - pl * ct;
+                    if (ch < g.Cb)
+                        *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+                    else
+                        *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + i * g.Cbb + (ch - g.Cb)) = v;
+                }
+            }
+        }
+        __syncthreads();            // the stores have read the staging tile / Gt is free: the next tile may overwrite both
+    }
+    // partial weight gradient of this workgroup: added to its slab
+#pragma unroll
+    for (int v = 0; v < NWT; ++v) {
+        const int tau = wave + NWAVE * v, ib = tau & 3, jb = tau >> 2;
+        if (jb < NJB) {
+            float* sl = f.slab + (int64_t)blockIdx.x * f.Kt * G4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * ib + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < f.Kt) sl[(int64_t)row * G4 + 32 * jb + l32] += accw[v][r];
+            }
+        }
+    }
+    block_param_reduce_n<LPN, NWAVE, 11>(pacc, h, sm, part_row, g.accumulate);
+}
+
 }  // namespace
 
 // shared argument checks / operand setup of the node-feature operand
@@ -1383,6 +1642,68 @@ extern "C" int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, i
     return QT_OK;
 }
 
+extern "C" int qt_num_cus(void) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;         // (no device visible: the MI355X count; only sizes host-side buffers)
+    }
+    return n_cu;
+}
+
+extern "C" int qt_lstm_bwd_fused(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,
+                                 const float* gates, const float* Cprev, int ld_c, const float* wc, const float* ln, int N,
+                                 const int32_t* n_dev, int h, float* gCprev, float* part, int accumulate,
+                                 const float* Wrows, int Kb, int Cb, int Cbb, float* out, float* outb,
+                                 const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb,
+                                 int Ka, int Ca, int Cab, const float* S, int Ks, float* slab, int nslab, void* stream) {
+    QT_ARG(gates && wc && part && Wrows && out && slab, "null pointer");
+    QT_ARG(h == 8 || h == 16, "fused for hidden sizes 8 and 16");
+    QT_ARG(Kb >= 1 && Cb >= 4 && Cb % 4 == 0 && Cbb >= 0 && Cbb % 4 == 0 && (Cbb == 0 || outb), "bad output planes");
+    const int NB = Kb * (Cb + Cbb);
+    QT_ARG(NB <= (h == 16 ? 128 : 64), "the output planes must fit the column tiles of the launch");
+    QT_ARG((!gHn || ld_gh >= h) && (!gCn || ld_gc >= h) && (!gO || ld_go >= h) && ld_gh % 4 == 0 && ld_gc % 4 == 0 &&
+               ld_go % 4 == 0 && ld_c % 4 == 0 && (!Cprev || ld_c >= h), "bad row stride");
+    QT_ARG((((uintptr_t)Wrows | (uintptr_t)gates | (uintptr_t)out | (uintptr_t)outb | (uintptr_t)slab) & 15) == 0, "operands must be 16-byte aligned");
+    CellBwdFusedArgs f = {};
+    if (int rc = plane_src(&f.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N)) return rc;
+    f.Kt = Ka * (Ca + Cab) + Ks;
+    QT_ARG(f.Kt <= 128, "the weight must have at most 128 rows (one accumulator tile column per wave)");
+    const int NTc = qt_cdiv(NB, 32);
+    // 64-row tiles, two 256-thread workgroups per CU (their LDS fits twice up to three column tiles); else 128-row tiles
+    static const bool tr128 = getenv("QT_FUSED_TR128") != nullptr;
+    const bool small = !tr128 && NTc <= 3;
+    const int grid = small ? min(2 * qt_num_cus(), qt_cdiv(N, 64)) : min(qt_num_cus(), qt_cdiv(N, 128));
+    QT_ARG(nslab >= grid, "slab too small: one (Kt, 4h) slab per workgroup, qt_lstm_fused_blocks() of them");
+    if (N <= 0) return QT_OK;
+    DgradCellArgs& g = f.d;
+    g.gO = gO; g.gHn = gHn; g.gCn = gCn; g.gates = gates; g.Cprev = Cprev; g.wc = wc; g.ln = ln;
+    g.ld_go = ld_go; g.ld_gh = ld_gh; g.ld_gc = ld_gc; g.ld_c = ld_c; g.h = h;
+    g.gG = nullptr; g.gCprev = gCprev; g.part = part; g.accumulate = accumulate;
+    g.BT = Wrows; g.M = N; g.NB = NB; g.Kb = Kb; g.Cb = Cb; g.Cbb = Cbb; g.out = out; g.outb = outb; g.n_dev = n_dev;
+    f.slab = slab;
+#define QT_FUSED(NT_, LPN_)                                                                                                  \
+    do {                                                                                                                     \
+        if (small) hipLaunchKernelGGL((k_cell_bwd_fused<NT_, LPN_, 64>), dim3(grid), dim3(256), 0, (hipStream_t)stream, f);  \
+        else hipLaunchKernelGGL((k_cell_bwd_fused<NT_, LPN_, 128>), dim3(grid), dim3(512), 0, (hipStream_t)stream, f);       \
+    } while (0)
+    if (h == 16) {
+        if (NTc <= 1) QT_FUSED(1, 4);
+        else if (NTc == 2) QT_FUSED(2, 4);
+        else if (NTc == 3) QT_FUSED(3, 4);
+        else hipLaunchKernelGGL((k_cell_bwd_fused<4, 4, 128>), dim3(grid), dim3(512), 0, (hipStream_t)stream, f);
+    } else {
+        if (NTc <= 1) QT_FUSED(1, 2);
+        else QT_FUSED(2, 2);
+    }
+#undef QT_FUSED
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_lstm_fused_blocks(void) { return 2 * qt_num_cus(); }
+
 extern "C" int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb,
                              int Ka, int Ca, int Cab, const float* W, const float* WT, const float* S, int Ks,
                              const float* Ws, int h, int N, const int32_t* n_dev, const float* Cprev, int ld_c,
@@ -1408,13 +1729,7 @@ extern "C" int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, con
     static const bool persistent = getenv("QT_GATE_CELL_TILED") == nullptr;
     if (persistent && (h == 8 || h == 16) && g.K <= GATE_P_MAXK) {
         const int pitch = g.K + (((g.K >> 2) & 1) ? 8 : 4);                 // pitch / 4 odd
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-            if (n_cu <= 0) n_cu = 256;
-        }
+        const int n_cu = qt_num_cus();
         const dim3 pgrid(min(n_cu, qt_cdiv(N, 32)), 1, 1);
         const int nj = (g.K + 7) >> 3;
 #define QT_GATE_P(NT_, LPN_)                                                                                              \

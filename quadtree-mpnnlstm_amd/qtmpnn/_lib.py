@@ -54,6 +54,10 @@ _SIGNATURES = {
     'qt_attn_bwd': [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
     'qt_lstm_dgrad_blocks': [_I],
     'qt_lstm_bwd_dgrad': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P],
+    'qt_num_cus': [],
+    'qt_lstm_fused_blocks': [],
+    'qt_lstm_bwd_fused': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P,
+                          _P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
     'qt_compose_step_fwd': [_P] * 4 + [_I] * 5 + [_P] * 3,
     'qt_compose_step_bwd': [_P] * 4 + [_I] * 5 + [_P] * 7,
     'qt_compose2_fwd': [_P] * 8 + [_I] * 6 + [_P, _P, _P, _P, _P],
@@ -61,7 +65,7 @@ _SIGNATURES = {
     'qt_head_fwd': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P],
     'qt_head_bwd': [_P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
 }
-_PLAIN = {'qt_abi_version', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_lstm_dgrad_blocks', 'qt_attn_blocks'}  # return a value, not an error code
+_PLAIN = {'qt_abi_version', 'qt_num_cus', 'qt_lstm_fused_blocks', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_lstm_dgrad_blocks', 'qt_attn_blocks'}  # return a value, not an error code
 
 _lib = None
 

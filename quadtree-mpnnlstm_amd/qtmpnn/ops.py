@@ -63,10 +63,10 @@ class GradAcc:
     forward use -- the last one to run in the backward pass, because the recurrent state chains the uses --
     reduces the slabs and hands the gradient to autograd.
     """
-    __slots__ = ('uses', 'done', 'part', 'wt', 'pending')
+    __slots__ = ('uses', 'done', 'part', 'wt', 'pending', 'wslab')
 
     def __init__(self):
-        self.uses, self.done, self.part, self.wt, self.pending = 0, 0, None, {}, []
+        self.uses, self.done, self.part, self.wt, self.pending, self.wslab = 0, 0, None, {}, [], None
 
     def enter(self):
         self.uses += 1
@@ -76,6 +76,13 @@ class GradAcc:
         if self.part is None:
             self.part = like.new_zeros(nblk, width)
         return self.part
+
+    def weight_slab(self, like, rows, cols):
+        """(qt_lstm_fused_blocks(), rows, cols) zeros: the fused cell backward (qt_lstm_bwd_fused) adds every use's partial weight
+        gradient of workgroup b into slab b; the pass's last backward sums the slabs."""
+        if self.wslab is None:
+            self.wslab = like.new_zeros(_lib.value('qt_lstm_fused_blocks'), rows, cols)
+        return self.wslab
 
     def leave(self, use_idx):
         """True when this use must emit the summed gradient."""
@@ -282,8 +289,9 @@ def _dgrad_weight(W, K, Cs, live, acc):
     return Wb, skinny
 
 
-def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, gTs_pre=None):
-    """(gZ parts, gW) of Y = [T_0 .. T_{K-1} | S] W from G = dL/dY (N, Co)."""
+def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, gTs_pre=None, w_fused=False):
+    """(gZ parts, gW) of Y = [T_0 .. T_{K-1} | S] W from G = dL/dY (N, Co).  w_fused: this use's weight-gradient partials are
+    already in acc.wslab (qt_lstm_bwd_fused; G is then None)."""
     N = Zs[0].shape[0]
     Cs = [Z.shape[1] for Z in Zs]
     C = sum(Cs)
@@ -332,10 +340,16 @@ def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, g
         else:
             # deferred: the weight gradient is off the critical path, so all uses of this pass (<= 16 per launch) are
             # reduced together by the last backward -- one long launch instead of one short one per rollout step
-            acc.pending.append((Zs, TZs, S, G, N, mesh.n_dev))
+            if not w_fused:
+                acc.pending.append((Zs, TZs, S, G, N, mesh.n_dev))
             if acc.leave(use_idx):
-                gW = _wgrad_group(acc.pending, W, K, Cs, ksp, Co)
+                gW = _wgrad_group(acc.pending, W, K, Cs, ksp, Co) if acc.pending else None
                 acc.pending = []
+                if acc.wslab is not None:          # + the partials the fused launches added, slab by slab
+                    gf = torch.empty_like(W)
+                    _lib.call('qt_colsum', ptr(acc.wslab), acc.wslab.shape[0], W.numel(), ptr(gf))
+                    gW = gf if gW is None else gW + gf
+                    acc.wslab = None
     return gZs, gW
 
 
@@ -687,16 +701,26 @@ def _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, mesh, acc, use_idx, dgrad
     N, h = gates.shape[0], gates.shape[1] // 4
     (gHn, ld_gh), (gCn, ld_gc) = _rows(gHn), _rows(gCn)
     (gO, ld_go), (Cprev, ld_c) = _rows(gO), _rows(Cprev)
-    gG = torch.empty_like(gates)
+    fused_w = dgrad is not None and len(dgrad) > 4
+    gG = None if (fused_w and N > 0) else torch.empty_like(gates)
     gCp = gates.new_empty(N, h) if Cprev is not None else None
-    rows_of = lambda n: max(_lib.value('qt_lstm_bwd_blocks', n, h), _lib.value('qt_lstm_dgrad_blocks', n), 1)
+    # (one slab row per workgroup of whichever kernel serves a use: k_lstm_bwd, k_dgrad_cell or the persistent fused launch)
+    rows_of = lambda n: max(_lib.value('qt_lstm_bwd_blocks', n, h), _lib.value('qt_lstm_dgrad_blocks', n),
+                            min(_lib.value('qt_lstm_fused_blocks'), -(n // -64)), 1)
     if acc is None:
         nblk = rows_of(N)
         part = gates.new_empty(nblk, 11 * h) if dgrad is None else gates.new_zeros(nblk, 11 * h)
     else:
         nblk = rows_of(max(mesh.B * mesh.P, N))      # one slab for every use of the pass, whichever kernel serves it
         part = acc.slab(gates, nblk, 11 * h)
-    if N > 0 and dgrad is not None:
+    if N > 0 and dgrad is not None and len(dgrad) > 4:
+        Wrows, K, Cl, planes, (Zs, TZs, S, ksp, Cs, wslab) = dgrad
+        gG = None                                   # the gate gradients stay inside the launch
+        _lib.call('qt_lstm_bwd_fused', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Cprev), ld_c,
+                  ptr(wc), ptr(ln), N, ptr(mesh.n_dev), h, ptr(gCp), ptr(part), 0 if acc is None else 1,
+                  ptr(Wrows), K, Cl[0], Cl[1] if len(Cl) > 1 else 0, ptr(planes[0]), ptr(planes[1]) if len(Cl) > 1 else None,
+                  *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(S), ksp, ptr(wslab), wslab.shape[0])
+    elif N > 0 and dgrad is not None:
         Wrows, K, Cl, planes = dgrad
         _lib.call('qt_lstm_bwd_dgrad', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Cprev), ld_c,
                   ptr(wc), ptr(ln), N, ptr(mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part), 0 if acc is None else 1,
@@ -759,14 +783,26 @@ class _GateCell(Function):
         live = [i for i, f in enumerate(need) if f]
         NB = K * sum(Cs[i] for i in live)
         dgrad = planes = None
+        w_fused = False
         if N > 0 and live and h in (8, 16) and 16 < NB <= 128 and os.environ.get('QT_NO_DGRAD_FUSION') != '1':
             # the cell backward and the data gradient of the gate GEMM in one launch: gG feeds the MFMA loop from LDS
             Wb, _ = _dgrad_weight(W, K, Cs, live, ctx.acc_w)
             planes = [Zs[0].new_empty(K, N, Cs[i]) for i in live]
             dgrad = (Wb, K, [Cs[i] for i in live], planes)
+            # ... and, on request, the weight gradient too (qt_lstm_bwd_fused: gG never leaves the launch).  OFF by default: at
+            # the bench shape the persistent launch takes 71 us against 47 + 21 us for this launch plus its share of the
+            # deferred weight gradient -- fp32 MFMA issues on the vector pipe, so its 18 us of MFMA time, the cell arithmetic
+            # and the memory phases add up instead of overlapping; 9.17 vs 8.98 ms per step.
+            if (os.environ.get('QT_WGRAD_FUSION') == '1' and ctx.needs_input_grad[2] and ctx.acc_w is not None
+                    and W.shape[0] <= 128 and NB <= (128 if h == 16 else 64)):
+                ksp = (ctx.Ks + 3) // 4 * 4
+                S = ctx.mesh.cheb_ones(ctx.Ks) if ctx.Ks else None
+                wslab = ctx.acc_w.weight_slab(W, W.shape[0], W.shape[1])
+                dgrad = dgrad + ((Zs, TZs, S, ksp, Cs, wslab),)
+                w_fused = True
         gG, gCp, gwc, gb, gln = _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, ctx.mesh, ctx.acc_p, ctx.use_p, dgrad)
         gZs, gW = _cheb_backward(Zs, TZs, W, gG, ctx.mesh, K, ctx.Ks, ctx.acc_w, ctx.use_w, need, ctx.needs_input_grad[2],
-                                 gTs_pre=planes)
+                                 gTs_pre=planes, w_fused=w_fused)
         gZa = gZs[0] if gZs is not None else None
         gZb = gZs[1] if gZs is not None and nz > 1 else None
         return gZa, gZb, gW, gCp, gwc, gb, gln, None, None, None, None, None

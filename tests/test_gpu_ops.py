@@ -538,3 +538,31 @@ def test_attention_dropout_epoch_counter():
     # about half of the coefficients survive, scaled by 1 / keep: the mean over many targets stays near the undropped output
     rel = float((c - d0).abs().mean() / d0.abs().mean())
     assert 0.05 < rel < 2.0, rel
+
+
+@pytest.mark.parametrize('name', ['mnist64_h16', 'mnist64_noise_h8'])
+def test_fused_cell_backward_with_weight_gradient_matches_reference(name, monkeypatch):
+    """qt_lstm_bwd_fused (opt-in: QT_WGRAD_FUSION=1 -- cell backward, data gradient and weight gradient of a gate-cell use in
+    one persistent launch, gG never written): the rollout's loss and all parameter gradients against the reference trace,
+    hidden 16 (64-row tiles, 2 + 3 column tiles) and hidden 8."""
+    from helpers import golden, grad_close, load_state
+    from model.mpnnlstm import masked_mse
+    from model.seq2seq import Seq2Seq
+    monkeypatch.setenv('QT_WGRAD_FUSION', '1')
+    g = golden(f'rollout_{name}.npz')
+    x, y, concat = (torch.from_numpy(g[k]).to(dev()) for k in ('x', 'y', 'concat'))
+    model = Seq2Seq(hidden_size=int(g['hidden']), dropout=0.0, thresh=float(g['thresh']), input_timesteps=x.shape[0],
+                    input_features=x.shape[-1] + 3, output_timesteps=y.shape[0], n_layers=int(g['n_layers']),
+                    n_conv_layers=int(g['n_conv']), convolution_type='ChebConv')
+    load_state(model, g, 'w/')
+    model.to(dev())
+    outs, meshes = model(x, y, concat, teacher_forcing_ratio=0, mask=g['mask'])
+    loss = masked_mse(outs, meshes, y, g['mask'])
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    loss.backward()
+    for k, p in model.named_parameters():
+        ref = g['g/' + k]
+        if p.grad is None:
+            assert not ref.any(), k
+            continue
+        grad_close(p.grad, ref, msg=k)

@@ -71,6 +71,17 @@ def shape(name, K, Ca, Cab):
     part.zero_()
     us = graph_time(bwd)
     NB = K * sum(live)
+    if os.environ.get('QT_FUSED', '1') == '1':
+        ncu = _lib.value('qt_lstm_fused_blocks')
+        slab = torch.zeros(ncu, Kt, 4 * h, device=dev)
+        Zs, TZs = ([X, Hh], [TX, TH]) if Cab else ([X], [TX])
+        fus = lambda: _lib.call('qt_lstm_bwd_fused', ptr(gO), h, ptr(gH), h, ptr(gC), h, ptr(gates), ptr(Cp), h, ptr(wc), ptr(ln), CAP,
+                                ptr(nvalid), h, ptr(gCp), ptr(part), 1, ptr(Wb), K, live[0], live[1] if len(live) > 1 else 0,
+                                ptr(planes[0]), ptr(planes[1]) if len(live) > 1 else None,
+                                ptr(Zs[0]), Ca, ptr(TZs[0]), ptr(Zs[1]) if Cab else None, Cab, ptr(TZs[1]) if Cab else None,
+                                K, Ca, Cab, ptr(S), 4, ptr(slab), ncu)
+        usf = graph_time(fus)
+        print(f'{name}: FUSED bwd cell + dgrad + wgrad: {usf:7.2f} us   slab checksum {float(slab.double().sum()):.4f}')
     byts = 4.0 * N * (3 * h + 4 * h + h + 4 * h + h + NB)
     print(f'{name}: bwd cell + dgrad NB={NB}: {us:7.2f} us  {2.0 * N * 4 * h * NB / us / 1e6:6.1f} TFLOP/s  {byts / us / 1e3:7.0f} GB/s   '
           f'checksum {float(gG[:N].double().sum()):.6f} {float(gCp[:N].double().sum()):.6f} {sum(float(p[:, :N].double().sum()) for p in planes):.6f}')
