@@ -345,6 +345,13 @@ int qt_compose2_bwd(const float* Px0, const float* Bx0, const float* Px1, const 
                     const float* gW1, const float* gW0, float* gPx0, float* gBx0, float* gPx1, float* gBx1,
                     float* gPh0, float* gBh0, float* gPh1, float* gBh1, void* stream);
 
+/* clip_grad_norm_(max_norm) + one Adam step (model/mpnnlstm.py:251-257; torch.optim.Adam defaults: no weight decay, no amsgrad)
+ * on ONE flat fp32 parameter vector p (n) with gradient g, moments m, v: g is scaled in place by min(1, max_norm / (|g| + 1e-6))
+ * (max_norm <= 0: no clipping), *step is incremented on the device, stat[0] receives |g| before clipping.  lr_dev != NULL: the
+ * learning rate is read on the device (a scheduler updates it in place; hipGraph replays follow), else lr_host. */
+int qt_flat_adam(float* p, float* g, float* m, float* v, int n, int32_t* step, const float* lr_dev, float lr_host,
+                 float beta1, float beta2, float eps, float max_norm, float* stat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""MFMA utilisation and wave-stall breakdown of the gate GEMM + cell launches from one rocprofv3 PMC pass (SQ counters).
+
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES \\
+              SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d gpurun_out/pmc_g -o r \\
+              -- python3 bench.py --steps 2 --warmup 3 --frozen-steps 0 --no-cpu-baseline --no-roofline
+    python profiles/pmc_gemm.py gpurun_out/pmc_g > profiles/r02_pmc_gemm.json
+
+Units (MI355X_MICROARCH.md, cycle constants): SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs (= 64 x the number
+of v_mfma_f32_32x32x2_f32 wave instructions); SQ_BUSY_CYCLES is summed over the 32 shader engines, so kernel cycles =
+SQ_BUSY_CYCLES / 32; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles per wave and are used as ratios only.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+N_SIMD, N_SE = 1024, 32
+
+
+def main(d, pat):
+    f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        if pat in r['Kernel_Name']:
+            name = r['Kernel_Name'].split('::')[-1].split('(')[0]
+            per[name][r['Counter_Name']].append(float(r['Counter_Value']))
+    out = {'source': 'rocprofv3 --pmc (SQ counters, one pass, --kernel-trace only) -- python3 bench.py --steps 2 --warmup 3 '
+                     '--frozen-steps 0 --no-cpu-baseline --no-roofline', 'kernels': {}}
+    tot_mfma = tot_cyc = tot_wave = tot_wait = tot_stall = tot_act = 0.0
+    for name, cs in sorted(per.items()):
+        avg = {k: sum(v) / len(v) for k, v in cs.items()}
+        cyc = avg['SQ_BUSY_CYCLES'] / N_SE
+        rec = {'dispatches': len(cs['SQ_BUSY_CYCLES']), 'kernel_cycles': round(cyc),
+               'mfma_busy_cycles_per_simd': round(avg['SQ_VALU_MFMA_BUSY_CYCLES'] / N_SIMD),
+               'mfma_busy_frac': round(avg['SQ_VALU_MFMA_BUSY_CYCLES'] / N_SIMD / cyc, 3),
+               'wave_wait_memory_frac': round(avg['SQ_WAIT_ANY'] / avg['SQ_WAVE_CYCLES'], 3),
+               'wave_issue_stall_frac': round(avg['SQ_WAIT_INST_ANY'] / avg['SQ_WAVE_CYCLES'], 3),
+               'wave_active_frac': round(avg['SQ_ACTIVE_INST_ANY'] / avg['SQ_WAVE_CYCLES'], 3),
+               'mfma_mops_f32': round(avg.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0))}
+        out['kernels'][name] = rec
+        n = rec['dispatches']
+        tot_mfma += avg['SQ_VALU_MFMA_BUSY_CYCLES'] * n
+        tot_cyc += cyc * n
+        tot_wave += avg['SQ_WAVE_CYCLES'] * n
+        tot_wait += avg['SQ_WAIT_ANY'] * n
+        tot_stall += avg['SQ_WAIT_INST_ANY'] * n
+        tot_act += avg['SQ_ACTIVE_INST_ANY'] * n
+    out['mfma_busy_frac'] = round(tot_mfma / N_SIMD / tot_cyc, 3)
+    out['wave_stall_frac'] = {'waiting_on_memory_or_barrier': round(tot_wait / tot_wave, 3),
+                              'issue_stalled_mfma_dependency_or_pipe': round(tot_stall / tot_wave, 3),
+                              'issuing': round(tot_act / tot_wave, 3)}
+    out['reading'] = ('the fp32 MFMA pipe is busy for about a third of the launch and no wave class is saturated: 1.8 units of '
+                      '32 rows per wave leave no steady state, so the launch is the sum of its phases (operand latency, MFMA chain, '
+                      'cell arithmetic on the same vector pipe, store drain) rather than their maximum -- see DESIGN.md section 6')
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'k_gate_cell_p')

@@ -326,3 +326,61 @@ extern "C" int qt_compose_step_bwd(const float* P0, const float* B0, const float
     QT_LAUNCHED();
     return QT_OK;
 }
+
+// ---- clip_grad_norm_ + Adam on ONE flat parameter vector (model/mpnnlstm.py:251-257 on the flat buffer of qtmpnn/flat.py).
+// torch's fused Adam walks a single 34.5k-element tensor with one 512-thread block (52 us per step in the round-2 profile) and
+// the clipping is another eight small launches; here: one block sums the squares in a fixed order (bit-reproducible) and bumps
+// the step counter, then an elementwise launch scales the gradient by min(1, max_norm / (norm + 1e-6)) -- in place, like
+// clip_grad_norm_ -- and applies Adam (no weight decay, no amsgrad: the reference's torch.optim.Adam(lr) defaults).
+namespace {
+
+__global__ __launch_bounds__(1024) void k_flat_sumsq(const float* __restrict__ g, int n, float* __restrict__ stat,
+                                                     int32_t* __restrict__ step) {
+    __shared__ float red[16];
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 1024) acc += g[i] * g[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += red[w];
+        stat[0] = sqrtf(s);                   // total gradient norm (before clipping), what clip_grad_norm_ returns
+        *step += 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_flat_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int n, const float* __restrict__ stat,
+                                                   const int32_t* __restrict__ step, const float* __restrict__ lr_dev,
+                                                   float lr_host, float beta1, float beta2, float eps, float max_norm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float lr = lr_dev ? *lr_dev : lr_host;
+    float coef = 1.0f;
+    if (max_norm > 0.0f) coef = fminf(max_norm / (stat[0] + 1e-6f), 1.0f);
+    const float t = (float)*step;
+    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
+    const float gi = g[i] * coef;
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    g[i] = gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+}
+
+}  // namespace
+
+extern "C" int qt_flat_adam(float* p, float* g, float* m, float* v, int n, int32_t* step, const float* lr_dev, float lr_host,
+                            float beta1, float beta2, float eps, float max_norm, float* stat, void* stream) {
+    QT_ARG(p && g && m && v && step && stat && n > 0, "bad arguments");
+    hipLaunchKernelGGL(k_flat_sumsq, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, n, stat, step);
+    QT_LAUNCHED();
+    hipLaunchKernelGGL(k_flat_adam, dim3(qt_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, stat, step, lr_dev,
+                       lr_host, beta1, beta2, eps, max_norm);
+    QT_LAUNCHED();
+    return QT_OK;
+}

@@ -107,13 +107,16 @@ class NextFramePredictorS2S:
         fused = self.device is not None and torch.device(self.device).type == 'cuda'
         # Plain ChebConv models on the GPU: every parameter is a view of one flat buffer and the backward pass returns one
         # flat gradient vector (qtmpnn.flat), so the optimizer sees ONE tensor -- Adam is elementwise, and the clipping norm is
-        # the norm of all gradients either way, so the update is the reference's; only the launch count differs (1 fused-Adam
-        # kernel instead of 16, no per-tensor clipping kernels, the all-reduce without a gather copy).
+        # the norm of all gradients either way, so the update is the reference's; only the launch count differs (two launches
+        # for clip + Adam instead of ~25, the all-reduce without a gather copy).
         self.flat = None
         if fused and self.model.encoder.plannable and self.model.decoder.plannable:
             self.flat = flat_params(self.model)
-        opt_params = [self.flat.param] if self.flat is not None else self.model.parameters()
-        self.optimizer = torch.optim.Adam(opt_params, lr=lr, capturable=capturable, fused=fused or None)
+        if self.flat is not None:
+            from qtmpnn.optim import FlatAdam
+            self.optimizer = FlatAdam(self.flat.param, lr=lr, capturable=capturable)      # clip + Adam in two launches
+        else:
+            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, capturable=capturable, fused=fused or None)
         self.scheduler = StepLR(self.optimizer, step_size=3, gamma=lr_decay)
         self.writer = SummaryWriter('runs/' + self.experiment_name + '_' + datetime.datetime.now().strftime('%Y%m%d_%H_%M_%S'))
         self.test_loss, self.train_loss = [], []
@@ -151,6 +154,15 @@ class NextFramePredictorS2S:
         self.flat.param.grad = g
         return [self.flat.param]
 
+    def _clip_and_step(self, clip_params, max_norm):
+        """clip_grad_norm_(max_norm) + optimizer.step() (mpnnlstm.py:251, 257); max_norm None: no clipping (:311)."""
+        if self.flat is not None:
+            self.optimizer.step(max_norm=max_norm)
+            return
+        if max_norm is not None:
+            torch.nn.utils.clip_grad_norm_(clip_params, max_norm=max_norm)
+        self.optimizer.step()
+
     def _world(self):
         d = torch.distributed
         if self.process_group is not None:
@@ -164,8 +176,7 @@ class NextFramePredictorS2S:
         self.zero_grad()
         loss = self.forward_loss(x, y, concat_layers, mask, high_interest_region, graph_structure)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(self._grads_ready(self._world(), self.process_group), max_norm=max_norm)
-        self.optimizer.step()
+        self._clip_and_step(self._grads_ready(self._world(), self.process_group), max_norm)
         return loss.detach()
 
     def truncated_backward(self, x, y, concat_layers, mask, high_interest_region=None, graph_structure=None,
@@ -218,8 +229,7 @@ class NextFramePredictorS2S:
             return loss.detach()
 
         def update(clip_params):
-            torch.nn.utils.clip_grad_norm_(clip_params, max_norm=max_norm)
-            self.optimizer.step()
+            self._clip_and_step(clip_params, max_norm)
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -300,8 +310,8 @@ class NextFramePredictorS2S:
                 if truncate:
                     loss = self.truncated_backward(x, y, concat, mask, high_interest_region, graph_structure,
                                                    truncated_backprop)[-1]
-                    self._grads_ready(self._world(), self.process_group)
-                    self.optimizer.step()                 # no gradient clipping in this branch (:311 is commented out)
+                    # no gradient clipping in this branch (:311 is commented out)
+                    self._clip_and_step(self._grads_ready(self._world(), self.process_group), None)
                 elif use_graph:
                     key = (tuple(x.shape), tuple(y.shape), None if concat is None else tuple(concat.shape))
                     if key not in graphed:      # first sight of this batch shape: its update runs eagerly, then the capture

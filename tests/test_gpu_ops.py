@@ -566,3 +566,30 @@ def test_fused_cell_backward_with_weight_gradient_matches_reference(name, monkey
             assert not ref.any(), k
             continue
         grad_close(p.grad, ref, msg=k)
+
+
+@pytest.mark.parametrize('capturable', [False, True])
+def test_flat_adam_equals_clip_grad_norm_plus_torch_adam(capturable):
+    """qt_flat_adam (clip + Adam on the flat parameter vector, two launches) against torch.nn.utils.clip_grad_norm_ +
+    torch.optim.Adam over a few steps, with gradients above and below the clipping norm and a learning-rate change."""
+    from qtmpnn.optim import FlatAdam
+    torch.manual_seed(0)
+    n = 34513
+    p0 = torch.randn(n, device=dev())
+    pa, pb = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
+    oa = FlatAdam(pa, lr=0.01, capturable=capturable)
+    ob = torch.optim.Adam([pb], lr=0.01)
+    sched = torch.optim.lr_scheduler.StepLR(oa, step_size=2, gamma=0.5)
+    for it in range(5):
+        g = torch.randn(n, device=dev()) * (0.2 if it % 2 else 0.01)         # norm ~37 (clipped to 10) / ~1.9 (not clipped)
+        pa.grad, pb.grad = g.clone(), g.clone()
+        norm = torch.nn.utils.clip_grad_norm_([pb], 10.0)
+        ob.step()
+        oa.step(max_norm=10.0)
+        assert abs(float(oa.last_norm[0]) - float(norm)) <= 1e-5 * float(norm)
+        close(pa.grad, pb.grad, rtol=1e-5, atol=1e-8, msg=f'clipped gradient, step {it}')
+        close(pa, pb, rtol=1e-5, atol=1e-6, msg=f'weights, step {it}')
+        sched.step()
+        for gr in ob.param_groups:
+            gr['lr'] = float(sched.get_last_lr()[0])
+    assert int(oa.state[pa]['step']) == 5
