@@ -60,6 +60,9 @@ def test_bad_arguments_fail_loudly_without_gpu():
     # every entry point refuses NULL / inconsistent arguments with an error code and a message naming itself -- no launch
     null_calls = {
         'qt_lstm_bwd_dgrad': (None, 0, None, 0, None, 0, None, None, 0, None, None, 4, None, 16, None, None, None, 0, None, 3, 16, 0, None, None, None),
+        'qt_lstm_bwd_fused': (None, 0, None, 0, None, 0, None, None, 0, None, None, 4, None, 16, None, None, 0, None, 3, 16, 0, None, None,
+                              None, 0, None, None, 0, None, 3, 16, 0, None, 0, None, 0, None),
+        'qt_flat_adam': (None, None, None, None, 0, None, None, 0.0, 0.9, 0.999, 1e-8, 10.0, None, None),
         'qt_compose2_fwd': (None,) * 8 + (3, 1, 3, 4, 4, 16, None, None, None, None, None),
         'qt_compose_step_fwd': (None,) * 4 + (3, 1, 3, 4, 16, None, None, None),
         'qt_remesh': (None, None, None, 0, None, None, 0, None, None, None, 1, 1, 64, 64, 4, None, None, None, None, 0, None),
