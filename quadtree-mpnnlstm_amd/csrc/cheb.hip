@@ -1093,11 +1093,17 @@ struct DgradCellArgs {
     const int32_t* n_dev;
 };
 
-template <int NT, int LPN>
-__global__ __launch_bounds__(256, 2) void k_dgrad_cell(DgradCellArgs g) {
+// BG: the right operand (the weight rows, <= 32 KB, L1 / L2 resident) is read straight from global memory by the lanes that
+// need it instead of being staged in LDS: the workgroup's LDS drops from 64 KB to 38 KB, so THREE workgroups fit a CU instead
+// of two -- more workgroups whose load / arithmetic / MFMA / store phases overlap.
+#ifndef QT_DGRAD_BG
+#define QT_DGRAD_BG 1
+#endif
+template <int NT, int LPN, bool BG = (QT_DGRAD_BG != 0)>
+__global__ __launch_bounds__(256, BG ? 3 : 2) void k_dgrad_cell(DgradCellArgs g) {
     using namespace qtcell;
     constexpr int BNT = 32 * NT, K = 16 * LPN, PITCH = K + 4, RP = 256 / LPN;
-    __shared__ __attribute__((aligned(16))) float Bt[BNT * PITCH];
+    __shared__ __attribute__((aligned(16))) float Bt[BG ? 4 : BNT * PITCH];
     __shared__ __attribute__((aligned(16))) float As[128 * (PITCH > 64 ? PITCH : 64)];
     __shared__ float sm[4 * LPN * 11 * 4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1107,11 +1113,13 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_cell(DgradCellArgs g) {
     const int h = g.h;
     if (i0 >= rows) return;        // past the valid rows: nothing to add to the partials (the slab rows start at zero)
     // W chunk (all of it: K = 4h fits one pass) -> LDS; independent of the cell phase below
-    for (int e = t; e < BNT * (K / 4); e += 256) {
-        const int c = e / (K / 4), kq = e - c * (K / 4);
-        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < g.NB) w = *reinterpret_cast<const float4*>(g.BT + (int64_t)c * K + 4 * kq);
-        *reinterpret_cast<float4*>(&Bt[c * PITCH + 4 * kq]) = w;
+    if constexpr (!BG) {
+        for (int e = t; e < BNT * (K / 4); e += 256) {
+            const int c = e / (K / 4), kq = e - c * (K / 4);
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < g.NB) w = *reinterpret_cast<const float4*>(g.BT + (int64_t)c * K + 4 * kq);
+            *reinterpret_cast<float4*>(&Bt[c * PITCH + 4 * kq]) = w;
+        }
     }
     // cell backward of this workgroup's rows (rows past the valid count contribute zeros)
     {
@@ -1165,8 +1173,15 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_cell(DgradCellArgs g) {
         const float4 a = *reinterpret_cast<const float4*>(&As[(wave * 32 + l32) * PITCH + 8 * j + 4 * half]);
         float4 bq[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            bq[nt] = *reinterpret_cast<const float4*>(&Bt[(nt * 32 + l32) * PITCH + 8 * j + 4 * half]);
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (BG) {
+                const int c = nt * 32 + l32;                  // (columns past NB: clamped load, zeroed value)
+                const float4 w = gload4(g.BT + (int64_t)(c < g.NB ? c : 0) * K + 8 * j + 4 * half);
+                bq[nt] = c < g.NB ? w : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                bq[nt] = *reinterpret_cast<const float4*>(&Bt[(nt * 32 + l32) * PITCH + 8 * j + 4 * half]);
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[nt].x, acc2[nt], 0, 0, 0);

@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libqtmpnn_hip.so')
+# QT_LIB_PATH: an alternative build of the same library (A/B timing of kernel variants on one box; diagnostics only)
+LIB_PATH = os.environ.get('QT_LIB_PATH') or os.path.join(_HERE, 'libqtmpnn_hip.so')
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
