@@ -247,12 +247,18 @@ int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_gh, const f
  * its 128 nodes, writes them (the weight gradient reads them later) and multiplies them from LDS with W^T:
  * out planes (Kb, N, Cb) [+ outb (Kb, N, Cbb)] = gG (N, 4h) @ Wrows^T, Wrows = the first Kb (Cb + Cbb) rows of the forward
  * weight (row k (Cb + Cbb) + c, 4h columns), Kb (Cb + Cbb) <= 128.  Same planes, bit for bit, as qt_lstm_bwd + qt_dense2.
- * part: (qt_lstm_dgrad_blocks(N), 11 h) partial sums as in qt_lstm_bwd (one row per 128-node workgroup). */
+ * part: (qt_lstm_dgrad_blocks(N), 11 h) partial sums as in qt_lstm_bwd (one row per 128-node workgroup).
+ * Whi / Wlo (optional pair, bf16 (Kb (Cb + Cbb), 4h) from qt_split_bf16(Wrows)): the data gradient then runs as a split-bf16
+ * product on bf16 MFMA (gG and W as two bf16 terms each, three products: relative error ~2^-16, gradients only) instead of
+ * fp32 MFMA; NULL: exact fp32, bit for bit qt_lstm_bwd + qt_dense2. */
 int qt_lstm_dgrad_blocks(int N);
 int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,
                       const float* gates, const float* Cprev, int ld_c, const float* wc, const float* ln,
                       int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
-                      const float* Wrows, int Kb, int Cb, int Cbb, float* out, float* outb, void* stream);
+                      const float* Wrows, const void* Whi, const void* Wlo, int Kb, int Cb, int Cbb, float* out, float* outb,
+                      void* stream);
+/* x (n fp32) -> hi, lo (n bf16 each) with x ~ hi + lo (hi = round(x), lo = round(x - hi)) */
+int qt_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream);
 
 /* The whole backward pass of one gate-cell use (hidden 8 / 16) in one persistent launch: qt_lstm_bwd's cell backward, the data
  * gradient of qt_lstm_bwd_dgrad (same planes) AND the weight gradient gW = [T_0 .. T_{K-1} | S]^T gG of the forward

@@ -254,6 +254,7 @@ struct GemmArgs {
 // lane fetch its A operand as one float4 (4 consecutive k of its own row): in step (j, i) lane half h feeds
 // k = 8 j + 4 h + i.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BM = 128;       // block rows (4 waves x 32)
 constexpr int BN = 64;        // block columns (2 MFMA tiles per wave)
 constexpr int MAXQ = 128;     // quads (4 consecutive k) in the reduction dimension
@@ -1088,6 +1089,7 @@ struct DgradCellArgs {
     float *gG, *gCprev, *part;
     int accumulate;
     const float* BT;        // (NB, 4h): rows k*C + c of the forward weight (= the transposed right operand)
+    const __bf16 *BThi, *BTlo;   // optional: the same rows split into two bf16 terms (qt_split_bf16): the product runs on bf16 MFMA
     int M, NB, Kb, Cb, Cbb;
     float *out, *outb;
     const int32_t* n_dev;
@@ -1168,6 +1170,40 @@ __global__ __launch_bounds__(256, BG ? 3 : 2) void k_dgrad_cell(DgradCellArgs g)
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[nt][r] = 0.0f;
+    if (g.BThi) {
+        // Split-bf16 product (backward only: gradients, 1e-3 tolerance): gG = hi + lo, W = Whi + Wlo (two bf16 terms each, the
+        // weight split once per pass by qt_split_bf16), gG W^T ~ hi Whi + hi Wlo + lo Whi -- relative error ~2^-16 per
+        // product -- on v_mfma_f32_32x32x16_bf16: 3 MFMAs of 32 cycles per 16 k instead of 8 fp32 MFMAs of 64 cycles (the
+        // fp32 MFMA issues on the vector pipe: its 10.7 us per launch at the bench shape added to the cell arithmetic).
+        // Lane (r = l & 31, hh = l >> 5) holds A[row r][k = 16 s + 8 hh + j] and B[k = 16 s + 8 hh + j][column r], j = 0 .. 7.
+#pragma unroll
+        for (int s_ = 0; s_ < K / 16; ++s_) {
+            const float* ap = &As[(wave * 32 + l32) * PITCH + 16 * s_ + 8 * half];
+            const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+            const float af[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            bf16x8 ahi, alo;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const __bf16 hq = (__bf16)af[q];
+                ahi[q] = hq;
+                alo[q] = (__bf16)(af[q] - (float)hq);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = nt * 32 + l32;                  // (columns past NB: clamped load, zeroed value)
+                const int64_t off = (int64_t)(c < g.NB ? c : 0) * K + 16 * s_ + 8 * half;
+                bf16x8 bhi = *(const __attribute__((address_space(1))) bf16x8*)(g.BThi + off);
+                bf16x8 blo = *(const __attribute__((address_space(1))) bf16x8*)(g.BTlo + off);
+                if (c >= g.NB) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { bhi[q] = (__bf16)0.0f; blo[q] = (__bf16)0.0f; }
+                }
+                acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc2[nt], 0, 0, 0);
+                acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc2[nt], 0, 0, 0);
+                acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc2[nt], 0, 0, 0);
+            }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < K / 8; ++j) {
         const float4 a = *reinterpret_cast<const float4*>(&As[(wave * 32 + l32) * PITCH + 8 * j + 4 * half]);
@@ -1189,6 +1225,7 @@ __global__ __launch_bounds__(256, BG ? 3 : 2) void k_dgrad_cell(DgradCellArgs g)
             acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[nt].z, acc2[nt], 0, 0, 0);
             acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[nt].w, acc2[nt], 0, 0, 0);
         }
+    }
     }
     // epilogue as in k_gemm_fwd: the tile goes through LDS (As is free now) so that rows leave as float4 pieces
     float* Cs = As;
@@ -1627,8 +1664,10 @@ extern "C" int qt_lstm_dgrad_blocks(int N) { return N <= 0 ? 0 : qt_cdiv(N, BM);
 extern "C" int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,
                                  const float* gates, const float* Cprev, int ld_c, const float* wc, const float* ln, int N,
                                  const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
-                                 const float* Wrows, int Kb, int Cb, int Cbb, float* out, float* outb, void* stream) {
+                                 const float* Wrows, const void* Whi, const void* Wlo, int Kb, int Cb, int Cbb, float* out,
+                                 float* outb, void* stream) {
     QT_ARG(gates && wc && gG && part && Wrows && out, "null pointer");
+    QT_ARG((Whi == nullptr) == (Wlo == nullptr) && (((uintptr_t)Whi | (uintptr_t)Wlo) & 15) == 0, "Whi / Wlo come as a 16-byte aligned pair");
     QT_ARG(h == 8 || h == 16, "fused for hidden sizes 8 and 16 (others: qt_lstm_bwd + qt_dense2)");
     QT_ARG(Kb >= 1 && Cb >= 4 && Cb % 4 == 0 && Cbb >= 0 && Cbb % 4 == 0 && (Cbb == 0 || outb), "bad output planes");
     const int NB = Kb * (Cb + Cbb);
@@ -1642,6 +1681,7 @@ extern "C" int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, i
     g.ld_go = ld_go; g.ld_gh = ld_gh; g.ld_gc = ld_gc; g.ld_c = ld_c; g.h = h;
     g.gG = gG; g.gCprev = gCprev; g.part = part; g.accumulate = accumulate;
     g.BT = Wrows; g.M = N; g.NB = NB; g.Kb = Kb; g.Cb = Cb; g.Cbb = Cbb; g.out = out; g.outb = outb; g.n_dev = n_dev;
+    g.BThi = (const __bf16*)Whi; g.BTlo = (const __bf16*)Wlo;
     const dim3 grid(qt_cdiv(N, BM));
     // 32-column MFMA tiles: as many as the output planes need (K' C = 80 or 96 columns take three, not four)
     if (h == 16) {

@@ -384,3 +384,23 @@ extern "C" int qt_flat_adam(float* p, float* g, float* m, float* v, int n, int32
     QT_LAUNCHED();
     return QT_OK;
 }
+
+// ---- x = hi + lo with two bf16 terms (hi = round(x), lo = round(x - hi)): the right operand of a split-bf16 MFMA product
+// (qt_lstm_bwd_dgrad's data gradient), split once per pass instead of per workgroup.
+namespace {
+__global__ __launch_bounds__(256) void k_split_bf16(const float* __restrict__ x, int64_t n, __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const __bf16 h = (__bf16)v;
+    hi[i] = h;
+    lo[i] = (__bf16)(v - (float)h);
+}
+}  // namespace
+
+extern "C" int qt_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream) {
+    QT_ARG(x && hi && lo && n > 0, "bad arguments");
+    hipLaunchKernelGGL(k_split_bf16, dim3(qt_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, (__bf16*)hi, (__bf16*)lo);
+    QT_LAUNCHED();
+    return QT_OK;
+}

@@ -284,6 +284,12 @@ def _dgrad_weight(W, K, Cs, live, acc):
             Wb = Wb.view(K, C, Co)[:, lo:lo + Cs[live[0]]].reshape(-1, Co)     # shared by every use in this pass
         if skinny:
             Wb = Wb.t().contiguous()
+        elif acc is not None and Wb.is_cuda and os.environ.get('QT_DGRAD_FP32') != '1':
+            # two bf16 terms of the same rows for the split-bf16 data gradient of qt_lstm_bwd_dgrad (once per pass)
+            Wb = Wb.contiguous()
+            hi, lo = (torch.empty(Wb.shape, dtype=torch.bfloat16, device=Wb.device) for _ in range(2))
+            _lib.call('qt_split_bf16', ptr(Wb), Wb.numel(), ptr(hi), ptr(lo))
+            Wb._qt_split = (hi, lo)
         if acc is not None:
             acc.wt[key] = Wb
     return Wb, skinny
@@ -721,10 +727,12 @@ def _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, mesh, acc, use_idx, dgrad
                   ptr(Wrows), K, Cl[0], Cl[1] if len(Cl) > 1 else 0, ptr(planes[0]), ptr(planes[1]) if len(Cl) > 1 else None,
                   *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(S), ksp, ptr(wslab), wslab.shape[0])
     elif N > 0 and dgrad is not None:
-        Wrows, K, Cl, planes = dgrad
+        Wrows, K, Cl, planes = dgrad[:4]
+        split = Wrows.__dict__.get('_qt_split') if hasattr(Wrows, '__dict__') else None
         _lib.call('qt_lstm_bwd_dgrad', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Cprev), ld_c,
                   ptr(wc), ptr(ln), N, ptr(mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part), 0 if acc is None else 1,
-                  ptr(Wrows), K, Cl[0], Cl[1] if len(Cl) > 1 else 0, ptr(planes[0]), ptr(planes[1]) if len(Cl) > 1 else None)
+                  ptr(Wrows), ptr(split[0]) if split else None, ptr(split[1]) if split else None, K, Cl[0],
+                  Cl[1] if len(Cl) > 1 else 0, ptr(planes[0]), ptr(planes[1]) if len(Cl) > 1 else None)
     elif N > 0:
         if acc is None and nblk > _lib.value('qt_lstm_bwd_blocks', N, h):
             part.zero_()
