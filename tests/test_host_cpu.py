@@ -259,3 +259,17 @@ def test_flat_params_views_and_single_tensor_update_equal_per_tensor_update():
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), k
     moved = copy.deepcopy(net)                          # a copy owns separate tensors: its own FlatParams is made on demand
     assert not fp.intact(moved) and flat_params(moved) is not fp
+
+
+def test_library_issues_only_kernels_on_the_callers_stream():
+    """Every device write of the C-ABI library is a kernel launched on the stream the caller passes: no hipMemset / hipMemcpy
+    (sync or async), no stream or event of its own, no allocation.  That is what makes every entry capturable into the caller's
+    hipGraph; round 1 lost a run to a memset issued inside a captured step by code that was never committed (DESIGN.md
+    section 10 records what a controlled experiment showed about memset nodes themselves)."""
+    import glob
+    src = ''
+    for f in glob.glob(os.path.join(ROOT, 'quadtree-mpnnlstm_amd', 'csrc', '*.h*')):
+        src += re.sub(r'//[^\n]*', '', open(f).read())
+    for banned in ('hipMemset', 'hipMemcpy', 'hipMalloc', 'hipFree', 'hipStreamCreate', 'hipEventCreate', 'hipDeviceSynchronize',
+                   'hipStreamSynchronize'):
+        assert banned not in src, f'{banned} found in csrc/: device work must be kernels on the caller stream'
