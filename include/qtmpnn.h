@@ -75,7 +75,12 @@ int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_offsets /* ex
                        float size_norm, float* feat /* (Nmax,3) or NULL */, float* npix /* (Nmax) or NULL: the
                        qt_node_features outputs, written by the same pass */,
                        int raw_counts /* != 0: cnt_offsets is stage 1's cnt itself (B*nbase <= 1024 counts), scanned by
-                       every workgroup in LDS: no qt_scan_i32 launch in between (static capacities) */, void* stream);
+                       every workgroup in LDS: no qt_scan_i32 launch in between (static capacities) */,
+                       const int32_t* old_labels, const uint8_t* old_level /* the mesh this one was built from, or NULL */,
+                       int32_t* fwd_src /* (Nmax) or NULL: per node of THIS mesh the old node under its pixel if the node
+                       is a single pixel, else -1: qt_remesh's `direct` index for the transfer old -> this mesh */,
+                       int32_t* bwd_src /* (Nmax_old) or NULL: the same for the transposed transfer this mesh -> old */,
+                       void* stream);
 
 /* exclusive scan: out[0]=0, out[i+1]=sum(in[0..i]); len+1 outputs.  tmp: (len/1024+2) int32. */
 int qt_scan_i32(const int32_t* in, int32_t* out, int64_t len, int32_t* tmp, void* stream);
@@ -135,7 +140,10 @@ int qt_pool(const float* img, int S, int64_t img_clip_stride /* floats between c
 int qt_remesh(const float* const* src_parts, const int* widths, const int* lds, int nparts,
               const int32_t* src_labels, const float* src_npix, int src_inv, const int32_t* labels, const uint8_t* level,
               const float* npix, int mean, int B, int n, int m, int N, const int32_t* cell, const int32_t* n_dev,
-              float* const* out_parts, const int* out_widths, int nout, void* stream);
+              float* const* out_parts, const int* out_widths, int nout,
+              const int32_t* direct /* (N) or NULL: fwd_src / bwd_src of qt_quadtree_stage3 for this pair of meshes: the
+              single-pixel nodes then read their source row through it (same rows, two dependent loads instead of three) */,
+              void* stream);
 
 /* masked MSE, model/mpnnlstm.py:243-246: partial[b*ntile + tile] = sum over the tile's unmasked pixels of
  * (out[labels[p]] - y[p])^2 ; y (B, n*m).  Pixels with label < 0 are the masked ones. */

@@ -208,7 +208,9 @@ __global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const in
                                   int B, int n, int m, int MS, int nbj, int nbase,
                                   int32_t* __restrict__ labels, const uint8_t* __restrict__ level,
                                   int32_t* __restrict__ cell, int32_t* __restrict__ node_off, float size_norm,
-                                  float* __restrict__ feat, float* __restrict__ npix) {
+                                  float* __restrict__ feat, float* __restrict__ npix,
+                                  const int32_t* __restrict__ old_labels, const uint8_t* __restrict__ old_level,
+                                  int32_t* __restrict__ fwd_src, int32_t* __restrict__ bwd_src) {
     // raw != 0: offs_in holds the per-cell leaf COUNTS (stage 1's output) and every workgroup scans the B * nbase <= 1024 of
     // them itself in LDS -- the separate scan launch between the two stages is gone (static capacities: nobody on the host
     // needs the total)
@@ -247,6 +249,17 @@ __global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const in
             int4 cl = make_int4(r, c, s, b);
             reinterpret_cast<int4*>(cell)[lab] = cl;
             if (feat) node_features(cl, lab, n, m, size_norm, feat, npix);
+            // state transfer old mesh -> this mesh: a single-pixel node takes the row of the old node under its pixel
+            // (qt_remesh reads this index instead of walking cell -> pixel -> old label); larger nodes: -1 = general path
+            if (fwd_src) fwd_src[lab] = s == 1 ? old_labels[idx] : -1;
+        }
+    }
+    if (bwd_src) {
+        // ... and the transposed transfer (the gradient back onto the old mesh): for the old node whose head pixel this is
+        const int ol = old_labels[idx];
+        if (ol >= 0) {
+            const int so = 1 << old_level[idx];
+            if ((r & (so - 1)) == 0 && (c & (so - 1)) == 0) bwd_src[ol] = so == 1 ? lab : -1;
         }
     }
     labels[idx] = lab;
@@ -377,14 +390,18 @@ extern "C" int qt_quadtree_stage1(const float* src, int src_rows, int src_cols, 
 
 extern "C" int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_offsets, int B, int n, int m,
                                   int max_size, int32_t* labels, const uint8_t* level, int32_t* cell,
-                                  int32_t* node_off, float size_norm, float* feat, float* npix, int raw_counts, void* stream) {
+                                  int32_t* node_off, float size_norm, float* feat, float* npix, int raw_counts,
+                                  const int32_t* old_labels, const uint8_t* old_level, int32_t* fwd_src, int32_t* bwd_src,
+                                  void* stream) {
     QT_ARG(local_id && cnt_offsets && labels && level && cell && node_off, "null pointer");
+    QT_ARG((!fwd_src && !bwd_src) || (old_labels && old_level), "fwd_src / bwd_src need the old mesh's labels and levels");
     QT_ARG((feat == nullptr) == (npix == nullptr), "give both feat and npix or neither");
     const int nbi = qt_cdiv(n, max_size), nbj = qt_cdiv(m, max_size);
     QT_ARG(!raw_counts || (int64_t)B * nbi * nbj <= 1024, "raw_counts: at most 1024 base cells (scan them with qt_scan_i32 instead)");
     const int64_t total = (int64_t)B * n * m;
     hipLaunchKernelGGL(k_quadtree_stage3, dim3(qt_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, local_id,
-                       cnt_offsets, raw_counts, B, n, m, max_size, nbj, nbi * nbj, labels, level, cell, node_off, size_norm, feat, npix);
+                       cnt_offsets, raw_counts, B, n, m, max_size, nbj, nbi * nbj, labels, level, cell, node_off, size_norm, feat, npix,
+                       old_labels, old_level, fwd_src, bwd_src);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -35,6 +35,9 @@ struct PoolArgs {
     const int32_t* cell;     // (N, 4) r, c, size, clip: given -> nodes up to 4x4 pixels go through k_pool_nodes
     const int32_t* n_dev;
     int big_only;            // tile kernel: only nodes of 8x8 pixels and more
+    const int32_t* direct;   // mesh -> mesh, optional: per destination node the source node under its ONE pixel (written
+                             // by qt_quadtree_stage3 when the destination mesh was built from the source mesh, or the
+                             // transposed index), -1 = multi-pixel node (general path); NULL: general path for all
 };
 
 template <int VEC>
@@ -262,6 +265,36 @@ __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
     if (i >= qt_rows(a.n_dev, a.N)) return;
     const int rem = (int)(idx - (unsigned)i * (unsigned)per);
     const int s = rem / nch, ch = rem - s * nch;
+    if (a.direct) {
+        // single-pixel destination node whose source node is known: index -> row, two dependent loads instead of the
+        // cell -> pixel label -> row chain (and 4 bytes of index per thread instead of the 16-byte cell record: the index
+        // traffic was as large as the payload).  Same arithmetic as the single-pixel branch below: bit-identical rows.
+        const int d = a.direct[i];
+        if (d >= 0) {
+            Vec<VEC> x = vload<VEC>(src_chunk<VEC>(a, d, ch));
+            if (a.src_inv) {
+                const float sc = 1.0f / a.src_npix[d];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) x.v[k] *= sc;
+            }
+            vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), x, 1.0f);
+            return;
+        }
+    }
+#if defined(QT_EXP_POOL) && QT_EXP_POOL == 1
+    {   // diagnostics: identity source index, no cell / label loads -- the pure row copy
+        Vec<VEC> x0 = vload<VEC>(src_chunk<VEC>(a, i, ch));
+        vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), x0, 1.0f);
+        return;
+    }
+#elif defined(QT_EXP_POOL) && QT_EXP_POOL == 2
+    {   // diagnostics: one dependent index load (a direct per-node source index would look like this)
+        const int sl = a.src_labels[i];
+        Vec<VEC> x0 = vload<VEC>(src_chunk<VEC>(a, sl >= 0 ? sl : 0, ch));
+        vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), x0, 1.0f);
+        return;
+    }
+#endif
     const int4 cl = reinterpret_cast<const int4*>(a.cell)[i];
     if (cl.z > 4) return;
     const int64_t P = (int64_t)a.n * a.m, base = (int64_t)cl.w * P;
@@ -552,8 +585,10 @@ extern "C" int qt_pool(const float* img, int S, int64_t img_clip_stride, const f
 extern "C" int qt_remesh(const float* const* src_parts, const int* widths, const int* lds, int nparts,
                          const int32_t* src_labels, const float* src_npix, int src_inv, const int32_t* labels,
                          const uint8_t* level, const float* npix, int mean, int B, int n, int m, int N, const int32_t* cell,
-                         const int32_t* n_dev, float* const* out_parts, const int* out_widths, int nout, void* stream) {
+                         const int32_t* n_dev, float* const* out_parts, const int* out_widths, int nout, const int32_t* direct,
+                         void* stream) {
     QT_ARG(src_parts && widths && lds && nparts >= 1 && nparts <= 8 && src_labels && labels && level && B > 0, "bad arguments");
+    QT_ARG(!direct || cell, "the direct source index serves the node kernel (needs cell)");
     QT_ARG(out_parts && out_widths && nout >= 1 && nout <= 8, "bad output parts");
     QT_ARG(!mean || npix, "mean pooling needs npix");
     QT_ARG(!src_inv || src_npix, "src_inv needs src_npix");
@@ -586,6 +621,7 @@ extern "C" int qt_remesh(const float* const* src_parts, const int* widths, const
     a.noparts = nout > 1 ? nout : 0;
     a.B = B; a.n = n; a.m = m; a.N = N; a.out = out_parts[0]; a.out_stride = 4 * c4; a.out_coff = 0;
     a.tiles_r = qt_cdiv(n, 64); a.tiles_c = qt_cdiv(m, 64);
+    a.direct = direct;
     return pool_launch(a, true, cell, n_dev, (hipStream_t)stream);
 }
 

@@ -54,6 +54,9 @@ class Mesh:
         self.recipe = None       # arguments that rebuild a data-independent mesh for another batch size
         self.loss_mask = None    # (n, m) u8 when the labels do not encode the mask (homogeneous preset mesh): the loss
         self.npix_valid = None   # masks pixels explicitly and counts a node's unmasked pixels
+        self.built_from = None   # weak reference to the mesh this one was decomposed from (build_mesh(prev=...)), with
+        self.fwd_src = None      # fwd_src (N) / bwd_src (N_old) int32: per single-pixel node the other mesh's node under
+        self.bwd_src = None      # its pixel (-1: larger node) -- the state transfer's direct row index (qt_remesh)
 
     # -- sizes ------------------------------------------------------------------
     @property
@@ -250,8 +253,16 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     ms.posfeat = torch.empty(N, 3, device=device)
     ms.npix = torch.empty(N, device=device)
     size_norm = size_norm if size_norm is not None else (max_size / 2) ** 2
+    old_lab = old_lvl = None
+    if src is None and os.environ.get('QT_NO_DIRECT_SRC') != '1':
+        import weakref
+        ms.built_from = weakref.ref(old)
+        ms.fwd_src = torch.empty(max(N, 1), **i32)
+        ms.bwd_src = torch.empty(max(old.N, 1), **i32)
+        old_lab, old_lvl = old.labels, old.level
     _lib.call('qt_quadtree_stage3', ptr(local_id), ptr(cnt if fused_scan else offs), B, n, m, max_size, ptr(ms.labels), ptr(level),
-              ptr(ms.cell), ptr(ms.node_off), float(size_norm), ptr(ms.posfeat), ptr(ms.npix), int(fused_scan))
+              ptr(ms.cell), ptr(ms.node_off), float(size_norm), ptr(ms.posfeat), ptr(ms.npix), int(fused_scan),
+              ptr(old_lab), ptr(old_lvl), ptr(ms.fwd_src), ptr(ms.bwd_src))
     nd = None
     if static:
         ms.n_dev = ms.node_off[B:]                # view of the last entry = N

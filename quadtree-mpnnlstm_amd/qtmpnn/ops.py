@@ -981,8 +981,14 @@ def _remesh_raw(dst, src, parts, outs, src_inv, mean):
     lds = (ctypes.c_int * n)(*[_ld(t) for t in parts])
     optrs = (ctypes.c_void_p * no)(*[t.data_ptr() for t in outs])
     owidths = (ctypes.c_int * no)(*[t.shape[1] for t in outs])
+    # the direct row index of the single-pixel nodes, when one mesh of the pair was decomposed from the other
+    direct = None
+    if dst.built_from is not None and dst.built_from() is src:
+        direct = dst.fwd_src
+    elif src.built_from is not None and src.built_from() is dst:
+        direct = src.bwd_src
     _lib.call('qt_remesh', ptrs, widths, lds, n, ptr(src.labels), ptr(src.npix), int(src_inv), ptr(dst.labels), ptr(dst.level),
-              ptr(dst.npix), int(mean), dst.B, dst.n, dst.m, dst.N, ptr(dst.cell), ptr(dst.n_dev), optrs, owidths, no)
+              ptr(dst.npix), int(mean), dst.B, dst.n, dst.m, dst.N, ptr(dst.cell), ptr(dst.n_dev), optrs, owidths, no, ptr(direct))
 
 
 class _Remesh(Function):

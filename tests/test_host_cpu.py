@@ -65,7 +65,7 @@ def test_bad_arguments_fail_loudly_without_gpu():
         'qt_flat_adam': (None, None, None, None, 0, None, None, 0.0, 0.9, 0.999, 1e-8, 10.0, None, None),
         'qt_compose2_fwd': (None,) * 8 + (3, 1, 3, 4, 4, 16, None, None, None, None, None),
         'qt_compose_step_fwd': (None,) * 4 + (3, 1, 3, 4, 16, None, None, None),
-        'qt_remesh': (None, None, None, 0, None, None, 0, None, None, None, 1, 1, 64, 64, 4, None, None, None, None, 0, None),
+        'qt_remesh': (None, None, None, 0, None, None, 0, None, None, None, 1, 1, 64, 64, 4, None, None, None, None, 0, None, None),
         'qt_attn_fwd': (None,) * 6 + (0, None, 8, 8, 4, None, 1.0, 0, None, None, None, None),
         'qt_dense2': (None, 0, None, None, 0, None, 1, 4, 0, None, None, None, 0, None, 1, 4, 0, 4, None, 0, None, 0, None, None, None, None),
     }

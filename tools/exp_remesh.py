@@ -27,7 +27,9 @@ def graph_time(fn, reps=20):
     a.record(); g.replay(); b.record(); b.synchronize()
     return a.elapsed_time(b) * 1e3 / reps
 for noise in (0.15, 0.05):
-    old, new = mesh(100, noise), mesh(200, noise)
+    old = mesh(100, noise)
+    # the new mesh is decomposed from per-node values on the old one, like the decoder's re-mesh (direct row indices exist then)
+    new = build_mesh(prev=(torch.rand(old.N, device=dev) * (4 * noise), old), thresh=0.1, static=True)
     widths = [4, 16, 16, 16, 16]
     parts = [torch.randn(old.N, w, device=dev) for w in widths]
     outs = [torch.empty(new.N, w, device=dev) for w in widths]
