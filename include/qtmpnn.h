@@ -304,6 +304,15 @@ int qt_concat(const float* const* srcs, const int* widths, const int* lds, int n
 int qt_decoder_input(const float* val4, int ld /* row stride of val4 in floats, 0 = 4 */, const float* posfeat, int N,
                      const int32_t* n_dev, float* out, void* stream);
 
+/* One-column message aggregate with strided operands: out[i * ldo] = act(alpha (L^ x)_i + beta p_i + gamma q_i) on single
+ * columns x[j * ldx], p[i * ldp], q[i * ldq] (p, q nullable); act = QT_ACT_NONE or QT_ACT_TANH_RES (tanh(drop_i v) + res[i * ldr],
+ * drop nullable); pad4: the output row is written as the 16 bytes (v, 0, 0, 0).  ell: the first-four-edges array of
+ * qt_edges_norm, or NULL.  Serves the Clenshaw recurrence of a ChebConv with ONE output channel (the decoder's fc_out2,
+ * model/seq2seq.py:121) after its coefficient columns have been applied: u = z [w_0 w_1 w_2], y = u_0 + L^ (u_1 + 2 L^ u_2) - u_2. */
+int qt_spmm1(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, int N, const int32_t* n_dev,
+             const float* x, int ldx, float alpha, const float* p, int ldp, float beta, const float* q, int ldq, float gamma,
+             float* out, int ldo, int pad4, int act, const float* res, int ldr, const float* drop, void* stream);
+
 /* backward of the qt_dense epilogue activations: G = gY * act'(Y) (QT_ACT_RELU, QT_ACT_TANH_RES with res / drop as in
  * qt_dense); gres (N, res_stride) or NULL receives the gradient of the residual operand (column 0 = gY[:, 0], rest 0). */
 int qt_act_bwd(const float* gY, const float* Y, const float* res, int res_stride, const float* drop, int act, int N,

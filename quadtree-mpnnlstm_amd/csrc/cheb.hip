@@ -200,6 +200,83 @@ __global__ __launch_bounds__(QT_SPMM_BS) void k_spmm(const int32_t* __restrict__
     }
 }
 
+// One-column message aggregate with strided operands and an optional output epilogue: the Clenshaw recurrence of a
+// ChebConv with ONE output channel (the decoder's fc_out2, model/seq2seq.py:121) after its coefficient columns have been
+// applied -- u = z [w_0 w_1 w_2] first, then y = u_0 + L^ (u_1 + 2 L^ u_2) - u_2 on single columns of the (N, 4) matrix u:
+// the two propagations move 4 bytes per row and neighbour instead of the 64-byte rows of z.  Thread = row.
+struct Spmm1Args {
+    const int32_t* rowptr;
+    const int32_t* col;
+    const float* nrm;
+    const int4* ell;
+    int Ncap;
+    const int32_t* n_dev;
+    const float *x, *p, *q;
+    int ldx, ldp, ldq;
+    float alpha, beta, gamma;
+    float* out;
+    int ldo, pad4;          // pad4: the row is written as (v, 0, 0, 0)
+    int act;                // QT_ACT_NONE or QT_ACT_TANH_RES: v = tanh(drop * v) + res
+    const float* res;
+    int ldr;
+    const float* drop;
+};
+__global__ __launch_bounds__(64) void k_spmm1(Spmm1Args a) {
+    const int rows = qt_rows(a.n_dev, a.Ncap);
+    const int nblk = (rows + 63) >> 6, chunk = (nblk + 7) >> 3;           // XCD-wise row ranges, as k_spmm
+    const int bid = blockIdx.x;
+    if ((bid >> 3) >= chunk) return;
+    const int64_t row = (int64_t)((bid & 7) * chunk + (bid >> 3)) * 64 + threadIdx.x;
+    if (row >= rows) return;
+    const float pv = a.p ? a.p[row * a.ldp] : 0.0f, qv = a.q ? a.q[row * a.ldq] : 0.0f;
+    const float* __restrict__ x = a.x;
+    float acc = 0.0f;
+    int e0, e1;
+    if (a.ell) {
+        int4 c4 = a.ell[2 * row];
+        const int4 wb = a.ell[2 * row + 1];
+        const bool more4 = c4.w < 0;
+        if (more4) c4.w = ~c4.w;
+        const float f0 = x[(int64_t)c4.x * a.ldx], f1 = x[(int64_t)c4.y * a.ldx], f2 = x[(int64_t)c4.z * a.ldx],
+                    f3 = x[(int64_t)c4.w * a.ldx];
+        acc += __int_as_float(wb.x) * f0;
+        acc += __int_as_float(wb.y) * f1;
+        acc += __int_as_float(wb.z) * f2;
+        acc += __int_as_float(wb.w) * f3;
+        e0 = e1 = 0;
+        if (more4) {
+            e0 = a.rowptr[row] + 4;
+            e1 = a.rowptr[row + 1];
+        }
+    } else {
+        e0 = a.rowptr[row];
+        e1 = a.rowptr[row + 1];
+    }
+    for (int eb = e0; eb < e1; eb += 4) {
+        int cj[4];
+        float w[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const bool ok = eb + v < e1;
+            cj[v] = ok ? a.col[eb + v] : (int)row;
+            w[v] = ok ? a.nrm[eb + v] : 0.0f;
+        }
+        float f[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) f[v] = x[(int64_t)cj[v] * a.ldx];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc += w[v] * f[v];
+    }
+    float v = a.alpha * acc;
+    if (a.p) v += a.beta * pv;
+    if (a.q) v += a.gamma * qv;
+    if (a.act == QT_ACT_TANH_RES) v = tanhf((a.drop ? a.drop[row] : 1.0f) * v) + a.res[row * a.ldr];
+    if (a.pad4)
+        *reinterpret_cast<float4*>(a.out + row * a.ldo) = make_float4(v, 0.0f, 0.0f, 0.0f);
+    else
+        a.out[row * a.ldo] = v;
+}
+
 // ------------------------------------------------------------------ tiled GEMM
 // Node-feature operand made of Ka planes plus an optional (N, Ks) block.  A plane is one (N, Ca) matrix or two matrices side
 // by side, (N, Ca) | (N, Cab): the recurrent cells feed Z = [X | H] without ever concatenating it -- rows of 64 bytes (H)
@@ -1583,6 +1660,23 @@ extern "C" int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* 
         hipLaunchKernelGGL((k_spmm<4, 1, 8>), dim3(na + nb), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, reinterpret_cast<const int4*>(ell), N, n_dev, A, B, na, alpha, beta, gamma);
     else
         hipLaunchKernelGGL((k_spmm<4, 1, 4>), dim3(na + nb), dim3(QT_SPMM_BS), 0, (hipStream_t)stream, rowptr, col, nrm, reinterpret_cast<const int4*>(ell), N, n_dev, A, B, na, alpha, beta, gamma);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_spmm1(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, int N, const int32_t* n_dev,
+                        const float* x, int ldx, float alpha, const float* p, int ldp, float beta, const float* q, int ldq,
+                        float gamma, float* out, int ldo, int pad4, int act, const float* res, int ldr, const float* drop,
+                        void* stream) {
+    QT_ARG(rowptr && col && nrm && x && out && ldx >= 1 && ldo >= 1 && (!p || ldp >= 1) && (!q || ldq >= 1), "bad arguments");
+    QT_ARG(act == QT_ACT_NONE || (act == QT_ACT_TANH_RES && res && ldr >= 1), "the epilogue is none or tanh(drop v) + res");
+    QT_ARG(!pad4 || (ldo % 4 == 0 && ((uintptr_t)out & 15) == 0), "pad4 writes 16-byte rows");
+    QT_ARG(((uintptr_t)ell & 15) == 0, "ell must be 16-byte aligned");
+    if (N <= 0) return QT_OK;
+    Spmm1Args a = {rowptr, col, nrm, reinterpret_cast<const int4*>(ell), N, n_dev, x, p, q, ldx, ldp, ldq, alpha, beta, gamma,
+                   out, ldo, pad4, act, res, ldr, drop};
+    const int grid = qt_cdiv(qt_cdiv(N, 64), 8) * 8;
+    hipLaunchKernelGGL(k_spmm1, dim3(grid), dim3(64), 0, (hipStream_t)stream, a);
     QT_LAUNCHED();
     return QT_OK;
 }

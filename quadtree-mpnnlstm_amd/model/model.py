@@ -49,6 +49,14 @@ class ChebConv(nn.Module):
         tail = nn.functional.pad(T[self.K].unsqueeze(0), (0, cout - self.out_channels, 0, 3), value=fill)
         return torch.cat([w.reshape(self.K * cin, cout), tail], dim=0)
 
+    def plan_layout_projected(self, T, fill):
+        """A K = 3 layer with ONE output channel as the (in + 4, 4) matrix [w_0 w_1 w_2 0 ; b 0 0 0 ; 0 ...]: the operand of
+        `project first, then propagate` (ops.scalar_cheb3) -- U = z @ this gives the three coefficient products and the bias."""
+        assert self.K == 3 and self.out_channels == 1 and self.in_channels % 4 == 0
+        w = nn.functional.pad(torch.stack(T[:3])[:, 0, :].t(), (0, 1), value=fill)             # (in, 4)
+        tail = nn.functional.pad(T[3].view(1, 1), (0, 3, 0, 3), value=fill)                      # (4, 4): [b 0 0 0] + 3 zero rows
+        return torch.cat([w, tail], dim=0)
+
     def forward(self, x, edge_index, edge_weight=None):
         mesh = _need_mesh(edge_index)
         pad = (-x.shape[1]) % 4

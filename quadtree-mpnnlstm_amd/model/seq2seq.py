@@ -16,6 +16,9 @@ from qtmpnn.flat import flat_params
 from qtmpnn.mesh import build_mesh, build_pixel_mesh
 
 
+_PROJECT_FC2 = __import__('os').environ.get('QT_NO_PROJECT_FC2') != '1'      # (A/B switch, diagnostics)
+
+
 def _ln_params(*norms):
     return torch.stack([p for n in norms for p in (n.weight, n.bias)])
 
@@ -158,7 +161,10 @@ class Decoder(nn.Module):
                 o += n
             out['fc1'] = self.fc_out1.plan_layout(T[o:o + n1], fill, self.head_width, self.hidden_size)
             o += n1
-            out['fc2'] = self.fc_out2.plan_layout(T[o:o + n2], fill, self.hidden_size, 4)
+            if _PROJECT_FC2 and self.fc_out2.K == 3:
+                out['fc2c'] = self.fc_out2.plan_layout_projected(T[o:o + n2], fill)
+            else:
+                out['fc2'] = self.fc_out2.plan_layout(T[o:o + n2], fill, self.hidden_size, 4)
             o += n2
             out['ln'] = torch.stack(T[o:o + 4])
             out['ln_o'] = torch.stack(T[o + 4:o + 6])
@@ -169,7 +175,7 @@ class Decoder(nn.Module):
             return dict(ln_o=outs['ln_o'], acc_o=ops.GradAcc(),
                         rnns=[r.pack_from(outs, f'r{i}.', in_pad if i == 0 else None, ln, (True,))[0]
                               for i, r in enumerate(self.rnns)],
-                        fc1=outs['fc1'], acc1=ops.GradAcc(), fc2=outs['fc2'], acc2=ops.GradAcc())
+                        fc1=outs['fc1'], acc1=ops.GradAcc(), fc2=outs.get('fc2'), fc2c=outs.get('fc2c'), acc2=ops.GradAcc())
         return params, layout, finish
 
     def _pack_planned(self, in_pad):
@@ -210,8 +216,14 @@ class Decoder(nn.Module):
             y = torch.tanh(y if drop is None else y * drop.unsqueeze(1)) + X[:, :1]
             return (torch.sigmoid(y) if self.binary else y), hs, cs
         z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'])
-        # the head GEMM writes float4 rows; column 0 is the prediction (the rest is tanh(0) + X[:, 0], never read as data)
-        y = ops.cheb_poly(z, pk['fc2'], mesh, self.fc_out2.K, 1, ops.ACT_TANH_RES, res=X, drop=drop, acc=pk['acc2'])[:, :1]
+        if pk.get('fc2c') is not None:
+            # fc_out2 has ONE output channel: its three coefficient columns are applied first (a 16 -> 4 product) and the
+            # Chebyshev recurrence then runs on single columns -- 4 bytes per row and neighbour instead of z's 64-byte rows
+            U = ops.cheb_poly(z, pk['fc2c'], mesh, 1, 1, acc=pk['acc2'])                     # (N, 4) = z [w_0 w_1 w_2 0] + [b 0 0 0]
+            y = ops.scalar_cheb3(U, X, drop, mesh)[:, :1]
+        else:
+            # the head GEMM writes float4 rows; column 0 is the prediction (the rest is tanh(0) + X[:, 0], never read as data)
+            y = ops.cheb_poly(z, pk['fc2'], mesh, self.fc_out2.K, 1, ops.ACT_TANH_RES, res=X, drop=drop, acc=pk['acc2'])[:, :1]
         if self.binary:
             y = torch.sigmoid(y)
         return y, hs, cs

@@ -444,6 +444,58 @@ def _wgrad_group(uses, W, K, Cs, ksp, Co):
     return gW
 
 
+def _spmm1(mesh, x, ldx, alpha, out, ldo, p=None, ldp=0, beta=0.0, q=None, ldq=0, gamma=0.0, pad4=0, act=ACT_NONE, res=None,
+           ldr=0, drop=None):
+    """Raw qt_spmm1 on data pointers (ints): single strided columns of (N, 4) matrices."""
+    _lib.call('qt_spmm1', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), mesh.N, ptr(mesh.n_dev), x, ldx, alpha,
+              p, ldp, beta, q, ldq, gamma, out, ldo, pad4, act, ptr(res), ldr, ptr(drop))
+
+
+class _ScalarCheb3(Function):
+    """y = tanh(drop (u_0 + L^ u_1 + T_2(L^) u_2)) + res[:, 0] from U = [u_0 u_1 u_2 0] (N, 4): the propagation half of a
+    K = 3 ChebConv with ONE output channel whose coefficient columns were applied first (U = z [w_0 w_1 w_2] + [b 0 0 0],
+    an ordinary cheb_poly with K = 1).  Clenshaw on single columns: b_1 = u_1 + 2 L^ u_2, y_pre = u_0 + L^ b_1 - u_2 -- two
+    launches that move 4 bytes per row and neighbour where propagating z first moves its 64-byte rows (the reference order,
+    model/seq2seq.py:174-186 through PyG's ChebConv; the same sum, associated differently).  Returns (N, 4): column 0 = y."""
+
+    @staticmethod
+    def forward(ctx, U, res, drop, mesh):
+        assert U.dim() == 2 and U.shape[1] == 4 and U.is_contiguous() and U.dtype == torch.float32
+        N = U.shape[0]
+        res, ldr = _rows(res)
+        drop = _c(drop)
+        b1 = U.new_empty(N)
+        Y = U.new_empty(N, 4)
+        u = U.data_ptr()
+        _spmm1(mesh, u + 8, 4, 2.0, b1.data_ptr(), 1, p=u + 4, ldp=4, beta=1.0)
+        _spmm1(mesh, b1.data_ptr(), 1, 1.0, Y.data_ptr(), 4, p=u, ldp=4, beta=1.0, q=u + 8, ldq=4, gamma=-1.0, pad4=1,
+               act=ACT_TANH_RES, res=res, ldr=ldr, drop=drop)
+        ctx.save_for_backward(Y, res, drop)
+        ctx.mesh = mesh
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        Y, res, drop = ctx.saved_tensors
+        mesh = ctx.mesh
+        N = Y.shape[0]
+        gin = _c(gY.float())
+        G = torch.empty_like(gin)
+        gres = torch.empty_like(res) if ctx.needs_input_grad[1] else None
+        if N > 0:
+            _lib.call('qt_act_bwd', ptr(gin), ptr(Y), ptr(res), _row_stride(res), ptr(drop), ACT_TANH_RES, N, ptr(mesh.n_dev), 4,
+                      ptr(G), ptr(gres))
+            # G[:, 0] = g = dL/dy_pre;  gu_1 = L^ g -> column 1;  gu_2 = 2 L^ gu_1 - g -> column 2  (L^ symmetric)
+            g = G.data_ptr()
+            _spmm1(mesh, g, 4, 1.0, g + 4, 4)
+            _spmm1(mesh, g + 4, 4, 2.0, g + 8, 4, p=g, ldp=4, beta=-1.0)
+        return G, gres, None, None
+
+
+def scalar_cheb3(U, res, drop, mesh):
+    return _ScalarCheb3.apply(U, res, drop, mesh)
+
+
 def pad_bias_rows(W, Ks):
     """Zero-pad the Ks bias rows of a packed weight to a multiple of 4 (they pair with mesh.cheb_ones columns)."""
     pad = (-Ks) % 4
