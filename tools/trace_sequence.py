@@ -10,7 +10,7 @@ def short(n):
     if m: return m.group(1)
     m = re.search(r'(multi_tensor_apply_kernel|CatArrayBatchedCopy[a-z_]*|index_elementwise_kernel|direct_copy_kernel|FillFunctor|CUDAFunctor_add|rocclr_[A-Za-z]+|reduce_kernel|[A-Za-z_]+Functor[A-Za-z_]*|distribution_[a-z_]+)', n)
     return 'torch:' + (m.group(1) if m else n[:50])
-adam = [i for i, r in enumerate(rows) if 'FusedAdam' in r['Kernel_Name']]
+adam = [i for i, r in enumerate(rows) if 'FusedAdam' in r['Kernel_Name'] or 'k_flat_adam' in r['Kernel_Name']]
 # steps are delimited by the last Adam kernel of a step: group consecutive adam launches
 ends = [i for k, i in enumerate(adam) if k + 1 == len(adam) or adam[k + 1] - i > 5]
 a, b = ends[-2] + 1, ends[-1] + 1
