@@ -1229,13 +1229,21 @@ __global__ __launch_bounds__(256, BG ? 3 : 2) void k_dgrad_cell(DgradCellArgs g)
                 if (g.gCn) gyc = ld4(g.gCn + node * g.ld_gc + j0);
                 if (g.gO) go_in = ld4(g.gO + node * g.ld_go + j0);
             }
+#ifdef QT_EXP_DG_NOCELL
+            CellBwdOut o;
+            o.ggi = I; o.ggf = F; o.ggc = T; o.ggo = Og; o.gcp = cp;
+            acc[0][0] += gyh.v[0] + gyc.v[0] + go_in.v[0] + wci.v[0] + wcf.v[0] + wco.v[0] + gam_h.v[0] + gam_c.v[0];
+#else
             const CellBwdOut o = cell_backward<LPN>(I, F, T, Og, cp, gyh, gyc, go_in, wci, wcf, wco, gam_h, gam_c,
                                                     g.ln != nullptr, h, acc);
+#endif
             float* as = As + r * PITCH + j0;
             st4(as, o.ggi); st4(as + h, o.ggf); st4(as + 2 * h, o.ggc); st4(as + 3 * h, o.ggo);
             if (ok) {
+#ifndef QT_EXP_DG_NOGG
                 float* gg = g.gG + node * 4 * h + j0;
                 st4(gg, o.ggi); st4(gg + h, o.ggf); st4(gg + 2 * h, o.ggc); st4(gg + 3 * h, o.ggo);
+#endif
                 if (g.gCprev) st4(g.gCprev + node * h + j0, o.gcp);
             }
         }
@@ -1275,9 +1283,13 @@ __global__ __launch_bounds__(256, BG ? 3 : 2) void k_dgrad_cell(DgradCellArgs g)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) { bhi[q] = (__bf16)0.0f; blo[q] = (__bf16)0.0f; }
                 }
+#ifdef QT_EXP_DG_NOMFMA
+                acc2[nt][0] += (float)ahi[0] * (float)bhi[0] + (float)alo[1] * (float)blo[1];
+#else
                 acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc2[nt], 0, 0, 0);
                 acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc2[nt], 0, 0, 0);
                 acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc2[nt], 0, 0, 0);
+#endif
             }
         }
     } else {

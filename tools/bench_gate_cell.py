@@ -65,13 +65,16 @@ def shape(name, K, Ca, Cab):
         lo = 0 if not Cab or live[0] == Ca and not name.startswith('enc') else Ca
         Wb = W[:K * (Ca + Cab)].view(K, Ca + Cab, 4 * h)[:, lo:lo + live[0]].reshape(-1, 4 * h).contiguous()
     planes = [torch.zeros(K, CAP, c, device=dev) for c in live]
+    Wb = Wb.contiguous()
+    whi, wlo = (torch.empty(Wb.shape, dtype=torch.bfloat16, device=dev) for _ in range(2))
+    _lib.call('qt_split_bf16', ptr(Wb), Wb.numel(), ptr(whi), ptr(wlo))
     bwd = lambda: _lib.call('qt_lstm_bwd_dgrad', ptr(gO), h, ptr(gH), h, ptr(gC), h, ptr(gates), ptr(Cp), h, ptr(wc), ptr(ln), CAP,
-                            ptr(nvalid), h, ptr(gG), ptr(gCp), ptr(part), 1, ptr(Wb), K, live[0], live[1] if len(live) > 1 else 0,
+                            ptr(nvalid), h, ptr(gG), ptr(gCp), ptr(part), 1, ptr(Wb), ptr(whi), ptr(wlo), K, live[0], live[1] if len(live) > 1 else 0,
                             ptr(planes[0]), ptr(planes[1]) if len(live) > 1 else None)
     part.zero_()
     us = graph_time(bwd)
     NB = K * sum(live)
-    if os.environ.get('QT_FUSED', '1') == '1':
+    if os.environ.get('QT_FUSED', '0') == '1':
         ncu = _lib.value('qt_lstm_fused_blocks')
         slab = torch.zeros(ncu, Kt, 4 * h, device=dev)
         Zs, TZs = ([X, Hh], [TX, TH]) if Cab else ([X], [TX])
