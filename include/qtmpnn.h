@@ -219,6 +219,22 @@ int qt_wgrad_group_blocks(int nseg, const int* N);
 int qt_wgrad_group(int nseg, const float* const* a0, const int* lda0, const float* const* a_rest, const float* const* a0b,
                    const int* lda0b, const float* const* a_restb, const float* const* S, const float* const* G, const int* N,
                    const int32_t* const* n_dev, int Ka, int Ca, int Cab, int Ks, int Co, float* part, void* stream);
+/* qt_wgrad_group for the Gn weights of qt_proj_group at once: use s multiplies [A_g | S]^T (A_g = a0[s] + g gsA, Cin columns, row
+ * stride lda0[s]) with the gradient rows G[s] + g gsG (Co columns, row stride ldg; gpl > 0: stored as Co / gpl planes (N[s], gpl),
+ * row stride ldg); per_node != 0: gsA / gsG count floats per node of the use (group stride = gs x N[s]: head-major arrays of uses with
+ * different capacities).  part: (qt_wgrad_group_blocks(nseg, N), Gn, Cin + Ks, Co), overwritten; qt_colsum over the blocks gives the
+ * (Gn, Cin + Ks, Co) weight gradient. */
+int qt_wgrad_groups(int nseg, const float* const* a0, const int* lda0, const float* const* S, const float* const* G, const int* N,
+                    const int32_t* const* n_dev, int Cin, int Ks, int Co, int ldg, int gpl, int Gn, int64_t gsA, int64_t gsG,
+                    int per_node, float* part, void* stream);
+/* G independent products in one launch: group g multiplies [A_g | S] with W_g.  A_g = Ka planes (N, Ca) from A + g gsA (one plane
+ * may have any row stride lda; several are dense and contiguous), S (N, 4) = [1 0 0 0] rows or NULL (then no bias rows), W_g = W + g gsW
+ * ((Ka Ca + 4 or Ka Ca), Kb Cb) row-major -- or its transpose WT + g gsW with rows of Ka Ca (+ 4) floats; the result leaves as Kb planes
+ * (N, Cb) from out + g gsO, rows ldo apart (Kb = 1: a column block of a wider matrix).  The eight GraphConv stacks of a GConvLSTM built
+ * from attention convolutions (model/model.py:394-424, TransformerConv :51) run layer by layer: group g is stack g's projection
+ * [q | k | v | skip].  Same arithmetic as G qt_dense2 calls. */
+int qt_proj_group(const float* A, int lda, int64_t gsA, int Ka, int Ca, const float* S, const float* W, const float* WT, int64_t gsW,
+                  int G, int Kb, int Cb, float* out, int ldo, int64_t gsO, int N, const int32_t* n_dev, void* stream);
 /* out[j] = sum_i part[i*len + j], i < nblk */
 int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream);
 
@@ -336,13 +352,23 @@ int qt_attn_edge_attrs(const int32_t* rowptr, const int32_t* col, const float* x
 int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                 const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
                 float keep, uint32_t seed, const uint32_t* seed_dev /* optional device-side step counter mixed into seed */,
-                float* out, float* stats, void* stream);
+                float* out, float* stats, int G /* heads, 0 = 1 */, int ld_o /* row stride of out, 0 = G C */,
+                int64_t ps, int64_t hs, int64_t hs_o /* strides, see below; 0 = C, 4C, C: rows side by side */, void* stream);
 int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                 const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
                 float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, int ld_g /* row stride of g, 0 = C */,
                 const float* stats, float* gproj, float* Dn, float* part, int accumulate /* add into part */,
                 const int32_t* rev, float* coef /* optional scratch (E + N, 2): the target pass leaves (alpha, alpha t) per edge
-                and the source pass reads them through rev instead of recomputing the scores */, int E, void* stream);
+                and the source pass reads them through rev instead of recomputing the scores */, int E,
+                int G /* heads, 0 = 1 */, int gmod /* g holds gmod column blocks, head g reads block g % gmod; 0 = G */,
+                int64_t ps, int64_t hs, int64_t hs_g /* 0 = C, 4C, C */, void* stream);
+/* G > 1: G convolutions on the same mesh in one launch (the eight GraphConv stacks of a GConvLSTM, model/model.py:394-424,
+ * run layer by layer).  Head g reads the column block [g 4C, (g+1) 4C) of the proj rows (ld >= G 4C) and We[g] ((G, C, 2)), and
+ * writes the column block g C of the out rows; stats (G, N, 2), Dn (G, N), coef (G, E + N, 2), part (qt_attn_blocks, G, 2C), gproj
+ * laid out like proj; every head draws its own dropout mask.  The results are those of G separate calls.
+ * Strides in floats: ps between the q / k / v / skip blocks of a proj (gproj) row, hs between the heads of proj, hs_o / hs_g between
+ * the heads of out / g.  One dense (N, C) plane per block and head is ld = C, ps = N C, hs = 4 N C (what qt_proj_group writes with
+ * Kb = 4): a gathered k or v row is then one whole 128-byte line of a contiguous array. */
 
 /* ---------------------------------------------------------------- gate-weight packing of stacked ChebConvs
  * A GraphConv stack applies its ChebConvs with no nonlinearity in between (model/model.py:59-97, :95-96), so the eight

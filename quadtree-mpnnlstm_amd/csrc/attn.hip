@@ -55,7 +55,27 @@ struct AttnArgs {
     uint32_t seed;
     const uint32_t* seed_dev;   // optional step counter on the device, mixed into the seed: a captured launch (fixed `seed`
                                 // argument) then still draws a new dropout mask at every replay
+    // G convolutions on the same mesh in one launch (blockIdx.y = head): head g reads the column block [g 4C, (g+1) 4C) of the
+    // proj rows (ld >= G 4C), We[g], writes the column block g C of the out rows (ld_o) and its own stats / Dn / coef / part
+    // slabs.  gmod: head g reads the column block (g % gmod) C of the incoming gradient (a sum of head groups downstream).
+    int ld_o, gmod;
+    // strides in floats: ps between the q / k / v / skip blocks of a proj (and gproj) row, hs between heads of proj, hs_o of out,
+    // hs_g of g.  Rows side by side (one (N, G 4C) matrix): ld = G 4C, ps = C, hs = 4C; one dense (N, C) plane per block and head:
+    // ld = C, ps = N C, hs = 4 N C -- gathered k / v rows are then whole 128-byte lines of a contiguous array.
+    int64_t ps, hs, hs_o, hs_g;
 };
+
+// per-head views of the operands (head = blockIdx.y; a single convolution is head 0 of 1)
+__device__ __forceinline__ int head_setup(AttnArgs& a) {
+    const int hd = blockIdx.y;
+    if (hd) {
+        a.proj += hd * a.hs;
+        a.We += (int64_t)hd * 2 * a.C;
+        if (a.coef) a.coef += (int64_t)hd * 2 * ((int64_t)a.E + a.Ncap);
+        a.seed += (uint32_t)hd * 0x632BE5ABu;        // every head draws its own attention-dropout mask
+    }
+    return hd;
+}
 
 __device__ __forceinline__ uint32_t eff_seed(const AttnArgs& a) {
     return a.seed_dev ? a.seed ^ (*a.seed_dev * 0x9E3779B9u) : a.seed;
@@ -93,6 +113,9 @@ __device__ __forceinline__ int xcd_block(int rows, int nodes_per_block) {
 #endif
 template <int LPN>
 __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __restrict__ out, float* __restrict__ stats) {
+    const int hd = head_setup(a);
+    out += hd * a.hs_o;
+    stats += (int64_t)hd * 2 * a.Ncap;
     const int rows = qt_rows(a.n_dev, a.Ncap);
     const int blk = xcd_block(rows, QT_ATTN_BS / LPN);
     if (blk < 0) return;
@@ -101,7 +124,7 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __re
     const int j0 = ((int)threadIdx.x % LPN) * 4;
     const float* pi = a.proj + (int64_t)i * a.ld;
     const F4 q = ld4(pi + j0);
-    const F4 sk = ld4(pi + 3 * a.C + j0);          // (requested now, not after the edge loop: no dependent load at the end)
+    const F4 sk = ld4(pi + 3 * a.ps + j0);          // (requested now, not after the edge loop: no dependent load at the end)
     const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
     const F4 w1 = {{a.We[2 * j0 + 1], a.We[2 * j0 + 3], a.We[2 * j0 + 5], a.We[2 * j0 + 7]}};
     float m = -INFINITY, l = 0.0f;
@@ -125,8 +148,8 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __re
         for (int u = 0; u < 4; ++u)
             if (jj[u] >= 0) {
                 const float* pj = a.proj + (int64_t)jj[u] * a.ld;
-                kk[u] = ld4(pj + a.C + j0);
-                vv[u] = ld4(pj + 2 * a.C + j0);
+                kk[u] = ld4(pj + a.ps + j0);
+                vv[u] = ld4(pj + 2 * a.ps + j0);
                 if (a.eattr) {                      // stored per edge: no atan2 / sqrt in the loop (8 lanes repeated them)
                     const int e = eb + u;
                     xj[u] = e < e1 ? a.eattr[2 * e] : 0.0f;
@@ -168,7 +191,7 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __re
     F4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) o.v[c] = acc.v[c] * inv + sk.v[c];
-    st4(out + (int64_t)i * a.C + j0, o);
+    st4(out + (int64_t)i * a.ld_o + j0, o);
     if (j0 == 0) {
         stats[2 * i] = m;
         stats[2 * i + 1] = l;
@@ -179,6 +202,11 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __re
 template <int LPN>
 __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_bwd_target(AttnArgs a, const float* __restrict__ g, const float* __restrict__ stats,
                                                          float* __restrict__ gproj, float* __restrict__ Dn) {
+    const int hd = head_setup(a);
+    g += (hd % a.gmod) * a.hs_g;
+    stats += (int64_t)hd * 2 * a.Ncap;
+    gproj += hd * a.hs;
+    Dn += (int64_t)hd * a.Ncap;
     const int rows = qt_rows(a.n_dev, a.Ncap);
     const int blk = xcd_block(rows, QT_ATTN_BS / LPN);
     if (blk < 0) return;
@@ -211,8 +239,8 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_bwd_target(AttnArgs a, cons
         for (int u = 0; u < 4; ++u)
             if (jj[u] >= 0) {
                 const float* pj = a.proj + (int64_t)jj[u] * a.ld;
-                kk[u] = ld4(pj + a.C + j0);
-                vv[u] = ld4(pj + 2 * a.C + j0);
+                kk[u] = ld4(pj + a.ps + j0);
+                vv[u] = ld4(pj + 2 * a.ps + j0);
                 if (a.eattr) {                      // stored per edge: no atan2 / sqrt in the loop (8 lanes repeated them)
                     const int e = eb + u;
                     xj[u] = e < e1 ? a.eattr[2 * e] : 0.0f;
@@ -261,7 +289,7 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_bwd_target(AttnArgs a, cons
     for (int c = 0; c < 4; ++c) o.v[c] = a.scale * (dq.v[c] - D * dqk.v[c]);
     float* gp = gproj + (int64_t)i * a.ld;
     st4(gp + j0, o);
-    st4(gp + 3 * a.C + j0, gi);          // skip branch: identity
+    st4(gp + 3 * a.ps + j0, gi);          // skip branch: identity
     if (j0 == 0) Dn[i] = D;
 }
 
@@ -271,6 +299,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
                                                          const float* __restrict__ Dn, float* __restrict__ gproj,
                                                          float* __restrict__ part) {
     __shared__ float sm[4 * LPN * 2 * 4];
+    const int hd = head_setup(a);
+    g += (hd % a.gmod) * a.hs_g;
+    stats += (int64_t)hd * 2 * a.Ncap;
+    gproj += hd * a.hs;
+    Dn += (int64_t)hd * a.Ncap;
     const int lj = threadIdx.x % LPN, j0 = lj * 4;
     const int N = qt_rows(a.n_dev, a.Ncap);
     const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
@@ -340,11 +373,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
                 }
             }
             float* gpc = gproj + j * a.ld;
-            st4(gpc + a.C + j0, dk);
-            st4(gpc + 2 * a.C + j0, dv);
+            st4(gpc + a.ps + j0, dk);
+            st4(gpc + 2 * a.ps + j0, dv);
             continue;
         }
-        const F4 kj0 = ld4(pj + a.C + j0), vj0 = ld4(pj + 2 * a.C + j0);
+        const F4 kj0 = ld4(pj + a.ps + j0), vj0 = ld4(pj + 2 * a.ps + j0);
         const float xj = a.xy[2 * j], yj = a.xy[2 * j + 1];
         for (int eb = e0; eb < eend; eb += 4) {
             int ii[4];
@@ -412,8 +445,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
             }
         }
         float* gp = gproj + j * a.ld;
-        st4(gp + a.C + j0, dk);
-        st4(gp + 2 * a.C + j0, dv);
+        st4(gp + a.ps + j0, dk);
+        st4(gp + 2 * a.ps + j0, dv);
     }
     // block reduction of the We partials (same scheme as the LSTM parameter gradients): [2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -437,7 +470,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += sm[(w * LPN + (ch >> 2)) * 8 + k * 4 + (ch & 3)];
-        float* pp = part + (int64_t)blockIdx.x * 2 * a.C + idx;     // layout [k][channel]; the host transposes to (C, 2)
+        float* pp = part + ((int64_t)blockIdx.x * gridDim.y + hd) * 2 * a.C + idx;     // (block, head)[k][channel]; the host transposes to (C, 2)
         *pp = a.accumulate ? *pp + s : s;
     }
 }
@@ -512,15 +545,23 @@ extern "C" int qt_attn_edge_attrs(const int32_t* rowptr, const int32_t* col, con
 
 extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                            const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
-                           float keep, uint32_t seed, const uint32_t* seed_dev, float* out, float* stats, void* stream) {
+                           float keep, uint32_t seed, const uint32_t* seed_dev, float* out, float* stats, int G, int ld_o, int64_t ps, int64_t hs,
+                           int64_t hs_o, void* stream) {
     QT_ARG(rowptr && col && xy && proj && We && out && stats, "null pointer");
-    QT_ARG(c_ok(C) && ld >= 4 * C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
+    if (G <= 0) G = 1;
+    if (ps == 0) ps = C;
+    if (hs == 0) hs = 4 * C;
+    if (hs_o == 0) hs_o = C;
+    if (ld_o == 0) ld_o = G * C;
+    QT_ARG(c_ok(C) && ld >= C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
+    QT_ARG(G <= 64 && ld_o >= C && ld_o % 4 == 0 && ps % 4 == 0 && hs % 4 == 0 && hs_o % 4 == 0, "bad head count / strides");
     if (N <= 0) return QT_OK;
     AttnArgs a;
     fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
-    a.ld_g = C; a.accumulate = 0; a.rev = nullptr; a.coef = nullptr; a.E = 0;
+    a.ld_g = C; a.accumulate = 0; a.rev = nullptr; a.coef = nullptr; a.E = 0; a.ld_o = ld_o; a.gmod = G;
+    a.ps = ps; a.hs = hs; a.hs_o = hs_o; a.hs_g = C;
     const int grid = (qt_cdiv((int64_t)N * (C / 4), QT_ATTN_BS) + 7) & ~7;      // whole rounds over the 8 XCDs (xcd_block)
-    QT_ATTN_DISPATCH_BS(C, k_attn_fwd, grid, QT_ATTN_BS, stream, a, out, stats);
+    QT_ATTN_DISPATCH_BS(C, k_attn_fwd, dim3(grid, G), QT_ATTN_BS, stream, a, out, stats);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -528,20 +569,28 @@ extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const floa
 extern "C" int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                            const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
                            float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, int ld_g, const float* stats, float* gproj,
-                           float* Dn, float* part, int accumulate, const int32_t* rev, float* coef, int E, void* stream) {
+                           float* Dn, float* part, int accumulate, const int32_t* rev, float* coef, int E, int G, int gmod,
+                           int64_t ps, int64_t hs, int64_t hs_g, void* stream) {
     QT_ARG(rowptr && col && xy && proj && We && g && stats && gproj && Dn && part, "null pointer");
-    QT_ARG(c_ok(C) && ld >= 4 * C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
-    if (ld_g == 0) ld_g = C;
-    QT_ARG(ld_g >= C && ld_g % 4 == 0 && ((uintptr_t)g & 15) == 0, "bad g row stride / alignment");
+    if (G <= 0) G = 1;
+    if (gmod <= 0) gmod = G;
+    if (ps == 0) ps = C;
+    if (hs == 0) hs = 4 * C;
+    if (hs_g == 0) hs_g = C;
+    QT_ARG(c_ok(C) && ld >= C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
+    if (ld_g == 0) ld_g = gmod * C;
+    QT_ARG(G <= 64 && gmod <= G && ld_g >= C && ld_g % 4 == 0 && ((uintptr_t)g & 15) == 0 && ps % 4 == 0 && hs % 4 == 0 && hs_g % 4 == 0,
+           "bad head count / strides / alignment");
     if (N <= 0) return QT_OK;
     AttnArgs a;
     fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
     QT_ARG(!coef || (rev && eattr && E >= 0), "coef needs rev, eattr and the edge capacity E");
-    a.ld_g = ld_g; a.accumulate = accumulate; a.rev = rev; a.coef = coef; a.E = E;
+    a.ld_g = ld_g; a.accumulate = accumulate; a.rev = rev; a.coef = coef; a.E = E; a.ld_o = 0; a.gmod = gmod;
+    a.ps = ps; a.hs = hs; a.hs_o = 0; a.hs_g = hs_g;
     const int grid = (qt_cdiv((int64_t)N * (C / 4), QT_ATTN_BS) + 7) & ~7;
-    QT_ATTN_DISPATCH_BS(C, k_attn_bwd_target, grid, QT_ATTN_BS, stream, a, g, stats, gproj, Dn);
+    QT_ATTN_DISPATCH_BS(C, k_attn_bwd_target, dim3(grid, G), QT_ATTN_BS, stream, a, g, stats, gproj, Dn);
     const int gridB = qt_attn_blocks(N, C);
-    QT_ATTN_DISPATCH(C, k_attn_bwd_source, gridB, stream, a, g, stats, Dn, gproj, part);
+    QT_ATTN_DISPATCH(C, k_attn_bwd_source, dim3(gridB, G), stream, a, g, stats, Dn, gproj, part);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -314,6 +314,10 @@ struct GemmArgs {
     const float* ln;
     int ld_c, h;
     float *O, *Hn, *Cn, *gates;
+    // grouped use (qt_proj_group): blockIdx.z = group; plane 0, the weight and the output of group z start gsA / gsB / gsO
+    // floats after those of group z - 1.  ldo: row stride of the output plane (0 = Cb; a column block of a wider matrix)
+    int ldo;
+    int64_t gsA, gsB, gsO;
 #ifdef QT_GEMM_TIMING
     long long* dbg;
 #endif
@@ -389,6 +393,13 @@ __global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : QT_GEMM_OCC) void
     const int64_t rows = qt_rows(g.n_dev, g.M);      // g.M stays the plane stride (capacity)
     if (i0 >= rows) return;
     QT_STAMP(0);
+    if (blockIdx.z) {
+        g.A.a0 += blockIdx.z * g.gsA;
+        if (g.A.a_rest) g.A.a_rest += blockIdx.z * g.gsA;
+        if (g.B) g.B += blockIdx.z * g.gsB;
+        if (g.BT) g.BT += blockIdx.z * g.gsB;
+        g.out += blockIdx.z * g.gsO;
+    }
     const int nquad = g.K >> 2;
     build_quad_table(g.A, qptr, qstr, nquad);
     const int64_t my_row = i0 + wave * 32 + l32;
@@ -549,7 +560,7 @@ __global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : QT_GEMM_OCC) void
             const int ct = g.Cb + g.Cbb;
             const int pl = j / ct, ch = j - pl * ct;              // Cb, Cbb % 4 == 0: a float4 never straddles two parts
             if (ch < g.Cb)
-                *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+                *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * (g.ldo ? g.ldo : g.Cb) + ch) = v;
             else
                 *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + i * g.Cbb + (ch - g.Cb)) = v;
         }
@@ -946,7 +957,8 @@ constexpr int WR = 32;
 // (their partial tiles are added through LDS at the end, in a fixed order), with CT = 1 the second column tile is skipped.
 template <int FW, int CT>
 __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __restrict__ G, int M, int NB, int64_t rbeg,
-                                           int64_t rend, float* obase, int accumulate) {
+                                           int64_t rend, float* obase, int accumulate, int jt, int ldg, int gpl = 0,
+                                           int64_t gps = 0) {       // gpl > 0: G columns in planes of gpl floats, gps apart
     constexpr int RG = 4 / FW;             // row groups
     constexpr int KS = WR / 2 / RG;        // k-steps (2 rows each) per row group and pass
     constexpr int BMF = FW * 32;           // features per block
@@ -962,7 +974,7 @@ __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __res
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l32 = lane & 31, half = lane >> 5;
     const int fw = wave % FW, rg = wave / FW;
-    const int f0 = blockIdx.x * BMF, j0 = blockIdx.y * BN;
+    const int f0 = blockIdx.x * BMF, j0 = jt * BN;
     const int nquad = M >> 2;
     build_quad_table(A, qptr, qstr, nquad);
     __syncthreads();
@@ -989,7 +1001,10 @@ __device__ __forceinline__ void wgrad_body(const PlaneSrc& A, const float* __res
         for (int u = 0; u < 2; ++u) {
             const int jq = (u * 8 + g_q) * 4;
             qg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rgw < rend && j0 + jq < NB && jq < CT * 32) qg[u] = gload4(G + rgw * NB + j0 + jq);
+            if (rgw < rend && j0 + jq < NB && jq < CT * 32) {
+                const int j = j0 + jq, pl = gpl ? j / gpl : 0;
+                qg[u] = gload4(G + pl * gps + rgw * ldg + (j - pl * gpl));
+            }
         }
     };
     auto stash = [&](int buf, const float4 (&qa)[4], const float4 (&qg)[2]) {
@@ -1075,7 +1090,7 @@ template <int FW, int CT>
 __global__ __launch_bounds__(256) void k_gemm_wgrad(GemmArgs g) {
     const int64_t rbeg = (int64_t)blockIdx.z * g.row0_step;
     const int64_t rend = min((int64_t)qt_rows(g.n_dev, g.A.N), rbeg + g.row0_step);
-    wgrad_body<FW, CT>(g.A, g.B, g.M, g.NB, rbeg, rend, g.out + (int64_t)blockIdx.z * g.M * g.NB, g.accumulate);
+    wgrad_body<FW, CT>(g.A, g.B, g.M, g.NB, rbeg, rend, g.out + (int64_t)blockIdx.z * g.M * g.NB, g.accumulate, blockIdx.y, g.NB);
 }
 
 // The same reduction for up to 16 uses of ONE weight in a single launch (the rollout steps of a pass): z-blocks
@@ -1092,6 +1107,10 @@ struct WgradGroup {
     int N[MAXSEG], zend[MAXSEG], lda0[MAXSEG], lda0b[MAXSEG];
     int nseg, Ka, Ca, Cab, Ks, Co, rows;
     float* part;
+    // Gn weights per use (the stacks of one layer, qt_proj_group): grid y = (group, column tile); group g reads plane 0 at
+    // a0 + g gsA and the gradient rows at G + g gsG (row stride ldg), and owns slab (z, g) of part
+    int Gn, ytiles, ldg, gpl, per_node;      // per_node: gsA / gsG are floats per node of the use (x N[s])
+    int64_t gsA, gsG;
 };
 template <int FW, int CT>
 __global__ __launch_bounds__(256) void k_gemm_wgrad_group(WgradGroup w) {
@@ -1104,7 +1123,11 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_group(WgradGroup w) {
     const int M = w.Ka * (w.Ca + w.Cab) + w.Ks;
     const int64_t rbeg = (int64_t)zl * w.rows;
     const int64_t rend = min((int64_t)qt_rows(w.n_dev[s], w.N[s]), rbeg + w.rows);
-    wgrad_body<FW, CT>(A, w.G[s], M, w.Co, rbeg, rend, w.part + (int64_t)blockIdx.z * M * w.Co, 0);
+    const int grp = blockIdx.y / w.ytiles, jt = blockIdx.y - grp * w.ytiles;
+    const int64_t gmul = w.per_node ? (int64_t)grp * w.N[s] : grp;
+    A.a0 += gmul * w.gsA;
+    wgrad_body<FW, CT>(A, w.G[s] + gmul * w.gsG, M, w.Co, rbeg, rend, w.part + ((int64_t)blockIdx.z * w.Gn + grp) * M * w.Co, 0, jt, w.ldg, w.gpl,
+                       (int64_t)w.N[s] * w.gpl);
 }
 
 // 32 columns x 32 row groups per workgroup, four slabs in flight per thread; fixed summation order (deterministic).
@@ -1758,6 +1781,36 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
     return QT_OK;
 }
 
+// G independent products in one launch (grid z = group): group g multiplies [A_g | S], A_g = Ka planes (N, Ca) starting at
+// A + g gsA, with W_g and writes Kb planes (N, Cb) starting at out + g gsO (row stride ldo).
+// The eight GraphConv stacks of a GConvLSTM with attention convolutions (model/model.py:394-424) run layer by layer: group g
+// is stack g's projection [q | k | v | skip], read from and written to blocks of arrays shared by all stacks.
+extern "C" int qt_proj_group(const float* A, int lda, int64_t gsA, int Ka, int Ca, const float* S, const float* W, const float* WT,
+                             int64_t gsW, int G, int Kb, int Cb, float* out, int ldo, int64_t gsO, int N, const int32_t* n_dev,
+                             void* stream) {
+    QT_ARG((W || WT) && out && G >= 1 && G <= 65535 && Kb >= 1 && Cb >= 4 && Cb % 4 == 0 && Ka >= 1, "bad arguments");
+    if (ldo == 0) ldo = Cb;
+    QT_ARG(ldo >= Cb && ldo % 4 == 0 && gsA % 4 == 0 && gsW % 4 == 0 && gsO % 4 == 0, "strides must be multiples of 4 floats");
+    QT_ARG(Ka == 1 || lda == 0 || lda == Ca, "several input planes must be dense");
+    QT_ARG((((uintptr_t)W | (uintptr_t)WT | (uintptr_t)out) & 15) == 0, "W / WT / out must be 16-byte aligned");
+    GemmArgs g = {};
+    if (int rc = plane_src(&g.A, __func__, A, lda, Ka > 1 ? A + (int64_t)N * Ca : nullptr, nullptr, 0, nullptr, Ka, Ca, 0, S, S ? 4 : 0, N))
+        return rc;
+    if (N <= 0) return QT_OK;
+    g.B = W; g.BT = WT; g.M = N; g.K = Ka * Ca + (S ? 4 : 0); g.NB = Kb * Cb;
+    g.Kb = Kb; g.Cb = Cb; g.act = QT_ACT_NONE; g.out = out; g.n_dev = n_dev;
+    g.ldo = ldo; g.gsA = gsA; g.gsB = gsW; g.gsO = gsO;
+#ifdef QT_GEMM_TIMING
+    g.dbg = nullptr;
+#endif
+    if (g.NB > 64)
+        hipLaunchKernelGGL((k_gemm_fwd<4, 64>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128), G), dim3(256), 0, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL((k_gemm_fwd<2, 128>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 64), G), dim3(256), 0, (hipStream_t)stream, g);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
 extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, const float* W, const float* S, int Ks,
                         const float* Ws, int Kb, int Cb, int N, const int32_t* n_dev, int act, const float* res,
                         int res_stride, const float* drop, float* out, void* stream) {
@@ -1944,23 +1997,23 @@ extern "C" int qt_wgrad_group_blocks(int nseg, const int* N) {
     return z;
 }
 
-extern "C" int qt_wgrad_group(int nseg, const float* const* a0, const int* lda0, const float* const* a_rest,
-                              const float* const* a0b, const int* lda0b, const float* const* a_restb, const float* const* S, const float* const* G, const int* N,
-                              const int32_t* const* n_dev, int Ka, int Ca, int Cab, int Ks, int Co, float* part, void* stream) {
-    QT_ARG(nseg >= 1 && nseg <= MAXSEG && a0 && G && N && n_dev && part, "1..16 uses per launch");
-    QT_ARG(Ka >= 1 && Ca >= 1 && Cab >= 0 && Co >= 1 && (Ka == 1 || a_rest) && (Ks == 0 || S) && (Cab == 0 || (a0b && (Ka == 1 || a_restb))),
-           "bad arguments");
-    QT_ARG(Co % 4 == 0, "Co must be a multiple of 4 (float4 operands)");
+static int wgrad_group_launch(const char* fn, int nseg, const float* const* a0, const int* lda0, const float* const* a_rest,
+                              const float* const* a0b, const int* lda0b, const float* const* a_restb, const float* const* S,
+                              const float* const* G, const int* N, const int32_t* const* n_dev, int Ka, int Ca, int Cab, int Ks,
+                              int Co, int ldg, int gpl, int Gn, int64_t gsA, int64_t gsG, int per_node, float* part, void* stream) {
     WgradGroup w;
     int z = 0, k = 0;
     for (int i = 0; i < nseg; ++i) {
         if (N[i] <= 0) continue;
         PlaneSrc A;
-        if (int rc = plane_src(&A, __func__, a0[i], lda0 ? lda0[i] : 0, Ka > 1 ? a_rest[i] : nullptr, Cab ? a0b[i] : nullptr,
+        if (int rc = plane_src(&A, fn, a0[i], lda0 ? lda0[i] : 0, Ka > 1 ? a_rest[i] : nullptr, Cab ? a0b[i] : nullptr,
                                (Cab && lda0b) ? lda0b[i] : 0, (Cab && Ka > 1) ? a_restb[i] : nullptr, Ka, Ca, Cab,
                                Ks ? S[i] : nullptr, Ks, N[i]))
             return rc;
-        QT_ARG(G[i] && ((uintptr_t)G[i] & 15) == 0, "G must be 16-byte aligned");
+        if (!G[i] || ((uintptr_t)G[i] & 15) != 0) {
+            qt_set_error("%s: G must be 16-byte aligned", fn);
+            return QT_E_ARG;
+        }
         w.a0[k] = A.a0; w.a_rest[k] = A.a_rest; w.a0b[k] = A.a0b; w.a_restb[k] = A.a_restb; w.S[k] = A.S; w.G[k] = G[i];
         w.lda0[k] = A.lda0; w.lda0b[k] = A.lda0b;
         w.n_dev[k] = n_dev[i]; w.N[k] = N[i];
@@ -1974,11 +2027,37 @@ extern "C" int qt_wgrad_group(int nseg, const float* const* a0, const int* lda0,
         w.n_dev[i] = nullptr; w.N[i] = 0; w.zend[i] = z; w.lda0[i] = w.lda0b[i] = 0;
     }
     w.nseg = k; w.Ka = Ka; w.Ca = Ca; w.Cab = Cab; w.Ks = Ks; w.Co = Co; w.rows = WGRAD_GROUP_ROWS; w.part = part;
+    w.Gn = Gn; w.ytiles = qt_cdiv(Co, BN); w.ldg = ldg; w.gpl = gpl; w.gsA = gsA; w.gsG = gsG; w.per_node = per_node;
     const int M = Ka * (Ca + Cab) + Ks;
-    const dim3 grid(qt_cdiv(M, wgrad_fw(M) * 32), qt_cdiv(Co, BN), z);
+    const dim3 grid(qt_cdiv(M, wgrad_fw(M) * 32), w.ytiles * Gn, z);
     QT_WGRAD_DISPATCH(k_gemm_wgrad_group, M, Co, grid, stream, w);
     QT_LAUNCHED();
     return QT_OK;
+}
+
+extern "C" int qt_wgrad_group(int nseg, const float* const* a0, const int* lda0, const float* const* a_rest,
+                              const float* const* a0b, const int* lda0b, const float* const* a_restb, const float* const* S, const float* const* G, const int* N,
+                              const int32_t* const* n_dev, int Ka, int Ca, int Cab, int Ks, int Co, float* part, void* stream) {
+    QT_ARG(nseg >= 1 && nseg <= MAXSEG && a0 && G && N && n_dev && part, "1..16 uses per launch");
+    QT_ARG(Ka >= 1 && Ca >= 1 && Cab >= 0 && Co >= 1 && (Ka == 1 || a_rest) && (Ks == 0 || S) && (Cab == 0 || (a0b && (Ka == 1 || a_restb))),
+           "bad arguments");
+    QT_ARG(Co % 4 == 0, "Co must be a multiple of 4 (float4 operands)");
+    return wgrad_group_launch(__func__, nseg, a0, lda0, a_rest, a0b, lda0b, a_restb, S, G, N, n_dev, Ka, Ca, Cab, Ks, Co, Co, 0, 1, 0, 0, 0,
+                              part, stream);
+}
+
+// qt_wgrad_group for the Gn weights of qt_proj_group at once: use s multiplies [A_g | S]^T (A_g = a0[s] + g gsA, Cin columns,
+// row stride lda0[s]) with the gradient rows G[s] + g gsG (Co columns, row stride ldg; gpl > 0: in Co / gpl planes (N[s], gpl)); per_node: gsA / gsG count floats per node (x N[s]).
+// part: (qt_wgrad_group_blocks(nseg, N), Gn, Cin + Ks, Co), overwritten; qt_colsum over the blocks gives the (Gn, Cin + Ks, Co) gradient.
+extern "C" int qt_wgrad_groups(int nseg, const float* const* a0, const int* lda0, const float* const* S, const float* const* G,
+                               const int* N, const int32_t* const* n_dev, int Cin, int Ks, int Co, int ldg, int gpl, int Gn,
+                               int64_t gsA, int64_t gsG, int per_node, float* part, void* stream) {
+    QT_ARG(nseg >= 1 && nseg <= MAXSEG && a0 && lda0 && G && N && n_dev && part, "1..16 uses per launch");
+    QT_ARG(Cin >= 4 && Co >= 4 && Co % 4 == 0 && (Ks == 0 || S) && Gn >= 1 && ldg % 4 == 0 && gsA % 4 == 0 && gsG % 4 == 0 &&
+           (gpl ? (gpl % 4 == 0 && Co % gpl == 0 && ldg >= gpl) : ldg >= Co), "bad arguments");
+    QT_ARG((int64_t)qt_cdiv(Co, BN) * Gn <= 65535, "too many groups");
+    return wgrad_group_launch(__func__, nseg, a0, lda0, nullptr, nullptr, nullptr, nullptr, S, G, N, n_dev, 1, Cin, 0, Ks, Co, ldg, gpl, Gn,
+                              gsA, gsG, per_node, part, stream);
 }
 
 extern "C" int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream) {

@@ -5,11 +5,15 @@ by fused HIP kernels (qtmpnn.ops) on a `Mesh` instead of per-module PyG calls.
 Where the reference passes (edge_index, edge_weight) these modules take the Mesh in the edge_index
 slot; the Mesh already holds the ChebConv normalisation, which PyG recomputes in every call.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from qtmpnn import ops
 from qtmpnn.mesh import Mesh
+
+_MULTI_CONV = os.environ.get('QT_NO_MULTI_CONV') != '1'      # (diagnostics: one projection + attention launch pair per convolution)
 
 
 class ChebConv(nn.Module):
@@ -117,6 +121,22 @@ class TransformerConv(nn.Module):
         W = torch.cat([w, nn.functional.pad(b, (0, 0, 0, 3))], dim=0)                   # bias row + 3 zero rows
         We = nn.functional.pad(self.lin_edge.weight, (0, 0, 0, cp - cout))
         return PackedConv(W, We, ops.GradAcc(), ops.GradAcc())
+
+    @staticmethod
+    def stack_proj(convs):
+        """(W (n, cin_p + 4, 4 cp), We (n, cp, 2)) of n convolutions of one (in, out) shape: W[i] = [q | k | v | skip] of
+        convolution i with its bias row (the matrices pack() builds, in three stack / pad / cat launches)."""
+        c0 = convs[0]
+        cin, cout = c0.in_channels, c0.out_channels
+        cin_p, cp = cin + (-cin) % 4, cout + (-cout) % 4
+        blocks = [[c.lin_query, c.lin_key, c.lin_value, c.lin_skip] for c in convs]
+        w = torch.stack([l.weight for b4 in blocks for l in b4]).view(len(convs), 4, cout, cin)          # (n, 4, cout, cin)
+        w = nn.functional.pad(w.permute(0, 3, 1, 2), (0, cp - cout, 0, 0, 0, cin_p - cin))                 # (n, cin_p, 4, cp)
+        b = torch.stack([l.bias for b4 in blocks for l in b4]).view(len(convs), 1, 4, cout)
+        b = nn.functional.pad(b, (0, cp - cout, 0, 0, 0, 3))                                                # bias row + 3 zero rows
+        W = torch.cat([w, b], dim=1).reshape(len(convs), cin_p + 4, 4 * cp)
+        We = nn.functional.pad(torch.stack([c.lin_edge.weight for c in convs]), (0, 0, 0, cp - cout))     # (n, cp, 2)
+        return W, We
 
     @staticmethod
     def pack_many(convs):
@@ -261,6 +281,12 @@ class GConvLSTM(nn.Module):
             b = torch.cat([self.b_i, self.b_f, self.b_c, self.b_o], dim=0)
             acc_p = ops.GradAcc()
             names = [f'{br}_{g}' for br in ('conv_x', 'conv_h') for g in self.GATES]
+            if isinstance(self.conv_x_i.convolutions[0], TransformerConv) and _MULTI_CONV and h % 4 == 0:
+                cells = [PackedCell(None, 0, 0, wc, b, ln, None, acc_p) for _ in variants]
+                multi = self._pack_multi(names)
+                for c in cells:
+                    c.multi = multi
+                return cells
             if isinstance(self.conv_x_i.convolutions[0], TransformerConv):
                 # all convolutions of one shape are packed together: a handful of stack / pad / cat launches per shape
                 # instead of a dozen per convolution (24+ convolutions per cell)
@@ -280,6 +306,26 @@ class GConvLSTM(nn.Module):
         wc = torch.cat([self.w_c_i, self.w_c_f, self.w_c_o], dim=0)
         b = torch.cat([self.b_i, self.b_f, self.b_c, self.b_o], dim=0)
         return self._assemble(Px, bx, Ph, bh, wc, b, in_pad, ln, variants, ops.GradAcc())
+
+    def _pack_multi(self, names):
+        """Per layer ([W segments], We (8, C, 2), accumulator) for ops.multi_conv: the eight stacks run layer by layer, stack g =
+        head g in the order conv_x_{i,f,c,o}, conv_h_{i,f,c,o}.  Layer 0 has two input segments (X and H: the four stacks of a
+        branch share their input, so their projections are ONE matrix with 4 x 4C columns), deeper layers one (head g reads column
+        block g of the previous layer's output)."""
+        layers = []
+        for l in range(self.n_conv_layers):
+            convs = [getattr(self, n).convolutions[l] for n in names]
+            if l == 0:
+                Ws, Wes = [], []
+                for part in (convs[:4], convs[4:]):
+                    W, We = TransformerConv.stack_proj(part)                    # (4, cin_p + 4, 4C)
+                    Ws.append(W.permute(1, 0, 2).reshape(1, W.shape[1], 4 * W.shape[2]))
+                    Wes.append(We)
+                layers.append((Ws, torch.cat(Wes, dim=0), ops.GradAcc()))
+            else:
+                W, We = TransformerConv.stack_proj(convs)                       # (8, C + 4, 4C)
+                layers.append(([W], We, ops.GradAcc()))
+        return layers
 
     # -- packing through one gather (ops.PackPlan): plain ChebConv stacks only ------------------------------------------
     @property
@@ -367,6 +413,18 @@ class GConvLSTM(nn.Module):
 
     def step(self, X, mesh, H, C, pk):
         """One cell update with packed weights `pk`; pk.ln = (4, h) LayerNorm parameters fused onto H', C' or None."""
+        if pk.W is None and pk.multi is not None:
+            Hz = H if H is not None else X.new_zeros(X.shape[0], self.out_channels)     # conv_h(0) is not 0 (biases)
+            c0 = self.conv_x_i.convolutions[0]
+            cin_p = c0.in_channels + (-c0.in_channels) % 4
+            if X.shape[1] != cin_p:
+                X = X[:, :c0.in_channels] if X.shape[1] > cin_p else X
+                X = nn.functional.pad(X, (0, cin_p - X.shape[1])) if X.shape[1] < cin_p else X
+            y, L = None, len(pk.multi)
+            for l, (Ws, We, acc) in enumerate(pk.multi):
+                segs = [(X, Ws[0]), (Hz, Ws[1])] if l == 0 else [(y, Ws[0])]
+                y = ops.multi_conv(segs, We, mesh, self.out_channels, c0.dropout, self.training, acc, gmod=4 if l == L - 1 else 0)
+            return ops.lstm_cell(y, C, pk.wc, pk.b, pk.ln, mesh, pk.acc_p)
         if pk.W is None:
             Hz = H if H is not None else X.new_zeros(X.shape[0], self.out_channels)     # conv_h(0) is not 0 (biases)
 
@@ -387,11 +445,12 @@ class GConvLSTM(nn.Module):
 
 class PackedCell:
     """Packed weights of one GConvLSTM for one forward pass (+ the gradient accumulators of that pass)."""
-    __slots__ = ('W', 'K', 'Ks', 'wc', 'b', 'ln', 'acc_w', 'acc_p', 'convs')
+    __slots__ = ('W', 'K', 'Ks', 'wc', 'b', 'ln', 'acc_w', 'acc_p', 'convs', 'multi')
 
     def __init__(self, W, K, Ks, wc, b, ln, acc_w, acc_p):
         self.W, self.K, self.Ks, self.wc, self.b, self.ln, self.acc_w, self.acc_p = W, K, Ks, wc, b, ln, acc_w, acc_p
         self.convs = None
+        self.multi = None
 
 
 def _not_built(name):

@@ -670,58 +670,209 @@ def advance_dropout_epoch(device):
 class _Attention(Function):
     """out = edge-softmax attention over the mesh adjacency + skip, from the fused projection proj = [q | k | v | skip]
     (N, 4C) and the edge-feature weight We (C, 2)  (PyG TransformerConv as configured by model/model.py:51).
+    With heads = G > 1: G convolutions on the same mesh in one launch -- proj (N, G 4C), We (G, C, 2), out (N, G C), head g in
+    column block g; gmod < G: the incoming gradient has only gmod column blocks and head g reads block g % gmod (the caller
+    summed groups of gmod heads).
     acc: GradAcc shared by all uses of We in this forward pass (the dWe partials of every use add up in one slab and the
     pass's last backward reduces it), or None."""
 
     @staticmethod
-    def forward(ctx, proj, We, mesh, c_real, keep, seed, acc):
+    def forward(ctx, proj, We, mesh, c_real, keep, seed, acc, heads=1, gmod=0):
         proj, We = _c(proj.float()), _c(We.float())
         ctx.epoch = dropout_epoch(proj.device) if keep < 1.0 else None
-        N, C = proj.shape[0], proj.shape[1] // 4
+        G = heads
+        N, C = proj.shape[0], proj.shape[1] // (4 * G)
         xy, selfpair, eattr, _ = mesh.attn_geometry()
-        out = proj.new_empty(N, C)
-        stats = proj.new_empty(N, 2)
-        _lib.call('qt_attn_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(proj), 4 * C, ptr(We), C, c_real,
-                  N, ptr(mesh.n_dev), keep, seed, ptr(ctx.epoch), ptr(out), ptr(stats))
+        out = proj.new_empty(N, G * C)
+        stats = proj.new_empty(G, N, 2)
+        _lib.call('qt_attn_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(proj), 4 * C * G, ptr(We), C, c_real,
+                  N, ptr(mesh.n_dev), keep, seed, ptr(ctx.epoch), ptr(out), ptr(stats), G, 0, 0, 0, 0)
         ctx.save_for_backward(proj, We, stats)
-        ctx.mesh, ctx.c_real, ctx.keep, ctx.seed, ctx.acc = mesh, c_real, keep, seed, acc
+        ctx.mesh, ctx.c_real, ctx.keep, ctx.seed, ctx.acc, ctx.G, ctx.gmod = mesh, c_real, keep, seed, acc, G, gmod or G
         ctx.use_idx = acc.enter() if acc is not None else 0
+        if ctx.gmod < G:            # the sum over the head groups (conv_x + conv_h of a gate, model/model.py:394-424)
+            return out.view(N, G // ctx.gmod, ctx.gmod * C).sum(dim=1)
         return out
 
     @staticmethod
     def backward(ctx, g):
         proj, We, stats = ctx.saved_tensors
-        mesh, acc = ctx.mesh, ctx.acc
-        N, C = proj.shape[0], proj.shape[1] // 4
+        mesh, acc, G, gmod = ctx.mesh, ctx.acc, ctx.G, ctx.gmod
+        N, C = proj.shape[0], proj.shape[1] // (4 * G)
         xy, selfpair, eattr, rev = mesh.attn_geometry()
-        coef = proj.new_empty(rev.numel() + N, 2)       # (alpha, alpha t) per edge: target pass -> source pass
+        coef = proj.new_empty(G, rev.numel() + N, 2)       # (alpha, alpha t) per edge: target pass -> source pass
         g, ld_g = _rows(g.float())                  # a column block of the gates' gradient is read in place
         gproj = torch.empty_like(proj)
-        Dn = proj.new_empty(N)
+        Dn = proj.new_empty(G, N)
         if acc is None:
             nblk = max(_lib.value('qt_attn_blocks', N, C), 1)
-            part = proj.new_empty(nblk, 2 * C) if N > 0 else proj.new_zeros(nblk, 2 * C)
+            part = proj.new_empty(nblk, G * 2 * C) if N > 0 else proj.new_zeros(nblk, G * 2 * C)
         else:
             nblk = max(_lib.value('qt_attn_blocks', max(mesh.B * mesh.P, N), C), 1)
-            part = acc.slab(proj, nblk, 2 * C)
+            part = acc.slab(proj, nblk, G * 2 * C)
         if N > 0:
-            _lib.call('qt_attn_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(proj), 4 * C, ptr(We), C,
+            _lib.call('qt_attn_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(proj), 4 * C * G, ptr(We), C,
                       ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(ctx.epoch), ptr(g), ld_g, ptr(stats), ptr(gproj), ptr(Dn),
-                      ptr(part), 0 if acc is None else 1, ptr(rev), ptr(coef), rev.numel())
+                      ptr(part), 0 if acc is None else 1, ptr(rev), ptr(coef), rev.numel(), G, gmod, 0, 0, 0)
         else:
             gproj.zero_()
+        none = (None,) * 7
         if acc is not None and not acc.leave(ctx.use_idx):
-            return gproj, None, None, None, None, None, None
-        psum = proj.new_empty(2 * C)
-        _lib.call('qt_colsum', ptr(part), nblk, 2 * C, ptr(psum))
-        return gproj, psum.view(2, C).t().contiguous(), None, None, None, None, None
+            return (gproj, None) + none
+        psum = proj.new_empty(G * 2 * C)
+        _lib.call('qt_colsum', ptr(part), nblk, G * 2 * C, ptr(psum))         # part (block, head, 2C)
+        gWe = psum.view(G, 2, C).transpose(1, 2).contiguous()
+        return (gproj, gWe[0] if We.dim() == 2 else gWe) + none
 
 
-def attention(proj, We, mesh, c_real, dropout_p=0.0, training=False, acc=None):
+def attention(proj, We, mesh, c_real, dropout_p=0.0, training=False, acc=None, heads=1, gmod=0):
     keep = 1.0 - dropout_p if (training and dropout_p > 0) else 1.0
     _ATTN_CALLS[0] += 1
     seed = (_ATTN_CALLS[0] * 2654435761 + int(torch.initial_seed())) & 0xFFFFFFFF       # host-side counter: no device sync
-    return _Attention.apply(proj, We, mesh, c_real, keep, seed, acc)
+    return _Attention.apply(proj, We, mesh, c_real, keep, seed, acc, heads, gmod)
+
+
+class _MultiConv(Function):
+    """One layer of the G attention-convolution stacks of a recurrent cell (model/model.py:394-424 with TransformerConv :51) in
+    three launches instead of 2 G: the projections [q | k | v | skip] of all stacks go into ONE array P (qt_proj_group, one
+    launch per input segment), the edge softmax of the G heads is one launch (qt_attn_fwd, G heads).
+
+    P is (G, 4, N, C): one dense (N, C) plane per head and block, so the k / v rows the edge loop gathers are whole 128-byte
+    lines of contiguous arrays (rows of one (N, G 4C) matrix sit 4 KB apart: every gather of a head then hits the same
+    few L2 channels).
+    segments: [(A_s, W_s (Gin_s, Cin_s + 4, Co_s))]: group g of segment s multiplies A_s (N, Cin_s) (Gin_s = 1) or A_s[g] of
+    (Gin_s, N, Cin_s) with W_s[g] (bias in row Cin_s) and fills the next Co_s / C planes of P.  Layer 0 of a cell has the segments
+    (X, Wx (1, ., 4 4C)) and (H, Wh (1, ., 4 4C)), deeper layers one segment (previous layer's output (8, N, C), W (8, C + 4, 4C)).
+    Output: (G, N, C), or with gmod < G the (N, gmod C) sum of the head groups (conv_x + conv_h per gate), whose gradient alone
+    comes back.  acc: GradAcc of this layer's weights for the pass (dWe slab + deferred grouped weight gradients), or None."""
+
+    @staticmethod
+    def forward(ctx, mesh, c_real, keep, seed, acc, gmod, nseg, *args):
+        As = [_c(a.float()) if a.dim() == 3 else _rows(a.float())[0] for a in args[:nseg]]
+        Ws = [_c(w.float()) for w in args[nseg:2 * nseg]]
+        We = _c(args[2 * nseg].float())
+        G, C = We.shape[0], We.shape[1]
+        N = As[0].shape[-2]
+        ctx.epoch = dropout_epoch(We.device) if keep < 1.0 else None
+        P = As[0].new_empty(G, 4, N, C)
+        ones = mesh.cheb_ones(1)
+        hoff, segs = 0, []
+        for A, W in zip(As, Ws):
+            gin, kin, co = W.shape
+            cin = kin - 4
+            assert A.shape[-1] == cin and (A.dim() == 3) == (gin > 1) and co % (4 * C) == 0, (A.shape, W.shape)
+            lda, gsa = (cin, N * cin) if gin > 1 else (_ld(A), 0)
+            if N > 0:
+                _lib.call('qt_proj_group', ptr(A), lda, gsa, 1, cin, ptr(ones), ptr(W), None, kin * co, gin, co // C, C,
+                          P.data_ptr() + 4 * hoff * 4 * N * C, C, (co // C) * N * C, N, ptr(mesh.n_dev))
+            segs.append((hoff, gin, cin, co, lda, gsa))
+            hoff += gin * co // (4 * C)
+        assert hoff == G, (hoff, G)
+        xy, selfpair, eattr, _ = mesh.attn_geometry()
+        gmod = gmod or G
+        summed = gmod < G
+        out = P.new_empty(N, G * C) if summed else P.new_empty(G, N, C)
+        stats = P.new_empty(G, N, 2)
+        _lib.call('qt_attn_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(P), C, ptr(We), C, c_real,
+                  N, ptr(mesh.n_dev), keep, seed, ptr(ctx.epoch), ptr(out), ptr(stats), G, G * C if summed else C, N * C, 4 * N * C,
+                  C if summed else N * C)
+        ctx.save_for_backward(P, We, stats, *As, *Ws)
+        ctx.mesh, ctx.c_real, ctx.keep, ctx.seed, ctx.acc, ctx.G, ctx.gmod, ctx.segs = mesh, c_real, keep, seed, acc, G, gmod, segs
+        ctx.use_idx = acc.enter() if acc is not None else 0
+        if summed:
+            return out.view(N, G // gmod, gmod * C).sum(dim=1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        P, We, stats = ctx.saved_tensors[:3]
+        nseg = len(ctx.segs)
+        As, Ws = ctx.saved_tensors[3:3 + nseg], ctx.saved_tensors[3 + nseg:]
+        mesh, acc, G, gmod = ctx.mesh, ctx.acc, ctx.G, ctx.gmod
+        N, C = P.shape[2], P.shape[3]
+        xy, selfpair, eattr, rev = mesh.attn_geometry()
+        coef = P.new_empty(G, rev.numel() + N, 2)
+        if gmod < G:
+            g, ld_g = _rows(g.float())
+            hs_g = C
+        else:
+            g, ld_g, hs_g = _c(g.float()), C, N * C
+        gP = torch.empty_like(P)
+        Dn = P.new_empty(G, N)
+        if acc is None:
+            nblk = max(_lib.value('qt_attn_blocks', N, C), 1)
+            part = P.new_empty(nblk, G * 2 * C) if N > 0 else P.new_zeros(nblk, G * 2 * C)
+        else:
+            nblk = max(_lib.value('qt_attn_blocks', max(mesh.B * mesh.P, N), C), 1)
+            part = acc.slab(P, nblk, G * 2 * C)
+        if N > 0:
+            _lib.call('qt_attn_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(P), C, ptr(We), C,
+                      ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(ctx.epoch), ptr(g), ld_g, ptr(stats), ptr(gP), ptr(Dn),
+                      ptr(part), 0 if acc is None else 1, ptr(rev), ptr(coef), rev.numel(), G, gmod, N * C, 4 * N * C, hs_g)
+        else:
+            gP.zero_()
+        gAs = []
+        for s, ((hoff, gin, cin, co, lda, gsa), A, W) in enumerate(zip(ctx.segs, As, Ws)):
+            if not ctx.needs_input_grad[7 + s]:
+                gAs.append(None)
+                continue
+            gA = A.new_empty(A.shape)
+            if N > 0:         # gA_g = gP_g W_g[:cin]^T: the forward weight's own rows are the transposed operand
+                _lib.call('qt_proj_group', gP.data_ptr() + 4 * hoff * 4 * N * C, C, (co // C) * N * C, co // C, C, None, None, ptr(W),
+                          (cin + 4) * co, gin, 1, cin, ptr(gA), cin, N * cin if gin > 1 else 0, N, ptr(mesh.n_dev))
+            else:
+                gA.zero_()
+            gAs.append(gA)
+        last = acc is None or acc.leave(ctx.use_idx)
+        need_w = any(ctx.needs_input_grad[7 + nseg:7 + 2 * nseg])
+        pending = acc.pending if acc is not None else []
+        if need_w and N > 0:
+            pending.append((As, gP, N, mesh.n_dev, mesh.cheb_ones(1)))
+        if not last:
+            return (None,) * 7 + tuple(gAs) + (None,) * (nseg + 1)
+        gWs = [None] * nseg
+        if need_w:
+            for s, (seg, W) in enumerate(zip(ctx.segs, Ws)):
+                gWs[s] = _wgrad_groups(pending, s, seg, C, W)
+        if acc is not None:
+            acc.pending = []
+        psum = P.new_empty(G * 2 * C)
+        _lib.call('qt_colsum', ptr(part), nblk, G * 2 * C, ptr(psum))
+        gWe = psum.view(G, 2, C).transpose(1, 2).contiguous()
+        return (None,) * 7 + tuple(gAs) + tuple(gWs) + (gWe,)
+
+
+def _wgrad_groups(uses, s, seg, C, W):
+    """(gin, cin + 4, co) gradient of segment s's weights, summed over the uses [(As, gP (G, 4, N, C), N, n_dev, ones)] of a pass."""
+    import ctypes
+    hoff, gin, cin, co, lda, gsa = seg
+    if not uses:
+        return torch.zeros_like(W)
+    chunks = [uses[i:i + 16] for i in range(0, len(uses), 16)]
+    counts = []
+    for ch in chunks:
+        Ns = (ctypes.c_int * len(ch))(*[u[2] for u in ch])
+        counts.append((Ns, _lib.value('qt_wgrad_group_blocks', len(ch), Ns)))
+    part = W.new_empty(sum(c for _, c in counts), gin, cin + 4, co)
+    off = 0
+    for ch, (Ns, nb) in zip(chunks, counts):
+        vp, ip = ctypes.c_void_p * len(ch), ctypes.c_int * len(ch)
+        _lib.call('qt_wgrad_groups', len(ch), vp(*[u[0][s].data_ptr() for u in ch]),
+                  ip(*[(cin if gin > 1 else _ld(u[0][s])) for u in ch]),
+                  vp(*[u[4].data_ptr() for u in ch]), vp(*[u[1].data_ptr() + 4 * hoff * 4 * u[2] * C for u in ch]), Ns,
+                  vp(*[ptr(u[3]) for u in ch]), cin, 4, co, C, C, gin, cin if gin > 1 else 0, co, 1, ptr(part[off:]))
+        off += nb
+    gW = torch.empty_like(W)
+    _lib.call('qt_colsum', ptr(part), part.shape[0], W.numel(), ptr(gW))
+    return gW
+
+
+def multi_conv(segments, We, mesh, c_real, dropout_p=0.0, training=False, acc=None, gmod=0):
+    """segments: [(A, W)] as in _MultiConv; We (G, C, 2).  Returns (N, G C), or (N, gmod C) summed over the head groups."""
+    keep = 1.0 - dropout_p if (training and dropout_p > 0) else 1.0
+    _ATTN_CALLS[0] += 1
+    seed = (_ATTN_CALLS[0] * 2654435761 + int(torch.initial_seed())) & 0xFFFFFFFF
+    return _MultiConv.apply(mesh, c_real, keep, seed, acc, gmod, len(segments), *[a for a, _ in segments], *[w for _, w in segments], We)
 
 
 # ------------------------------------------------------------------------------ LSTM cell

@@ -1,6 +1,6 @@
 """Time the edge-softmax attention kernels (TransformerConv) at the cfg4 shapes (diagnostics).
 
-    python tools/bench_attn.py [C]
+    python tools/bench_attn.py [C] [heads] [rows|planes]
 Mesh: 16 ice-like 128x128 clips, land mask, transform_func, thresh 0.15 (BASELINE configs[3]).  Prints the launch times and
 the compulsory bytes (every proj / g / out row once, CSR once) and gather bytes (rows re-read per edge) they move.
 """
@@ -22,14 +22,18 @@ src = tf(x[..., 0]).amax(dim=1)
 mesh = build_mesh(src=src, thresh=0.15, mask=mask)
 N, E = mesh.N, mesh.E
 xy, selfpair, eattr, rev = mesh.attn_geometry()
-coef = torch.empty(rev.numel() + N, 2, device=dev)
 print('N', N, 'E', E, 'self pairs', int((selfpair > 0).sum()) if selfpair is not None else 0, 'C', C)
-proj = torch.randn(N, 4 * C, device=dev)
-We = torch.randn(C, 2, device=dev)
-out = torch.empty(N, C, device=dev); stats = torch.empty(N, 2, device=dev)
-g = torch.randn(N, C, device=dev); gproj = torch.empty_like(proj); Dn = torch.empty(N, device=dev)
-nblk = _lib.value('qt_attn_blocks', N, C); part = torch.zeros(nblk, 2 * C, device=dev)
-common = (ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr) if os.environ.get('QT_NO_EATTR') != '1' else None, ptr(selfpair), ptr(proj), 4 * C, ptr(We), C, C, N, ptr(mesh.n_dev))
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+planes = (sys.argv[3] if len(sys.argv) > 3 else 'rows') == 'planes'
+print('heads', G, 'layout', 'planes (G, 4, N, C)' if planes else 'rows (N, G 4C)')
+proj = torch.randn(G * N * 4 * C, device=dev)
+We = torch.randn(G, C, 2, device=dev)
+out = torch.empty(G * N * C, device=dev); stats = torch.empty(G, N, 2, device=dev)
+g = torch.randn(G * N * C, device=dev); gproj = torch.empty_like(proj); Dn = torch.empty(G, N, device=dev)
+coef = torch.empty(G, rev.numel() + N, 2, device=dev)
+nblk = _lib.value('qt_attn_blocks', N, C); part = torch.zeros(nblk, G * 2 * C, device=dev)
+ld, ps, hs, ld_o, hs_o = (C, N * C, 4 * N * C, C, N * C) if planes else (G * 4 * C, C, 4 * C, G * C, C)
+common = (ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr) if os.environ.get('QT_NO_EATTR') != '1' else None, ptr(selfpair), ptr(proj), ld, ptr(We), C, C, N, ptr(mesh.n_dev))
 
 
 def timeit(fn, reps=20):
@@ -47,12 +51,13 @@ def timeit(fn, reps=20):
 
 
 for keep in (1.0, 0.9):
-    fwd = lambda: _lib.call('qt_attn_fwd', *common, keep, 7, None, ptr(out), ptr(stats))
-    bwd = lambda: _lib.call('qt_attn_bwd', *common, keep, 7, None, ptr(g), 0, ptr(stats), ptr(gproj), ptr(Dn), ptr(part), 0,
-                              *((ptr(rev), ptr(coef), rev.numel()) if os.environ.get('QT_NO_COEF') != '1' else (None, None, 0)))
+    fwd = lambda: _lib.call('qt_attn_fwd', *common, keep, 7, None, ptr(out), ptr(stats), G, ld_o, ps, hs, hs_o)
+    bwd = lambda: _lib.call('qt_attn_bwd', *common, keep, 7, None, ptr(g), ld_o, ptr(stats), ptr(gproj), ptr(Dn), ptr(part), 0,
+                              *((ptr(rev), ptr(coef), rev.numel()) if os.environ.get('QT_NO_COEF') != '1' else (None, None, 0)), G, 0,
+                              ps, hs, hs_o)
     tf_, tb = timeit(fwd), timeit(bwd)
-    cf = 4 * (N * 5 * C + N * 2 + 2 * E + N)                     # proj rows + out + stats + CSR
-    gf = 4 * ((E + N) * 2 * C + N * 3 * C)                       # k, v per edge; q, skip, out per node
-    cb = 4 * (N * 4 * C + N * C + N * 4 * C + 2 * 2 * E)         # proj + g + gproj, CSR twice
+    cf = 4 * G * (N * 5 * C + N * 2 + 2 * E + N)                     # proj rows + out + stats + CSR
+    gf = 4 * G * ((E + N) * 2 * C + N * 3 * C)                       # k, v per edge; q, skip, out per node
+    cb = 4 * G * (N * 4 * C + N * C + N * 4 * C + 2 * 2 * E)         # proj + g + gproj, CSR twice
     print(f'keep {keep}: fwd {tf_:.1f} us ({cf / tf_ / 1e3:.0f} GB/s compulsory, {gf / tf_ / 1e3:.0f} GB/s gathered)   '
           f'bwd (target + source) {tb:.1f} us ({cb / tb / 1e3:.0f} GB/s compulsory)')
