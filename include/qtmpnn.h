@@ -342,7 +342,7 @@ int qt_act_bwd(const float* gY, const float* Y, const float* res, int res_stride
  * proj (N, ld): q | k | v | skip column blocks of C (multiple of 4, zero padded above c_real) columns each;
  * xy (N, 2) node centroids in edge-attribute units; selfloop (N) > 0 where get_adj emits the pair (i, i), or NULL;
  * incoming edges of i = CSR row i (symmetric adjacency).  stats (N, 2) = running max / sum of the softmax.
- * qt_attn_bwd: g (N, C) -> gproj (N, ld) [dq | dk | dv | g], Dn (N) scratch, part (qt_attn_blocks, 2*C) partials of dWe^T.
+ * qt_attn_bwd: g (N, C) -> gproj (N, ld) [dq | dk | dv | g], part (qt_attn_blocks, 2*C) partials of dWe^T.
  */
 int qt_attn_blocks(int N, int C);
 /* eattr (E, 2): [angle, dist] of the message col[e] -> row(e) for every stored edge, computed once per mesh by
@@ -357,14 +357,17 @@ int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, cons
 int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                 const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
                 float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, int ld_g /* row stride of g, 0 = C */,
-                const float* stats, float* gproj, float* Dn, float* part, int accumulate /* add into part */,
-                const int32_t* rev, float* coef /* optional scratch (E + N, 2): the target pass leaves (alpha, alpha t) per edge
-                and the source pass reads them through rev instead of recomputing the scores */, int E,
+                const float* stats, const float* out /* the forward's output */, int ld_o, float* gproj, float* part,
+                int accumulate /* add into part */, const int32_t* rev, float* coef /* scratch (E + N, 2), see below */, int E,
                 int G /* heads, 0 = 1 */, int gmod /* g holds gmod column blocks, head g reads block g % gmod; 0 = G */,
-                int64_t ps, int64_t hs, int64_t hs_g /* 0 = C, 4C, C */, void* stream);
+                int64_t ps, int64_t hs, int64_t hs_g, int64_t hs_o /* 0 = C, 4C, C, C */, void* stream);
+/* Backward in two gather passes without atomics.  D_i = sum_e alpha_e t_e equals g_i . (out_i - skip_i) (the forward output is the
+ * alpha-weighted sum of the messages), so the target pass knows it before its edge loop and leaves every message's final
+ * coefficients (scale alpha (t - D), alpha d) at coef[rev[e]] -- the slot of the transposed entry, in the SOURCE's row -- and the
+ * source pass reads its row's slots in order and gathers only the q_i / g_i rows. */
 /* G > 1: G convolutions on the same mesh in one launch (the eight GraphConv stacks of a GConvLSTM, model/model.py:394-424,
  * run layer by layer).  Head g reads the column block [g 4C, (g+1) 4C) of the proj rows (ld >= G 4C) and We[g] ((G, C, 2)), and
- * writes the column block g C of the out rows; stats (G, N, 2), Dn (G, N), coef (G, E + N, 2), part (qt_attn_blocks, G, 2C), gproj
+ * writes the column block g C of the out rows; stats (G, N, 2), coef (G, E + N, 2), part (qt_attn_blocks, G, 2C), gproj
  * laid out like proj; every head draws its own dropout mask.  The results are those of G separate calls.
  * Strides in floats: ps between the q / k / v / skip blocks of a proj (gproj) row, hs between the heads of proj, hs_o / hs_g between
  * the heads of out / g.  One dense (N, C) plane per block and head is ld = C, ps = N C, hs = 4 N C (what qt_proj_group writes with

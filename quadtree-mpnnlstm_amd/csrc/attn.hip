@@ -9,7 +9,7 @@
 // row i of the mesh CSR (the quadtree adjacency is symmetric) plus the self pair (i, i) that get_adj emits for
 // multi-pixel cells (attrs (0, 0)); edge attributes are recomputed from the node centroids instead of being stored.
 // One node per group of C/4 lanes (float4 each), online softmax, dot products reduced with xor shuffles.
-// Backward in gather form, no atomics: pass A per target (D_i, dq_i), pass B per source (dk_j, dv_j, dWe partials).
+// Backward in gather form, no atomics: pass A per target (dq_i + the messages' coefficients), pass B per source (dk_j, dv_j, dWe partials).
 #include "qt_common.h"
 #include <math.h>
 
@@ -48,7 +48,7 @@ struct AttnArgs {
     float scale;            // 1 / sqrt(real channel count)
     float keep;             // 1 - dropout p (1 = no dropout)
     const int32_t* rev;     // (E) position of the transposed entry (row col[e], column row(e)), with coef: see k_attn_bwd_source
-    float* coef;            // (E + N, 2) backward scratch: (alpha, alpha t) of every stored edge, then of the self pairs
+    float* coef;            // (E + N, 2) backward scratch: (ds, alpha d) of the message whose transposed entry is stored at the slot, then of the self pairs
     int E;
     int ld_g;               // backward: row stride of g (a column block of a wider gradient is read in place)
     int accumulate;         // backward: add the We partials into `part` (several uses of one convolution share the slab)
@@ -198,15 +198,20 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __re
     }
 }
 
-// pass A: per target i -- D_i = sum_e alpha_e t_e (t_e = d_e g_i.(v_j + e)), dq_i = scale * sum_e alpha_e (t_e - D_i)(k_j + e)
+// pass A: per target i -- dq_i = scale * sum_e alpha_e (t_e - D_i)(k_j + e), t_e = d_e g_i.(v_j + e), D_i = sum_e alpha_e t_e.
+// D_i needs no edge loop of its own: sum_e alpha_e d_e (v_j + e) is the forward's attention output out_i - skip_i, so
+// D_i = g_i . (out_i - skip_i) is known BEFORE the loop, and the loop can hand every message's final coefficients
+// (ds_e, ad_e) = (scale alpha_e (t_e - D_i), alpha_e d_e) to the SOURCE of the message: they are written at rev[e], the slot of the
+// transposed entry (row j, column i), which pass B then reads in row order -- no gather of coefficients, softmax statistics or D_i
+// over there, only the q_i / g_i rows.
 template <int LPN>
 __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_bwd_target(AttnArgs a, const float* __restrict__ g, const float* __restrict__ stats,
-                                                         float* __restrict__ gproj, float* __restrict__ Dn) {
+                                                         const float* __restrict__ outf, float* __restrict__ gproj) {
     const int hd = head_setup(a);
     g += (hd % a.gmod) * a.hs_g;
     stats += (int64_t)hd * 2 * a.Ncap;
     gproj += hd * a.hs;
-    Dn += (int64_t)hd * a.Ncap;
+    outf += hd * a.hs_o;
     const int rows = qt_rows(a.n_dev, a.Ncap);
     const int blk = xcd_block(rows, QT_ATTN_BS / LPN);
     if (blk < 0) return;
@@ -215,25 +220,30 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_bwd_target(AttnArgs a, cons
     const int j0 = ((int)threadIdx.x % LPN) * 4;
     const float* pi = a.proj + (int64_t)i * a.ld;
     const F4 q = ld4(pi + j0), gi = ld4(g + (int64_t)i * a.ld_g + j0);
+    const F4 sk = ld4(pi + 3 * a.ps + j0), of = ld4(outf + (int64_t)i * a.ld_o + j0);
     const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
     const F4 w1 = {{a.We[2 * j0 + 1], a.We[2 * j0 + 3], a.We[2 * j0 + 5], a.We[2 * j0 + 7]}};
     const float m = stats[2 * i], l = stats[2 * i + 1];
     const float inv = l > 0.0f ? 1.0f / l : 0.0f;
     const int e0 = a.rowptr[i], e1 = a.rowptr[i + 1];
     const int extra = (a.selfloop && a.selfloop[i] > 0.0f) ? 1 : 0;
-    float D = 0.0f;
-    F4 dq = {{0, 0, 0, 0}}, dqk = {{0, 0, 0, 0}};      // dq = sum alpha t (k+e) ; dqk = sum alpha (k+e)
+    F4 att;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) att.v[c] = of.v[c] - sk.v[c];
+    const float D = group_sum<LPN>(dot4(gi, att));
+    F4 dq = {{0, 0, 0, 0}};
     const uint32_t seed = eff_seed(a);
     const float xi = a.xy[2 * i], yi = a.xy[2 * i + 1];
     const int eend = e1 + extra;
     for (int eb = e0; eb < eend; eb += 4) {
-        int jj[4];
+        int jj[4], rv[4];
         F4 kk[4], vv[4];
         float xj[4], yj[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = eb + u;
             jj[u] = e < e1 ? a.col[e] : (e < eend ? i : -1);
+            rv[u] = e < e1 ? a.rev[e] : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -270,48 +280,37 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_bwd_target(AttnArgs a, cons
             }
             const float s = group_sum<LPN>(dot4(q, kj)) * a.scale;
             const float alpha = __expf(s - m) * inv;
-            const float t = drop_mult(seed, i, j, a.keep) * group_sum<LPN>(dot4(gi, vj));
-            if (a.coef && j0 == 0) {
-                const int64_t slot = eb + u < e1 ? eb + u : (int64_t)a.E + i;
-                a.coef[2 * slot] = alpha;
-                a.coef[2 * slot + 1] = alpha * t;
+            const float d = drop_mult(seed, i, j, a.keep);
+            const float t = d * group_sum<LPN>(dot4(gi, vj));
+            const float ds = alpha * (t - D) * a.scale;
+            if (j0 == 0) {
+                const int64_t slot = eb + u < e1 ? rv[u] : (int64_t)a.E + i;
+                *reinterpret_cast<float2*>(a.coef + 2 * slot) = make_float2(ds, alpha * d);
             }
-            D += alpha * t;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                dq.v[c] += alpha * t * kj.v[c];
-                dqk.v[c] += alpha * kj.v[c];
-            }
+            for (int c = 0; c < 4; ++c) dq.v[c] += ds * kj.v[c];
         }
     }
-    F4 o;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) o.v[c] = a.scale * (dq.v[c] - D * dqk.v[c]);
     float* gp = gproj + (int64_t)i * a.ld;
-    st4(gp + j0, o);
+    st4(gp + j0, dq);
     st4(gp + 3 * a.ps + j0, gi);          // skip branch: identity
-    if (j0 == 0) Dn[i] = D;
 }
 
-// pass B: per source j over its outgoing messages j -> i (i runs over row j: the adjacency is symmetric)
+// pass B: per source j over its outgoing messages j -> i (i runs over row j: the adjacency is symmetric).  Row j stores i -> j;
+// the coefficients of j -> i were left at this row's own slots by pass A:
+//   dk_j = sum_i ds q_i,  dv_j = sum_i ad g_i,  dWe = sum_edges (dk + dv terms) [angle, dist]
 template <int LPN>
-__global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float* __restrict__ g, const float* __restrict__ stats,
-                                                         const float* __restrict__ Dn, float* __restrict__ gproj,
+__global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float* __restrict__ g, float* __restrict__ gproj,
                                                          float* __restrict__ part) {
     __shared__ float sm[4 * LPN * 2 * 4];
     const int hd = head_setup(a);
     g += (hd % a.gmod) * a.hs_g;
-    stats += (int64_t)hd * 2 * a.Ncap;
     gproj += hd * a.hs;
-    Dn += (int64_t)hd * a.Ncap;
     const int lj = threadIdx.x % LPN, j0 = lj * 4;
     const int N = qt_rows(a.n_dev, a.Ncap);
-    const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
-    const F4 w1 = {{a.We[2 * j0 + 1], a.We[2 * j0 + 3], a.We[2 * j0 + 5], a.We[2 * j0 + 7]}};
     float acc[2][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[0][c] = acc[1][c] = 0.0f;
-    const uint32_t seed = eff_seed(a);
     // XCD x sweeps the contiguous eighth [x * per, (x + 1) * per) of the nodes with its share of the workgroups
     const bool split = gridDim.x >= 8;                      // (a handful of workgroups: plain sweep)
     const int xcd = split ? blockIdx.x & 7 : 0, wg = split ? blockIdx.x >> 3 : blockIdx.x;
@@ -320,69 +319,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
     const int64_t jlo = xcd * per, jhi = jlo + per < N ? jlo + per : N;
     const int64_t stride = (int64_t)nwg * (256 / LPN);
     for (int64_t j = jlo + (int64_t)wg * (256 / LPN) + threadIdx.x / LPN; j < jhi; j += stride) {
-        const float* pj = a.proj + j * a.ld;
         F4 dk = {{0, 0, 0, 0}}, dv = {{0, 0, 0, 0}};
         const int e0 = a.rowptr[j], e1 = a.rowptr[j + 1];
         const int extra = (a.selfloop && a.selfloop[j] > 0.0f) ? 1 : 0;
         const int eend = e1 + extra;
-        if (a.coef) {
-            // the target pass left (alpha, alpha t) of every edge: no dot products, shuffles or exponentials here, only the
-            // gathers of q_i and g_i; row j stores i -> j, the message j -> i sits at rev[e] (in row i)
-            for (int eb = e0; eb < eend; eb += 4) {
-                int ii[4];
-                F4 qq[4], gg[4];
-                float al[4], at[4], Di[4], ea[4], ed[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e = eb + u;
-                    ii[u] = e < e1 ? a.col[e] : (e < eend ? (int)j : -1);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (ii[u] >= 0) {
-                        const int i = ii[u], e = eb + u;
-                        const int64_t slot = e < e1 ? a.rev[e] : (int64_t)a.E + j;
-                        qq[u] = ld4(a.proj + (int64_t)i * a.ld + j0);
-                        gg[u] = ld4(g + (int64_t)i * a.ld_g + j0);
-                        al[u] = a.coef[2 * slot];
-                        at[u] = a.coef[2 * slot + 1];
-                        Di[u] = Dn[i];
-                        ea[u] = e < e1 ? a.eattr[2 * e] : 0.0f;
-                        ed[u] = e < e1 ? a.eattr[2 * e + 1] : 0.0f;
-                    }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (ii[u] < 0) break;
-                    const int i = ii[u];
-                    float ang = 0.0f, dst = 0.0f;
-                    if (i != j) {
-                        ang = ea[u] + 0.5f;
-                        if (ang >= 1.0f) ang -= 1.0f;
-                        dst = ed[u];
-                    }
-                    const float ds = (at[u] - al[u] * Di[u]) * a.scale;
-                    const float ad = al[u] * drop_mult(seed, i, (int)j, a.keep);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float dkc = ds * qq[u].v[c], dvc = ad * gg[u].v[c];
-                        dk.v[c] += dkc;
-                        dv.v[c] += dvc;
-                        acc[0][c] += (dkc + dvc) * ang;
-                        acc[1][c] += (dkc + dvc) * dst;
-                    }
-                }
-            }
-            float* gpc = gproj + j * a.ld;
-            st4(gpc + a.ps + j0, dk);
-            st4(gpc + 2 * a.ps + j0, dv);
-            continue;
-        }
-        const F4 kj0 = ld4(pj + a.ps + j0), vj0 = ld4(pj + 2 * a.ps + j0);
-        const float xj = a.xy[2 * j], yj = a.xy[2 * j + 1];
         for (int eb = e0; eb < eend; eb += 4) {
             int ii[4];
             F4 qq[4], gg[4];
-            float xi[4], yi[4], mi[4], li[4], Di[4];
+            float2 cf[4];
+            float ea[4], ed[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = eb + u;
@@ -391,52 +336,27 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (ii[u] >= 0) {
-                    const int i = ii[u];
+                    const int i = ii[u], e = eb + u;
+                    const int64_t slot = e < e1 ? e : (int64_t)a.E + j;
                     qq[u] = ld4(a.proj + (int64_t)i * a.ld + j0);
                     gg[u] = ld4(g + (int64_t)i * a.ld_g + j0);
-                    if (a.eattr) {
-                        const int e = eb + u;
-                        xi[u] = e < e1 ? a.eattr[2 * e] : 0.0f;
-                        yi[u] = e < e1 ? a.eattr[2 * e + 1] : 0.0f;
-                    } else {
-                        xi[u] = a.xy[2 * i];
-                        yi[u] = a.xy[2 * i + 1];
-                    }
-                    mi[u] = stats[2 * i];
-                    li[u] = stats[2 * i + 1];
-                    Di[u] = Dn[i];
+                    cf[u] = *reinterpret_cast<const float2*>(a.coef + 2 * slot);
+                    ea[u] = e < e1 ? a.eattr[2 * e] : 0.0f;
+                    ed[u] = e < e1 ? a.eattr[2 * e + 1] : 0.0f;
                 }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (ii[u] < 0) break;
-                const int i = ii[u];
                 float ang = 0.0f, dst = 0.0f;
-                if (a.eattr) {
-                    // row j stores the attributes of i -> j; the message here runs j -> i: same distance, opposite direction
-                    if (i != j) {
-                        ang = xi[u] + 0.5f;
-                        if (ang >= 1.0f) ang -= 1.0f;
-                        dst = yi[u];
-                    }
-                } else if (i != j) {
-                    edge_attr_xy(xj - xi[u], yj - yi[u], &ang, &dst);
+                if (ii[u] != j) {                        // row j holds the attributes of i -> j: same distance, opposite direction
+                    ang = ea[u] + 0.5f;
+                    if (ang >= 1.0f) ang -= 1.0f;
+                    dst = ed[u];
                 }
-                const F4 qi = qq[u], gi = gg[u];
-                F4 kj = kj0, vj = vj0;
+                const float ds = cf[u].x, ad = cf[u].y;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float ee = w0.v[c] * ang + w1.v[c] * dst;
-                    kj.v[c] += ee;
-                    vj.v[c] += ee;
-                }
-                const float s = group_sum<LPN>(dot4(qi, kj)) * a.scale;
-                const float alpha = li[u] > 0.0f ? __expf(s - mi[u]) / li[u] : 0.0f;
-                const float d = drop_mult(seed, i, (int)j, a.keep);
-                const float t = d * group_sum<LPN>(dot4(gi, vj));
-                const float ds = alpha * (t - Di[u]) * a.scale;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float dkc = ds * qi.v[c], dvc = alpha * d * gi.v[c];
+                    const float dkc = ds * qq[u].v[c], dvc = ad * gg[u].v[c];
                     dk.v[c] += dkc;
                     dv.v[c] += dvc;
                     acc[0][c] += (dkc + dvc) * ang;      // d We[:, 0]
@@ -568,29 +488,31 @@ extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const floa
 
 extern "C" int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
                            const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
-                           float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, int ld_g, const float* stats, float* gproj,
-                           float* Dn, float* part, int accumulate, const int32_t* rev, float* coef, int E, int G, int gmod,
-                           int64_t ps, int64_t hs, int64_t hs_g, void* stream) {
-    QT_ARG(rowptr && col && xy && proj && We && g && stats && gproj && Dn && part, "null pointer");
+                           float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, int ld_g, const float* stats,
+                           const float* out, int ld_o, float* gproj, float* part, int accumulate, const int32_t* rev, float* coef, int E,
+                           int G, int gmod, int64_t ps, int64_t hs, int64_t hs_g, int64_t hs_o, void* stream) {
+    QT_ARG(rowptr && col && xy && eattr && proj && We && g && stats && out && gproj && part && rev && coef, "null pointer");
     if (G <= 0) G = 1;
     if (gmod <= 0) gmod = G;
     if (ps == 0) ps = C;
     if (hs == 0) hs = 4 * C;
     if (hs_g == 0) hs_g = C;
+    if (hs_o == 0) hs_o = C;
+    if (ld_o == 0) ld_o = G * C;
     QT_ARG(c_ok(C) && ld >= C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
     if (ld_g == 0) ld_g = gmod * C;
-    QT_ARG(G <= 64 && gmod <= G && ld_g >= C && ld_g % 4 == 0 && ((uintptr_t)g & 15) == 0 && ps % 4 == 0 && hs % 4 == 0 && hs_g % 4 == 0,
+    QT_ARG(G <= 64 && gmod <= G && ld_g >= C && ld_g % 4 == 0 && ((uintptr_t)g & 15) == 0 && ps % 4 == 0 && hs % 4 == 0 && hs_g % 4 == 0 &&
+           ld_o >= C && ld_o % 4 == 0 && hs_o % 4 == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)coef & 7) == 0 && E >= 0,
            "bad head count / strides / alignment");
     if (N <= 0) return QT_OK;
     AttnArgs a;
     fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
-    QT_ARG(!coef || (rev && eattr && E >= 0), "coef needs rev, eattr and the edge capacity E");
-    a.ld_g = ld_g; a.accumulate = accumulate; a.rev = rev; a.coef = coef; a.E = E; a.ld_o = 0; a.gmod = gmod;
-    a.ps = ps; a.hs = hs; a.hs_o = 0; a.hs_g = hs_g;
+    a.ld_g = ld_g; a.accumulate = accumulate; a.rev = rev; a.coef = coef; a.E = E; a.ld_o = ld_o; a.gmod = gmod;
+    a.ps = ps; a.hs = hs; a.hs_o = hs_o; a.hs_g = hs_g;
     const int grid = (qt_cdiv((int64_t)N * (C / 4), QT_ATTN_BS) + 7) & ~7;
-    QT_ATTN_DISPATCH_BS(C, k_attn_bwd_target, dim3(grid, G), QT_ATTN_BS, stream, a, g, stats, gproj, Dn);
+    QT_ATTN_DISPATCH_BS(C, k_attn_bwd_target, dim3(grid, G), QT_ATTN_BS, stream, a, g, stats, out, gproj);
     const int gridB = qt_attn_blocks(N, C);
-    QT_ATTN_DISPATCH(C, k_attn_bwd_source, dim3(gridB, G), stream, a, g, stats, Dn, gproj, part);
+    QT_ATTN_DISPATCH(C, k_attn_bwd_source, dim3(gridB, G), stream, a, g, gproj, part);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -687,7 +687,7 @@ class _Attention(Function):
         stats = proj.new_empty(G, N, 2)
         _lib.call('qt_attn_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(proj), 4 * C * G, ptr(We), C, c_real,
                   N, ptr(mesh.n_dev), keep, seed, ptr(ctx.epoch), ptr(out), ptr(stats), G, 0, 0, 0, 0)
-        ctx.save_for_backward(proj, We, stats)
+        ctx.save_for_backward(proj, We, stats, out)
         ctx.mesh, ctx.c_real, ctx.keep, ctx.seed, ctx.acc, ctx.G, ctx.gmod = mesh, c_real, keep, seed, acc, G, gmod or G
         ctx.use_idx = acc.enter() if acc is not None else 0
         if ctx.gmod < G:            # the sum over the head groups (conv_x + conv_h of a gate, model/model.py:394-424)
@@ -696,14 +696,13 @@ class _Attention(Function):
 
     @staticmethod
     def backward(ctx, g):
-        proj, We, stats = ctx.saved_tensors
+        proj, We, stats, out = ctx.saved_tensors
         mesh, acc, G, gmod = ctx.mesh, ctx.acc, ctx.G, ctx.gmod
         N, C = proj.shape[0], proj.shape[1] // (4 * G)
         xy, selfpair, eattr, rev = mesh.attn_geometry()
-        coef = proj.new_empty(G, rev.numel() + N, 2)       # (alpha, alpha t) per edge: target pass -> source pass
+        coef = proj.new_empty(G, rev.numel() + N, 2)       # per message: target pass -> source pass
         g, ld_g = _rows(g.float())                  # a column block of the gates' gradient is read in place
         gproj = torch.empty_like(proj)
-        Dn = proj.new_empty(G, N)
         if acc is None:
             nblk = max(_lib.value('qt_attn_blocks', N, C), 1)
             part = proj.new_empty(nblk, G * 2 * C) if N > 0 else proj.new_zeros(nblk, G * 2 * C)
@@ -712,8 +711,8 @@ class _Attention(Function):
             part = acc.slab(proj, nblk, G * 2 * C)
         if N > 0:
             _lib.call('qt_attn_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(proj), 4 * C * G, ptr(We), C,
-                      ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(ctx.epoch), ptr(g), ld_g, ptr(stats), ptr(gproj), ptr(Dn),
-                      ptr(part), 0 if acc is None else 1, ptr(rev), ptr(coef), rev.numel(), G, gmod, 0, 0, 0)
+                      ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(ctx.epoch), ptr(g), ld_g, ptr(stats), ptr(out), 0, ptr(gproj),
+                      ptr(part), 0 if acc is None else 1, ptr(rev), ptr(coef), rev.numel(), G, gmod, 0, 0, 0, 0)
         else:
             gproj.zero_()
         none = (None,) * 7
@@ -776,7 +775,7 @@ class _MultiConv(Function):
         _lib.call('qt_attn_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(P), C, ptr(We), C, c_real,
                   N, ptr(mesh.n_dev), keep, seed, ptr(ctx.epoch), ptr(out), ptr(stats), G, G * C if summed else C, N * C, 4 * N * C,
                   C if summed else N * C)
-        ctx.save_for_backward(P, We, stats, *As, *Ws)
+        ctx.save_for_backward(P, We, stats, out, *As, *Ws)
         ctx.mesh, ctx.c_real, ctx.keep, ctx.seed, ctx.acc, ctx.G, ctx.gmod, ctx.segs = mesh, c_real, keep, seed, acc, G, gmod, segs
         ctx.use_idx = acc.enter() if acc is not None else 0
         if summed:
@@ -785,9 +784,9 @@ class _MultiConv(Function):
 
     @staticmethod
     def backward(ctx, g):
-        P, We, stats = ctx.saved_tensors[:3]
+        P, We, stats, out = ctx.saved_tensors[:4]
         nseg = len(ctx.segs)
-        As, Ws = ctx.saved_tensors[3:3 + nseg], ctx.saved_tensors[3 + nseg:]
+        As, Ws = ctx.saved_tensors[4:4 + nseg], ctx.saved_tensors[4 + nseg:]
         mesh, acc, G, gmod = ctx.mesh, ctx.acc, ctx.G, ctx.gmod
         N, C = P.shape[2], P.shape[3]
         xy, selfpair, eattr, rev = mesh.attn_geometry()
@@ -798,7 +797,6 @@ class _MultiConv(Function):
         else:
             g, ld_g, hs_g = _c(g.float()), C, N * C
         gP = torch.empty_like(P)
-        Dn = P.new_empty(G, N)
         if acc is None:
             nblk = max(_lib.value('qt_attn_blocks', N, C), 1)
             part = P.new_empty(nblk, G * 2 * C) if N > 0 else P.new_zeros(nblk, G * 2 * C)
@@ -807,8 +805,9 @@ class _MultiConv(Function):
             part = acc.slab(P, nblk, G * 2 * C)
         if N > 0:
             _lib.call('qt_attn_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(P), C, ptr(We), C,
-                      ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(ctx.epoch), ptr(g), ld_g, ptr(stats), ptr(gP), ptr(Dn),
-                      ptr(part), 0 if acc is None else 1, ptr(rev), ptr(coef), rev.numel(), G, gmod, N * C, 4 * N * C, hs_g)
+                      ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(ctx.epoch), ptr(g), ld_g, ptr(stats), ptr(out),
+                      G * C if gmod < G else C, ptr(gP), ptr(part), 0 if acc is None else 1, ptr(rev), ptr(coef), rev.numel(), G, gmod,
+                      N * C, 4 * N * C, hs_g, C if gmod < G else N * C)
         else:
             gP.zero_()
         gAs = []

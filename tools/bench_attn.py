@@ -52,9 +52,8 @@ def timeit(fn, reps=20):
 
 for keep in (1.0, 0.9):
     fwd = lambda: _lib.call('qt_attn_fwd', *common, keep, 7, None, ptr(out), ptr(stats), G, ld_o, ps, hs, hs_o)
-    bwd = lambda: _lib.call('qt_attn_bwd', *common, keep, 7, None, ptr(g), ld_o, ptr(stats), ptr(gproj), ptr(Dn), ptr(part), 0,
-                              *((ptr(rev), ptr(coef), rev.numel()) if os.environ.get('QT_NO_COEF') != '1' else (None, None, 0)), G, 0,
-                              ps, hs, hs_o)
+    bwd = lambda: _lib.call('qt_attn_bwd', *common, keep, 7, None, ptr(g), ld_o, ptr(stats), ptr(out), ld_o, ptr(gproj), ptr(part), 0,
+                              ptr(rev), ptr(coef), rev.numel(), G, 0, ps, hs, hs_o, hs_o)
     tf_, tb = timeit(fwd), timeit(bwd)
     cf = 4 * G * (N * 5 * C + N * 2 + 2 * E + N)                     # proj rows + out + stats + CSR
     gf = 4 * G * ((E + N) * 2 * C + N * 3 * C)                       # k, v per edge; q, skip, out per node
