@@ -248,8 +248,9 @@ int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream
  *   gates (N, 4h) activated I, F, T, O saved for the backward (which recomputes C' before its LayerNorm as
  *   fma(F, Cprev, I T), the forward's own rounding, instead of reading a saved copy).
  */
-int qt_lstm_fwd(const float* G, const float* Cprev, int ld_c /* row stride of Cprev, floats */, const float* wc,
-                const float* b, const float* ln,
+int qt_lstm_fwd(const float* G, const float* G2 /* optional second addend of the pre-activations (conv_x + conv_h) */,
+                int ld_g /* row stride of G and G2, 0 = 4h */, const float* Cprev, int ld_c /* row stride of Cprev, floats */,
+                const float* wc, const float* b, const float* ln,
                 int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates,
                 void* stream);
 /* qt_dense (act none, Kb = 1, Cb = 4h) with qt_lstm_fwd as its epilogue, for hidden sizes 8, 16, 32: the gate pre-activations stay in

@@ -12,7 +12,8 @@ namespace {
 using namespace qtcell;
 
 template <int LPN>
-__global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, const float* __restrict__ Cprev,
+__global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, const float* __restrict__ G2, int ld_g,
+                                                  const float* __restrict__ Cprev,
                                                   const float* __restrict__ wc, const float* __restrict__ b,
                                                   const float* __restrict__ ln, int Ncap, const int32_t* __restrict__ n_dev,
                                                   int h, int ld_c, float* __restrict__ O, float* __restrict__ Hn,
@@ -21,8 +22,19 @@ __global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ G, c
     const int64_t node = gid / LPN;
     if (node >= qt_rows(n_dev, Ncap)) return;
     const int j0 = (int)(gid % LPN) * 4;
-    const float* g = G + node * 4 * h + j0;
-    const F4 gi = ld4(g), gf = ld4(g + h), gc = ld4(g + 2 * h), go = ld4(g + 3 * h);
+    const float* g = G + node * ld_g + j0;
+    F4 gi = ld4(g), gf = ld4(g + h), gc = ld4(g + 2 * h), go = ld4(g + 3 * h);
+    if (G2) {                   // conv_x(X) + conv_h(H) of the four gates (model/model.py:394-424), summed here
+        const float* g2 = G2 + node * ld_g + j0;
+        const F4 hi = ld4(g2), hf = ld4(g2 + h), hc = ld4(g2 + 2 * h), ho = ld4(g2 + 3 * h);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            gi.v[c] += hi.v[c];
+            gf.v[c] += hf.v[c];
+            gc.v[c] += hc.v[c];
+            go.v[c] += ho.v[c];
+        }
+    }
     F4 cp = {{0, 0, 0, 0}};
     if (Cprev) cp = ld4(Cprev + node * ld_c + j0);
     const CellOut r = cell_forward<LPN>(gi, gf, gc, go, cp, wc, b, ln, h, j0);
@@ -213,15 +225,17 @@ inline bool h_ok(int h) { return h == 8 || h == 16 || h == 32 || h == 64 || h ==
         default: hipLaunchKernelGGL(KERNEL<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
     }
 
-extern "C" int qt_lstm_fwd(const float* G, const float* Cprev, int ld_c, const float* wc, const float* b, const float* ln,
-                           int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates,
+extern "C" int qt_lstm_fwd(const float* G, const float* G2, int ld_g, const float* Cprev, int ld_c, const float* wc, const float* b,
+                           const float* ln, int N, const int32_t* n_dev, int h, float* O, float* Hn, float* Cn, float* gates,
                            void* stream) {
     QT_ARG(G && wc && b && O && Hn && Cn && gates, "null pointer");
+    if (ld_g == 0) ld_g = 4 * h;
+    QT_ARG(ld_g >= 4 * h && ld_g % 4 == 0 && (((uintptr_t)G | (uintptr_t)G2) & 15) == 0, "bad gate row stride / alignment");
     QT_ARG(h_ok(h), "hidden size must be 8, 16, 32, 64 or 128");
     if (N <= 0) return QT_OK;
     const int grid = qt_cdiv((int64_t)N * lanes_per_node(h), 256);
     QT_ARG(!Cprev || (ld_c >= h && ld_c % 4 == 0), "bad Cprev row stride");
-    QT_DISPATCH_LPN(h, k_lstm_fwd, grid, stream, G, Cprev, wc, b, ln, N, n_dev, h, ld_c, O, Hn, Cn, gates);
+    QT_DISPATCH_LPN(h, k_lstm_fwd, grid, stream, G, G2, ld_g, Cprev, wc, b, ln, N, n_dev, h, ld_c, O, Hn, Cn, gates);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -40,7 +40,7 @@ _SIGNATURES = {
     'qt_wgrad_blocks': [_I],
     'qt_wgrad': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P],
     'qt_colsum': [_P, _I, _L, _P, _P],
-    'qt_lstm_fwd': [_P, _P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P],
+    'qt_lstm_fwd': [_P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P],
     'qt_lstm_bwd_blocks': [_I, _I],
     'qt_lstm_bwd': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P],
     'qt_sse_bwd': [_P, _I, _P, _P, _P, _I, _P, _I, _P, _P],

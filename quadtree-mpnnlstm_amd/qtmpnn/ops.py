@@ -742,8 +742,8 @@ class _MultiConv(Function):
     segments: [(A_s, W_s (Gin_s, Cin_s + 4, Co_s))]: group g of segment s multiplies A_s (N, Cin_s) (Gin_s = 1) or A_s[g] of
     (Gin_s, N, Cin_s) with W_s[g] (bias in row Cin_s) and fills the next Co_s / C planes of P.  Layer 0 of a cell has the segments
     (X, Wx (1, ., 4 4C)) and (H, Wh (1, ., 4 4C)), deeper layers one segment (previous layer's output (8, N, C), W (8, C + 4, 4C)).
-    Output: (G, N, C), or with gmod < G the (N, gmod C) sum of the head groups (conv_x + conv_h per gate), whose gradient alone
-    comes back.  acc: GradAcc of this layer's weights for the pass (dWe slab + deferred grouped weight gradients), or None."""
+    Output: (G, N, C), or with gmod < G the rows (N, G / gmod, gmod C) whose head groups the consumer sums (conv_x + conv_h per
+    gate: ops.lstm_cell adds them inside its kernel and hands back ONE gradient for both, as a stride-0 view).  acc: GradAcc of this layer's weights for the pass (dWe slab + deferred grouped weight gradients), or None."""
 
     @staticmethod
     def forward(ctx, mesh, c_real, keep, seed, acc, gmod, nseg, *args):
@@ -778,8 +778,8 @@ class _MultiConv(Function):
         ctx.save_for_backward(P, We, stats, out, *As, *Ws)
         ctx.mesh, ctx.c_real, ctx.keep, ctx.seed, ctx.acc, ctx.G, ctx.gmod, ctx.segs = mesh, c_real, keep, seed, acc, G, gmod, segs
         ctx.use_idx = acc.enter() if acc is not None else 0
-        if summed:
-            return out.view(N, G // gmod, gmod * C).sum(dim=1)
+        if summed:                  # (N, G / gmod, gmod C): the consumer adds the head groups (lstm_cell: inside its kernel)
+            return out.view(N, G // gmod, gmod * C)
         return out
 
     @staticmethod
@@ -791,9 +791,12 @@ class _MultiConv(Function):
         N, C = P.shape[2], P.shape[3]
         xy, selfpair, eattr, rev = mesh.attn_geometry()
         coef = P.new_empty(G, rev.numel() + N, 2)
-        if gmod < G:
-            g, ld_g = _rows(g.float())
+        summed = gmod < G
+        if summed and g.stride(1) == 0:       # the head groups were summed downstream: one gradient for all of them
+            g, ld_g = _rows(g[:, 0].float())
             hs_g = C
+        elif summed:
+            g, ld_g, hs_g, gmod = _c(g.float()), G * C, C, G
         else:
             g, ld_g, hs_g = _c(g.float()), C, N * C
         gP = torch.empty_like(P)
@@ -806,8 +809,8 @@ class _MultiConv(Function):
         if N > 0:
             _lib.call('qt_attn_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(P), C, ptr(We), C,
                       ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(ctx.epoch), ptr(g), ld_g, ptr(stats), ptr(out),
-                      G * C if gmod < G else C, ptr(gP), ptr(part), 0 if acc is None else 1, ptr(rev), ptr(coef), rev.numel(), G, gmod,
-                      N * C, 4 * N * C, hs_g, C if gmod < G else N * C)
+                      G * C if summed else C, ptr(gP), ptr(part), 0 if acc is None else 1, ptr(rev), ptr(coef), rev.numel(), G, gmod,
+                      N * C, 4 * N * C, hs_g, C if summed else N * C)
         else:
             gP.zero_()
         gAs = []
@@ -882,14 +885,16 @@ class _LstmCell(Function):
     @staticmethod
     def forward(ctx, G, Cprev, wc, b, ln, mesh, acc):
         G = _c(G)
-        N, h4 = G.shape
+        ctx.pair = G.dim() == 3             # (N, 2, 4h): the conv_x and conv_h sums side by side, added inside the kernel
+        assert not ctx.pair or G.shape[1] == 2
+        N, h4 = G.shape[0], G.shape[-1]
         h = h4 // 4
         wc, b, ln = _c(wc), _c(b), _c(ln)
         Cprev, ld_c = _rows(Cprev)
         O, Hn, Cn = (G.new_empty(N, h) for _ in range(3))
         gates = G.new_empty(N, h4)
-        _lib.call('qt_lstm_fwd', ptr(G), ptr(Cprev), ld_c, ptr(wc), ptr(b), ptr(ln), N, ptr(mesh.n_dev), h, ptr(O),
-                  ptr(Hn), ptr(Cn), ptr(gates))
+        _lib.call('qt_lstm_fwd', ptr(G), G.data_ptr() + 4 * h4 if ctx.pair else None, 2 * h4 if ctx.pair else h4, ptr(Cprev), ld_c, ptr(wc),
+                  ptr(b), ptr(ln), N, ptr(mesh.n_dev), h, ptr(O), ptr(Hn), ptr(Cn), ptr(gates))
         ctx.save_for_backward(gates, Cprev, wc, ln)
         ctx.mesh, ctx.acc = mesh, acc
         ctx.use_idx = acc.enter() if acc is not None else 0
@@ -899,7 +904,10 @@ class _LstmCell(Function):
     @staticmethod
     def backward(ctx, gO, gHn, gCn):
         gates, Cprev, wc, ln = ctx.saved_tensors
-        return (*_lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, ctx.mesh, ctx.acc, ctx.use_idx), None, None)
+        res = _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, ctx.mesh, ctx.acc, ctx.use_idx)
+        if ctx.pair:            # both addends receive the same gradient: a stride-0 view, no copy
+            res = (res[0].unsqueeze(1).expand(-1, 2, -1),) + tuple(res[1:])
+        return (*res, None, None)
 
 
 def _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, mesh, acc, use_idx, dgrad=None):

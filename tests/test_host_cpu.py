@@ -56,7 +56,7 @@ def test_bad_arguments_fail_loudly_without_gpu():
     lib = _lib.load()
     rc = lib.qt_spmm(None, None, None, 4, None, 4, None, 1.0, None, 0.0, None, 0.0, None, None)
     assert rc == -1 and b'qt_spmm' in lib.qt_last_error()
-    assert lib.qt_lstm_fwd(None, None, 0, None, None, None, 1, None, 16, None, None, None, None, None) == -1
+    assert lib.qt_lstm_fwd(None, None, 0, None, 0, None, None, None, 1, None, 16, None, None, None, None, None) == -1
     # every entry point refuses NULL / inconsistent arguments with an error code and a message naming itself -- no launch
     null_calls = {
         'qt_lstm_bwd_dgrad': (None, 0, None, 0, None, 0, None, None, 0, None, None, 4, None, 16, None, None, None, 0, None, None, None, 3, 16, 0, None, None, None),
