@@ -356,6 +356,127 @@ def test_transformer_gconvlstm_cell_golden():
         grad_close(got, g['g/' + k], msg=k, floor=0.05 if k.endswith('lin_key.bias') else 1e-3)
 
 
+@pytest.mark.parametrize('keep_h', [True, False])
+def test_transformer_cell_layerwise_launches_equal_per_convolution_path(keep_h):
+    """The eight TransformerConv stacks of a cell run layer by layer (qt_proj_group + one 8-head attention launch per layer,
+    grouped weight gradients) must give what one projection + attention launch pair per convolution gives: same O, H', C' and the
+    same gradient of every input and parameter (three layers deep, hidden 32 as ice_exp.py configures it; ragged node count)."""
+    from model import model as M
+    from qtmpnn import synthetic
+    from qtmpnn.mesh import build_mesh
+    c = synthetic.make_clip(7, canvas=(64, 64), n_digits=2, n_frames=1, pixel_noise=0.0)
+    mesh = build_mesh(src=torch.from_numpy(c[..., 0]).to(dev()), thresh=0.1)
+    torch.manual_seed(5)
+    cell = M.GConvLSTM(5, 32, 3, 'TransformerConv').to(dev()).eval()
+    for p in cell.parameters():
+        torch.nn.init.normal_(p, std=0.2)
+    N = mesh.N
+    X = torch.randn(N, 8, device=dev(), requires_grad=True)        # (5 features padded to 8 columns, as Seq2Seq feeds them)
+    H = torch.randn(N, 32, device=dev(), requires_grad=True) if keep_h else None
+    C = torch.randn(N, 32, device=dev(), requires_grad=True)
+    gs = [torch.randn(N, 32, device=dev()) for _ in range(3)]
+
+    def run(multi):
+        old, M._MULTI_CONV = M._MULTI_CONV, multi
+        try:
+            outs = cell(X, mesh, None, H, C)
+            ins = [t for t in (X, H, C) if t is not None]
+            grads = torch.autograd.grad(list(outs), ins + list(cell.parameters()), gs)
+        finally:
+            M._MULTI_CONV = old
+        return [o.detach() for o in outs], grads
+
+    (o1, g1), (o0, g0) = run(True), run(False)
+    for a, b, name in zip(o1, o0, ('O', 'Hn', 'Cn')):
+        close(a, b, rtol=1e-5, atol=1e-6, msg=name)
+    names = [n for n, t in (('gX', X), ('gH', H), ('gC', C)) if t is not None] + [k for k, _ in cell.named_parameters()]
+    for a, b, name in zip(g1, g0, names):
+        grad_close(a, b, rtol=1e-5, rel_atol=2e-6, msg=name)
+
+
+def test_multi_head_attention_equals_separate_calls():
+    """qt_attn_fwd / qt_attn_bwd with G heads in one launch, in both layouts (rows side by side; one dense plane per head and
+    block): the results of G single-head calls on the same operands, bit for bit (dropout off: every head draws its own mask)."""
+    from qtmpnn import _lib, synthetic
+    from qtmpnn._lib import ptr
+    from qtmpnn.mesh import build_mesh
+    c = synthetic.make_clip(9, canvas=(64, 64), n_digits=2, n_frames=1, pixel_noise=0.0)
+    mesh = build_mesh(src=torch.from_numpy(c[..., 0]).to(dev()), thresh=0.1)
+    N, G, C = mesh.N, 3, 8
+    xy, selfpair, eattr, rev = mesh.attn_geometry()
+    E = rev.numel()
+    torch.manual_seed(2)
+    P = torch.randn(G, 4, N, C, device=dev())                       # planes
+    Prow = P.permute(2, 0, 1, 3).reshape(N, G * 4 * C).contiguous()   # rows side by side
+    We = torch.randn(G, C, 2, device=dev())
+    g = torch.randn(G, N, C, device=dev())
+    grow = g.permute(1, 0, 2).reshape(N, G * C).contiguous()
+    nblk = _lib.value('qt_attn_blocks', N, C)
+    geo = (ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair))
+
+    def run(proj, ld, ps, hs, gin, ld_g, hs_g, heads, out_shape, ld_o, hs_o, we):
+        out, stats = torch.empty(out_shape, device=dev()), torch.empty(heads, N, 2, device=dev())
+        _lib.call('qt_attn_fwd', *geo, ptr(proj), ld, ptr(we), C, C, N, ptr(mesh.n_dev), 1.0, 3, None, ptr(out), ptr(stats), heads, ld_o,
+                  ps, hs, hs_o)
+        gp, part, coef = torch.zeros_like(proj), torch.zeros(nblk, heads * 2 * C, device=dev()), torch.empty(heads, E + N, 2, device=dev())
+        _lib.call('qt_attn_bwd', *geo, ptr(proj), ld, ptr(we), C, C, N, ptr(mesh.n_dev), 1.0, 3, None, ptr(gin), ld_g, ptr(stats), ptr(out),
+                  ld_o, ptr(gp), ptr(part), 0, ptr(rev), ptr(coef), E, heads, 0, ps, hs, hs_g, hs_o)
+        return out, gp, part.sum(0)
+
+    o_pl, gp_pl, w_pl = run(P, C, N * C, 4 * N * C, g, C, N * C, G, (G, N, C), C, N * C, We)
+    o_rw, gp_rw, w_rw = run(Prow, G * 4 * C, C, 4 * C, grow, G * C, C, G, (N, G * C), G * C, C, We)
+    assert torch.equal(o_pl.permute(1, 0, 2).reshape(N, G * C), o_rw)
+    assert torch.equal(gp_pl.permute(2, 0, 1, 3).reshape(N, G * 4 * C), gp_rw)
+    assert torch.equal(w_pl, w_rw)
+    for h in range(G):
+        ph = P[h].permute(1, 0, 2).reshape(N, 4 * C).contiguous()
+        o1, gp1, w1 = run(ph, 4 * C, C, 4 * C, g[h].contiguous(), C, C, 1, (N, C), C, C, We[h].contiguous())
+        assert torch.equal(o1, o_pl[h]), h
+        assert torch.equal(gp1.view(N, 4, C).permute(1, 0, 2), gp_pl[h]), h
+        assert torch.equal(w1, w_pl[h * 2 * C:(h + 1) * 2 * C]), h
+
+
+def test_proj_group_and_grouped_weight_gradient_equal_dense_calls():
+    """qt_proj_group (G products in one launch, planes in / planes out) against G qt_dense2 calls, bit for bit; qt_wgrad_groups
+    against the fp64 product."""
+    import ctypes
+    from qtmpnn import _lib
+    from qtmpnn._lib import ptr
+    torch.manual_seed(3)
+    N, G, cin, C = 1000, 3, 8, 8
+    co = 4 * C
+    A = torch.randn(G, N, cin, device=dev())
+    W = torch.randn(G, cin + 4, co, device=dev())
+    ones = torch.zeros(N, 4, device=dev())
+    ones[:, 0] = 1
+    P = torch.empty(G, 4, N, C, device=dev())
+    _lib.call('qt_proj_group', ptr(A), cin, N * cin, 1, cin, ptr(ones), ptr(W), None, (cin + 4) * co, G, 4, C, ptr(P), C, 4 * N * C, N, None)
+    for h in range(G):
+        Y = torch.empty(N, co, device=dev())
+        _lib.call('qt_dense2', ptr(A[h]), 0, None, None, 0, None, 1, cin, 0, ptr(W[h]), None, ptr(ones), 4, ptr(W[h][cin:]), 1, co, 0, N, None,
+                  0, None, 0, None, ptr(Y), None)
+        assert torch.equal(P[h].permute(1, 0, 2).reshape(N, co), Y), h
+    # data gradient: gA_g = gP_g W_g[:cin]^T from the planes of gP (the forward weight's rows are the transposed operand)
+    gP = torch.randn_like(P)
+    gA = torch.empty_like(A)
+    _lib.call('qt_proj_group', ptr(gP), C, 4 * N * C, 4, C, None, None, ptr(W), (cin + 4) * co, G, 1, cin, ptr(gA), cin, N * cin, N, None)
+    for h in range(G):
+        ref = gP[h].permute(1, 0, 2).reshape(N, co).double() @ W[h][:cin].double().t()
+        close(gA[h], ref.float(), rtol=1e-5, atol=1e-5, msg=f'dgrad {h}')
+    # weight gradient of all groups: [A_g | 1]^T gP_g
+    Ns = (ctypes.c_int * 1)(N)
+    nb = _lib.value('qt_wgrad_group_blocks', 1, Ns)
+    part = torch.empty(nb, G, cin + 4, co, device=dev())
+    vp = ctypes.c_void_p * 1
+    _lib.call('qt_wgrad_groups', 1, vp(A.data_ptr()), (ctypes.c_int * 1)(cin), vp(ones.data_ptr()), vp(gP.data_ptr()), Ns, vp(None), cin, 4, co,
+              C, C, G, cin, co, 1, ptr(part))
+    gW = part.sum(0)
+    for h in range(G):
+        Ah = torch.cat([A[h], ones], dim=1).double()
+        ref = Ah.t() @ gP[h].permute(1, 0, 2).reshape(N, co).double()
+        close(gW[h], ref.float(), rtol=1e-5, atol=1e-4, msg=f'wgrad {h}')
+
+
 def test_bf16x3_gemm_matches_fp32_gemm():
     """Opt-in bf16x3 GEMM (QT_GEMM_BF16X3=1; three bf16 terms per operand, six MFMAs per product group) must agree with
     the default exact-fp32 MFMA GEMM to fp32 rounding level.  Run in a child process: the switch is read once per process."""
