@@ -108,11 +108,45 @@ __device__ __forceinline__ int xcd_block(int rows, int nodes_per_block) {
     return (bid & 7) * chunk + (bid >> 3);
 }
 
+#ifndef QT_ATTN_EPT
+#define QT_ATTN_EPT 2     // edges per trip (their gathers are issued together).  8 heads at the cfg4 shapes, forward / target /
+                          // source pass: 1: 178 / 258 / 194 us, 2: 158 / 266 / 181, 4: 202 / 313 / 231 -- fewer registers, more waves
+#endif
+constexpr int EPT = QT_ATTN_EPT;
+// register budgets: waves per SIMD the forward / target / source kernels are compiled for (0 = the compiler's choice)
+#ifndef QT_ATTN_OCC_F
+#define QT_ATTN_OCC_F 0
+#endif
+#ifndef QT_ATTN_OCC_T
+#define QT_ATTN_OCC_T 0
+#endif
+#ifndef QT_ATTN_OCC_S
+#define QT_ATTN_OCC_S 0
+#endif
+#define QT_WAVES_ATTR_(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#define QT_WAVES_ATTR(n) QT_WAVES_ATTR_(n)
+#if QT_ATTN_OCC_F
+#define QT_ATTN_WAVES_F QT_WAVES_ATTR(QT_ATTN_OCC_F)
+#else
+#define QT_ATTN_WAVES_F
+#endif
+#if QT_ATTN_OCC_T
+#define QT_ATTN_WAVES_T QT_WAVES_ATTR(QT_ATTN_OCC_T)
+#else
+#define QT_ATTN_WAVES_T
+#endif
+#if QT_ATTN_OCC_S
+#define QT_ATTN_WAVES_S QT_WAVES_ATTR(QT_ATTN_OCC_S)
+#else
+#define QT_ATTN_WAVES_S
+#endif
 #ifndef QT_ATTN_BS
 #define QT_ATTN_BS 64      // one wave per workgroup (forward 32.4 -> 31.0 us at the cfg4 shapes; 128: 31.3)
 #endif
+// Addresses: the block bases (head, q / k / v / skip block) are uniform, so a row is reached as base + a 32-bit element offset
+// (one VGPR per address instead of a 64-bit pair; the host checks that a head's rows span < 2^31 floats).
 template <int LPN>
-__global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __restrict__ out, float* __restrict__ stats) {
+__global__ __launch_bounds__(QT_ATTN_BS) QT_ATTN_WAVES_F void k_attn_fwd(AttnArgs a, float* __restrict__ out, float* __restrict__ stats) {
     const int hd = head_setup(a);
     out += hd * a.hs_o;
     stats += (int64_t)hd * 2 * a.Ncap;
@@ -121,10 +155,10 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __re
     if (blk < 0) return;
     const int i = blk * (QT_ATTN_BS / LPN) + (int)threadIdx.x / LPN;
     if (i >= rows) return;
-    const int j0 = ((int)threadIdx.x % LPN) * 4;
-    const float* pi = a.proj + (int64_t)i * a.ld;
-    const F4 q = ld4(pi + j0);
-    const F4 sk = ld4(pi + 3 * a.ps + j0);          // (requested now, not after the edge loop: no dependent load at the end)
+    const uint32_t j0 = ((uint32_t)threadIdx.x % LPN) * 4, ld = a.ld;
+    const float* __restrict__ kb = a.proj + a.ps;
+    const float* __restrict__ vb = a.proj + 2 * a.ps;
+    const F4 q = ld4(a.proj + ((uint32_t)i * ld + j0));
     const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
     const F4 w1 = {{a.We[2 * j0 + 1], a.We[2 * j0 + 3], a.We[2 * j0 + 5], a.We[2 * j0 + 7]}};
     float m = -INFINITY, l = 0.0f;
@@ -132,44 +166,30 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __re
     const int e0 = a.rowptr[i], e1 = a.rowptr[i + 1];
     const int extra = (a.selfloop && a.selfloop[i] > 0.0f) ? 1 : 0;
     const uint32_t seed = eff_seed(a);
-    const float xi = a.xy[2 * i], yi = a.xy[2 * i + 1];
     const int eend = e1 + extra;
-    for (int eb = e0; eb < eend; eb += 4) {
-        // the gathers of up to four edges are issued together; the online-softmax updates then run in edge order
-        int jj[4];
-        F4 kk[4], vv[4];
-        float xj[4], yj[4];
+    for (int eb = e0; eb < eend; eb += EPT) {
+        // the gathers of EPT edges are issued together; the online-softmax updates then run in edge order
+        int jj[EPT];
+        F4 kk[EPT], vv[EPT];
+        float2 ea[EPT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < EPT; ++u) {
             const int e = eb + u;
             jj[u] = e < e1 ? a.col[e] : (e < eend ? i : -1);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < EPT; ++u)
             if (jj[u] >= 0) {
-                const float* pj = a.proj + (int64_t)jj[u] * a.ld;
-                kk[u] = ld4(pj + a.ps + j0);
-                vv[u] = ld4(pj + 2 * a.ps + j0);
-                if (a.eattr) {                      // stored per edge: no atan2 / sqrt in the loop (8 lanes repeated them)
-                    const int e = eb + u;
-                    xj[u] = e < e1 ? a.eattr[2 * e] : 0.0f;
-                    yj[u] = e < e1 ? a.eattr[2 * e + 1] : 0.0f;
-                } else {
-                    xj[u] = a.xy[2 * jj[u]];
-                    yj[u] = a.xy[2 * jj[u] + 1];
-                }
+                const uint32_t off = (uint32_t)jj[u] * ld + j0;
+                kk[u] = ld4(kb + off);
+                vv[u] = ld4(vb + off);
+                ea[u] = eb + u < e1 ? *reinterpret_cast<const float2*>(a.eattr + 2 * (uint32_t)(eb + u)) : make_float2(0.0f, 0.0f);
             }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < EPT; ++u) {
             if (jj[u] < 0) break;                  // (uniform over the node's lane group)
             const int j = jj[u];
-            float ang = 0.0f, dst = 0.0f;
-            if (a.eattr) {
-                ang = xj[u];
-                dst = yj[u];
-            } else if (j != i) {
-                edge_attr_xy(xj[u] - xi, yj[u] - yi, &ang, &dst);
-            }
+            const float ang = ea[u].x, dst = ea[u].y;       // stored per edge: no atan2 / sqrt in the loop
             F4 kj = kk[u], vj = vv[u];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -187,11 +207,12 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __re
             m = mn;
         }
     }
+    const F4 sk = ld4(a.proj + 3 * a.ps + ((uint32_t)i * ld + j0));
     const float inv = l > 0.0f ? 1.0f / l : 0.0f;
     F4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) o.v[c] = acc.v[c] * inv + sk.v[c];
-    st4(out + (int64_t)i * a.ld_o + j0, o);
+    st4(out + ((uint32_t)i * (uint32_t)a.ld_o + j0), o);
     if (j0 == 0) {
         stats[2 * i] = m;
         stats[2 * i + 1] = l;
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_fwd(AttnArgs a, float* __re
 // transposed entry (row j, column i), which pass B then reads in row order -- no gather of coefficients, softmax statistics or D_i
 // over there, only the q_i / g_i rows.
 template <int LPN>
-__global__ __launch_bounds__(QT_ATTN_BS) void k_attn_bwd_target(AttnArgs a, const float* __restrict__ g, const float* __restrict__ stats,
+__global__ __launch_bounds__(QT_ATTN_BS) QT_ATTN_WAVES_T void k_attn_bwd_target(AttnArgs a, const float* __restrict__ g, const float* __restrict__ stats,
                                                          const float* __restrict__ outf, float* __restrict__ gproj) {
     const int hd = head_setup(a);
     g += (hd % a.gmod) * a.hs_g;
@@ -217,60 +238,51 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_bwd_target(AttnArgs a, cons
     if (blk < 0) return;
     const int i = blk * (QT_ATTN_BS / LPN) + (int)threadIdx.x / LPN;
     if (i >= rows) return;
-    const int j0 = ((int)threadIdx.x % LPN) * 4;
-    const float* pi = a.proj + (int64_t)i * a.ld;
-    const F4 q = ld4(pi + j0), gi = ld4(g + (int64_t)i * a.ld_g + j0);
-    const F4 sk = ld4(pi + 3 * a.ps + j0), of = ld4(outf + (int64_t)i * a.ld_o + j0);
+    const uint32_t j0 = ((uint32_t)threadIdx.x % LPN) * 4, ld = a.ld;
+    const uint32_t oi = (uint32_t)i * ld + j0;
+    const float* __restrict__ kb = a.proj + a.ps;
+    const float* __restrict__ vb = a.proj + 2 * a.ps;
+    const F4 q = ld4(a.proj + oi), gi = ld4(g + ((uint32_t)i * (uint32_t)a.ld_g + j0));
+    float D;
+    {
+        const F4 sk = ld4(a.proj + 3 * a.ps + oi), of = ld4(outf + ((uint32_t)i * (uint32_t)a.ld_o + j0));
+        F4 att;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) att.v[c] = of.v[c] - sk.v[c];
+        D = group_sum<LPN>(dot4(gi, att));
+    }
     const F4 w0 = {{a.We[2 * j0], a.We[2 * j0 + 2], a.We[2 * j0 + 4], a.We[2 * j0 + 6]}};
     const F4 w1 = {{a.We[2 * j0 + 1], a.We[2 * j0 + 3], a.We[2 * j0 + 5], a.We[2 * j0 + 7]}};
     const float m = stats[2 * i], l = stats[2 * i + 1];
     const float inv = l > 0.0f ? 1.0f / l : 0.0f;
     const int e0 = a.rowptr[i], e1 = a.rowptr[i + 1];
     const int extra = (a.selfloop && a.selfloop[i] > 0.0f) ? 1 : 0;
-    F4 att;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) att.v[c] = of.v[c] - sk.v[c];
-    const float D = group_sum<LPN>(dot4(gi, att));
     F4 dq = {{0, 0, 0, 0}};
     const uint32_t seed = eff_seed(a);
-    const float xi = a.xy[2 * i], yi = a.xy[2 * i + 1];
     const int eend = e1 + extra;
-    for (int eb = e0; eb < eend; eb += 4) {
-        int jj[4], rv[4];
-        F4 kk[4], vv[4];
-        float xj[4], yj[4];
+    for (int eb = e0; eb < eend; eb += EPT) {
+        int jj[EPT], rv[EPT];
+        F4 kk[EPT], vv[EPT];
+        float2 ea[EPT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < EPT; ++u) {
             const int e = eb + u;
             jj[u] = e < e1 ? a.col[e] : (e < eend ? i : -1);
-            rv[u] = e < e1 ? a.rev[e] : 0;
+            rv[u] = e < e1 ? a.rev[e] : a.E + i;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < EPT; ++u)
             if (jj[u] >= 0) {
-                const float* pj = a.proj + (int64_t)jj[u] * a.ld;
-                kk[u] = ld4(pj + a.ps + j0);
-                vv[u] = ld4(pj + 2 * a.ps + j0);
-                if (a.eattr) {                      // stored per edge: no atan2 / sqrt in the loop (8 lanes repeated them)
-                    const int e = eb + u;
-                    xj[u] = e < e1 ? a.eattr[2 * e] : 0.0f;
-                    yj[u] = e < e1 ? a.eattr[2 * e + 1] : 0.0f;
-                } else {
-                    xj[u] = a.xy[2 * jj[u]];
-                    yj[u] = a.xy[2 * jj[u] + 1];
-                }
+                const uint32_t off = (uint32_t)jj[u] * ld + j0;
+                kk[u] = ld4(kb + off);
+                vv[u] = ld4(vb + off);
+                ea[u] = eb + u < e1 ? *reinterpret_cast<const float2*>(a.eattr + 2 * (uint32_t)(eb + u)) : make_float2(0.0f, 0.0f);
             }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < EPT; ++u) {
             if (jj[u] < 0) break;
             const int j = jj[u];
-            float ang = 0.0f, dst = 0.0f;
-            if (a.eattr) {
-                ang = xj[u];
-                dst = yj[u];
-            } else if (j != i) {
-                edge_attr_xy(xj[u] - xi, yj[u] - yi, &ang, &dst);
-            }
+            const float ang = ea[u].x, dst = ea[u].y;
             F4 kj = kk[u], vj = vv[u];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -283,30 +295,26 @@ __global__ __launch_bounds__(QT_ATTN_BS) void k_attn_bwd_target(AttnArgs a, cons
             const float d = drop_mult(seed, i, j, a.keep);
             const float t = d * group_sum<LPN>(dot4(gi, vj));
             const float ds = alpha * (t - D) * a.scale;
-            if (j0 == 0) {
-                const int64_t slot = eb + u < e1 ? rv[u] : (int64_t)a.E + i;
-                *reinterpret_cast<float2*>(a.coef + 2 * slot) = make_float2(ds, alpha * d);
-            }
+            if (j0 == 0) *reinterpret_cast<float2*>(a.coef + 2 * (uint32_t)rv[u]) = make_float2(ds, alpha * d);
 #pragma unroll
             for (int c = 0; c < 4; ++c) dq.v[c] += ds * kj.v[c];
         }
     }
-    float* gp = gproj + (int64_t)i * a.ld;
-    st4(gp + j0, dq);
-    st4(gp + 3 * a.ps + j0, gi);          // skip branch: identity
+    st4(gproj + oi, dq);
+    st4(gproj + 3 * a.ps + oi, gi);          // skip branch: identity
 }
 
 // pass B: per source j over its outgoing messages j -> i (i runs over row j: the adjacency is symmetric).  Row j stores i -> j;
 // the coefficients of j -> i were left at this row's own slots by pass A:
 //   dk_j = sum_i ds q_i,  dv_j = sum_i ad g_i,  dWe = sum_edges (dk + dv terms) [angle, dist]
 template <int LPN>
-__global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float* __restrict__ g, float* __restrict__ gproj,
+__global__ __launch_bounds__(256) QT_ATTN_WAVES_S void k_attn_bwd_source(AttnArgs a, const float* __restrict__ g, float* __restrict__ gproj,
                                                          float* __restrict__ part) {
     __shared__ float sm[4 * LPN * 2 * 4];
     const int hd = head_setup(a);
     g += (hd % a.gmod) * a.hs_g;
     gproj += hd * a.hs;
-    const int lj = threadIdx.x % LPN, j0 = lj * 4;
+    const uint32_t lj = threadIdx.x % LPN, j0 = lj * 4, ld = a.ld, ldg = a.ld_g;
     const int N = qt_rows(a.n_dev, a.Ncap);
     float acc[2][4];
 #pragma unroll
@@ -315,43 +323,41 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
     const bool split = gridDim.x >= 8;                      // (a handful of workgroups: plain sweep)
     const int xcd = split ? blockIdx.x & 7 : 0, wg = split ? blockIdx.x >> 3 : blockIdx.x;
     const int nwg = split ? (gridDim.x + 7 - xcd) >> 3 : gridDim.x;
-    const int64_t per = split ? ((int64_t)N + 7) >> 3 : N;
-    const int64_t jlo = xcd * per, jhi = jlo + per < N ? jlo + per : N;
-    const int64_t stride = (int64_t)nwg * (256 / LPN);
-    for (int64_t j = jlo + (int64_t)wg * (256 / LPN) + threadIdx.x / LPN; j < jhi; j += stride) {
+    const int per = split ? (N + 7) >> 3 : N;
+    const int jlo = xcd * per, jhi = jlo + per < N ? jlo + per : N;
+    const int stride = nwg * (256 / LPN);
+    for (int j = jlo + wg * (256 / LPN) + (int)threadIdx.x / LPN; j < jhi; j += stride) {
         F4 dk = {{0, 0, 0, 0}}, dv = {{0, 0, 0, 0}};
         const int e0 = a.rowptr[j], e1 = a.rowptr[j + 1];
         const int extra = (a.selfloop && a.selfloop[j] > 0.0f) ? 1 : 0;
         const int eend = e1 + extra;
-        for (int eb = e0; eb < eend; eb += 4) {
-            int ii[4];
-            F4 qq[4], gg[4];
-            float2 cf[4];
-            float ea[4], ed[4];
+        for (int eb = e0; eb < eend; eb += EPT) {
+            int ii[EPT];
+            F4 qq[EPT], gg[EPT];
+            float2 cf[EPT], ea[EPT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < EPT; ++u) {
                 const int e = eb + u;
-                ii[u] = e < e1 ? a.col[e] : (e < eend ? (int)j : -1);
+                ii[u] = e < e1 ? a.col[e] : (e < eend ? j : -1);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < EPT; ++u)
                 if (ii[u] >= 0) {
-                    const int i = ii[u], e = eb + u;
-                    const int64_t slot = e < e1 ? e : (int64_t)a.E + j;
-                    qq[u] = ld4(a.proj + (int64_t)i * a.ld + j0);
-                    gg[u] = ld4(g + (int64_t)i * a.ld_g + j0);
+                    const int e = eb + u;
+                    const uint32_t slot = e < e1 ? e : a.E + j;
+                    qq[u] = ld4(a.proj + ((uint32_t)ii[u] * ld + j0));
+                    gg[u] = ld4(g + ((uint32_t)ii[u] * ldg + j0));
                     cf[u] = *reinterpret_cast<const float2*>(a.coef + 2 * slot);
-                    ea[u] = e < e1 ? a.eattr[2 * e] : 0.0f;
-                    ed[u] = e < e1 ? a.eattr[2 * e + 1] : 0.0f;
+                    ea[u] = e < e1 ? *reinterpret_cast<const float2*>(a.eattr + 2 * (uint32_t)e) : make_float2(0.0f, 0.0f);
                 }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < EPT; ++u) {
                 if (ii[u] < 0) break;
                 float ang = 0.0f, dst = 0.0f;
                 if (ii[u] != j) {                        // row j holds the attributes of i -> j: same distance, opposite direction
-                    ang = ea[u] + 0.5f;
+                    ang = ea[u].x + 0.5f;
                     if (ang >= 1.0f) ang -= 1.0f;
-                    dst = ed[u];
+                    dst = ea[u].y;
                 }
                 const float ds = cf[u].x, ad = cf[u].y;
 #pragma unroll
@@ -364,9 +370,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd_source(AttnArgs a, const float
                 }
             }
         }
-        float* gp = gproj + j * a.ld;
-        st4(gp + a.ps + j0, dk);
-        st4(gp + 2 * a.ps + j0, dv);
+        const uint32_t oj = (uint32_t)j * ld + j0;
+        st4(gproj + a.ps + oj, dk);
+        st4(gproj + 2 * a.ps + oj, dv);
     }
     // block reduction of the We partials (same scheme as the LSTM parameter gradients): [2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -467,7 +473,7 @@ extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const floa
                            const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
                            float keep, uint32_t seed, const uint32_t* seed_dev, float* out, float* stats, int G, int ld_o, int64_t ps, int64_t hs,
                            int64_t hs_o, void* stream) {
-    QT_ARG(rowptr && col && xy && proj && We && out && stats, "null pointer");
+    QT_ARG(rowptr && col && eattr && proj && We && out && stats, "null pointer");
     if (G <= 0) G = 1;
     if (ps == 0) ps = C;
     if (hs == 0) hs = 4 * C;
@@ -475,6 +481,7 @@ extern "C" int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const floa
     if (ld_o == 0) ld_o = G * C;
     QT_ARG(c_ok(C) && ld >= C && ld % 4 == 0 && c_real >= 1 && c_real <= C, "bad channel count / row stride");
     QT_ARG(G <= 64 && ld_o >= C && ld_o % 4 == 0 && ps % 4 == 0 && hs % 4 == 0 && hs_o % 4 == 0, "bad head count / strides");
+    QT_ARG((int64_t)N * ld < (1ll << 31) && (int64_t)N * ld_o < (1ll << 31), "a head's rows must span fewer than 2^31 floats");
     if (N <= 0) return QT_OK;
     AttnArgs a;
     fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
@@ -504,15 +511,21 @@ extern "C" int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const floa
     QT_ARG(G <= 64 && gmod <= G && ld_g >= C && ld_g % 4 == 0 && ((uintptr_t)g & 15) == 0 && ps % 4 == 0 && hs % 4 == 0 && hs_g % 4 == 0 &&
            ld_o >= C && ld_o % 4 == 0 && hs_o % 4 == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)coef & 7) == 0 && E >= 0,
            "bad head count / strides / alignment");
+    QT_ARG((int64_t)N * ld < (1ll << 31) && (int64_t)N * ld_o < (1ll << 31) && (int64_t)N * ld_g < (1ll << 31) && (int64_t)E + N < (1ll << 30),
+           "a head's rows must span fewer than 2^31 floats");
     if (N <= 0) return QT_OK;
     AttnArgs a;
     fill_args(&a, rowptr, col, xy, eattr, selfloop, proj, ld, We, C, c_real, N, n_dev, keep, seed, seed_dev);
     a.ld_g = ld_g; a.accumulate = accumulate; a.rev = rev; a.coef = coef; a.E = E; a.ld_o = ld_o; a.gmod = gmod;
     a.ps = ps; a.hs = hs; a.hs_o = hs_o; a.hs_g = hs_g;
     const int grid = (qt_cdiv((int64_t)N * (C / 4), QT_ATTN_BS) + 7) & ~7;
+#if !defined(QT_EXP_ATTN_ONLY) || QT_EXP_ATTN_ONLY == 1       // (diagnostics builds time one pass alone)
     QT_ATTN_DISPATCH_BS(C, k_attn_bwd_target, dim3(grid, G), QT_ATTN_BS, stream, a, g, stats, out, gproj);
+#endif
     const int gridB = qt_attn_blocks(N, C);
+#if !defined(QT_EXP_ATTN_ONLY) || QT_EXP_ATTN_ONLY == 2
     QT_ATTN_DISPATCH(C, k_attn_bwd_source, dim3(gridB, G), stream, a, g, gproj, part);
+#endif
     QT_LAUNCHED();
     return QT_OK;
 }
