@@ -136,7 +136,10 @@ class Decoder(nn.Module):
             return self._pack_planned(in_pad)
         ln = _ln_params(self.norm_h, self.norm_c)
         series = hasattr(self.fc_out1, 'packed')
-        return dict(ln_o=_ln_params(self.norm_o), acc_o=ops.GradAcc(),
+        heads = None
+        if hasattr(type(self.fc_out1), 'pack_many'):        # attention head: both convolutions packed once per pass, not per step
+            heads = type(self.fc_out1).pack_many([self.fc_out1, self.fc_out2])
+        return dict(ln_o=_ln_params(self.norm_o), acc_o=ops.GradAcc(), heads=heads,
                     rnns=[r.pack(in_pad if i == 0 else None, ln, (True,))[0] for i, r in enumerate(self.rnns)],
                     fc1=self.fc_out1.packed(self.head_width, self.hidden_size) if series else None, acc1=ops.GradAcc(),
                     fc2=self.fc_out2.packed(self.hidden_size, 4) if series else None, acc2=ops.GradAcc())
@@ -212,7 +215,8 @@ class Decoder(nn.Module):
         if drop is None and self.training and self.dropout.p > 0:
             drop = self.dropout_masks(1, z[0].shape[0], z[0].device)[0]
         if pk['fc1'] is None:           # attention head (TransformerConv): activations as plain tensor ops
-            y = self.fc_out2(torch.relu(self.fc_out1(torch.cat(z, dim=1), mesh)), mesh)
+            p1, p2 = pk.get('heads') or (None, None)
+            y = self.fc_out2(torch.relu(self.fc_out1(torch.cat(z, dim=1), mesh, packed=p1)), mesh, packed=p2)
             y = torch.tanh(y if drop is None else y * drop.unsqueeze(1)) + X[:, :1]
             return (torch.sigmoid(y) if self.binary else y), hs, cs
         z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'])
