@@ -347,7 +347,7 @@ int qt_act_bwd(const float* gY, const float* Y, const float* res, int res_stride
  */
 int qt_attn_blocks(int N, int C);
 /* eattr (E, 2): [angle, dist] of the message col[e] -> row(e) for every stored edge, computed once per mesh by
- * qt_attn_edge_attrs and passed to qt_attn_fwd / _bwd (NULL there: recomputed from xy inside the edge loops, slower). */
+ * qt_attn_edge_attrs and passed to qt_attn_fwd / _bwd (required there; xy is kept in their signatures and unused). */
 int qt_attn_edge_attrs(const int32_t* rowptr, const int32_t* col, const float* xy, int N, const int32_t* n_dev,
                        float* eattr, int32_t* rev /* optional (E): position of the transposed entry */, void* stream);
 int qt_attn_fwd(const int32_t* rowptr, const int32_t* col, const float* xy, const float* eattr, const float* selfloop,
