@@ -4,6 +4,7 @@
 cfg3: Moving-MNIST-like 128x128, 2 digits, in=10/out=20, 8 clips per GPU (the per-GPU share of the 8-GPU config).
 cfg4: ice-like 128x128 patches, 5 channels, in=12/out=6, 16 clips, land mask, transform_func, hidden 32, 1 layer, 3 conv layers.
 cfg4t: cfg4 with convolution_type='TransformerConv' (what ice_exp.py hard-codes).
+cfg4tp: cfg4t on the pixelwise mesh (thresh=-inf: what ice_exp.py:145 really runs -- no quadtree, one node per unmasked pixel).
 """
 import json, os, sys, time
 ROOT = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,8 +26,10 @@ if cfg == 'cfg3':
 else:
     B, t_in, t_out, shape = 16, 12, 6, (128, 128)
     kw, thresh, feat = dict(hidden_size=32, dropout=0.1, n_layers=1, n_conv_layers=3), 0.15, 5
-    if cfg == 'cfg4t':
+    if cfg in ('cfg4t', 'cfg4tp'):
         kw['convolution_type'] = 'TransformerConv'
+    if cfg == 'cfg4tp':
+        thresh = -np.inf
     tf = lambda a: abs(abs(a - 0.5) - 0.5)
     mask = synthetic.make_ice_like(40, shape=shape, channels=5, n_frames=2)[1]
     def batch(i):
