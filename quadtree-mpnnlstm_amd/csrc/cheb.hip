@@ -1201,8 +1201,11 @@ struct DgradCellArgs {
 #ifndef QT_DGRAD_BG
 #define QT_DGRAD_BG 1
 #endif
+#ifndef QT_DGRAD_OCC
+#define QT_DGRAD_OCC 4      // 128 VGPRs (8-10 spilled): FOUR workgroups per CU = all 940 tiles of the bench shape resident at once
+#endif                    // (3: 138-155 VGPRs, 768 resident + a second round; 8.41 -> 8.34 ms per frozen step)
 template <int NT, int LPN, bool BG = (QT_DGRAD_BG != 0)>
-__global__ __launch_bounds__(256, BG ? 3 : 2) void k_dgrad_cell(DgradCellArgs g) {
+__global__ __launch_bounds__(256, BG ? QT_DGRAD_OCC : 2) void k_dgrad_cell(DgradCellArgs g) {
     using namespace qtcell;
     constexpr int BNT = 32 * NT, K = 16 * LPN, PITCH = K + 4, RP = 256 / LPN;
     __shared__ __attribute__((aligned(16))) float Bt[BG ? 4 : BNT * PITCH];
