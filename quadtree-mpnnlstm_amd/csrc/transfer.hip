@@ -251,67 +251,70 @@ __global__ __launch_bounds__(256) void k_pool_targets(PoolArgs a, LossSeg sg, in
 // source-row gathers and the output stores move whole rows and consecutive threads write consecutive memory.  (The tile
 // kernel above touches 16 bytes of every row per workgroup and has only B * tiles workgroups of pixel-serial work:
 // 39 us for 68 channels at 64x64x32, against a ~16 us stream.)  Masked pixels inside a cell carry another label.
-template <int VEC>
 #ifndef QT_NODES_BS
 #define QT_NODES_BS 256
 #endif
+#ifndef QT_POOL_CPT
+#define QT_POOL_CPT 1      // row chunks per thread
+#endif
+// thread = (node, group of CPT consecutive VEC-float chunks of its row), group fastest.  One chunk per thread is the fastest:
+// at the bench shape (68 channels, forward / backward transfer) 23.2 / 36.8 us with 1, 28.1 / 44.2 with 2, 37.1 / 66.6 with 4 --
+// the waves that hold a 2x2 / 4x4 node set the launch time, and more chunks per thread lengthen exactly those.
+template <int VEC, int CPT = (VEC == 4 ? QT_POOL_CPT : 1)>
 __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
     const int nch = a.C / VEC;
-    const int per = (a.src_labels ? 1 : a.S) * nch;
+    const int ngrp = (nch + CPT - 1) / CPT;
+    const int per = (a.src_labels ? 1 : a.S) * ngrp;
     // 32-bit thread index and division (pool_launch checks N * per < 2^31): the 64-bit division by a run-time value that
     // stood here is a ~100-instruction routine per thread
     const unsigned idx = blockIdx.x * QT_NODES_BS + threadIdx.x;
     const int64_t i = idx / (unsigned)per;
     if (i >= qt_rows(a.n_dev, a.N)) return;
     const int rem = (int)(idx - (unsigned)i * (unsigned)per);
-    const int s = rem / nch, ch = rem - s * nch;
+    const int s = rem / ngrp, ch0 = (rem - s * ngrp) * CPT;
+    Vec<VEC> acc[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[u].v[k] = 0.0f;
+    auto store_all = [&](float scale) {
+#pragma unroll
+        for (int u = 0; u < CPT; ++u)
+            if (ch0 + u < nch) vstore<VEC>(dst_chunk<VEC>(a, s, i, ch0 + u), acc[u], scale);
+    };
+    // the chunks of source row sl, scaled by 1 / its pixel count where the source holds sums, added into acc
+    auto add_row = [&](int64_t sl) {
+        Vec<VEC> x[CPT];
+#pragma unroll
+        for (int u = 0; u < CPT; ++u)
+            if (ch0 + u < nch) x[u] = vload<VEC>(src_chunk<VEC>(a, sl, ch0 + u));
+        const float sc = a.src_inv ? 1.0f / a.src_npix[sl] : 1.0f;
+#pragma unroll
+        for (int u = 0; u < CPT; ++u)
+            if (ch0 + u < nch)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[u].v[k] += x[u].v[k] * sc;
+    };
     if (a.direct) {
         // single-pixel destination node whose source node is known: index -> row, two dependent loads instead of the
         // cell -> pixel label -> row chain (and 4 bytes of index per thread instead of the 16-byte cell record: the index
         // traffic was as large as the payload).  Same arithmetic as the single-pixel branch below: bit-identical rows.
         const int d = a.direct[i];
         if (d >= 0) {
-            Vec<VEC> x = vload<VEC>(src_chunk<VEC>(a, d, ch));
-            if (a.src_inv) {
-                const float sc = 1.0f / a.src_npix[d];
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) x.v[k] *= sc;
-            }
-            vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), x, 1.0f);
+            add_row(d);
+            store_all(1.0f);
             return;
         }
     }
-#if defined(QT_EXP_POOL) && QT_EXP_POOL == 1
-    {   // diagnostics: identity source index, no cell / label loads -- the pure row copy
-        Vec<VEC> x0 = vload<VEC>(src_chunk<VEC>(a, i, ch));
-        vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), x0, 1.0f);
-        return;
-    }
-#elif defined(QT_EXP_POOL) && QT_EXP_POOL == 2
-    {   // diagnostics: one dependent index load (a direct per-node source index would look like this)
-        const int sl = a.src_labels[i];
-        Vec<VEC> x0 = vload<VEC>(src_chunk<VEC>(a, sl >= 0 ? sl : 0, ch));
-        vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), x0, 1.0f);
-        return;
-    }
-#endif
     const int4 cl = reinterpret_cast<const int4*>(a.cell)[i];
     if (cl.z > 4) return;
     const int64_t P = (int64_t)a.n * a.m, base = (int64_t)cl.w * P;
-    Vec<VEC> acc;
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) acc.v[k] = 0.0f;
     if (cl.z == 1 && a.src_labels) {
         // a single-pixel node (almost all of them on noisy frames) owns its pixel: straight-line code, no pixel loop, no
         // label check, and its pixel count is 1 (no npix load for the mean)
         const int sl = a.src_labels[base + (int64_t)cl.x * a.m + cl.y];
-        if (sl >= 0) {
-            const Vec<VEC> x = vload<VEC>(src_chunk<VEC>(a, sl, ch));
-            const float sc = a.src_inv ? 1.0f / a.src_npix[sl] : 1.0f;
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc.v[k] = x.v[k] * sc;
-        }
-        vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), acc, 1.0f);
+        if (sl >= 0) add_row(sl);
+        store_all(1.0f);
         return;
     }
     const float oscale = a.mean ? 1.0f / a.npix[i] : 1.0f;      // (requested before the pixel loop, not after it)
@@ -333,24 +336,30 @@ __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
                     sl[q] = own == (int)i ? s_ : -1;
                 }
             }
-            Vec<VEC> x[4];
+            Vec<VEC> x[4][CPT];
             float sc[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) x[q].v[k] = 0.0f;
+                for (int u = 0; u < CPT; ++u)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) x[q][u].v[k] = 0.0f;
                 sc[q] = 1.0f;
                 if (sl[q] >= 0) {
-                    x[q] = vload<VEC>(src_chunk<VEC>(a, sl[q], ch));
+#pragma unroll
+                    for (int u = 0; u < CPT; ++u)
+                        if (ch0 + u < nch) x[q][u] = vload<VEC>(src_chunk<VEC>(a, sl[q], ch0 + u));
                     if (a.src_inv) sc[q] = 1.0f / a.src_npix[sl[q]];
                 }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) acc.v[k] += x[q].v[k] * sc[q];
+                for (int u = 0; u < CPT; ++u)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[u].v[k] += x[q][u].v[k] * sc[q];
         }
-        vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), acc, oscale);
+        store_all(oscale);
         return;
     }
     for (int dr = 0; dr < cl.z; ++dr)
@@ -359,11 +368,15 @@ __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
             if (r >= a.n || c >= a.m) continue;
             const int64_t p = (int64_t)r * a.m + c;
             if (cl.z > 1 && a.labels[base + p] != (int)i) continue;      // (a single-pixel node owns its pixel)
-            const Vec<VEC> x = vload<VEC>(a.img + (int64_t)cl.w * a.img_clip_stride + ((int64_t)s * P + p) * a.C + ch * VEC);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc.v[k] += x.v[k];
+            for (int u = 0; u < CPT; ++u)
+                if (ch0 + u < nch) {
+                    const Vec<VEC> x = vload<VEC>(a.img + (int64_t)cl.w * a.img_clip_stride + ((int64_t)s * P + p) * a.C + (ch0 + u) * VEC);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[u].v[k] += x.v[k];
+                }
         }
-    vstore<VEC>(dst_chunk<VEC>(a, s, i, ch), acc, oscale);
+    store_all(oscale);
 }
 
 template <int VEC>
@@ -527,7 +540,8 @@ static int pool_launch(PoolArgs& a, bool v4, const int32_t* cell, const int32_t*
             qt_set_error("%s: N * channels too large for 32-bit thread indices", __func__);
             return QT_E_ARG;
         }
-        const int grid = qt_cdiv((int64_t)a.N * total, QT_NODES_BS);
+        const int cpt = v4 ? QT_POOL_CPT : 1, nch = v4 ? a.C / 4 : a.C;
+        const int grid = qt_cdiv((int64_t)a.N * (a.src_labels ? 1 : a.S) * ((nch + cpt - 1) / cpt), QT_NODES_BS);
         if (v4)
             hipLaunchKernelGGL(k_pool_nodes<4>, dim3(grid), dim3(QT_NODES_BS), 0, stream, a);
         else
