@@ -81,6 +81,13 @@ __device__ __forceinline__ void vstore(float* p, const Vec<VEC>& r, float scale)
     for (int k = 0; k < VEC; ++k) p[k] = r.v[k] * scale;
 }
 
+// (experiment switches: the node kernel takes nodes up to QT_NODE_MAX_Z pixels wide, the tile kernel those from level QT_TILE_MIN_LV)
+#ifndef QT_TILE_MIN_LV
+#define QT_TILE_MIN_LV 3
+#endif
+#ifndef QT_NODE_MAX_Z
+#define QT_NODE_MAX_Z 4
+#endif
 template <int VEC>
 __device__ __forceinline__ void tile_body(const PoolArgs& a, int bx, int by, int ny, float* pyr) {
     const int t = threadIdx.x;
@@ -99,10 +106,11 @@ __device__ __forceinline__ void tile_body(const PoolArgs& a, int bx, int by, int
     // big-only mode: a node of 8x8 pixels or more covers whole 4x4 blocks, so the block's first pixel tells whether any
     // of its 16 pixels is this kernel's business
     bool mine = true;
-    if (a.big_only) {
+    if (a.big_only && QT_TILE_MIN_LV >= 3) {
         const int r = R0 + 4 * br, c = C0 + 4 * bc;
         mine = r < a.n && c < a.m && lvl_img[(int64_t)r * a.m + c] >= 3;
     }
+    bool any_mine_t = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -118,15 +126,20 @@ __device__ __forceinline__ void tile_body(const PoolArgs& a, int bx, int by, int
                 const unsigned lv = lvl_img[p];
                 lv_pack[i] |= lv << (8 * j);
                 big |= (lv >= 3);
-                if (a.src_labels && (!a.big_only || lv >= 3)) {
+                any_mine_t |= (lv >= QT_TILE_MIN_LV);
+                if (a.src_labels && (!a.big_only || lv >= QT_TILE_MIN_LV)) {
                     slab[q] = a.src_labels[b * P + p];
                     if (a.src_inv && slab[q] >= 0) sscale[q] = 1.0f / a.src_npix[slab[q]];
                 }
-                if (a.big_only && lv < 3) lab[q] = -1;       // not this kernel's pixel: no load, no store
+                if (a.big_only && lv < QT_TILE_MIN_LV) lab[q] = -1;       // not this kernel's pixel: no load, no store
             }
         }
     const bool any_big = __syncthreads_or(big ? 1 : 0) != 0;
-    if (a.big_only && !any_big) return;
+    if (QT_TILE_MIN_LV >= 3) {
+        if (a.big_only && !any_big) return;
+    } else if (a.big_only && __syncthreads_or(any_mine_t ? 1 : 0) == 0) {
+        return;
+    }
 
     const int nch = a.C / VEC;
     const int total = (a.src_labels ? 1 : a.S) * nch;
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
         }
     }
     const int4 cl = reinterpret_cast<const int4*>(a.cell)[i];
-    if (cl.z > 4) return;
+    if (cl.z > QT_NODE_MAX_Z) return;
     const int64_t P = (int64_t)a.n * a.m, base = (int64_t)cl.w * P;
     if (cl.z == 1 && a.src_labels) {
         // a single-pixel node (almost all of them on noisy frames) owns its pixel: straight-line code, no pixel loop, no
