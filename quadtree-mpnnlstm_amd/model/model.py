@@ -276,7 +276,8 @@ class GConvLSTM(nn.Module):
         """One PackedCell per requested variant (with_h True / False); the variants share the peephole / bias
         tensors and their gradient accumulator.  W: ((K*C + Ks_padded), 4h) for Z = [X (padded to in_pad) | H]."""
         h = self.out_channels
-        if not self.is_series:          # attention convolutions are nonlinear: the eight stacks run one after another
+        if not self.is_series:          # attention convolutions are nonlinear: no weight-space composition; TransformerConv stacks run
+                                        # layer by layer (_pack_multi), other kinds one convolution after another
             wc = torch.cat([self.w_c_i, self.w_c_f, self.w_c_o], dim=0)
             b = torch.cat([self.b_i, self.b_f, self.b_c, self.b_o], dim=0)
             acc_p = ops.GradAcc()
