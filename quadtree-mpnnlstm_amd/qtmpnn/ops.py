@@ -736,9 +736,9 @@ class _MultiConv(Function):
     three launches instead of 2 G: the projections [q | k | v | skip] of all stacks go into ONE array P (qt_proj_group, one
     launch per input segment), the edge softmax of the G heads is one launch (qt_attn_fwd, G heads).
 
-    P is (G, 4, N, C): one dense (N, C) plane per head and block, so the k / v rows the edge loop gathers are whole 128-byte
-    lines of contiguous arrays (rows of one (N, G 4C) matrix sit 4 KB apart: every gather of a head then hits the same
-    few L2 channels).
+    P is (G, 4, N, C): one dense (N, C) plane per head and block -- the layout the GEMMs write and read as planes, with gathered
+    k / v rows that are whole 128-byte lines (measured against rows side by side in one (N, G 4C) matrix: the same 224 us per
+    8-head forward launch, so the layout is a convenience, not a speed-up).
     segments: [(A_s, W_s (Gin_s, Cin_s + 4, Co_s))]: group g of segment s multiplies A_s (N, Cin_s) (Gin_s = 1) or A_s[g] of
     (Gin_s, N, Cin_s) with W_s[g] (bias in row Cin_s) and fills the next Co_s / C planes of P.  Layer 0 of a cell has the segments
     (X, Wx (1, ., 4 4C)) and (H, Wh (1, ., 4 4C)), deeper layers one segment (previous layer's output (8, N, C), W (8, C + 4, 4C)).
@@ -870,7 +870,8 @@ def _wgrad_groups(uses, s, seg, C, W):
 
 
 def multi_conv(segments, We, mesh, c_real, dropout_p=0.0, training=False, acc=None, gmod=0):
-    """segments: [(A, W)] as in _MultiConv; We (G, C, 2).  Returns (N, G C), or (N, gmod C) summed over the head groups."""
+    """segments: [(A, W)] as in _MultiConv; We (G, C, 2).  Returns (G, N, C), or with gmod < G the rows (N, G / gmod, gmod C)
+    whose head groups the consumer adds (ops.lstm_cell does, inside its kernel)."""
     keep = 1.0 - dropout_p if (training and dropout_p > 0) else 1.0
     _ATTN_CALLS[0] += 1
     seed = (_ATTN_CALLS[0] * 2654435761 + int(torch.initial_seed())) & 0xFFFFFFFF
