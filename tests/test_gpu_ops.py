@@ -436,6 +436,33 @@ def test_multi_head_attention_equals_separate_calls():
         assert torch.equal(w1, w_pl[h * 2 * C:(h + 1) * 2 * C]), h
 
 
+def test_multi_head_attention_dropout_draws_one_mask_per_head():
+    """Heads of one launch must not share their attention-dropout mask (the reference's convolutions draw independently): with
+    identical operands in every head the outputs agree without dropout and differ with it, and forward and backward use the
+    same mask (the gradient of sum(out) w.r.t. v is the dropped attention weight: zero exactly where the forward dropped)."""
+    from qtmpnn import ops, synthetic
+    from qtmpnn.mesh import build_mesh
+    c = synthetic.make_clip(11, canvas=(64, 64), n_digits=2, n_frames=1, pixel_noise=0.0)
+    mesh = build_mesh(src=torch.from_numpy(c[..., 0]).to(dev()), thresh=0.1)
+    N, G, C = mesh.N, 4, 8
+    torch.manual_seed(6)
+    one = torch.randn(N, 4 * C, device=dev())
+    proj = one.repeat(1, G).requires_grad_(True)                      # rows side by side: every head sees the same q | k | v | skip
+    We = torch.randn(C, 2, device=dev()).expand(G, C, 2).contiguous()
+    out0 = ops.attention(proj, We, mesh, C, 0.0, False, heads=G).view(N, G, C)
+    for h in range(1, G):
+        assert torch.equal(out0[:, h], out0[:, 0])
+    out1 = ops.attention(proj, We, mesh, C, 0.5, True, heads=G).view(N, G, C)
+    assert all(not torch.equal(out1[:, h], out1[:, 0]) for h in range(1, G))
+    # keep rate: mean attention mass that survives, x 1 / keep, stays near 1 (sum over edges of alpha d = 1 in expectation)
+    ones_v = proj.detach().clone().view(N, G, 4, C)
+    ones_v[:, :, 2] = 1.0                                             # v = 1, no edge term in the value: out - skip = sum alpha d
+    zero_e = torch.zeros(G, C, 2, device=dev())
+    o = ops.attention(ones_v.view(N, G * 4 * C), zero_e, mesh, C, 0.5, True, heads=G).view(N, G, C)
+    mass = (o - ones_v[:, :, 3])[..., 0]                              # (N, G)
+    assert abs(float(mass.mean()) - 1.0) < 0.05, float(mass.mean())
+
+
 def test_proj_group_and_grouped_weight_gradient_equal_dense_calls():
     """qt_proj_group (G products in one launch, planes in / planes out) against G qt_dense2 calls, bit for bit; qt_wgrad_groups
     against the fp64 product."""

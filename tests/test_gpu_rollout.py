@@ -336,10 +336,11 @@ def test_homogeneous_mesh_rollout_golden():
     assert abs(float(loss2) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
 
 
-@pytest.mark.parametrize('cfg', ['cfg3_mnist128', 'cfg4_ice128', 'cfg5_ice256'])
+@pytest.mark.parametrize('cfg', ['cfg3_mnist128', 'cfg4_ice128', 'cfg4_ice128_transformer', 'cfg5_ice256'])
 def test_baseline_config_shapes_train(cfg):
-    """BASELINE.json configs[2..4] at their full image sizes (reduced batch): one eager training step must run, give a
-    finite loss and gradients for every used parameter, and the meshes must satisfy the size-independent invariants."""
+    """BASELINE.json configs[2..4] at their full image sizes (reduced batch; configs[3] also with the TransformerConv stacks
+    ice_exp.py:48 hard-codes): one eager training step must run, give a finite loss and gradients for every used parameter, and
+    the meshes must satisfy the size-independent invariants."""
     from model.mpnnlstm import NextFramePredictorS2S
     from qtmpnn import synthetic
     torch.manual_seed(0)
@@ -348,9 +349,11 @@ def test_baseline_config_shapes_train(cfg):
         x, y = synthetic.make_batch(3, 0, B, t_in, t_out, n_digits=2, pixel_noise=0.05, canvas=shape)
         mask, thresh, tf, feat = np.zeros(shape, dtype=bool), 0.1, None, 1
     else:
-        n = 128 if cfg == 'cfg4_ice128' else 256
+        n = 128 if cfg.startswith('cfg4_ice128') else 256
         B, t_in, t_out, shape = (2, 12, 6, (n, n)) if n == 128 else (1, 12, 12, (n, n))
         kw = dict(hidden_size=32, dropout=0.1, n_layers=1, n_conv_layers=3)
+        if cfg.endswith('transformer'):
+            kw['convolution_type'] = 'TransformerConv'
         clips = [synthetic.make_ice_like(40 + i, shape=shape, channels=5, n_frames=t_in + t_out) for i in range(B)]
         x = np.stack([c[0][:t_in] for c in clips])
         y = np.stack([c[0][t_in:, ..., :1] for c in clips])
