@@ -359,7 +359,7 @@ int qt_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* xy, cons
                 const float* proj, int ld, const float* We, int C, int c_real, int N, const int32_t* n_dev,
                 float keep, uint32_t seed, const uint32_t* seed_dev, const float* g, int ld_g /* row stride of g, 0 = C */,
                 const float* stats, const float* out /* the forward's output */, int ld_o, float* gproj, float* part,
-                int accumulate /* add into part */, const int32_t* rev, float* coef /* scratch (E + N, 2), see below */, int E,
+                int accumulate /* bit 0: add into part; bit 1: g already IS the skip block of gproj (not stored again) */, const int32_t* rev, float* coef /* scratch (E + N, 2), see below */, int E,
                 int G /* heads, 0 = 1 */, int gmod /* g holds gmod column blocks, head g reads block g % gmod; 0 = G */,
                 int64_t ps, int64_t hs, int64_t hs_g, int64_t hs_o /* 0 = C, 4C, C, C */, void* stream);
 /* Backward in two gather passes without atomics.  D_i = sum_e alpha_e t_e equals g_i . (out_i - skip_i) (the forward output is the

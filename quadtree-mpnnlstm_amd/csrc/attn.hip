@@ -301,7 +301,7 @@ __global__ __launch_bounds__(QT_ATTN_BS) QT_ATTN_WAVES_T void k_attn_bwd_target(
         }
     }
     st4(gproj + oi, dq);
-    st4(gproj + 3 * a.ps + oi, gi);          // skip branch: identity
+    if (!(a.accumulate & 2)) st4(gproj + 3 * a.ps + oi, gi);          // skip branch: identity (bit 1: g IS that block already)
 }
 
 // pass B: per source j over its outgoing messages j -> i (i runs over row j: the adjacency is symmetric).  Row j stores i -> j;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) QT_ATTN_WAVES_S void k_attn_bwd_source(AttnArg
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += sm[(w * LPN + (ch >> 2)) * 8 + k * 4 + (ch & 3)];
         float* pp = part + ((int64_t)blockIdx.x * gridDim.y + hd) * 2 * a.C + idx;     // (block, head)[k][channel]; the host transposes to (C, 2)
-        *pp = a.accumulate ? *pp + s : s;
+        *pp = (a.accumulate & 1) ? *pp + s : s;
     }
 }
 

@@ -731,6 +731,9 @@ def attention(proj, We, mesh, c_real, dropout_p=0.0, training=False, acc=None, h
     return _Attention.apply(proj, We, mesh, c_real, keep, seed, acc, heads, gmod)
 
 
+_STATS = {'skip_alias': 0}      # (how often a layer's gradient array was completed in place: tests look at it)
+
+
 class _MultiConv(Function):
     """One layer of the G attention-convolution stacks of a recurrent cell (model/model.py:394-424 with TransformerConv :51) in
     three launches instead of 2 G: the projections [q | k | v | skip] of all stacks go into ONE array P (qt_proj_group, one
@@ -797,9 +800,19 @@ class _MultiConv(Function):
             hs_g = C
         elif summed:
             g, ld_g, hs_g, gmod = _c(g.float()), G * C, C, G
-        else:
-            g, ld_g, hs_g = _c(g.float()), C, N * C
-        gP = torch.empty_like(P)
+        gP, alias = None, 0
+        if not summed:
+            # the next layer's backward writes this gradient straight into the skip block of a (G, 4, N, C) array (see the data
+            # gradient below): that array becomes gP -- the skip block's gradient IS g, nothing to store again
+            base = g._base if (g.dim() == 3 and N > 0 and g.dtype == P.dtype) else None
+            if (base is not None and base.shape == P.shape and base.dtype == P.dtype and base.is_contiguous()
+                    and g.data_ptr() == base.data_ptr() + 4 * 3 * N * C and g.stride() == (4 * N * C, C, 1)):
+                gP, alias, ld_g, hs_g = base, 2, C, 4 * N * C
+                _STATS['skip_alias'] += 1
+            else:
+                g, ld_g, hs_g = _c(g.float()), C, N * C
+        if gP is None:
+            gP = torch.empty_like(P)
         if acc is None:
             nblk = max(_lib.value('qt_attn_blocks', N, C), 1)
             part = P.new_empty(nblk, G * 2 * C) if N > 0 else P.new_zeros(nblk, G * 2 * C)
@@ -809,8 +822,8 @@ class _MultiConv(Function):
         if N > 0:
             _lib.call('qt_attn_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(xy), ptr(eattr), ptr(selfpair), ptr(P), C, ptr(We), C,
                       ctx.c_real, N, ptr(mesh.n_dev), ctx.keep, ctx.seed, ptr(ctx.epoch), ptr(g), ld_g, ptr(stats), ptr(out),
-                      G * C if summed else C, ptr(gP), ptr(part), 0 if acc is None else 1, ptr(rev), ptr(coef), rev.numel(), G, gmod,
-                      N * C, 4 * N * C, hs_g, C if summed else N * C)
+                      G * C if summed else C, ptr(gP), ptr(part), (0 if acc is None else 1) | alias, ptr(rev), ptr(coef), rev.numel(), G,
+                      gmod, N * C, 4 * N * C, hs_g, C if summed else N * C)
         else:
             gP.zero_()
         gAs = []
@@ -818,10 +831,18 @@ class _MultiConv(Function):
             if not ctx.needs_input_grad[7 + s]:
                 gAs.append(None)
                 continue
-            gA = A.new_empty(A.shape)
+            if gin > 1 and N > 0:
+                # the input is the previous layer's output (gin, N, cin): its gradient goes into block 3 of a fresh (gin, 4, N, cin)
+                # array, which that layer's backward then completes as ITS gP (see above)
+                nxt = A.new_empty(gin, 4, N, cin)
+                gA = nxt[:, 3]
+                go, gso = nxt.data_ptr() + 4 * 3 * N * cin, 4 * N * cin
+            else:
+                gA = A.new_empty(A.shape)
+                go, gso = ptr(gA), 0
             if N > 0:         # gA_g = gP_g W_g[:cin]^T: the forward weight's own rows are the transposed operand
                 _lib.call('qt_proj_group', gP.data_ptr() + 4 * hoff * 4 * N * C, C, (co // C) * N * C, co // C, C, None, None, ptr(W),
-                          (cin + 4) * co, gin, 1, cin, ptr(gA), cin, N * cin if gin > 1 else 0, N, ptr(mesh.n_dev))
+                          (cin + 4) * co, gin, 1, cin, go, cin, gso, N, ptr(mesh.n_dev))
             else:
                 gA.zero_()
             gAs.append(gA)

@@ -386,7 +386,11 @@ def test_transformer_cell_layerwise_launches_equal_per_convolution_path(keep_h):
             M._MULTI_CONV = old
         return [o.detach() for o in outs], grads
 
+    from qtmpnn import ops
+    hits = ops._STATS['skip_alias']
     (o1, g1), (o0, g0) = run(True), run(False)
+    # the two inner layers complete the gradient array the layer above started (its skip block is the incoming gradient)
+    assert ops._STATS['skip_alias'] - hits == 2
     for a, b, name in zip(o1, o0, ('O', 'Hn', 'Cn')):
         close(a, b, rtol=1e-5, atol=1e-6, msg=name)
     names = [n for n, t in (('gX', X), ('gH', H), ('gC', C)) if t is not None] + [k for k, _ in cell.named_parameters()]
