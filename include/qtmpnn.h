@@ -234,7 +234,8 @@ int qt_wgrad_groups(int nseg, const float* const* a0, const int* lda0, const flo
  * from attention convolutions (model/model.py:394-424, TransformerConv :51) run layer by layer: group g is stack g's projection
  * [q | k | v | skip].  Same arithmetic as G qt_dense2 calls. */
 int qt_proj_group(const float* A, int lda, int64_t gsA, int Ka, int Ca, const float* S, const float* W, const float* WT, int64_t gsW,
-                  int G, int Kb, int Cb, float* out, int ldo, int64_t gsO, int N, const int32_t* n_dev, void* stream);
+                  int G, int Kb, int Cb, float* out, int ldo, int64_t gsO, int reverse /* groups from the last to the first */, int N,
+                  const int32_t* n_dev, void* stream);
 /* out[j] = sum_i part[i*len + j], i < nblk */
 int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream);
 

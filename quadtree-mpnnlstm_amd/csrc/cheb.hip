@@ -316,7 +316,7 @@ struct GemmArgs {
     float *O, *Hn, *Cn, *gates;
     // grouped use (qt_proj_group): blockIdx.z = group; plane 0, the weight and the output of group z start gsA / gsB / gsO
     // floats after those of group z - 1.  ldo: row stride of the output plane (0 = Cb; a column block of a wider matrix)
-    int ldo;
+    int ldo, zrev;
     int64_t gsA, gsB, gsO;
 #ifdef QT_GEMM_TIMING
     long long* dbg;
@@ -393,12 +393,13 @@ __global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : QT_GEMM_OCC) void
     const int64_t rows = qt_rows(g.n_dev, g.M);      // g.M stays the plane stride (capacity)
     if (i0 >= rows) return;
     QT_STAMP(0);
-    if (blockIdx.z) {
-        g.A.a0 += blockIdx.z * g.gsA;
-        if (g.A.a_rest) g.A.a_rest += blockIdx.z * g.gsA;
-        if (g.B) g.B += blockIdx.z * g.gsB;
-        if (g.BT) g.BT += blockIdx.z * g.gsB;
-        g.out += blockIdx.z * g.gsO;
+    if (gridDim.z > 1) {
+        const int z = g.zrev ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z;     // (zrev: groups from the last to the first)
+        g.A.a0 += z * g.gsA;
+        if (g.A.a_rest) g.A.a_rest += z * g.gsA;
+        if (g.B) g.B += z * g.gsB;
+        if (g.BT) g.BT += z * g.gsB;
+        g.out += z * g.gsO;
     }
     const int nquad = g.K >> 2;
     build_quad_table(g.A, qptr, qstr, nquad);
@@ -1789,8 +1790,8 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
 // The eight GraphConv stacks of a GConvLSTM with attention convolutions (model/model.py:394-424) run layer by layer: group g
 // is stack g's projection [q | k | v | skip], read from and written to blocks of arrays shared by all stacks.
 extern "C" int qt_proj_group(const float* A, int lda, int64_t gsA, int Ka, int Ca, const float* S, const float* W, const float* WT,
-                             int64_t gsW, int G, int Kb, int Cb, float* out, int ldo, int64_t gsO, int N, const int32_t* n_dev,
-                             void* stream) {
+                             int64_t gsW, int G, int Kb, int Cb, float* out, int ldo, int64_t gsO, int reverse, int N,
+                             const int32_t* n_dev, void* stream) {
     QT_ARG((W || WT) && out && G >= 1 && G <= 65535 && Kb >= 1 && Cb >= 4 && Cb % 4 == 0 && Ka >= 1, "bad arguments");
     if (ldo == 0) ldo = Cb;
     QT_ARG(ldo >= Cb && ldo % 4 == 0 && gsA % 4 == 0 && gsW % 4 == 0 && gsO % 4 == 0, "strides must be multiples of 4 floats");
@@ -1803,6 +1804,7 @@ extern "C" int qt_proj_group(const float* A, int lda, int64_t gsA, int Ka, int C
     g.B = W; g.BT = WT; g.M = N; g.K = Ka * Ca + (S ? 4 : 0); g.NB = Kb * Cb;
     g.Kb = Kb; g.Cb = Cb; g.act = QT_ACT_NONE; g.out = out; g.n_dev = n_dev;
     g.ldo = ldo; g.gsA = gsA; g.gsB = gsW; g.gsO = gsO;
+    g.zrev = reverse != 0;
 #ifdef QT_GEMM_TIMING
     g.dbg = nullptr;
 #endif

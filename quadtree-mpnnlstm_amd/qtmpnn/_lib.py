@@ -59,7 +59,7 @@ _SIGNATURES = {
     'qt_lstm_bwd_dgrad': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     'qt_split_bf16': [_P, _L, _P, _P, _P],
     'qt_flat_adam': [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P],
-    'qt_proj_group': [_P, _I, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _P, _I, _L, _I, _P, _P],
+    'qt_proj_group': [_P, _I, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _P, _I, _L, _I, _I, _P, _P],
     'qt_wgrad_groups': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _I, _P, _P],
     'qt_num_cus': [],
     'qt_lstm_fused_blocks': [],

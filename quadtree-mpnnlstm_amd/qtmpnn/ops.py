@@ -766,7 +766,7 @@ class _MultiConv(Function):
             lda, gsa = (cin, N * cin) if gin > 1 else (_ld(A), 0)
             if N > 0:
                 _lib.call('qt_proj_group', ptr(A), lda, gsa, 1, cin, ptr(ones), ptr(W), None, kin * co, gin, co // C, C,
-                          P.data_ptr() + 4 * hoff * 4 * N * C, C, (co // C) * N * C, N, ptr(mesh.n_dev))
+                          P.data_ptr() + 4 * hoff * 4 * N * C, C, (co // C) * N * C, 0, N, ptr(mesh.n_dev))
             segs.append((hoff, gin, cin, co, lda, gsa))
             hoff += gin * co // (4 * C)
         assert hoff == G, (hoff, G)
@@ -842,7 +842,7 @@ class _MultiConv(Function):
                 go, gso = ptr(gA), 0
             if N > 0:         # gA_g = gP_g W_g[:cin]^T: the forward weight's own rows are the transposed operand
                 _lib.call('qt_proj_group', gP.data_ptr() + 4 * hoff * 4 * N * C, C, (co // C) * N * C, co // C, C, None, None, ptr(W),
-                          (cin + 4) * co, gin, 1, cin, go, cin, gso, N, ptr(mesh.n_dev))
+                          (cin + 4) * co, gin, 1, cin, go, cin, gso, 1, N, ptr(mesh.n_dev))       # (groups last to first: see csrc/attn.hip)
             else:
                 gA.zero_()
             gAs.append(gA)

@@ -481,7 +481,7 @@ def test_proj_group_and_grouped_weight_gradient_equal_dense_calls():
     ones = torch.zeros(N, 4, device=dev())
     ones[:, 0] = 1
     P = torch.empty(G, 4, N, C, device=dev())
-    _lib.call('qt_proj_group', ptr(A), cin, N * cin, 1, cin, ptr(ones), ptr(W), None, (cin + 4) * co, G, 4, C, ptr(P), C, 4 * N * C, N, None)
+    _lib.call('qt_proj_group', ptr(A), cin, N * cin, 1, cin, ptr(ones), ptr(W), None, (cin + 4) * co, G, 4, C, ptr(P), C, 4 * N * C, 0, N, None)
     for h in range(G):
         Y = torch.empty(N, co, device=dev())
         _lib.call('qt_dense2', ptr(A[h]), 0, None, None, 0, None, 1, cin, 0, ptr(W[h]), None, ptr(ones), 4, ptr(W[h][cin:]), 1, co, 0, N, None,
@@ -490,7 +490,7 @@ def test_proj_group_and_grouped_weight_gradient_equal_dense_calls():
     # data gradient: gA_g = gP_g W_g[:cin]^T from the planes of gP (the forward weight's rows are the transposed operand)
     gP = torch.randn_like(P)
     gA = torch.empty_like(A)
-    _lib.call('qt_proj_group', ptr(gP), C, 4 * N * C, 4, C, None, None, ptr(W), (cin + 4) * co, G, 1, cin, ptr(gA), cin, N * cin, N, None)
+    _lib.call('qt_proj_group', ptr(gP), C, 4 * N * C, 4, C, None, None, ptr(W), (cin + 4) * co, G, 1, cin, ptr(gA), cin, N * cin, 1, N, None)
     for h in range(G):
         ref = gP[h].permute(1, 0, 2).reshape(N, co).double() @ W[h][:cin].double().t()
         close(gA[h], ref.float(), rtol=1e-5, atol=1e-5, msg=f'dgrad {h}')
