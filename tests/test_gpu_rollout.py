@@ -474,6 +474,39 @@ def test_transformer_rollout_golden():
     _check_grads(model, g)
 
 
+def test_transformer_rollout_batched_equals_single_and_is_deterministic():
+    """TransformerConv stacks (the layer-by-layer multi-head launches): a batch of 3 identical clips reproduces the single-clip
+    reference trace clip by clip (the batched mesh is block diagonal: no head, group or clip may leak into another), with the
+    same loss and gradients; two runs give bit-identical losses and gradients (no atomics anywhere in the attention backward)."""
+    from model.mpnnlstm import masked_mse
+    from model.seq2seq import Seq2Seq
+    g = golden('transformer_rollout.npz')
+
+    def run(batch):
+        model = Seq2Seq(hidden_size=8, dropout=0.0, thresh=0.15, input_timesteps=2, input_features=6, output_timesteps=3,
+                        n_layers=1, n_conv_layers=2, transform_func=dist_from_05, convolution_type='TransformerConv')
+        load_state(model, g, 'w/')
+        model.to(dev()).eval()
+        x, y, concat = (torch.from_numpy(np.stack([g[k]] * batch)).to(dev()) for k in ('x', 'y', 'concat'))
+        outs, meshes = model(x, y, concat, teacher_forcing_ratio=0, mask=g['mask'])
+        loss = masked_mse(outs, meshes, y, g['mask'])
+        loss.backward()
+        return model, outs, meshes, loss
+
+    model, outs, meshes, loss = run(3)
+    for i, (o, ms) in enumerate(zip(outs, meshes)):
+        off = ms.node_off.cpu().numpy()
+        for c in range(3):
+            assert off[c + 1] - off[c] == g[f'out_{i}'].shape[0], f'mesh size of step {i}, clip {c}'
+            close(o[off[c]:off[c + 1]], g[f'out_{i}'], msg=f'step {i} clip {c}')
+    assert abs(float(loss.detach()) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    _check_grads(model, g)
+    model2, _, _, loss2 = run(3)
+    assert torch.equal(loss.detach(), loss2.detach())
+    for a, b in zip(model.parameters(), model2.parameters()):
+        assert (a.grad is None) == (b.grad is None) and (a.grad is None or torch.equal(a.grad, b.grad))
+
+
 def test_train_loop_with_graph_replay_matches_eager_loop():
     """NextFramePredictorS2S.train(use_graph=True): the reference's epoch loop with the step replayed as a hipGraph gives the
     eager loop's losses (one update per batch, learning-rate schedule included) on a tiny in-memory loader."""
