@@ -206,6 +206,14 @@ int qt_dense2(const float* a0, int lda0, const float* a_rest, const float* a0b, 
               const int32_t* n_dev, int act, const float* res, int res_stride, const float* drop, float* out, float* outb,
               void* stream);
 
+/* Data-gradient product as a split-bf16 GEMM (gradients only): out planes (Kb, N, Cb) [| outb (Kb, N, Cbb)] = A (N rows of K floats,
+ * row stride lda) @ B, B^T given as the two bf16 terms Whi + Wlo (Kb (Cb + Cbb), K) of qt_split_bf16 -- for the data gradient of
+ * Y = [T_0 .. | S] W that is the forward weight's own rows.  A is split on the fly; three bf16 MFMAs per product group, relative
+ * error ~2^-16.  K % 16 == 0.  Replaces qt_dense2 in the backward of model/model.py:394-424 where the fp32-MFMA rate bounds it
+ * (hidden 32: K = 128). */
+int qt_dense_sb(const float* A, int lda, int K, const void* Whi, const void* Wlo, int Kb, int Cb, int Cbb, int N, const int32_t* n_dev,
+                float* out, float* outb, void* stream);
+
 /* qt_wgrad: partial sums of [A planes | S]^T @ G over row blocks, then qt_colsum over the blocks.
  *   G (N, Co); part (nblk, Ka*Ca + Ks, Co) with nblk = qt_wgrad_blocks(N).  accumulate != 0 adds into part
  *   (each block owns its slab, so the sum over several uses of one weight keeps a fixed order).  */

@@ -377,7 +377,7 @@ template <int NT, int KWT, int CELL = 0>     // CELL: 0 = plain epilogue, else t
 #ifndef QT_GEMM_OCC
 #define QT_GEMM_OCC 4
 #endif
-__global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : QT_GEMM_OCC) void k_gemm_fwd(GemmArgs g) {   // 4 workgroups per CU: all N/128 blocks of the
+__global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : (NT == 3 ? 3 : QT_GEMM_OCC)) void k_gemm_fwd(GemmArgs g) {   // 4 workgroups per CU: all N/128 blocks of the
                                                                       // bench shape are resident at once (<= 128 registers)
     constexpr int BNT = 32 * NT;
     constexpr int PITCH = KWT + 4;      // == 4 (mod 64) floats: the 16 lanes of a ds_read_b128 group hit distinct banks
@@ -532,14 +532,15 @@ __global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : QT_GEMM_OCC) void
     // every thread write float4 pieces of output ROWS instead (4x fewer, 16-byte wide, row-contiguous stores).
     static_assert(BNT * PITCH >= BM * 64, "LDS staging tile does not fit in the W buffer");
 #pragma unroll
-    for (int h2 = 0; h2 < NT / 2; ++h2) {        // two 32-column MFMA tiles per pass
+    for (int h2 = 0; h2 < (NT + 1) / 2; ++h2) {        // two 32-column MFMA tiles per pass (the last pass of an odd NT: one)
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int nt = 2 * h2 + u;
+            if (nt < NT)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Cs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + u * 32 + l32] = acc[nt][r];
+                for (int r = 0; r < 16; ++r)
+                    Cs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + u * 32 + l32] = acc[nt][r];
         }
         __syncthreads();
         QT_STAMP(4);
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : QT_GEMM_OCC) void
             const int row = e >> 4, c4 = (e & 15) * 4;
             const int64_t i = i0 + row;
             const int j = j0 + h2 * 64 + c4;
-            if (i >= rows || j >= g.NB) continue;
+            if (i >= rows || j >= g.NB || h2 * 64 + c4 >= BNT) continue;
             float4 v = *reinterpret_cast<const float4*>(&Cs[row * 64 + c4]);
             if (g.act == QT_ACT_RELU) {
                 v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
@@ -942,6 +943,109 @@ __global__ __launch_bounds__(256) void k_gemm_fwd3(GemmArgs g) {
                 const float d = g.drop ? g.drop[i] : 1.0f, rs = g.res[i * g.res_stride];
                 v.x = tanhf(d * v.x) + rs; v.y = tanhf(d * v.y) + rs; v.z = tanhf(d * v.z) + rs; v.w = tanhf(d * v.w) + rs;
             }
+            const int ct = g.Cb + g.Cbb;
+            const int pl = j / ct, ch = j - pl * ct;
+            if (ch < g.Cb)
+                *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+            else
+                *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + i * g.Cbb + (ch - g.Cb)) = v;
+        }
+    }
+}
+
+// Data-gradient GEMM as a split-bf16 product (gradients only): out planes = A (N x K fp32 rows) @ B, with B^T given as two bf16
+// terms per element (Bhi + Blo ~ B, qt_split_bf16) and A split on the fly; three bf16 MFMAs per product group (lo.hi, hi.lo, hi.hi:
+// the dropped lo.lo term is 2^-16 of the product) at 16 k per 32-cycle instruction.  The fp32-MFMA form of this product runs at
+// 60 % of the fp32-MFMA peak for hidden 32 (K = 128): the matrix pipe, not memory, sets its time.
+template <int NT>
+__global__ __launch_bounds__(256, 4) void k_gemm_sb(GemmArgs g, const __bf16* __restrict__ Bhi, const __bf16* __restrict__ Blo) {
+    constexpr int KWT = 64, BNT = 32 * NT;
+    constexpr int PITCH = KWT + 8;          // bf16 elements; row pitch in bytes = 16 (mod 32): conflict-free ds_read_b128
+    constexpr int PLANE = BNT * PITCH;
+    constexpr int LDS_BYTES = 2 * PLANE * 2 > BM * 64 * 4 ? 2 * PLANE * 2 : BM * 64 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    __bf16* Bt = reinterpret_cast<__bf16*>(lds);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l32 = lane & 31, half = lane >> 5;
+    const int64_t i0 = (int64_t)blockIdx.x * BM;
+    const int j0 = blockIdx.y * BNT;
+    const int64_t rows = qt_rows(g.n_dev, g.M);
+    if (i0 >= rows) return;
+    const int64_t my_row = i0 + wave * 32 + l32;
+    const bool row_ok = my_row < rows;
+    const float* arow = g.A.a0 + my_row * g.A.lda0;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    for (int k0 = 0; k0 < g.K; k0 += KWT) {
+        const int kn = min(KWT, g.K - k0);           // multiple of 16 (checked by the host entry)
+        __syncthreads();
+        const int k8 = kn >> 3;
+        for (int e = t; e < BNT * k8; e += 256) {     // both bf16 planes of the weight chunk: straight 16-byte copies
+            const int c = e / k8, kq = e - c * k8;
+            u32x4 wh = {0u, 0u, 0u, 0u}, wl = wh;
+            if (j0 + c < g.NB) {
+                const int64_t o = (int64_t)(j0 + c) * g.K + k0 + 8 * kq;
+                wh = *reinterpret_cast<const u32x4*>(Bhi + o);
+                wl = *reinterpret_cast<const u32x4*>(Blo + o);
+            }
+            *reinterpret_cast<u32x4*>(&Bt[c * PITCH + 8 * kq]) = wh;
+            *reinterpret_cast<u32x4*>(&Bt[PLANE + c * PITCH + 8 * kq]) = wl;
+        }
+        __syncthreads();
+        const int nJ = kn >> 4;
+        auto ldk = [&](int J, int u) {              // quad u of this lane's eight k of step J
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_ok && J < nJ) r = gload4(arow + k0 + 16 * J + 8 * half + 4 * u);
+            return r;
+        };
+        float4 c0 = ldk(0, 0), c1 = ldk(0, 1), n0 = ldk(1, 0), n1 = ldk(1, 1);
+        for (int J = 0; J < nJ; ++J) {
+            const float av[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            c0 = n0; c1 = n1;
+            n0 = ldk(J + 2, 0);
+            n1 = ldk(J + 2, 1);
+            bf16x8 ah, al;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const __bf16 h = (__bf16)av[i];
+                ah[i] = h;
+                al[i] = (__bf16)(av[i] - (float)h);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int o = (nt * 32 + l32) * PITCH + 16 * J + 8 * half;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bt[o]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bt[PLANE + o]);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);     // small terms first
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    float* Cs = reinterpret_cast<float*>(lds);    // 128 rows x 64 columns per pass
+#pragma unroll
+    for (int h2 = 0; h2 < NT / 2; ++h2) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int nt = 2 * h2 + u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + u * 32 + l32] = acc[nt][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < BM * 16 / 256; ++u) {
+            const int e = t + 256 * u;
+            const int row = e >> 4, c4 = (e & 15) * 4;
+            const int64_t i = i0 + row;
+            const int j = j0 + h2 * 64 + c4;
+            if (i >= rows || j >= g.NB) continue;
+            const float4 v = *reinterpret_cast<const float4*>(&Cs[row * 64 + c4]);
             const int ct = g.Cb + g.Cbb;
             const int pl = j / ct, ch = j - pl * ct;
             if (ch < g.Cb)
@@ -1740,6 +1844,27 @@ extern "C" int qt_spmm(const int32_t* rowptr, const int32_t* col, const float* n
     return QT_OK;
 }
 
+// Tile width of a plain product by its output width: the fewest 32-column MFMA tiles over all column blocks (NB = 280: 3 blocks of
+// 3 tiles = 9 tiles instead of 3 x 4 = 12), ties to the wider block (A is re-read per block).
+static inline int gemm_nt(int NB) {
+    int best = 4, cost = qt_cdiv(NB, 128) * 4;
+    for (int nt = 3; nt >= 2; --nt) {
+        const int c = qt_cdiv(NB, 32 * nt) * nt;
+        if (c < cost) {
+            best = nt;
+            cost = c;
+        }
+    }
+    return NB <= 64 ? 2 : best;
+}
+static void launch_gemm_fwd(const GemmArgs& g, int N, int G, hipStream_t stream) {
+    switch (gemm_nt(g.NB)) {
+        case 2: hipLaunchKernelGGL((k_gemm_fwd<2, 128>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 64), G), dim3(256), 0, stream, g); break;
+        case 3: hipLaunchKernelGGL((k_gemm_fwd<3, 128>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 96), G), dim3(256), 0, stream, g); break;
+        default: hipLaunchKernelGGL((k_gemm_fwd<4, 64>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128), G), dim3(256), 0, stream, g); break;
+    }
+}
+
 extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb, int Ka,
                          int Ca, int Cab,
                          const float* W, const float* WT, const float* S, int Ks, const float* Ws, int Kb, int Cb, int Cbb, int N,
@@ -1771,10 +1896,7 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
         else
             hipLaunchKernelGGL((k_gemm_skinny<64>), dim3(qt_cdiv(N, 64), qt_cdiv(g.NB, 16), 1), dim3(256), 0, (hipStream_t)stream, g);
     } else if (exact_fp32) {
-        if (g.NB > 64)
-            hipLaunchKernelGGL((k_gemm_fwd<4, 64>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128), 1), dim3(256), 0, (hipStream_t)stream, g);
-        else
-            hipLaunchKernelGGL((k_gemm_fwd<2, 128>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 64), 1), dim3(256), 0, (hipStream_t)stream, g);
+        launch_gemm_fwd(g, N, 1, (hipStream_t)stream);
     } else {
         if (g.NB > 64)
             hipLaunchKernelGGL((k_gemm_fwd3<4, 64>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128), 1), dim3(256), 0, (hipStream_t)stream, g);
@@ -1808,10 +1930,27 @@ extern "C" int qt_proj_group(const float* A, int lda, int64_t gsA, int Ka, int C
 #ifdef QT_GEMM_TIMING
     g.dbg = nullptr;
 #endif
+    launch_gemm_fwd(g, N, G, (hipStream_t)stream);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_dense_sb(const float* A, int lda, int K, const void* Whi, const void* Wlo, int Kb, int Cb, int Cbb, int N,
+                           const int32_t* n_dev, float* out, float* outb, void* stream) {
+    QT_ARG(A && Whi && Wlo && out && Kb >= 1 && Cb >= 4 && Cb % 4 == 0 && Cbb >= 0 && Cbb % 4 == 0 && (Cbb == 0 || outb), "bad arguments");
+    if (lda == 0) lda = K;
+    QT_ARG(K >= 16 && K % 16 == 0 && lda >= K && lda % 4 == 0, "the reduction length must be a multiple of 16");
+    QT_ARG((((uintptr_t)A | (uintptr_t)Whi | (uintptr_t)Wlo | (uintptr_t)out | (uintptr_t)outb) & 15) == 0, "operands must be 16-byte aligned");
+    if (N <= 0) return QT_OK;
+    GemmArgs g = {};
+    g.A.a0 = A; g.A.lda0 = lda; g.A.N = N; g.A.Ka = 1; g.A.Ca = K;
+    g.M = N; g.K = K; g.NB = Kb * (Cb + Cbb); g.Kb = Kb; g.Cb = Cb; g.Cbb = Cbb; g.out = out; g.outb = outb; g.n_dev = n_dev;
     if (g.NB > 64)
-        hipLaunchKernelGGL((k_gemm_fwd<4, 64>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128), G), dim3(256), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL((k_gemm_sb<4>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128)), dim3(256), 0, (hipStream_t)stream, g, (const __bf16*)Whi,
+                           (const __bf16*)Wlo);
     else
-        hipLaunchKernelGGL((k_gemm_fwd<2, 128>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 64), G), dim3(256), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL((k_gemm_sb<2>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 64)), dim3(256), 0, (hipStream_t)stream, g, (const __bf16*)Whi,
+                           (const __bf16*)Wlo);
     QT_LAUNCHED();
     return QT_OK;
 }

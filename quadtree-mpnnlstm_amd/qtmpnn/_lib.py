@@ -61,6 +61,7 @@ _SIGNATURES = {
     'qt_flat_adam': [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P],
     'qt_proj_group': [_P, _I, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _P, _I, _L, _I, _I, _P, _P],
     'qt_wgrad_groups': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _I, _P, _P],
+    'qt_dense_sb': [_P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     'qt_num_cus': [],
     'qt_lstm_fused_blocks': [],
     'qt_lstm_bwd_fused': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P,

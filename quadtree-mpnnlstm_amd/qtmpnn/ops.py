@@ -315,10 +315,17 @@ def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, g
         else:
             Wb, skinny = _dgrad_weight(W, K, Cs, live, acc)
             gTs = [Zs[0].new_empty(K, N, c) for c in Cl]
-            _lib.call('qt_dense2', ptr(G), 0, None, None, 0, None, 1, Co, 0, ptr(Wb) if skinny else None,
-                      None if skinny else ptr(Wb), None, 0, None, K, Cl[0],
-                      Cl[1] if len(Cl) > 1 else 0, N, ptr(mesh.n_dev), ACT_NONE, None, 0, None, ptr(gTs[0]),
-                      ptr(gTs[1]) if len(Cl) > 1 else None)
+            split = Wb.__dict__.get('_qt_split') if hasattr(Wb, '__dict__') else None
+            if split is not None and Co >= 64 and Co % 16 == 0 and K * sum(Cl) >= 64:
+                # wide gate matrices (hidden 32: 128 columns in, K C >= 64 out): the fp32-MFMA rate bounds the exact product (narrow
+                # products are memory-bound and stay exact); split-bf16, gradients only
+                _lib.call('qt_dense_sb', ptr(G), 0, Co, ptr(split[0]), ptr(split[1]), K, Cl[0], Cl[1] if len(Cl) > 1 else 0, N,
+                          ptr(mesh.n_dev), ptr(gTs[0]), ptr(gTs[1]) if len(Cl) > 1 else None)
+            else:
+                _lib.call('qt_dense2', ptr(G), 0, None, None, 0, None, 1, Co, 0, ptr(Wb) if skinny else None,
+                          None if skinny else ptr(Wb), None, 0, None, K, Cl[0],
+                          Cl[1] if len(Cl) > 1 else 0, N, ptr(mesh.n_dev), ACT_NONE, None, 0, None, ptr(gTs[0]),
+                          ptr(gTs[1]) if len(Cl) > 1 else None)
         # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
         for k in range(K - 2, 0, -1):
             spmm2(mesh, [g[k + 1] for g in gTs], 2.0, [g[k] for g in gTs], 1.0,

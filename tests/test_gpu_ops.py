@@ -508,6 +508,33 @@ def test_proj_group_and_grouped_weight_gradient_equal_dense_calls():
         close(gW[h], ref.float(), rtol=1e-5, atol=1e-4, msg=f'wgrad {h}')
 
 
+@pytest.mark.parametrize('K,Cb,Cbb,Kb', [(128, 8, 32, 7), (64, 16, 0, 3), (128, 32, 0, 1)])
+def test_split_bf16_data_gradient_gemm(K, Cb, Cbb, Kb):
+    """qt_dense_sb (the data gradient of wide gate matrices as a split-bf16 product: gradients only) against the fp64 product:
+    relative error of the 2-term split, ~2^-16 per product, far inside the gradient tolerance (1e-4); planes in two parts, ragged
+    row count, device-side row count."""
+    from qtmpnn import _lib
+    from qtmpnn._lib import ptr
+    torch.manual_seed(8)
+    N, NB = 3001, Kb * (Cb + Cbb)
+    A = torch.randn(N + 50, K, device=dev())
+    Wt = torch.randn(NB, K, device=dev()) * 0.3                  # B^T: row j = the K coefficients of output column j
+    hi, lo = (torch.empty(NB, K, dtype=torch.bfloat16, device=dev()) for _ in range(2))
+    _lib.call('qt_split_bf16', ptr(Wt), Wt.numel(), ptr(hi), ptr(lo))
+    out = torch.full((Kb, N + 50, Cb), 7.0, device=dev())
+    outb = torch.full((Kb, N + 50, Cbb), 7.0, device=dev()) if Cbb else None
+    n_dev = torch.tensor([N], dtype=torch.int32, device=dev())
+    _lib.call('qt_dense_sb', ptr(A), 0, K, ptr(hi), ptr(lo), Kb, Cb, Cbb, N + 50, ptr(n_dev), ptr(out), ptr(outb))
+    ref = (A[:N].double() @ Wt.double().t()).view(N, Kb, Cb + Cbb).permute(1, 0, 2)
+    scale = float(ref.abs().max())
+    err = float((out[:, :N].double() - ref[..., :Cb]).abs().max()) / scale
+    assert err < 2e-5, err
+    assert bool((out[:, N:] == 7.0).all())                       # rows past the device-side count stay untouched
+    if Cbb:
+        errb = float((outb[:, :N].double() - ref[..., Cb:]).abs().max()) / scale
+        assert errb < 2e-5, errb
+
+
 def test_bf16x3_gemm_matches_fp32_gemm():
     """Opt-in bf16x3 GEMM (QT_GEMM_BF16X3=1; three bf16 terms per operand, six MFMAs per product group) must agree with
     the default exact-fp32 MFMA GEMM to fp32 rounding level.  Run in a child process: the switch is read once per process."""
