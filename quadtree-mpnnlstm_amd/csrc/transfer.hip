@@ -228,8 +228,11 @@ __device__ __forceinline__ void tile_body(const PoolArgs& a, int bx, int by, int
     }
 }
 
+#ifndef QT_POOL_OCC
+#define QT_POOL_OCC 1
+#endif
 template <int VEC>
-__global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
+__global__ __launch_bounds__(256, QT_POOL_OCC) void k_pool(PoolArgs a) {
     __shared__ float pyr[(256 + 64 + 16 + 4 + 1) * VEC];
     tile_body<VEC>(a, blockIdx.x, blockIdx.y, gridDim.y, pyr);
 }
