@@ -276,8 +276,46 @@ __global__ __launch_bounds__(256) void k_pool_targets(PoolArgs a, LossSeg sg, in
 // thread = (node, group of CPT consecutive VEC-float chunks of its row), group fastest.  One chunk per thread is the fastest:
 // at the bench shape (68 channels, forward / backward transfer) 23.2 / 36.8 us with 1, 28.1 / 44.2 with 2, 37.1 / 66.6 with 4 --
 // the waves that hold a 2x2 / 4x4 node set the launch time, and more chunks per thread lengthen exactly those.
+#ifndef QT_POOL_CPT_A
+#define QT_POOL_CPT_A 2    // row chunks per thread of the direct-copy role
+#endif
+// Direct-copy role of k_pool_nodes: destination nodes whose single source row is known (a.direct[i] >= 0: a single-pixel node of a
+// mesh -> mesh transfer) are a gathered row copy -- index -> CPTA chunks of the row in flight -> stores, no cell record, no pixel
+// loop.  They are nine tenths of a noisy frame's nodes; in their own workgroups they stream, instead of sharing waves with the few
+// 2x2 / 4x4 nodes whose pixel loops set the time of every wave they sit in.
+template <int VEC, int CPTA>
+__device__ __forceinline__ void pool_direct_role(const PoolArgs& a, unsigned bid) {
+    const int nch = a.C / VEC;
+    const int ngrp = (nch + CPTA - 1) / CPTA;
+    const unsigned idx = bid * QT_NODES_BS + threadIdx.x;
+    const int64_t i = idx / (unsigned)ngrp;
+    if (i >= qt_rows(a.n_dev, a.N)) return;
+    const int g0 = (int)(idx - (unsigned)i * (unsigned)ngrp);      // this thread's chunks: g0, g0 + ngrp, ... (consecutive lanes take
+    const int d = a.direct[i];                                      // consecutive chunks in every load instruction)
+    if (d < 0) return;
+    Vec<VEC> x[CPTA];
+#pragma unroll
+    for (int u = 0; u < CPTA; ++u)
+        if (g0 + u * ngrp < nch) x[u] = vload<VEC>(src_chunk<VEC>(a, d, g0 + u * ngrp));
+    const float sc = a.src_inv ? 1.0f / a.src_npix[d] : 1.0f;
+#pragma unroll
+    for (int u = 0; u < CPTA; ++u)
+        if (g0 + u * ngrp < nch) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) x[u].v[k] *= sc;
+            vstore<VEC>(dst_chunk<VEC>(a, 0, i, g0 + u * ngrp), x[u], 1.0f);
+        }
+}
+
 template <int VEC, int CPT = (VEC == 4 ? QT_POOL_CPT : 1)>
-__global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
+__global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a, int grid_b) {
+    // workgroups [0, grid_b): every node that is not a direct copy (started first: they hold the long pixel loops);
+    // workgroups [grid_b, ..): the direct copies (grid_b == gridDim.x: no direct index, everything goes the general way)
+    if ((int)blockIdx.x >= grid_b) {
+        pool_direct_role<VEC, (VEC == 4 ? QT_POOL_CPT_A : 1)>(a, blockIdx.x - grid_b);
+        return;
+    }
+    const bool split = grid_b < (int)gridDim.x;
     const int nch = a.C / VEC;
     const int ngrp = (nch + CPT - 1) / CPT;
     const int per = (a.src_labels ? 1 : a.S) * ngrp;
@@ -286,6 +324,7 @@ __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
     const unsigned idx = blockIdx.x * QT_NODES_BS + threadIdx.x;
     const int64_t i = idx / (unsigned)per;
     if (i >= qt_rows(a.n_dev, a.N)) return;
+    if (split && a.direct[i] >= 0) return;          // a direct copy: the other role's
     const int rem = (int)(idx - (unsigned)i * (unsigned)per);
     const int s = rem / ngrp, ch0 = (rem - s * ngrp) * CPT;
     Vec<VEC> acc[CPT];
@@ -340,18 +379,24 @@ __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
         // loads per pixel -- 12 phases for a 2x2 node, 48 for a 4x4 one -- and although such nodes are a few per cent of a
         // noisy frame's mesh, a quarter of the waves holds one: those waves were the tail that set the launch time.
         const int z = cl.z;                           // 2 or 4 (3 never occurs: cells are powers of two)
-        for (int dr = 0; dr < z; dr += (z == 2 ? 2 : 1)) {
-            int sl[4];
+        // the labels of ALL the node's pixels first (one memory phase), then the row gathers four at a time in pixel order: 1 + 1
+        // dependent phases for a 2x2 node, 1 + 4 for a 4x4 one (label and gather phases alternated before: 2 and 8)
+        int sl[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = cl.x + dr + (z == 2 ? (q >> 1) : 0), c = cl.y + (z == 2 ? (q & 1) : q);
-                sl[q] = -1;
+        for (int q = 0; q < 16; ++q) {
+            sl[q] = -1;
+            if (q < z * z) {
+                const int r = cl.x + (z == 2 ? (q >> 1) : (q >> 2)), c = cl.y + (z == 2 ? (q & 1) : (q & 3));
                 if (r < a.n && c < a.m) {
                     const int64_t p = base + (int64_t)r * a.m + c;
                     const int own = a.labels[p], s_ = a.src_labels[p];       // independent loads
                     sl[q] = own == (int)i ? s_ : -1;
                 }
             }
+        }
+#pragma unroll
+        for (int q0 = 0; q0 < 16; q0 += 4) {
+            if (q0 >= z * z) break;
             Vec<VEC> x[4][CPT];
             float sc[4];
 #pragma unroll
@@ -361,11 +406,11 @@ __global__ __launch_bounds__(QT_NODES_BS) void k_pool_nodes(PoolArgs a) {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) x[q][u].v[k] = 0.0f;
                 sc[q] = 1.0f;
-                if (sl[q] >= 0) {
+                if (sl[q0 + q] >= 0) {
 #pragma unroll
                     for (int u = 0; u < CPT; ++u)
-                        if (ch0 + u < nch) x[q][u] = vload<VEC>(src_chunk<VEC>(a, sl[q], ch0 + u));
-                    if (a.src_inv) sc[q] = 1.0f / a.src_npix[sl[q]];
+                        if (ch0 + u < nch) x[q][u] = vload<VEC>(src_chunk<VEC>(a, sl[q0 + q], ch0 + u));
+                    if (a.src_inv) sc[q] = 1.0f / a.src_npix[sl[q0 + q]];
                 }
             }
 #pragma unroll
@@ -557,11 +602,14 @@ static int pool_launch(PoolArgs& a, bool v4, const int32_t* cell, const int32_t*
             return QT_E_ARG;
         }
         const int cpt = v4 ? QT_POOL_CPT : 1, nch = v4 ? a.C / 4 : a.C;
-        const int grid = qt_cdiv((int64_t)a.N * (a.src_labels ? 1 : a.S) * ((nch + cpt - 1) / cpt), QT_NODES_BS);
+        const int grid_b = qt_cdiv((int64_t)a.N * (a.src_labels ? 1 : a.S) * ((nch + cpt - 1) / cpt), QT_NODES_BS);
+        static const bool no_split = getenv("QT_POOL_NO_SPLIT") != nullptr;        // (diagnostics)
+        const int cpta = v4 ? QT_POOL_CPT_A : 1;
+        const int grid_a = (a.direct && a.src_labels && !no_split) ? qt_cdiv((int64_t)a.N * ((nch + cpta - 1) / cpta), QT_NODES_BS) : 0;
         if (v4)
-            hipLaunchKernelGGL(k_pool_nodes<4>, dim3(grid), dim3(QT_NODES_BS), 0, stream, a);
+            hipLaunchKernelGGL(k_pool_nodes<4>, dim3(grid_b + grid_a), dim3(QT_NODES_BS), 0, stream, a, grid_b);
         else
-            hipLaunchKernelGGL(k_pool_nodes<1>, dim3(grid), dim3(QT_NODES_BS), 0, stream, a);
+            hipLaunchKernelGGL(k_pool_nodes<1>, dim3(grid_b + grid_a), dim3(QT_NODES_BS), 0, stream, a, grid_b);
         QT_LAUNCHED();
     }
     const int blocks = a.B * a.tiles_r * a.tiles_c;
