@@ -10,6 +10,13 @@ pixel noise 0.05, thresh 0.1, hidden 16, 2 layers, ChebConv K=3, dropout 0.1) ->
 Rank 0 prints ONE JSON line.  `roofline` is measured on the message-aggregate kernel (k_spmm) with HIP
 events around every launch of one extra, untimed training step; `cpu_baseline` times the CPU oracle
 (a port of the reference algorithm, one clip per optimizer step like the reference) on the host cores.
+
+Arithmetic: fp32 everywhere (fp32 MFMA for every GEMM, forward and backward) -- `dtype` "f32" means that.  The opt-in
+split-bf16 data gradient of the gate GEMM (ops.DGRAD_SPLIT_BF16) is NOT part of `value`; the same captured step is timed
+with it as well and reported beside the headline as `split_bf16_dgrad` (frozen model, same invocation).
+Order: frozen phase -> warm-up -> the timed window (`value`) -> `--repeats` further windows (median / spread) -> then, on
+rank 0 alone while the other ranks wait at a host-side store barrier (not inside an RCCL collective): the kernel probes on
+a freshly initialised model, the split-bf16 variant, the CPU baseline.
 """
 import argparse
 import json
@@ -40,6 +47,9 @@ def parse():
     ap.add_argument('--cpu-clips', type=int, default=10)
     ap.add_argument('--frozen-steps', type=int, default=10,
                     help='steps timed with the learning rate at 0 before training starts (frozen_ms_per_step; 0 = skip)')
+    ap.add_argument('--repeats', type=int, default=4,
+                    help='further timed windows of --steps steps after the one `value` comes from (median / spread; 0 = none)')
+    ap.add_argument('--no-split-variant', action='store_true', help='skip the split-bf16 data-gradient comparison')
     ap.add_argument('--eager', action='store_true', help='Python-driven launches instead of hipGraph replay')
     ap.add_argument('--host-inputs', action='store_true',
                     help='keep the batches in pinned host memory and copy them in every step (PCIe-inclusive rate; informational)')
@@ -125,7 +135,7 @@ def spmm_roofline(nfp, batch, mask, reps=10):
     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes over this same command (they cannot be collected
     # in-process); the newest committed record is quoted and named
     traffic = source = None
-    for name in ('r02_pmc_spmm.json', 'r01_pmc_spmm.json'):
+    for name in ('r03_pmc_spmm.json', 'r02_pmc_spmm.json', 'r01_pmc_spmm.json'):
         pmc = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pmc):
             traffic, source = json.load(open(pmc))['traffic_bytes_per_launch'], 'profiles/' + name
@@ -190,9 +200,12 @@ def gemm_mfma(nfp, batch, mask, reps=20):
            'launch_us': round(us, 2), 'achieved_tflops': round(tflops, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
            'frac': round(tflops / MFMA_F32_PEAK_TFLOPS, 3),
            'hbm_gbs': round(4.0 * nv * (Kt + 7 * h) / us / 1e3, 1)}
-    pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_gemm.json')
-    if os.path.exists(pmc):
-        rec['counters'] = {k: v for k, v in json.load(open(pmc)).items() if k in ('mfma_busy_frac', 'wave_stall_frac', 'source')}
+    for name in ('r03_pmc_gemm.json', 'r02_pmc_gemm.json'):
+        pmc = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(pmc):
+            rec['counters'] = {k: v for k, v in json.load(open(pmc)).items() if k in ('mfma_busy_frac', 'wave_stall_frac', 'source')}
+            rec['counters']['file'] = 'profiles/' + name
+            break
     return rec
 
 
@@ -250,7 +263,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from qtmpnn import synthetic
+    from qtmpnn import ops, synthetic
     from qtmpnn.dist import broadcast_parameters, init_from_env
 
     # QT_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box); the real runs use RCCL
@@ -258,6 +271,7 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     device = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(device)
+    assert not ops.DGRAD_SPLIT_BF16, 'the headline is the exact-fp32 step: unset QT_DGRAD_SPLIT_BF16'
     nfp = make_predictor(device, capturable=not args.eager)
     if world > 1:
         broadcast_parameters(nfp.model)
@@ -282,15 +296,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def set_lr(v):
-        g = nfp.optimizer.param_groups[0]
+    hb_count = [0]
+
+    def host_barrier(poll=0.05):
+        """All ranks meet through the rendezvous store, polling on the HOST: a rank that waits here for rank 0's seconds of
+        single-rank work sits in no RCCL collective (nothing for the watchdog to time, no GPU spin)."""
+        if world == 1:
+            return
+        store = dist.distributed_c10d._get_default_store()
+        hb_count[0] += 1
+        key = f'qt_bench_hb{hb_count[0]}'
+        store.add(key, 1)
+        while int(store.add(key, 0)) < world:
+            time.sleep(poll)
+
+    def set_lr(opt, v):
+        g = opt.param_groups[0]
         if torch.is_tensor(g['lr']):
             g['lr'].fill_(v)
         else:
             g['lr'] = v
 
-    def timed(n):
-        """n steps bracketed by barrier + synchronize on both sides; max over ranks of the wall time."""
+    def timed(step, n):
+        """n steps bracketed by barrier + synchronize on both sides; max over ranks of the wall time.  Also returns every
+        rank's own time to finish its n steps (before the closing barrier): load imbalance from data-dependent meshes."""
         barrier()
         t0 = time.perf_counter()
         for i in range(n):
@@ -298,62 +327,106 @@ def main():
                 loss = step(*(t.to(device, non_blocking=True) for t in host_pool[i % n_pool]))
             else:
                 loss = step(*pool[i % n_pool])
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0
+        per_rank = [own]
         if world > 1:
             tmax = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        return dt, loss
+            owns = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(owns, torch.tensor([own], device=device, dtype=torch.float64))
+            per_rank = [float(o.item()) for o in owns]
+        return dt, loss, per_rank
+
+    def frozen_ms(p, step, n):
+        """ms per step of `step` with the learning rate at 0 (three untimed steps first); Adam's state is zeroed afterwards."""
+        lr = float(os.environ.get('QT_BENCH_LR', LR))
+        set_lr(p.optimizer, 0.0)
+        for i in range(3):
+            step(*pool[i % n_pool])
+        dtf, _, _ = timed(step, n)
+        set_lr(p.optimizer, lr)
+        for st in p.optimizer.state.values():         # the frozen steps leave no trace in Adam's moments / step counts
+            for v in st.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+        return dtf / n * 1e3
 
     # Phase 0 (untimed for `value`): the same step with the learning rate at 0.  The decoder's meshes follow the model's own
     # output, so the trained number below moves with the training trajectory; the frozen one is comparable between builds.
-    lr = float(os.environ.get('QT_BENCH_LR', LR))
-    frozen = args.frozen_steps > 0
-    if frozen:
-        set_lr(0.0)
     if args.eager:
         step = lambda x, y, c: nfp.train_step(x, y, c, mask)
     else:
         # the whole step (forward, loss, backward, clip, Adam) as ONE hipGraph; its 2 eager warm-up steps run first
         step = nfp.make_graphed_step(*pool[0], mask=mask, warmup=2)
         log('training step captured into a hipGraph')
-    frozen_ms = None
-    if frozen:
-        for i in range(3):
-            step(*pool[i % n_pool])
-        dtf, _ = timed(args.frozen_steps)
-        frozen_ms = dtf / args.frozen_steps * 1e3
-        set_lr(lr)
-        for st in nfp.optimizer.state.values():         # the frozen steps leave no trace in Adam's moments / step counts
-            for v in st.values():
-                if torch.is_tensor(v):
-                    v.zero_()
-        log(f'frozen model (lr = 0): {frozen_ms:.3f} ms per step over {args.frozen_steps} steps')
-
-    # Kernel probes (rank 0 alone, collective-free; the other ranks wait at the next barrier).  They run on the model as
-    # initialised -- before any training step -- so the launch mix they time is the same in every build.
-    probes = {}
-    if rank == 0 and not args.no_roofline:
-        try:
-            probes['roofline'] = spmm_roofline(nfp, pool[0], mask)
-            m = gemm_mfma(nfp, pool[0], mask)
-            if m is not None:
-                probes['mfma'] = m
-        except Exception as e:                                            # pragma: no cover
-            probes.setdefault('roofline', {'error': repr(e)[:200]})
-        log('roofline probes done')
+    frozen = None
+    if args.frozen_steps > 0:
+        frozen = frozen_ms(nfp, step, args.frozen_steps)
+        log(f'frozen model (lr = 0): {frozen:.3f} ms per step over {args.frozen_steps} steps')
 
     for i in range(args.warmup):
         l = step(*pool[i % n_pool])
         if rank == 0:
             log(f'warm-up step {i}: loss {float(l):.5f}')
-    dt, loss = timed(args.steps)
+    dt, loss, per_rank = timed(step, args.steps)
     assert torch.isfinite(loss).item(), 'non-finite loss in the timed region'
+    final_loss = float(loss)
+    log(f'timed {args.steps} steps in {dt:.3f} s')
+    # further windows of the same length (training goes on, so they are not the same steps: the spread shows how much of a
+    # difference between two runs is the box / the trajectory and how much is the build)
+    windows = [dt / args.steps * 1e3]
+    for _ in range(max(args.repeats, 0)):
+        dtr, lr_, _ = timed(step, args.steps)
+        assert torch.isfinite(lr_).item(), 'non-finite loss in a repeat window'
+        windows.append(dtr / args.steps * 1e3)
+
+    # ---- single-rank work AFTER every timed window.  The other ranks wait on the host (store barrier), not in a collective.
+    probes = {}
+    if rank == 0:
+        if not args.no_roofline or (not args.no_split_variant and not args.eager):
+            del step
+            nfp._graph = None
+            fresh = make_predictor(device, capturable=False)      # the model as initialised: the same launch mix in every build
+            fresh.model.train()
+        if not args.no_roofline:
+            try:
+                probes['roofline'] = spmm_roofline(fresh, pool[0], mask)
+                m = gemm_mfma(fresh, pool[0], mask)
+                if m is not None:
+                    probes['mfma'] = m
+            except Exception as e:                                            # pragma: no cover
+                probes.setdefault('roofline', {'error': repr(e)[:200]})
+            log('roofline probes done')
+        if not args.no_split_variant and not args.eager and args.frozen_steps > 0 and world == 1:
+            # the same captured step with the opt-in split-bf16 data gradient (2-term bf16 split on the bf16 MFMA, fp32
+            # accumulate; gradients only): frozen model, same box, same invocation -- beside the exact-fp32 headline
+            try:
+                prev = ops.set_dgrad_split_bf16(True)
+                sp = make_predictor(device, capturable=True)
+                sp.model.train()
+                sstep = sp.make_graphed_step(*pool[0], mask=mask, warmup=2)
+                sf = frozen_ms(sp, sstep, args.frozen_steps)
+                probes['split_bf16_dgrad'] = {
+                    'frozen_ms_per_step': round(sf, 3), 'exact_fp32_frozen_ms_per_step': round(frozen, 3),
+                    'frozen_value': round(args.batch * (T_IN + T_OUT) / sf * 1e3, 1),
+                    'what': 'opt-in (QT_DGRAD_SPLIT_BF16=1): backward gate-GEMM data gradient as hi*hi + hi*lo + lo*hi on '
+                            'v_mfma_f32_32x32x16_bf16, fp32 accumulate; NOT part of `value`'}
+                del sstep, sp
+            except Exception as e:                                            # pragma: no cover
+                probes['split_bf16_dgrad'] = {'error': repr(e)[:200]}
+            finally:
+                ops.set_dgrad_split_bf16(prev)
+            log('split-bf16 variant timed')
+    host_barrier()
 
     if rank == 0:
         global_batch = args.batch * world
         frames = global_batch * (T_IN + T_OUT) * args.steps
+        srt = sorted(windows)
         line = {
             'metric': 'frames/sec (train fwd+bwd), 64x64 MovingMNIST in=10/out=10', 'value': round(frames / dt, 1),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -365,10 +438,15 @@ def main():
                        'global_batch': global_batch, 'frames_per_clip': T_IN + T_OUT, 'parallelism': f'dp{world}',
                        'launch': 'eager' if args.eager else 'hipGraph replay',
                        'inputs': 'pinned host memory, copied every step' if args.host_inputs else 'resident in HBM',
-                       'final_loss': round(float(loss), 6)},
-            'frozen_ms_per_step': None if frozen_ms is None else round(frozen_ms, 3),
+                       'arithmetic': 'fp32 throughout: every GEMM (forward, data gradient, weight gradient) on '
+                                     'v_mfma_f32_32x32x2_f32; no reduced-precision operand anywhere in the timed step',
+                       'final_loss': round(final_loss, 6)},
+            'frozen_ms_per_step': None if frozen is None else round(frozen, 3),
+            'window_ms_per_step': [round(w, 3) for w in windows],
+            'median_ms_per_step': round(srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2]), 3),
+            'spread_ms_per_step': round(srt[-1] - srt[0], 3),
+            'rank_ms_per_step': {'min': round(min(per_rank) / args.steps * 1e3, 3), 'max': round(max(per_rank) / args.steps * 1e3, 3)},
         }
-        log(f'timed {args.steps} steps in {dt:.3f} s')
         line.update(probes)
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -377,6 +455,7 @@ def main():
                 line['cpu_baseline'] = {'error': repr(e)[:200]}
         print(json.dumps(line), flush=True)
     if world > 1:
+        host_barrier()
         dist.barrier()
         dist.destroy_process_group()
 

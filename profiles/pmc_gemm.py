@@ -19,12 +19,20 @@ import sys
 N_SIMD, N_SE = 1024, 32
 
 
+def kernel_key(full):
+    """'void (anonymous namespace)::k_gate_cell_p<4, 4, 8>((anonymous namespace)::GemmArgs, int)' -> 'k_gate_cell_p<4, 4, 8>'
+    (round 2 split at '::' and kept the tail of the ARGUMENT list, 'GemmArgs, int)')."""
+    import re
+    m = re.search(r'(k_\w+(?:<[^>]*>)?)', full)
+    return m.group(1) if m else full.split('(')[0]
+
+
 def main(d, pat):
     f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         if pat in r['Kernel_Name']:
-            name = r['Kernel_Name'].split('::')[-1].split('(')[0]
+            name = kernel_key(r['Kernel_Name'])
             per[name][r['Counter_Name']].append(float(r['Counter_Value']))
     out = {'source': 'rocprofv3 --pmc (SQ counters, one pass, --kernel-trace only) -- python3 bench.py --steps 2 --warmup 3 '
                      '--frozen-steps 0 --no-cpu-baseline --no-roofline', 'kernels': {}}

@@ -1391,7 +1391,7 @@ __global__ __launch_bounds__(256, BG ? QT_DGRAD_OCC : 2) void k_dgrad_cell(Dgrad
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[nt][r] = 0.0f;
     if (g.BThi) {
-        // Split-bf16 product (backward only: gradients, 1e-3 tolerance): gG = hi + lo, W = Whi + Wlo (two bf16 terms each, the
+        // OPT-IN split-bf16 product (ops.DGRAD_SPLIT_BF16; backward only; the default is the exact fp32 branch below): gG = hi + lo, W = Whi + Wlo (two bf16 terms each, the
         // weight split once per pass by qt_split_bf16), gG W^T ~ hi Whi + hi Wlo + lo Whi -- relative error ~2^-16 per
         // product -- on v_mfma_f32_32x32x16_bf16: 3 MFMAs of 32 cycles per 16 k instead of 8 fp32 MFMAs of 64 cycles (the
         // fp32 MFMA issues on the vector pipe: its 10.7 us per launch at the bench shape added to the cell arithmetic).

@@ -31,8 +31,8 @@ class FlatParams:
     def intact(self, module=None):
         """True while every parameter still is the view this object made (module.to(), a re-assigned Parameter or .data break
         it: the caller then builds a new FlatParams)."""
-        base = self.buffer.data_ptr()
-        ok = all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offs))
+        base, es = self.buffer.data_ptr(), self.buffer.element_size()
+        ok = all(p.data_ptr() == base + es * o for p, o in zip(self.params, self.offs))
         if ok and module is not None:
             ps = list(module.parameters())
             ok = len(ps) == len(self.params) and all(a is b for a, b in zip(ps, self.params))
@@ -43,9 +43,9 @@ class FlatParams:
         g = self.last_grad
         if g is None:
             return None
-        base = g.data_ptr()
+        base, es = g.data_ptr(), g.element_size()
         for p, o in zip(self.params, self.offs):
-            if p.grad is None or p.grad.data_ptr() != base + 4 * o:
+            if p.grad is None or p.grad.data_ptr() != base + es * o:
                 return None
         return g[:self.n]
 
@@ -62,7 +62,11 @@ class FlatParams:
 
 
 def flat_params(module):
-    """The module's FlatParams (made on first use, remade when the parameters were moved or replaced)."""
+    """The module's FlatParams (made on first use, remade when the parameters were moved or replaced), or None when the
+    parameters are not fp32 (model.double() / .half(): the packing gather and qt_flat_adam are fp32 kernels -- the callers
+    then fall back to per-tensor packing and torch.optim.Adam)."""
+    if any(p.dtype != torch.float32 for p in module.parameters()):
+        return None
     fp = module.__dict__.get('_flat_params')
     if fp is None or not fp.intact(module):
         fp = FlatParams(module)

@@ -13,6 +13,20 @@ from .mesh import spmm, spmm2
 
 ACT_NONE, ACT_RELU, ACT_TANH_RES = 0, 1, 2
 
+# Arithmetic of the backward pass's gate-GEMM data gradient (gG W^T).  False (default): exact fp32 products on the fp32 MFMA,
+# like every other product of the path and like the reference (model/model.py:394-463 is fp32 throughout).  True: the opt-in
+# 2-term split-bf16 product (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate; ~16 significand bits per
+# operand) -- gradients only, measured beside the exact path by bench.py (`split_bf16_dgrad`) and kept alive by
+# tests/test_gpu_headline.py.  Read when a pass packs its weights, so it can be switched between passes (not inside a
+# captured step: a hipGraph replays what it captured).
+DGRAD_SPLIT_BF16 = os.environ.get('QT_DGRAD_SPLIT_BF16') == '1'
+
+
+def set_dgrad_split_bf16(on):
+    global DGRAD_SPLIT_BF16
+    prev, DGRAD_SPLIT_BF16 = DGRAD_SPLIT_BF16, bool(on)
+    return prev
+
 
 def _c(t):
     return t if t is None or t.is_contiguous() else t.contiguous()
@@ -284,8 +298,8 @@ def _dgrad_weight(W, K, Cs, live, acc):
             Wb = Wb.view(K, C, Co)[:, lo:lo + Cs[live[0]]].reshape(-1, Co)     # shared by every use in this pass
         if skinny:
             Wb = Wb.t().contiguous()
-        elif acc is not None and Wb.is_cuda and os.environ.get('QT_DGRAD_FP32') != '1':
-            # two bf16 terms of the same rows for the split-bf16 data gradient of qt_lstm_bwd_dgrad (once per pass)
+        elif acc is not None and Wb.is_cuda and DGRAD_SPLIT_BF16:
+            # opt-in: two bf16 terms of the same rows for the split-bf16 data gradient of qt_lstm_bwd_dgrad (once per pass)
             Wb = Wb.contiguous()
             hi, lo = (torch.empty(Wb.shape, dtype=torch.bfloat16, device=Wb.device) for _ in range(2))
             _lib.call('qt_split_bf16', ptr(Wb), Wb.numel(), ptr(hi), ptr(lo))

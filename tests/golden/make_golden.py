@@ -256,11 +256,11 @@ def cells():
 
 # ------------------------------------------------------------------ full rollouts
 def rollout(name, x, y, concat, mask, hidden, n_layers, n_conv, thresh, t_in, t_out, transform=None, hir=None, seed=60,
-            scale=0.25, bscale=0.2):
+            scale=0.25, bscale=0.2, conv='ChebConv'):
     in_feat = x.shape[-1] + 3
     model = RS.Seq2Seq(hidden_size=hidden, dropout=0.0, thresh=thresh, input_timesteps=t_in, input_features=in_feat,
                        output_timesteps=t_out, n_layers=n_layers, n_conv_layers=n_conv, transform_func=transform,
-                       convolution_type='ChebConv')
+                       convolution_type=conv)
     randomize(model, seed, scale=scale, bscale=bscale)
     model.train()
     xt, yt, ct = torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(concat)
@@ -322,6 +322,37 @@ def rollouts():
     concat = f[2:5, ..., :1].copy() * 0.5
     rollout('ice64_masked_h8', f[:2], f[2:5, ..., :1].copy(), concat, m, hidden=8, n_layers=1, n_conv=3, thresh=0.15,
             t_in=2, t_out=3, transform=dist_from_05, seed=62, scale=0.1)
+
+
+def rollout_gcn():
+    """convolution_type='GCNConv' (model/model.py:41,50: GCNConv(add_self_loops=False)) through the reference's whole
+    Seq2Seq rollout with re-meshing: two layers, stacks of two convolutions, noisy frames (meshes of 1-3 k nodes)."""
+    x, y = synthetic.make_batch(9, 11, 1, 3, 4, n_digits=1, pixel_noise=0.04, canvas=(64, 64))
+    mask = np.zeros((64, 64), dtype=bool)
+    concat = (0.1 * np.random.default_rng(5).random((4, 64, 64, 1))).astype(np.float32)
+    rollout('gcn_mnist64_h8', x[0], y[0], concat, mask, hidden=8, n_layers=2, n_conv=2, thresh=0.1, t_in=3, t_out=4, seed=65,
+            scale=0.12, bscale=0.03, conv='GCNConv')
+
+
+def checkpoint_case():
+    """A checkpoint written the way the reference writes it (NextFramePredictorS2S.save, model/mpnnlstm.py:161-163:
+    torch.save(self.model.state_dict(), '<dir>/<experiment_name>.pth')) from the reference's own Seq2Seq, plus the outputs of
+    one eval-mode rollout with those weights: the build's load() must read the file (weights_only) and reproduce them."""
+    x, y = synthetic.make_batch(9, 13, 1, 3, 3, n_digits=1, pixel_noise=0.0, canvas=(64, 64))
+    mask = np.zeros((64, 64), dtype=bool)
+    concat = (0.1 * np.random.default_rng(6).random((3, 64, 64, 1))).astype(np.float32)
+    model = RS.Seq2Seq(hidden_size=8, dropout=0.0, thresh=0.1, input_timesteps=3, input_features=4, output_timesteps=3,
+                       n_layers=2, n_conv_layers=2, convolution_type='ChebConv')
+    randomize(model, 66, scale=0.06, bscale=0.02)
+    model.eval()
+    with torch.no_grad():
+        outs, maps = model(torch.from_numpy(x[0]), None, torch.from_numpy(concat), teacher_forcing_ratio=0, mask=mask)
+    torch.save(model.state_dict(), os.path.join(HERE, 'ref_checkpoint_h8.pth'))
+    out = dict(x=x[0], y=y[0], concat=concat, mask=mask, keys=np.array(list(model.state_dict().keys())))
+    for i, o in enumerate(outs):
+        out[f'out_{i}'] = o.numpy()
+    np.savez_compressed(os.path.join(HERE, 'checkpoint_case.npz'), **out)
+    print('checkpoint', len(out['keys']), 'tensors, N per step', [len(o) for o in outs])
 
 
 def rollout_headline():
@@ -645,6 +676,10 @@ if __name__ == '__main__':
         transformer_cases()
     if only in ('', 'rollouts'):
         rollouts()
+    if only in ('', 'gcn'):
+        rollout_gcn()
+    if only in ('', 'checkpoint'):
+        checkpoint_case()
     if only in ('', 'headline'):
         rollout_headline()
     if only in ('', 'ice_exp'):

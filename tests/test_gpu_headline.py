@@ -102,10 +102,10 @@ def test_headline_batch32_graph_replay_matches_reference_trace():
         close(outs[i][off[0]:off[1], :1], g[f'out_{i}'], msg=f'clip 0 output step {i}')
     per_clip = _clip_losses(outs, meshes, yt, (64, 64))
     assert abs(float(per_clip.mean()) - float(loss)) <= 1e-5 * float(loss), (float(per_clip.mean()), float(loss))
-    if flipped is None:
-        assert abs(float(per_clip[0]) - float(g['loss'])) <= 1e-4 * float(g['loss']), (float(per_clip[0]), float(g['loss']))
-    else:
-        pytest.skip(f'mesh {flipped}: a pixel on the threshold flipped (chaotic re-mesh); earlier steps matched')
+    # the fixture's seeds keep every pixel of every step away from the threshold (margin checked when it was generated): a
+    # flipped mesh is a regression, not chaos -- fail (everything before the flipped step was asserted above)
+    assert flipped is None, f'mesh {flipped} of clip 0 differs from the reference trace (earlier steps matched)'
+    assert abs(float(per_clip[0]) - float(g['loss'])) <= 1e-4 * float(g['loss']), (float(per_clip[0]), float(g['loss']))
     # every clip's meshes obey the size-independent invariants
     for ms in meshes:
         nv = int(ms.n_dev.item())
@@ -132,8 +132,7 @@ def test_headline_batch32_gradients_match_reference():
             lab = ms.labels[c].cpu().numpy() - off[c]
             if not np.array_equal(lab, g[f'labels_{i}']):
                 near = np.abs(g[f'image_{i}'] - float(g['thresh'])).min()
-                assert near < 1e-5, f'mesh {i} of clip {c} differs and no pixel sits on the threshold ({near})'
-                pytest.skip(f'mesh {i}: a pixel on the threshold flipped (chaotic re-mesh)')
+                pytest.fail(f'mesh {i} of clip {c} differs from the reference trace (nearest pixel to the threshold: {near})')
     assert abs(float(k['loss']) - float(g['loss'])) <= 1e-4 * float(g['loss'])
     for name, p in nfp.model.named_parameters():
         ref = g['g/' + name]
@@ -141,6 +140,45 @@ def test_headline_batch32_gradients_match_reference():
             assert not ref.any(), name
             continue
         grad_close(p.grad, ref, msg=name)
+
+
+def test_headline_split_bf16_dgrad_is_optin_and_its_error_is_known():
+    """The default backward is exact fp32 (ops.DGRAD_SPLIT_BF16 False: the gradient test above ran it).  The opt-in split-bf16
+    data gradient of the gate GEMM (bench.py reports it beside the headline as `split_bf16_dgrad`) stays alive here: the same
+    captured B=32 step in both modes, worst per-tensor error of split vs exact relative to the tensor's largest entry, and the
+    split gradients still inside the reference tolerance."""
+    from qtmpnn import ops
+    g = golden('rollout_cfg2_mnist64.npz')
+    mask = np.zeros((64, 64), dtype=bool)
+    rep = lambda a: torch.from_numpy(a).to(dev()).unsqueeze(0).repeat(B, 1, 1, 1, 1).contiguous()
+    xt, yt = rep(g['x']), rep(g['y'])
+    ct = torch.zeros(B, T_OUT, 64, 64, 1, device=dev())
+    assert ops.DGRAD_SPLIT_BF16 is False, 'the exact fp32 data gradient must be the default'
+    grads = {}
+    for mode in (False, True):
+        prev = ops.set_dgrad_split_bf16(mode)
+        try:
+            nfp = _predictor(g)
+            graph, k = _capture(nfp, xt.clone(), yt.clone(), ct, mask)
+            graph.replay()
+            torch.cuda.synchronize()
+            grads[mode] = {n: p.grad.detach().clone() for n, p in nfp.model.named_parameters() if p.grad is not None}
+            assert abs(float(k['loss']) - float(g['loss'])) <= 1e-4 * float(g['loss'])
+        finally:
+            ops.set_dgrad_split_bf16(prev)
+    worst, worst_name, differs = 0.0, None, False
+    for n, ge in grads[False].items():
+        gs = grads[True][n]
+        differs |= not torch.equal(ge, gs)
+        scale = float(ge.abs().max())
+        if scale > 0:
+            e = float((gs - ge).abs().max()) / scale
+            if e > worst:
+                worst, worst_name = e, n
+        grad_close(gs, g['g/' + n], msg=n + ' (split-bf16 data gradient)')
+    assert differs, 'the split-bf16 switch changed nothing: the opt-in path did not run'
+    print(f'split-bf16 vs exact data gradient: worst per-tensor max-error / max-entry = {worst:.3e} ({worst_name})')
+    assert worst < 2e-4, (worst, worst_name)
 
 
 @pytest.mark.parametrize('cfg', ['cfg1_mnist64_b4', 'cfg2_mnist64_b32'])

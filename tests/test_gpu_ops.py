@@ -602,8 +602,8 @@ def test_fused_gate_cell_equals_gemm_then_cell(with_c, h):
         del os.environ['QT_NO_DGRAD_FUSION']
     # default backward: the cell backward and the data gradient in one launch (qt_lstm_bwd_dgrad, h = 8 / 16).  The forward and
     # the state / weight gradients stay bit-identical; the parameter partials are summed per 128-node workgroup instead of
-    # per grid-stride sweep (fp32 rounding), and the data gradient runs as a split-bf16 product inside a pass that shares
-    # its weight (acc given) -- here, without one, it is the exact fp32 product.
+    # per grid-stride sweep (fp32 rounding); the data gradient is the exact fp32 product (the split-bf16 form is opt-in:
+    # ops.DGRAD_SPLIT_BF16, tests/test_gpu_headline.py).
     for a, r, n in zip(run(True), run(False), names):
         if n in ('gwc', 'gb', 'gln'):
             close(a, r, 1e-4, 1e-4 * float(r.abs().max()), msg=n)

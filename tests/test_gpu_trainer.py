@@ -131,3 +131,70 @@ def test_continued_unroll_equals_one_unroll(thresh):
     for i, (o, r) in enumerate(zip(a + b, whole)):
         assert o.shape == r.shape, f'step {i}'
         close(o, r, rtol=1e-6, atol=1e-7, msg=f'step {i}')
+
+
+def test_checkpoint_written_by_the_reference_loads_and_round_trips(tmp_path):
+    """NextFramePredictorS2S.load() reads a .pth written the way the reference writes it
+    (model/mpnnlstm.py:161-168: torch.save(model.state_dict()) of the reference's own Seq2Seq -- tests/golden/ref_checkpoint_h8.pth,
+    made by make_golden.py) with the weights-only loader, the loaded model reproduces the reference's eval-mode rollout, and
+    save() writes a file with the same keys, key order, shapes and values that a second instance loads back bit for bit."""
+    import os
+    import shutil
+    from helpers import GOLDEN
+    from model.mpnnlstm import NextFramePredictorS2S
+    g = golden('checkpoint_case.npz')
+    shutil.copy(os.path.join(GOLDEN, 'ref_checkpoint_h8.pth'), tmp_path / 'refrun.pth')
+    mk = lambda name: NextFramePredictorS2S(thresh=0.1, experiment_name=name, input_features=1, input_timesteps=3,
+                                            output_timesteps=3, device=dev(),
+                                            model_kwargs=dict(hidden_size=8, dropout=0.0, n_layers=2, n_conv_layers=2))
+    nfp = mk('refrun')
+    nfp.load(str(tmp_path))
+    ref_sd = torch.load(tmp_path / 'refrun.pth', map_location='cpu', weights_only=True)
+    assert list(ref_sd.keys()) == [str(k) for k in g['keys']] == list(nfp.model.state_dict().keys())
+    nfp.model.eval()
+    x, concat = torch.from_numpy(g['x']).to(dev()), torch.from_numpy(g['concat']).to(dev())
+    with torch.no_grad():
+        outs, meshes = nfp.model(x, None, concat, teacher_forcing_ratio=0, mask=g['mask'])
+    for i, o in enumerate(outs):
+        assert o.shape[0] == g[f'out_{i}'].shape[0], f'mesh size of step {i}'
+        close(o, g[f'out_{i}'], msg=f'step {i}')
+    # save -> a second instance loads it back; the file has the reference's layout
+    nfp.experiment_name = 'resaved'
+    nfp.save(str(tmp_path))
+    sd2 = torch.load(tmp_path / 'resaved.pth', map_location='cpu', weights_only=True)
+    assert list(sd2.keys()) == list(ref_sd.keys())
+    for k in ref_sd:
+        assert sd2[k].shape == ref_sd[k].shape and torch.equal(sd2[k], ref_sd[k]), k
+    other = mk('resaved')
+    other.load(str(tmp_path))
+    for (ka, a), (kb, b) in zip(nfp.model.state_dict().items(), other.model.state_dict().items()):
+        assert ka == kb and torch.equal(a, b), ka
+    # a loaded model trains: the flat parameter buffer is rebuilt around the loaded values
+    other.initiate_training(lr=1e-3, lr_decay=0.95)
+    other.model.train()
+    y = torch.from_numpy(g['y']).to(dev())
+    ls = [float(other.train_step(x, y, concat, g['mask'])) for _ in range(3)]
+    assert np.isfinite(ls).all() and ls[-1] < ls[0], ls
+
+
+def test_test_threshold_smoke():
+    """NextFramePredictorS2S.test_threshold (model/mpnnlstm.py:138-156): the mesh of a few frames at a trial threshold, the
+    per-node means painted back onto the image, one panel per frame, the node count in the title (Agg backend)."""
+    import matplotlib
+    matplotlib.use('Agg')
+    from model.mpnnlstm import NextFramePredictorS2S
+    from qtmpnn import synthetic
+    nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=3, output_timesteps=3, device=dev(),
+                                model_kwargs=dict(hidden_size=8, dropout=0.0, n_layers=1))
+    clip = synthetic.make_clip(5, n_digits=1, n_frames=2, pixel_noise=0.0)             # (2, 64, 64, 1)
+    x = torch.from_numpy(clip).to(dev())
+    fig, axs = nfp.test_threshold(x, 0.1, mask=np.zeros((64, 64), dtype=bool))
+    assert len(axs) == 2
+    title = fig._suptitle.get_text()
+    n_nodes = int(title.split('Num. nodes:')[1])
+    assert title.startswith('Threshold: 0.1') and 1 < n_nodes < 64 * 64
+    # the panel shows flatten -> unflatten of channel 0: pixels of one cell share the cell mean
+    img = axs[0].get_images()[0].get_array()
+    assert img.shape == (64, 64) and abs(float(img.mean()) - float(clip[0, ..., 0].mean())) < 1e-5
+    import matplotlib.pyplot as plt
+    plt.close(fig)

@@ -5,6 +5,9 @@ cfg3: Moving-MNIST-like 128x128, 2 digits, in=10/out=20, 8 clips per GPU (the pe
 cfg4: ice-like 128x128 patches, 5 channels, in=12/out=6, 16 clips, land mask, transform_func, hidden 32, 1 layer, 3 conv layers.
 cfg4t: cfg4 with convolution_type='TransformerConv' (what ice_exp.py hard-codes).
 cfg4tp: cfg4t on the pixelwise mesh (thresh=-inf: what ice_exp.py:145 really runs -- no quadtree, one node per unmasked pixel).
+cfg5: ice-like 256x256, 5 channels, in=12/out=12, 4 clips per GPU (the per-GPU share of BASELINE configs[4]: 32 clips over 8 GPUs),
+      quadtree rebuilt at every step (ice_exp_nwt.py:46,80,89-96 with a finite threshold); cfg5t: the same with TransformerConv.
+cfg2n0 / cfg3n0: the Moving-MNIST configs with noise-free inputs (SURVEY 8(d)'s second series: sparse input meshes).
 """
 import json, os, sys, time
 ROOT = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,17 +19,18 @@ dev = torch.device('cuda', 0)
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg3'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 torch.manual_seed(1)
-if cfg == 'cfg3':
-    B, t_in, t_out, shape = 8, 10, 20, (128, 128)
+if cfg in ('cfg3', 'cfg3n0', 'cfg2n0'):
+    B, t_in, t_out, shape = (8, 10, 20, (128, 128)) if cfg != 'cfg2n0' else (32, 10, 10, (64, 64))
     kw, thresh, tf, feat = dict(hidden_size=16, dropout=0.1, n_layers=2), 0.1, None, 1
     mask = np.zeros(shape, dtype=bool)
+    noise = 0.0 if cfg.endswith('n0') else 0.05
     def batch(i):
-        x, y = synthetic.make_batch(3, i * B, B, t_in, t_out, n_digits=2, pixel_noise=0.05, canvas=shape)
+        x, y = synthetic.make_batch(2 if cfg == 'cfg2n0' else 3, i * B, B, t_in, t_out, n_digits=2, pixel_noise=noise, canvas=shape)
         return x, y
 else:
-    B, t_in, t_out, shape = 16, 12, 6, (128, 128)
+    B, t_in, t_out, shape = (16, 12, 6, (128, 128)) if not cfg.startswith('cfg5') else (4, 12, 12, (256, 256))
     kw, thresh, feat = dict(hidden_size=32, dropout=0.1, n_layers=1, n_conv_layers=3), 0.15, 5
-    if cfg in ('cfg4t', 'cfg4tp'):
+    if cfg in ('cfg4t', 'cfg4tp', 'cfg5t'):
         kw['convolution_type'] = 'TransformerConv'
     if cfg == 'cfg4tp':
         thresh = -np.inf
