@@ -392,13 +392,16 @@ def test_baseline_config_shapes_train(cfg):
         nfp.model.train()
         return nfp
 
-    nfp = fresh(False)
-    outs, meshes = nfp.model(xt, yt, concat, teacher_forcing_ratio=0, mask=mask)
+    # (both predictors train with static capacities and the capturable optimizer, like the captured step's own warm-up steps:
+    # a rollout that re-meshes on its own output amplifies a last-bit difference between two optimizer variants within a few steps)
+    nfp = fresh(True)
+    outs, meshes = nfp.model(xt, yt, concat, teacher_forcing_ratio=0, mask=mask)          # exact node counts: invariants
     for ms in meshes:
         assert float(ms.npix.sum()) == B * P_valid
         lab = ms.labels
         assert int(lab.max()) == ms.N - 1 and bool(((lab < 0) == torch.from_numpy(mask).to(dev())).all())
     del outs, meshes
+    nfp.model.static_shapes = True
     le = [float(nfp.train_step(xt, yt, concat, mask)) for _ in range(4)]
     assert np.isfinite(le).all() and le[-1] < le[0], le
     missing = [k for k, p in nfp.model.named_parameters() if p.grad is None and 'rnns.1.conv_h' not in k]
