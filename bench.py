@@ -69,53 +69,76 @@ def make_predictor(device, capturable=False):
 
 
 def spmm_roofline(nfp, batch, mask, reps=10):
-    """Roofline of the message-aggregate kernel (k_spmm), measured live with HIP events on the launch stream.
+    """Roofline of the message-aggregate kernels, measured live with HIP events on the launch stream.
 
-    One extra (untimed) eager training step records every spmm launch of the real workload (mesh, channel count,
-    which addends).  Each distinct launch is then re-issued `reps` times back to back (captured into a hipGraph, so
-    that the device and not the host call is timed) between two events on the replay stream with same-shaped
-    operands, and the per-launch averages are summed, so the figure covers exactly the launch mix of one training step.  Algorithmic bytes per launch: 4(N+1) + 8E' + 8NC, C = the
-    channels of all column parts the launch propagates (Z = [X | H] travels as two matrices in one launch)."""
+    One extra (untimed) eager forward + backward records every message-aggregate launch of the real workload: the clip-resident
+    recurrence launches (k_cheb_clip: ALL K - 1 hops of a ChebConv pass in one launch, neighbour rows in LDS; csrc/chebclip.hip)
+    and any remaining per-hop k_spmm launches.  Each distinct launch is then re-issued `reps` times back to back (captured into a
+    hipGraph, so that the device and not the host call is timed) between two events on the replay stream with same-shaped
+    operands, and the per-launch averages are summed: the figure covers exactly the launch mix of one training step.
+
+    Algorithmic bytes.  Per hop, SURVEY.md 8(d): 4(N+1) + 8E' + 8NC (index arrays + every feature row read
+    once + every output row written once).  A fused launch of K - 1 hops must move the index arrays once, Z once and K - 1 planes
+    out (forward: 4(N+1) + 8E' + 4NC K), or K gradient planes in and one out (backward: 4(N+1) + 8E' + 4NC (K + 1)) -- the
+    intermediate planes are not re-read from HBM, so the fused launch is priced on THESE bytes (`achieved`, `frac`), which is
+    the smaller, stricter count; `per_hop_equivalent` prices the same launches at (K - 1) x the per-hop figure for comparison
+    with the round-2 numbers."""
     import torch
     from qtmpnn import mesh as qmesh, ops
     records = []
-    orig = qmesh.spmm2
+    orig_spmm, orig_fwd, orig_bwd = qmesh.spmm2, ops.clip_planes, ops.clip_clenshaw
 
-    def spy(ms, xs, alpha, ps, beta, qs, gamma, outs):
-        records.append((ms, tuple(x.shape[1] for x in xs), ps is not None, qs is not None))
-        orig(ms, xs, alpha, ps, beta, qs, gamma, outs)
-    qmesh.spmm2 = ops.spmm2 = spy
+    def spy_spmm(ms, xs, alpha, ps, beta, qs, gamma, outs):
+        records.append(('hop', ms, tuple(x.shape[1] for x in xs), ps is not None, qs is not None, 2))
+        orig_spmm(ms, xs, alpha, ps, beta, qs, gamma, outs)
+
+    def spy_fwd(ms, Zs, TZs, K):
+        records.append(('fwd', ms, tuple(z.shape[1] for z in Zs), False, False, K))
+        orig_fwd(ms, Zs, TZs, K)
+
+    def spy_bwd(ms, Gs, K):
+        records.append(('bwd', ms, tuple(g.shape[2] for g in Gs), False, False, K))
+        orig_bwd(ms, Gs, K)
+    qmesh.spmm2 = ops.spmm2 = spy_spmm
+    ops.clip_planes, ops.clip_clenshaw = spy_fwd, spy_bwd
     try:
-        # forward + loss + backward only: no all-reduce, no optimizer step -- rank 0 runs this alone, so nothing in it may
-        # be a collective (the other ranks are already waiting at the final barrier)
+        # forward + loss + backward only: no all-reduce, no optimizer step (rank 0 runs this alone)
         nfp.zero_grad()
         nfp.forward_loss(*batch, mask).backward()
         nfp.zero_grad()
         torch.cuda.synchronize()
     finally:
-        qmesh.spmm2 = ops.spmm2 = orig
+        qmesh.spmm2 = ops.spmm2 = orig_spmm
+        ops.clip_planes, ops.clip_clenshaw = orig_fwd, orig_bwd
     dev = batch[0].device
     bufs, timed = {}, {}
-    tot_us, tot_bytes, tot_moved = 0.0, 0.0, 0.0
     side = torch.cuda.Stream()
-    for ms, Cs, has_p, has_q in records:
-        key = (id(ms), Cs, has_p, has_q)
+    tot = {'us': 0.0, 'bytes': 0.0, 'hop_bytes': 0.0, 'moved': 0.0, 'hops': 0}
+    per_kind = {}
+    for kind, ms, Cs, has_p, has_q, K in records:
+        key = (kind, id(ms), Cs, has_p, has_q, K)
         if key not in timed:
-            bk = (ms.N, Cs)
-            if bk not in bufs:
-                bufs[bk] = [[torch.randn(ms.N, c, device=dev) for c in Cs] for _ in range(4)]
-            x, p, q, out = bufs[bk]
-            args = (ms, x, 2.0, p if has_p else None, -1.0, q if has_q else None, 1.0, out)
-            # the `reps` launches are captured into a hipGraph and replayed between two HIP events on the replay
-            # stream: what is timed is the device, not the Python / ctypes call that issues a launch
+            if kind == 'hop':
+                bk = (ms.N, Cs)
+                if bk not in bufs:
+                    bufs[bk] = [[torch.randn(ms.N, c, device=dev) for c in Cs] for _ in range(4)]
+                x, p, q, out = bufs[bk]
+                fn = lambda: orig_spmm(ms, x, 2.0, p if has_p else None, -1.0, q if has_q else None, 1.0, out)
+            elif kind == 'fwd':
+                Zs = [torch.randn(ms.N, c, device=dev) for c in Cs]
+                TZs = [torch.empty(K - 1, ms.N, c, device=dev) for c in Cs]
+                fn = lambda: orig_fwd(ms, Zs, TZs, K)
+            else:
+                Gs = [torch.randn(K, ms.N, c, device=dev) for c in Cs]
+                fn = lambda: orig_bwd(ms, Gs, K)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                orig(*args)
+                fn()
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
                 for _ in range(reps):
-                    orig(*args)
+                    fn()
             g.replay()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -124,27 +147,55 @@ def spmm_roofline(nfp, batch, mask, reps=10):
             b.synchronize()
             timed[key] = a.elapsed_time(b) * 1e3 / reps
             del g
-        tot_us += timed[key]
+        us = timed[key]
         nv = ms.n_valid                      # static mode: ms.N is the capacity, the count lives on the device
-        b = 4.0 * (nv + 1) + 8.0 * ms.E + 8.0 * nv * sum(Cs)
-        tot_bytes += b
-        tot_moved += b + 4.0 * nv * sum(Cs) * (int(has_p) + int(has_q))     # + the addend rows p, q of the recurrence
+        C = sum(Cs)
+        idx = 4.0 * (nv + 1) + 8.0 * ms.E
+        hop = idx + 8.0 * nv * C
+        if kind == 'hop':
+            by, hops = hop, 1
+            moved = hop + 4.0 * nv * C * (int(has_p) + int(has_q))
+        elif kind == 'fwd':
+            by, hops = idx + 4.0 * nv * C * K, K - 1
+            moved = by
+        else:
+            by, hops = idx + 4.0 * nv * C * (K + 1), K - 1
+            moved = by
+        tot['us'] += us
+        tot['bytes'] += by
+        tot['hop_bytes'] += hop * hops
+        tot['moved'] += moved
+        tot['hops'] += hops
+        pk = per_kind.setdefault(kind, {'launches': 0, 'us': 0.0, 'bytes': 0.0})
+        pk['launches'] += 1
+        pk['us'] += us
+        pk['bytes'] += by
     n = len(records)
-    achieved = tot_bytes / (tot_us * 1e-6) / 1e9
-    moved = tot_moved / (tot_us * 1e-6) / 1e9
+    achieved = tot['bytes'] / (tot['us'] * 1e-6) / 1e9
     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes over this same command (they cannot be collected
     # in-process); the newest committed record is quoted and named
     traffic = source = None
-    for name in ('r03_pmc_spmm.json', 'r02_pmc_spmm.json', 'r01_pmc_spmm.json'):
+    for name in ('r03_pmc_chebclip.json', 'r02_pmc_spmm.json'):
         pmc = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pmc):
             traffic, source = json.load(open(pmc))['traffic_bytes_per_launch'], 'profiles/' + name
             break
-    return {'bound': 'hbm', 'kernel': 'k_spmm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+    fused = per_kind.get('fwd', {'launches': 0})['launches'] + per_kind.get('bwd', {'launches': 0})['launches']
+    kinds = {('k_cheb_clip<fwd>' if k == 'fwd' else 'k_cheb_clip<bwd>' if k == 'bwd' else 'k_spmm'):
+             {'launches_per_step': v['launches'], 'avg_launch_us': round(v['us'] / v['launches'], 2),
+              'avg_bytes_per_launch': round(v['bytes'] / v['launches']),
+              'achieved_gbs': round(v['bytes'] / (v['us'] * 1e-6) / 1e9, 1)} for k, v in per_kind.items()}
+    return {'bound': 'hbm', 'kernel': 'k_cheb_clip (clip-resident multi-hop message aggregate)' if fused else 'k_spmm',
+            'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': source,
-            'launches_per_step': n, 'avg_launch_us': round(tot_us / n, 2), 'avg_bytes_per_launch': round(tot_bytes / n),
-            'achieved_incl_addends': round(moved, 1), 'frac_incl_addends': round(moved / HBM_PEAK_GBS, 4),
-            'bytes_formula': '4(N+1) + 8E\' + 8NC per launch (SURVEY 8(d)); incl_addends adds 4NC per addend operand'}
+            'launches_per_step': n, 'hops_per_step': tot['hops'], 'avg_launch_us': round(tot['us'] / n, 2),
+            'us_per_step': round(tot['us'], 1), 'avg_bytes_per_launch': round(tot['bytes'] / n), 'kernels': kinds,
+            'per_hop_equivalent': {'achieved': round(tot['hop_bytes'] / (tot['us'] * 1e-6) / 1e9, 1),
+                                   'frac': round(tot['hop_bytes'] / (tot['us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                   'avg_us_per_hop': round(tot['us'] / max(tot['hops'], 1), 2),
+                                   'note': 'the same launches priced at SURVEY 8(d)\'s per-hop figure x hops (round-2 accounting)'},
+            'bytes_formula': "per hop 4(N+1) + 8E' + 8NC (SURVEY 8(d)); fused K-1 hops: forward 4(N+1) + 8E' + 4NC K, "
+                             "backward 4(N+1) + 8E' + 4NC (K+1)"}
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= the fp32 vector rate)

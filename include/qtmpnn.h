@@ -184,6 +184,22 @@ int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* nrm, int N,
              float alpha, float beta, float gamma, const int32_t* ell /* optional, from qt_edges_norm */,
              void* stream);   /* ld*: row strides in floats, 0 = dense; out rows are dense */
 
+/* Clip-resident Chebyshev recurrences (csrc/chebclip.hip): ALL K - 1 message-aggregate hops of one ChebConv pass in ONE launch
+ * for block-diagonal meshes whose clips hold at most qt_cheb_clip_rows() nodes each (4096: a 64 x 64 frame).  One workgroup per
+ * (clip, 4-channel column slice) keeps two slice planes in LDS; gathers are LDS reads, hops are separated by a workgroup barrier.
+ * Replaces K - 1 qt_spmm2 calls of PyG ChebConv.forward's recurrence (model/model.py:53,96); bit-identical planes.
+ *   node_off (B + 1): first node of each clip (device; qt_quadtree_stage3 writes it), ell: required (qt_edges_norm).
+ *   N: plane stride in rows (the capacity in static mode; the valid rows come from node_off).
+ * qt_cheb_clip_fwd: T_k = 2 L^ T_{k-1} - T_{k-2} (T_0 = Z = [za | zb], T_1 = L^ Z) -> Ta (K - 1, N, Ca), Tb (K - 1, N, Cb).
+ * qt_cheb_clip_bwd: Clenshaw on the gradient planes Ga (K, N, Ca), Gb (K, N, Cb): plane 0 is overwritten with
+ *   A_0 + L^ b_1 - b_2, b_k = A_k + 2 L^ b_{k+1} - b_{k+2}; planes 1 .. K - 1 are left as given (the b_k stay in LDS). */
+int qt_cheb_clip_rows(void);
+int qt_cheb_clip_fwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* node_off,
+                     int B, int N, int K, int Ca, const float* za, int lda, float* Ta,
+                     int Cb, const float* zb, int ldb, float* Tb, void* stream);
+int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* node_off,
+                     int B, int N, int K, int Ca, float* Ga, int Cb, float* Gb, void* stream);
+
 /* qt_dense: out planes = act( [A planes | S] @ [W ; Ws] ), the gate GEMM.
  *   A: Ka planes, plane k at a0 (k == 0) or a_rest + (k-1)*N*Ca, each (N, Ca)   (T_0 = Z stays in the caller's tensor)
  *   W: (Ka*Ca, Kb*Cb) row-major;  S: (N, Ks) or NULL with Ws (Ks, Kb*Cb)

@@ -258,10 +258,41 @@ def _plane_args(Zs, TZs):
     return a + [None, 0, None]
 
 
+_CLIP_CHEB = os.environ.get('QT_NO_CLIP_CHEB') != '1'      # (A/B switch: 1 = one k_spmm launch per hop everywhere)
+_CLIP_ROWS = []
+
+
+def _clip_resident(mesh, widths, K):
+    """True when the K - 1 hops of a recurrence run as ONE clip-resident launch (csrc/chebclip.hip): every clip of the block-
+    diagonal mesh fits the kernel's LDS planes (n x m <= 4096 nodes), rows are float4 slices, the ELL side array exists."""
+    if not _CLIP_ROWS:
+        _CLIP_ROWS.append(_lib.value('qt_cheb_clip_rows'))
+    return (_CLIP_CHEB and K >= 2 and mesh.N > 0 and mesh.ell is not None and mesh.n * mesh.m <= _CLIP_ROWS[0]
+            and len(widths) <= 2 and all(w % 4 == 0 for w in widths) and getattr(mesh, 'node_off', None) is not None)
+
+
+def clip_planes(mesh, Zs, TZs, K):
+    """TZs[i] (K - 1, N, C_i) <- T_1 .. T_{K-1} of the recurrence on the parts Zs, all hops in ONE launch (qt_cheb_clip_fwd)."""
+    two = len(Zs) > 1
+    _lib.call('qt_cheb_clip_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off), mesh.B,
+              Zs[0].shape[0], K, Zs[0].shape[1], ptr(Zs[0]), _ld(Zs[0]), ptr(TZs[0]),
+              Zs[1].shape[1] if two else 0, ptr(Zs[1]) if two else None, _ld(Zs[1]) if two else 0, ptr(TZs[1]) if two else None)
+
+
+def clip_clenshaw(mesh, Gs, K):
+    """Gs[i] (K, N, C_i) gradient planes: plane 0 <- A_0 + L^ b_1 - b_2 (Clenshaw), all hops in ONE launch (qt_cheb_clip_bwd)."""
+    two = len(Gs) > 1
+    _lib.call('qt_cheb_clip_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off), mesh.B,
+              Gs[0].shape[1], K, Gs[0].shape[2], ptr(Gs[0]), Gs[1].shape[2] if two else 0, ptr(Gs[1]) if two else None)
+
+
 def _cheb_planes(Zs, mesh, K):
     """T_1 .. T_{K-1} of the Chebyshev recurrence on Z (T_0 = Z itself): per part (max(K-1, 1), N, C)."""
     N = Zs[0].shape[0]
     TZs = [Z.new_empty(max(K - 1, 1), N, Z.shape[1]) for Z in Zs]
+    if _clip_resident(mesh, [Z.shape[1] for Z in Zs], K):
+        clip_planes(mesh, Zs, TZs, K)
+        return TZs
     for k in range(1, K):
         if k == 1:
             spmm2(mesh, Zs, 1.0, None, 0.0, None, 0.0, [T[0] for T in TZs])
@@ -341,10 +372,15 @@ def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, g
                           Cl[1] if len(Cl) > 1 else 0, N, ptr(mesh.n_dev), ACT_NONE, None, 0, None, ptr(gTs[0]),
                           ptr(gTs[1]) if len(Cl) > 1 else None)
         # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
-        for k in range(K - 2, 0, -1):
+        if _clip_resident(mesh, Cl, K):         # all hops in one launch; only plane 0 (= gZ) is rewritten
+            clip_clenshaw(mesh, gTs, K)
+            K_hops = 0
+        else:
+            K_hops = K
+        for k in range(K_hops - 2, 0, -1):
             spmm2(mesh, [g[k + 1] for g in gTs], 2.0, [g[k] for g in gTs], 1.0,
                   [g[k + 2] for g in gTs] if k + 2 < K else None, -1.0, [g[k] for g in gTs])
-        if K > 1:
+        if K_hops > 1:
             spmm2(mesh, [g[1] for g in gTs], 1.0, [g[0] for g in gTs], 1.0, [g[2] for g in gTs] if K > 2 else None, -1.0,
                   [g[0] for g in gTs])
         gZs = [None] * len(Zs)

@@ -630,6 +630,70 @@ def test_spmm_two_row_strided_parts_equal_one_matrix():
     assert torch.equal(torch.cat([oa, ob], dim=1), ref)
 
 
+@pytest.mark.parametrize('K,widths,B', [(5, (4, 16), 3), (3, (16, 4), 2), (5, (16,), 1), (2, (8,), 2), (3, (32,), 2)])
+def test_clip_resident_recurrence_equals_per_hop_launches(K, widths, B):
+    """csrc/chebclip.hip (all hops of a ChebConv recurrence in one launch, a clip's rows in LDS) against one qt_spmm2 launch per
+    hop: forward planes T_1 .. T_{K-1} and the Clenshaw backward, bit for bit; row-strided column views as Z; a mesh with big
+    cells beside small ones (rows with more than four edges take the CSR tail); static capacities (node counts on the device,
+    capacity rows poisoned with NaN) give the same valid rows."""
+    from qtmpnn import _lib, ops
+    from qtmpnn._lib import ptr
+    from qtmpnn.mesh import spmm2
+    mesh, _ = _mesh_64(11, noise=0.0, B=B)                       # sparse mesh: cells of 1 .. 32 pixels side by side
+    deg = (mesh.rowptr[1:] - mesh.rowptr[:-1])
+    assert int(deg.max()) > 4 and ops._clip_resident(mesh, list(widths), K)
+    torch.manual_seed(K)
+    N = mesh.N
+    wide = torch.randn(N, sum(widths) + 8, device=dev())
+    Zs, o = [], 4
+    for w in widths:
+        Zs.append(wide[:, o:o + w])
+        o += w
+    fused = ops._cheb_planes(Zs, mesh, K)
+    prev, ops._CLIP_CHEB = ops._CLIP_CHEB, False          # one qt_spmm2 launch per hop
+    try:
+        ref = ops._cheb_planes(Zs, mesh, K)
+    finally:
+        ops._CLIP_CHEB = prev
+    for a, r in zip(fused, ref):
+        assert torch.equal(a, r)
+    # backward: Clenshaw on random gradient planes
+    G = [torch.randn(K, N, w, device=dev()) for w in widths]
+    Gf = [g.clone() for g in G]
+    ops.clip_clenshaw(mesh, Gf, K)
+    Gr = [g.clone() for g in G]
+    for k in range(K - 2, 0, -1):
+        spmm2(mesh, [g[k + 1] for g in Gr], 2.0, [g[k] for g in Gr], 1.0, [g[k + 2] for g in Gr] if k + 2 < K else None, -1.0,
+              [g[k] for g in Gr])
+    spmm2(mesh, [g[1] for g in Gr], 1.0, [g[0] for g in Gr], 1.0, [g[2] for g in Gr] if K > 2 else None, -1.0, [g[0] for g in Gr])
+    for a, r, g0 in zip(Gf, Gr, G):
+        assert torch.equal(a[0], r[0])
+        assert torch.equal(a[1:], g0[1:])                          # the fused launch leaves planes 1 .. K-1 as given
+
+
+def test_clip_resident_recurrence_static_capacities():
+    """The same launch on a static-capacity mesh (N = B n m rows, valid counts per clip in node_off on the device): valid rows
+    equal the exact-size mesh's, capacity rows are never read (NaN poison) or written."""
+    from qtmpnn import ops
+    from qtmpnn.mesh import build_mesh
+    mesh, img = _mesh_64(12, noise=0.02, B=2)
+    sm = build_mesh(src=torch.from_numpy(img).to(dev()), thresh=0.1, static=True)
+    nv = sm.n_valid
+    assert nv == mesh.N and sm.N == 2 * 64 * 64
+    torch.manual_seed(1)
+    Z = torch.randn(mesh.N, 16, device=dev())
+    Zs = torch.full((sm.N, 16), float('nan'), device=dev())
+    Zs[:nv] = Z
+    ref = ops._cheb_planes([Z], mesh, 4)[0]
+    got = torch.full((3, sm.N, 16), 7.0, device=dev())
+    from qtmpnn import _lib
+    from qtmpnn._lib import ptr
+    _lib.call('qt_cheb_clip_fwd', ptr(sm.rowptr), ptr(sm.col), ptr(sm.nrm), ptr(sm.ell), ptr(sm.node_off), sm.B, sm.N, 4,
+              16, ptr(Zs), 16, ptr(got), 0, None, 0, None)
+    assert torch.equal(got[:, :nv], ref)
+    assert bool((got[:, nv:] == 7.0).all())
+
+
 def test_concat_cols_kernel():
     """qt_concat: column concatenation of row-strided sources == torch.cat, and the backward hands out column views."""
     from qtmpnn import ops
