@@ -41,6 +41,9 @@ extern "C" {
 #define QT_COND_MIN_LARGER 2
 #define QT_COND_MIN_SMALLER 3
 
+/* tail edges (edges 5, 6, .. of a row) kept per clip for the clip-resident recurrence kernel: pool entries per clip */
+#define QT_TAIL_CAP 4080
+
 #define QT_ACT_NONE 0
 #define QT_ACT_RELU 1
 #define QT_ACT_TANH_RES 2 /* y = tanh(drop * acc) + res */
@@ -103,14 +106,21 @@ int qt_node_features(const int32_t* cell, int N, const int32_t* n_dev, int n, in
  */
 int qt_edges_blocks(int N);
 int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, const int32_t* n_dev, int n, int m,
-                   int32_t* cnt4, int32_t* sums /* nblk+1 */, void* stream);
+                   int32_t* cnt4, int32_t* sums /* nblk+1 */, int32_t* tail_cnt /* optional (B): zeroed here for
+                   qt_edges_norm */, int B, void* stream);
 int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* cnt4, const int32_t* sums /* as counted */,
                   int N, const int32_t* n_dev, int n, int m, float resolution,
                   int32_t* rowptr /* N+1 */, int32_t* col, float* w, float* dis /* N */, void* stream);
 int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, const float* dis, int N,
                   const int32_t* n_dev, float* nrm, int32_t* ell /* optional (N, 8): the first four edges of every row
                   again as [col x4 | nrm bits x4] (an unused slot = the row itself with weight 0; a complemented last column
-                  flags more than four edges): qt_spmm2 then reaches its gathers without the row pointer */, void* stream);
+                  flags more than four edges): qt_spmm2 then reaches its gathers without the row pointer */,
+                  const int32_t* cell, const int32_t* node_off /* (B + 1) */, int32_t* tail_cnt /* (B), zeroed by qt_edges_count */,
+                  int32_t* tail_pool /* (B, QT_TAIL_CAP, 2) */, int32_t* tail_info /* (N) */, void* stream);
+/* tail_info != NULL (then the four arrays before it are required): the edges beyond the fourth of every row, per clip, as
+ * {column - node_off[clip], weight bits} runs in tail_pool; tail_info[i] = run base | edge count << 16 (0: at most four edges;
+ * base 0xffff: the clip's pool was full, the row stays on the CSR arrays).  Read by qt_cheb_clip_fwd / _bwd. */
+int qt_tail_cap(void);
 
 /* ---------------------------------------------------------------- mesh <-> image transfers
  * flatten / unflatten, model/graph_functions.py:391-419, 451-458, by labels instead of the dense
@@ -188,16 +198,19 @@ int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* nrm, int N,
  * for block-diagonal meshes whose clips hold at most qt_cheb_clip_rows() nodes each (4096: a 64 x 64 frame).  One workgroup per
  * (clip, 4-channel column slice) keeps two slice planes in LDS; gathers are LDS reads, hops are separated by a workgroup barrier.
  * Replaces K - 1 qt_spmm2 calls of PyG ChebConv.forward's recurrence (model/model.py:53,96); bit-identical planes.
- *   node_off (B + 1): first node of each clip (device; qt_quadtree_stage3 writes it), ell: required (qt_edges_norm).
+ *   node_off (B + 1): first node of each clip (device; qt_quadtree_stage3 writes it); ell, tail_cnt / tail_pool / tail_info:
+ *   required, from qt_edges_norm (the first four edges of a row in registers, the rest from the clip's pool copied to LDS).
  *   N: plane stride in rows (the capacity in static mode; the valid rows come from node_off).
  * qt_cheb_clip_fwd: T_k = 2 L^ T_{k-1} - T_{k-2} (T_0 = Z = [za | zb], T_1 = L^ Z) -> Ta (K - 1, N, Ca), Tb (K - 1, N, Cb).
  * qt_cheb_clip_bwd: Clenshaw on the gradient planes Ga (K, N, Ca), Gb (K, N, Cb): plane 0 is overwritten with
  *   A_0 + L^ b_1 - b_2, b_k = A_k + 2 L^ b_{k+1} - b_{k+2}; planes 1 .. K - 1 are left as given (the b_k stay in LDS). */
 int qt_cheb_clip_rows(void);
 int qt_cheb_clip_fwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* node_off,
+                     const int32_t* tail_cnt, const int32_t* tail_pool, const int32_t* tail_info,
                      int B, int N, int K, int Ca, const float* za, int lda, float* Ta,
                      int Cb, const float* zb, int ldb, float* Tb, void* stream);
 int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* node_off,
+                     const int32_t* tail_cnt, const int32_t* tail_pool, const int32_t* tail_info,
                      int B, int N, int K, int Ca, float* Ga, int Cb, float* Gb, void* stream);
 
 /* qt_dense: out planes = act( [A planes | S] @ [W ; Ws] ), the gate GEMM.

@@ -47,9 +47,11 @@ constexpr int ET = 1024;
 
 __global__ __launch_bounds__(ET) void k_edges_count(const int32_t* __restrict__ labels, const int32_t* __restrict__ cell,
                                                     int Ncap, const int32_t* __restrict__ n_dev, int n, int m,
-                                                    int32_t* __restrict__ cnt4, int32_t* __restrict__ sums) {
+                                                    int32_t* __restrict__ cnt4, int32_t* __restrict__ sums,
+                                                    int32_t* __restrict__ tail_cnt, int B) {
     __shared__ int red[16];
     const int idx = blockIdx.x * ET + threadIdx.x;
+    if (tail_cnt && idx < B) tail_cnt[idx] = 0;      // the per-clip tail-edge counters k_edges_nrm adds to (two launches later)
     int cnt = 0;
     if (idx < 4 * qt_rows(n_dev, Ncap)) {
         const int4 cl = reinterpret_cast<const int4*>(cell)[idx >> 2];
@@ -117,7 +119,9 @@ __global__ __launch_bounds__(ET) void k_edges_fill(const int32_t* __restrict__ l
 
 __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
                             const float* __restrict__ dis, int Ncap, const int32_t* __restrict__ n_dev,
-                            float* __restrict__ nrm, int4* __restrict__ ell) {
+                            float* __restrict__ nrm, int4* __restrict__ ell, const int32_t* __restrict__ cell,
+                            const int32_t* __restrict__ node_off, int32_t* __restrict__ tail_cnt, int2* __restrict__ tail_pool,
+                            uint32_t* __restrict__ tail_info) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= qt_rows(n_dev, Ncap)) return;
     const float di = dis[i];
@@ -139,6 +143,28 @@ __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* _
         ell[2 * (int64_t)i] = make_int4(c4[0], c4[1], c4[2], c4[3]);
         ell[2 * (int64_t)i + 1] = make_int4(__float_as_int(w4[0]), __float_as_int(w4[1]), __float_as_int(w4[2]), __float_as_int(w4[3]));
     }
+    if (tail_info) {
+        // The edges beyond the fourth again, per CLIP, as {column relative to the clip's first node, weight}: the clip-resident
+        // recurrence kernel (chebclip.hip) copies a clip's pool into LDS once per launch.  A row reserves its run with one atomic
+        // add on the clip's counter (zeroed by k_edges_count), so the order of the runs varies from build to build, the contents
+        // of a run (CSR order) do not.  A clip with more than QT_TAIL_CAP tail edges keeps the rows that did not fit on the CSR
+        // walk (base 0xffff).
+        uint32_t info = 0;
+        const int cnt = min(e1 - e0 - 4, 0xffff);
+        if (cnt > 0) {
+            const int clip = cell[4 * (int64_t)i + 3];
+            const int r0 = node_off[clip];
+            const int base = atomicAdd(&tail_cnt[clip], cnt);
+            if (base + cnt <= QT_TAIL_CAP) {
+                int2* dst = tail_pool + (int64_t)clip * QT_TAIL_CAP + base;
+                for (int j = 0; j < cnt; ++j) dst[j] = make_int2(col[e0 + 4 + j] - r0, __float_as_int(nrm[e0 + 4 + j]));
+                info = (uint32_t)base | ((uint32_t)cnt << 16);
+            } else {
+                info = 0xffffu | ((uint32_t)cnt << 16);
+            }
+        }
+        tail_info[i] = info;
+    }
 }
 
 }  // namespace
@@ -146,11 +172,12 @@ __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* _
 extern "C" int qt_edges_blocks(int N) { return N > 0 ? qt_cdiv(4 * (int64_t)N + 1, ET) : 0; }
 
 extern "C" int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, const int32_t* n_dev, int n, int m,
-                              int32_t* cnt4, int32_t* sums, void* stream) {
+                              int32_t* cnt4, int32_t* sums, int32_t* tail_cnt, int B, void* stream) {
     QT_ARG(labels && cell && cnt4 && sums, "null pointer");
+    QT_ARG(!tail_cnt || (B > 0 && B <= ET), "tail_cnt: 1 .. 1024 clips");
     if (N <= 0) return QT_OK;
     hipLaunchKernelGGL(k_edges_count, dim3(qt_edges_blocks(N)), dim3(ET), 0, (hipStream_t)stream, labels, cell, N, n_dev, n, m,
-                       cnt4, sums);
+                       cnt4, sums, tail_cnt, B);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -166,13 +193,19 @@ extern "C" int qt_edges_fill(const int32_t* labels, const int32_t* cell, const i
     return QT_OK;
 }
 
+extern "C" int qt_tail_cap(void) { return QT_TAIL_CAP; }
+
 extern "C" int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, const float* dis, int N,
-                             const int32_t* n_dev, float* nrm, int32_t* ell, void* stream) {
+                             const int32_t* n_dev, float* nrm, int32_t* ell, const int32_t* cell, const int32_t* node_off,
+                             int32_t* tail_cnt, int32_t* tail_pool, int32_t* tail_info, void* stream) {
     QT_ARG(rowptr && col && w && dis && nrm, "null pointer");
     QT_ARG(((uintptr_t)ell & 15) == 0, "ell must be 16-byte aligned");
+    QT_ARG(!tail_info || (cell && node_off && tail_cnt && tail_pool && ((uintptr_t)tail_pool & 15) == 0),
+           "tail_info needs cell, node_off, tail_cnt (zeroed by qt_edges_count) and a 16-byte aligned tail_pool");
     if (N <= 0) return QT_OK;
     hipLaunchKernelGGL(k_edges_nrm, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, w, dis, N, n_dev, nrm,
-                       reinterpret_cast<int4*>(ell));
+                       reinterpret_cast<int4*>(ell), cell, node_off, tail_cnt, reinterpret_cast<int2*>(tail_pool),
+                       reinterpret_cast<uint32_t*>(tail_info));
     QT_LAUNCHED();
     return QT_OK;
 }

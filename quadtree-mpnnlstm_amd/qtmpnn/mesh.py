@@ -50,6 +50,7 @@ class Mesh:
         self._E = None
         self.n_dev = None        # device int32[1] with the valid node count when N is a capacity (static mode)
         self.ell = None          # (N, 8) int32: [col x4 | nrm bits x4] of the first four edges of every row
+        self.tail_cnt = self.tail_pool = self.tail_info = None     # the edges beyond the fourth, per clip (qt_edges_norm)
         self.pixelwise = False   # every unmasked pixel is a node (thresh = -inf); unflatten then NaN-fills the mask
         self.recipe = None       # arguments that rebuild a data-independent mesh for another batch size
         self.loss_mask = None    # (n, m) u8 when the labels do not encode the mask (homogeneous preset mesh): the loss
@@ -290,7 +291,12 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
     nblk = _lib.value('qt_edges_blocks', N)
     cnt4 = torch.empty(nblk * 1024, **i32)
     sums = torch.empty(nblk + 1, **i32)
-    _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4), ptr(sums))
+    # per-clip pool of the edges beyond a row's fourth (qt_edges_norm fills it; the clip-resident recurrence kernel reads it)
+    tcap = _lib.value('qt_tail_cap')
+    ms.tail_cnt = torch.empty(B, **i32)
+    ms.tail_pool = torch.empty(B, tcap, 2, **i32)
+    ms.tail_info = torch.empty(N, **i32)
+    _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4), ptr(sums), ptr(ms.tail_cnt), B)
     emax = 4 * B * n * m                          # every directed edge owns >= 1 of the 4*P pixel adjacencies
     ms.col = torch.empty(emax, **i32)
     ms.w = torch.empty(emax, device=device)
@@ -298,7 +304,8 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
     _lib.call('qt_edges_fill', ptr(ms.labels), ptr(ms.cell), ptr(cnt4), ptr(sums), N, nd, n, m, float(resolution),
               ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis))
     ms.ell = torch.empty(N, 8, **i32)             # first four edges per row as two 16-byte vectors (k_spmm's fast path)
-    _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm), ptr(ms.ell))
+    _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm), ptr(ms.ell), ptr(ms.cell),
+              ptr(ms.node_off), ptr(ms.tail_cnt), ptr(ms.tail_pool), ptr(ms.tail_info))
 
 
 def build_homogeneous_mesh(n, m, max_size, mask, B=1, device=None, resolution=0.25):

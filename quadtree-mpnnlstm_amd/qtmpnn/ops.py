@@ -259,6 +259,11 @@ def _plane_args(Zs, TZs):
 
 
 _CLIP_CHEB = os.environ.get('QT_NO_CLIP_CHEB') != '1'      # (A/B switch: 1 = one k_spmm launch per hop everywhere)
+# Recurrences of at least this many planes take the clip-resident launch.  Its fixed cost (~4 us: one memory phase that fills the
+# registers and LDS) is paid once per launch and a hop costs ~4 us against ~7.4 us for a k_spmm launch at the bench shape
+# (tools/exp_clip.py): K = 5 (stacks of two ChebConvs) 21.4 vs 29.6 us forward, 21.3 vs 31.4 us backward; K = 3 13.4 vs 14.6 and
+# 14.3 vs 15.4; K = 2 (one hop) 8.4 vs 6.3: a single hop stays on k_spmm.
+_CLIP_MIN_K = int(os.environ.get('QT_CLIP_MIN_K', '3'))
 _CLIP_ROWS = []
 
 
@@ -267,23 +272,23 @@ def _clip_resident(mesh, widths, K):
     diagonal mesh fits the kernel's LDS planes (n x m <= 4096 nodes), rows are float4 slices, the ELL side array exists."""
     if not _CLIP_ROWS:
         _CLIP_ROWS.append(_lib.value('qt_cheb_clip_rows'))
-    return (_CLIP_CHEB and K >= 2 and mesh.N > 0 and mesh.ell is not None and mesh.n * mesh.m <= _CLIP_ROWS[0]
+    return (_CLIP_CHEB and K >= max(_CLIP_MIN_K, 2) and mesh.N > 0 and mesh.ell is not None and mesh.tail_info is not None and mesh.n * mesh.m <= _CLIP_ROWS[0]
             and len(widths) <= 2 and all(w % 4 == 0 for w in widths) and getattr(mesh, 'node_off', None) is not None)
 
 
 def clip_planes(mesh, Zs, TZs, K):
     """TZs[i] (K - 1, N, C_i) <- T_1 .. T_{K-1} of the recurrence on the parts Zs, all hops in ONE launch (qt_cheb_clip_fwd)."""
     two = len(Zs) > 1
-    _lib.call('qt_cheb_clip_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off), mesh.B,
-              Zs[0].shape[0], K, Zs[0].shape[1], ptr(Zs[0]), _ld(Zs[0]), ptr(TZs[0]),
+    _lib.call('qt_cheb_clip_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off),
+              ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_info), mesh.B, Zs[0].shape[0], K, Zs[0].shape[1], ptr(Zs[0]), _ld(Zs[0]), ptr(TZs[0]),
               Zs[1].shape[1] if two else 0, ptr(Zs[1]) if two else None, _ld(Zs[1]) if two else 0, ptr(TZs[1]) if two else None)
 
 
 def clip_clenshaw(mesh, Gs, K):
     """Gs[i] (K, N, C_i) gradient planes: plane 0 <- A_0 + L^ b_1 - b_2 (Clenshaw), all hops in ONE launch (qt_cheb_clip_bwd)."""
     two = len(Gs) > 1
-    _lib.call('qt_cheb_clip_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off), mesh.B,
-              Gs[0].shape[1], K, Gs[0].shape[2], ptr(Gs[0]), Gs[1].shape[2] if two else 0, ptr(Gs[1]) if two else None)
+    _lib.call('qt_cheb_clip_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off),
+              ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_info), mesh.B, Gs[0].shape[1], K, Gs[0].shape[2], ptr(Gs[0]), Gs[1].shape[2] if two else 0, ptr(Gs[1]) if two else None)
 
 
 def _cheb_planes(Zs, mesh, K):

@@ -641,7 +641,7 @@ def test_clip_resident_recurrence_equals_per_hop_launches(K, widths, B):
     from qtmpnn.mesh import spmm2
     mesh, _ = _mesh_64(11, noise=0.0, B=B)                       # sparse mesh: cells of 1 .. 32 pixels side by side
     deg = (mesh.rowptr[1:] - mesh.rowptr[:-1])
-    assert int(deg.max()) > 4 and ops._clip_resident(mesh, list(widths), K)
+    assert int(deg.max()) > 4 and ops._clip_resident(mesh, list(widths), max(K, ops._CLIP_MIN_K))
     torch.manual_seed(K)
     N = mesh.N
     wide = torch.randn(N, sum(widths) + 8, device=dev())
@@ -649,7 +649,8 @@ def test_clip_resident_recurrence_equals_per_hop_launches(K, widths, B):
     for w in widths:
         Zs.append(wide[:, o:o + w])
         o += w
-    fused = ops._cheb_planes(Zs, mesh, K)
+    fused = [torch.empty(K - 1, N, w, device=dev()) for w in widths]
+    ops.clip_planes(mesh, Zs, fused, K)
     prev, ops._CLIP_CHEB = ops._CLIP_CHEB, False          # one qt_spmm2 launch per hop
     try:
         ref = ops._cheb_planes(Zs, mesh, K)
@@ -688,8 +689,8 @@ def test_clip_resident_recurrence_static_capacities():
     got = torch.full((3, sm.N, 16), 7.0, device=dev())
     from qtmpnn import _lib
     from qtmpnn._lib import ptr
-    _lib.call('qt_cheb_clip_fwd', ptr(sm.rowptr), ptr(sm.col), ptr(sm.nrm), ptr(sm.ell), ptr(sm.node_off), sm.B, sm.N, 4,
-              16, ptr(Zs), 16, ptr(got), 0, None, 0, None)
+    _lib.call('qt_cheb_clip_fwd', ptr(sm.rowptr), ptr(sm.col), ptr(sm.nrm), ptr(sm.ell), ptr(sm.node_off), ptr(sm.tail_cnt),
+              ptr(sm.tail_pool), ptr(sm.tail_info), sm.B, sm.N, 4, 16, ptr(Zs), 16, ptr(got), 0, None, 0, None)
     assert torch.equal(got[:, :nv], ref)
     assert bool((got[:, nv:] == 7.0).all())
 
