@@ -77,12 +77,12 @@ def spmm_roofline(nfp, batch, mask, reps=10):
     hipGraph, so that the device and not the host call is timed) between two events on the replay stream with same-shaped
     operands, and the per-launch averages are summed: the figure covers exactly the launch mix of one training step.
 
-    Algorithmic bytes.  Per hop, SURVEY.md 8(d): 4(N+1) + 8E' + 8NC (index arrays + every feature row read
-    once + every output row written once).  A fused launch of K - 1 hops must move the index arrays once, Z once and K - 1 planes
-    out (forward: 4(N+1) + 8E' + 4NC K), or K gradient planes in and one out (backward: 4(N+1) + 8E' + 4NC (K + 1)) -- the
-    intermediate planes are not re-read from HBM, so the fused launch is priced on THESE bytes (`achieved`, `frac`), which is
-    the smaller, stricter count; `per_hop_equivalent` prices the same launches at (K - 1) x the per-hop figure for comparison
-    with the round-2 numbers."""
+    Algorithmic bytes.  The unit of work is one message-aggregate hop, SURVEY.md 8(d): 4(N+1) + 8E' + 8NC
+    bytes (index arrays + every feature row read once + every output row written once); a launch is priced at that figure x the
+    hops it processes (`achieved`, `frac`: 1 hop for k_spmm, K - 1 for a clip-resident launch).  `fused_own_bytes` is the
+    stricter count for the fused launches: what THEY must move through HBM -- index arrays once, Z once and K - 1 planes out
+    (forward: 4(N+1) + 8E' + 4NC K), or K gradient planes in and one out (backward: 4(N+1) + 8E' + 4NC (K + 1)); the
+    intermediate planes of a fused recurrence are never re-read from HBM.  `traffic` (PMC) is what actually crossed the fabric."""
     import torch
     from qtmpnn import mesh as qmesh, ops
     records = []
@@ -171,11 +171,12 @@ def spmm_roofline(nfp, batch, mask, reps=10):
         pk['us'] += us
         pk['bytes'] += by
     n = len(records)
-    achieved = tot['bytes'] / (tot['us'] * 1e-6) / 1e9
+    achieved = tot['hop_bytes'] / (tot['us'] * 1e-6) / 1e9          # SURVEY 8(d)'s per-hop figure x the hops a launch processes
+    own = tot['bytes'] / (tot['us'] * 1e-6) / 1e9                   # the fused launches' own compulsory bytes (stricter)
     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes over this same command (they cannot be collected
     # in-process); the newest committed record is quoted and named
     traffic = source = None
-    for name in ('r03_pmc_chebclip.json', 'r02_pmc_spmm.json'):
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_spmm.json'):
         pmc = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pmc):
             traffic, source = json.load(open(pmc))['traffic_bytes_per_launch'], 'profiles/' + name
@@ -189,11 +190,12 @@ def spmm_roofline(nfp, batch, mask, reps=10):
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': source,
             'launches_per_step': n, 'hops_per_step': tot['hops'], 'avg_launch_us': round(tot['us'] / n, 2),
-            'us_per_step': round(tot['us'], 1), 'avg_bytes_per_launch': round(tot['bytes'] / n), 'kernels': kinds,
-            'per_hop_equivalent': {'achieved': round(tot['hop_bytes'] / (tot['us'] * 1e-6) / 1e9, 1),
-                                   'frac': round(tot['hop_bytes'] / (tot['us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                   'avg_us_per_hop': round(tot['us'] / max(tot['hops'], 1), 2),
-                                   'note': 'the same launches priced at SURVEY 8(d)\'s per-hop figure x hops (round-2 accounting)'},
+            'us_per_step': round(tot['us'], 1), 'avg_bytes_per_launch': round(tot['hop_bytes'] / n),
+            'avg_us_per_hop': round(tot['us'] / max(tot['hops'], 1), 2), 'kernels': kinds,
+            'fused_own_bytes': {'achieved': round(own, 1), 'frac': round(own / HBM_PEAK_GBS, 4),
+                                'avg_bytes_per_launch': round(tot['bytes'] / n),
+                                'note': 'the stricter count: a fused launch priced on the bytes IT must move (index arrays + Z '
+                                        'once + K-1 planes out; backward K planes in + one out), not on hops x the per-hop figure'},
             'bytes_formula': "per hop 4(N+1) + 8E' + 8NC (SURVEY 8(d)); fused K-1 hops: forward 4(N+1) + 8E' + 4NC K, "
                              "backward 4(N+1) + 8E' + 4NC (K+1)"}
 
