@@ -43,6 +43,7 @@ extern "C" {
 
 /* tail edges (edges 5, 6, .. of a row) kept per clip for the clip-resident recurrence kernel: pool entries per clip */
 #define QT_TAIL_CAP 4080
+#define QT_TAIL_CNT_STRIDE 32 /* ints between the per-clip tail counters (one 128-byte line each) */
 
 #define QT_ACT_NONE 0
 #define QT_ACT_RELU 1
@@ -106,8 +107,8 @@ int qt_node_features(const int32_t* cell, int N, const int32_t* n_dev, int n, in
  */
 int qt_edges_blocks(int N);
 int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, const int32_t* n_dev, int n, int m,
-                   int32_t* cnt4, int32_t* sums /* nblk+1 */, int32_t* tail_cnt /* optional (B): zeroed here for
-                   qt_edges_norm */, int B, void* stream);
+                   int32_t* cnt4, int32_t* sums /* nblk+1 */, int32_t* tail_cnt /* optional (B * QT_TAIL_CNT_STRIDE): clip c's counter
+                   [QT_TAIL_CNT_STRIDE * c] is zeroed here for qt_edges_norm */, int B, void* stream);
 int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* cnt4, const int32_t* sums /* as counted */,
                   int N, const int32_t* n_dev, int n, int m, float resolution,
                   int32_t* rowptr /* N+1 */, int32_t* col, float* w, float* dis /* N */, void* stream);
@@ -115,7 +116,7 @@ int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, con
                   const int32_t* n_dev, float* nrm, int32_t* ell /* optional (N, 8): the first four edges of every row
                   again as [col x4 | nrm bits x4] (an unused slot = the row itself with weight 0; a complemented last column
                   flags more than four edges): qt_spmm2 then reaches its gathers without the row pointer */,
-                  const int32_t* cell, const int32_t* node_off /* (B + 1) */, int32_t* tail_cnt /* (B), zeroed by qt_edges_count */,
+                  const int32_t* cell, const int32_t* node_off /* (B + 1) */, int32_t* tail_cnt /* (B * QT_TAIL_CNT_STRIDE), zeroed by qt_edges_count */,
                   int32_t* tail_pool /* (B, QT_TAIL_CAP, 2) */, int32_t* tail_info /* (N) */, void* stream);
 /* tail_info != NULL (then the four arrays before it are required): the edges beyond the fourth of every row, per clip, as
  * {column - node_off[clip], weight bits} runs in tail_pool; tail_info[i] = run base | edge count << 16 (0: at most four edges;

@@ -52,7 +52,7 @@ struct ClipArgs {
     const float* nrm;
     const int4* ell;
     const int32_t* node_off;       // (B + 1) first node of every clip (device): the valid rows of clip c are [off[c], off[c + 1])
-    const int32_t* tail_cnt;       // (B) tail edges of every clip in the pool (may exceed the capacity: see tail_info)
+    const int32_t* tail_cnt;       // (B * QT_TAIL_CNT_STRIDE) tail edges of every clip in the pool (may exceed the capacity: see tail_info)
     const int2* tail_pool;         // (B, CL_TAIL) {local column, weight bits}
     const uint32_t* tail_info;     // (N) per row: pool base | count << 16; 0 = at most four edges; base 0xffff = walk the CSR
     int B, K, nsa;                 // nsa: 4-channel slices of part a (part b's follow)
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
     const int r0 = g.node_off[c];
     const int nr = min(g.node_off[c + 1] - r0, CL_ROWS);
     if (nr <= 0) return;                                   // (workgroup-uniform)
-    const int ntail = min(g.tail_cnt[c], CL_TAIL);
+    const int ntail = min(g.tail_cnt[QT_TAIL_CNT_STRIDE * c], CL_TAIL);
     CL_STAMP(0);
     const int K = g.K;
     const unsigned pstride = (unsigned)g.Ncap * (unsigned)C;      // (K * Ncap * C < 2^31: checked by the host entry -- 32-bit offsets)

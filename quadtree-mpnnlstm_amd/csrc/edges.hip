@@ -51,7 +51,7 @@ __global__ __launch_bounds__(ET) void k_edges_count(const int32_t* __restrict__ 
                                                     int32_t* __restrict__ tail_cnt, int B) {
     __shared__ int red[16];
     const int idx = blockIdx.x * ET + threadIdx.x;
-    if (tail_cnt && idx < B) tail_cnt[idx] = 0;      // the per-clip tail-edge counters k_edges_nrm adds to (two launches later)
+    if (tail_cnt && idx < B) tail_cnt[QT_TAIL_CNT_STRIDE * idx] = 0;      // the per-clip tail-edge counters k_edges_nrm adds to (two launches later)
     int cnt = 0;
     if (idx < 4 * qt_rows(n_dev, Ncap)) {
         const int4 cl = reinterpret_cast<const int4*>(cell)[idx >> 2];
@@ -148,13 +148,14 @@ __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* _
         // recurrence kernel (chebclip.hip) copies a clip's pool into LDS once per launch.  A row reserves its run with one atomic
         // add on the clip's counter (zeroed by k_edges_count), so the order of the runs varies from build to build, the contents
         // of a run (CSR order) do not.  A clip with more than QT_TAIL_CAP tail edges keeps the rows that did not fit on the CSR
-        // walk (base 0xffff).
+        // walk (base 0xffff).  The counters sit QT_TAIL_CNT_STRIDE ints (one 128-byte line) apart: side by side in one line, the
+        // ~3500 atomic adds of a 32-clip mesh serialised on that line and the launch took 32 us instead of 8.
         uint32_t info = 0;
         const int cnt = min(e1 - e0 - 4, 0xffff);
         if (cnt > 0) {
             const int clip = cell[4 * (int64_t)i + 3];
             const int r0 = node_off[clip];
-            const int base = atomicAdd(&tail_cnt[clip], cnt);
+            const int base = atomicAdd(&tail_cnt[QT_TAIL_CNT_STRIDE * clip], cnt);
             if (base + cnt <= QT_TAIL_CAP) {
                 int2* dst = tail_pool + (int64_t)clip * QT_TAIL_CAP + base;
                 for (int j = 0; j < cnt; ++j) dst[j] = make_int2(col[e0 + 4 + j] - r0, __float_as_int(nrm[e0 + 4 + j]));

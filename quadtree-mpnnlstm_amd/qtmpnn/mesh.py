@@ -293,7 +293,7 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
     sums = torch.empty(nblk + 1, **i32)
     # per-clip pool of the edges beyond a row's fourth (qt_edges_norm fills it; the clip-resident recurrence kernel reads it)
     tcap = _lib.value('qt_tail_cap')
-    ms.tail_cnt = torch.empty(B, **i32)
+    ms.tail_cnt = torch.empty(B * 32, **i32)                 # (QT_TAIL_CNT_STRIDE ints apart: one cache line per clip's counter)
     ms.tail_pool = torch.empty(B, tcap, 2, **i32)
     ms.tail_info = torch.empty(N, **i32)
     _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4), ptr(sums), ptr(ms.tail_cnt), B)
