@@ -71,15 +71,20 @@ int qt_quadtree_stage1(const float* src, int src_rows, int src_cols,
                        int B, int n, int m, int max_size, float thresh, int condition,
                        const uint8_t* mask, const uint8_t* hir,
                        int32_t* local_id /* (B,n,m) */, uint8_t* level /* (B,n,m) */,
-                       int32_t* cnt /* (B*nbase) */, void* stream);
-int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_offsets /* exclusive scan of cnt, length B*nbase+1 */,
+                       int32_t* cnt /* (B*nbase), or (B*nbase*4) with quads */,
+                       int quads /* != 0 (max_size == 64 only): one workgroup per 32 x 32 quadrant of a base cell, leaf counts per
+                       quadrant in DFS order; stage 3 must get the same flag */,
+                       int32_t* fill_neg1 /* optional */, int fill_len /* fill_neg1[0 .. fill_len) = -1: the bwd_src array stage 3
+                       completes (entries it does not write must read "no direct source row") */, void* stream);
+int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_offsets /* exclusive scan of cnt, length B*nbase[*4]+1 */,
                        int B, int n, int m, int max_size,
                        int32_t* labels /* (B,n,m) */, const uint8_t* level, int32_t* cell /* (Nmax,4) */,
                        int32_t* node_off /* (B+1) */,
                        float size_norm, float* feat /* (Nmax,3) or NULL */, float* npix /* (Nmax) or NULL: the
                        qt_node_features outputs, written by the same pass */,
-                       int raw_counts /* != 0: cnt_offsets is stage 1's cnt itself (B*nbase <= 1024 counts), scanned by
+                       int raw_counts /* != 0: cnt_offsets is stage 1's cnt itself (<= 1024 counts), scanned by
                        every workgroup in LDS: no qt_scan_i32 launch in between (static capacities) */,
+                       int quads /* as given to stage 1: four count slots per base cell */,
                        const int32_t* old_labels, const uint8_t* old_level /* the mesh this one was built from, or NULL */,
                        int32_t* fwd_src /* (Nmax) or NULL: per node of THIS mesh the old node under its pixel if the node
                        is a single pixel, else -1: qt_remesh's `direct` index for the transfer old -> this mesh */,

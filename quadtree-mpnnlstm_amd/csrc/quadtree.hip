@@ -47,7 +47,40 @@ struct Stage1Args {
     int32_t* local_id;
     uint8_t* level;
     int32_t* cnt;
+    int32_t* fill;          // optional: fill[0 .. fill_len) = -1 (the old mesh's bwd_src: stage 3 writes only the entries of old nodes
+    int fill_len;           // whose head pixel carries their label, every other entry must read "no direct source row")
 };
+
+// criterion value and mask / high-interest flags of window element (gr, gc) of clip b, with the reference's clamps
+__device__ __forceinline__ void window_elem(const Stage1Args& a, int b, int gr, int gc, int n_pad, int m_pad, int64_t P, float* val,
+                                            uint8_t* flag) {
+    float v = -INFINITY;
+    uint8_t f = 0;
+    if (gr < n_pad && gc < m_pad) {
+        if (a.src) {
+            const int rr = min(gr, a.src_rows - 1), cc = min(gc, a.src_cols - 1);
+            v = a.src[((int64_t)b * a.src_rows + rr) * a.src_cols + cc];
+        } else {
+            const int rr = min(gr, a.n - 1), cc = min(gc, a.m - 1);
+            const int lab = a.old_labels[b * P + (int64_t)rr * a.m + cc];
+            v = lab >= 0 ? a.nodeval[(int64_t)lab * a.nodeval_stride] : 0.0f;
+        }
+        if (a.negate) v = -v;
+        if (gr < a.n && gc < a.m) {
+            const int64_t p = (int64_t)gr * a.m + gc;
+            if (a.mask && a.mask[p]) f |= 1;
+            if (a.hir && a.hir[p]) f |= 2;
+        }
+    }
+    *val = v;
+    *flag = f;
+}
+
+__device__ __forceinline__ void fill_neg1(const Stage1Args& a, int nthreads) {
+    if (!a.fill) return;
+    const int64_t i0 = (int64_t)blockIdx.x * nthreads + threadIdx.x, step = (int64_t)gridDim.x * nthreads;
+    for (int64_t i = i0; i < a.fill_len; i += step) a.fill[i] = -1;
+}
 
 constexpr int PITCH = 66;
 
@@ -74,29 +107,10 @@ __global__ __launch_bounds__(S1T) void k_quadtree_stage1(Stage1Args a) {
     const int64_t P = (int64_t)a.n * a.m;
 
     // ---- 1. criterion window (MS+1)^2 with the reference's clamps
+    fill_neg1(a, S1T);
     for (int idx = t; idx < W1 * W1; idx += S1T) {
         const int r = idx / W1, c = idx % W1;
-        const int gr = x0 + r, gc = y0 + c;
-        float val = -INFINITY;
-        uint8_t f = 0;
-        if (gr < n_pad && gc < m_pad) {
-            if (a.src) {
-                const int rr = min(gr, a.src_rows - 1), cc = min(gc, a.src_cols - 1);
-                val = a.src[((int64_t)b * a.src_rows + rr) * a.src_cols + cc];
-            } else {
-                const int rr = min(gr, a.n - 1), cc = min(gc, a.m - 1);
-                const int lab = a.old_labels[b * P + (int64_t)rr * a.m + cc];
-                val = lab >= 0 ? a.nodeval[(int64_t)lab * a.nodeval_stride] : 0.0f;
-            }
-            if (a.negate) val = -val;
-            if (gr < a.n && gc < a.m) {
-                const int64_t p = (int64_t)gr * a.m + gc;
-                if (a.mask && a.mask[p]) f |= 1;
-                if (a.hir && a.hir[p]) f |= 2;
-            }
-        }
-        v[r * PITCH + c] = val;
-        fm[r * PITCH + c] = f;
+        window_elem(a, b, x0 + r, y0 + c, n_pad, m_pad, P, &v[r * PITCH + c], &fm[r * PITCH + c]);
     }
     __syncthreads();
 
@@ -192,6 +206,163 @@ __global__ __launch_bounds__(S1T) void k_quadtree_stage1(Stage1Args a) {
     if (t == 0) a.cnt[b * nbase + (nbase - 1 - base)] = total;
 }
 
+// The same decomposition with a 64 x 64 base cell split over FOUR workgroups, one per 32 x 32 quadrant: a mesh build has only
+// B * nbase base cells (32 at the bench shape: an eighth of the CUs, each walking its 4096 pixels through a dozen barrier-
+// separated phases -- 18 us per launch).  A quadrant's workgroup decides the base cell's top-level split itself (max and
+// mask / high-interest flags over the whole 65 x 65 window: one load phase, a block reduction) and otherwise sees only its own
+// 33 x 33 window: levels 1 .. 5 of the pyramid, the leaf of every pixel, the leaf heads in reversed-Morton (= DFS) order, their
+// exclusive scan.  Leaf counts go out per QUADRANT in DFS order -- children are visited (1,1), (0,1), (1,0), (0,0), so quadrant
+// (qr, qc) has rank 3 - (qr + 2 qc) -- and stage 3's scan over the counts adds the offsets; a base cell that does not split is
+// one leaf, counted by the rank-0 workgroup and recognised in stage 3 by its level (6).
+constexpr int QS = 32, QW = QS + 1, QPITCH = 34, QT = 1024;
+__global__ __launch_bounds__(QT) void k_quadtree_stage1q(Stage1Args a) {
+    __shared__ float v[QW * QPITCH];
+    __shared__ uint8_t fm[QW * QPITCH];
+    __shared__ float D[341];
+    __shared__ uint8_t Fp[341];
+    __shared__ uint8_t split[341];
+    __shared__ int flags[QS * QS];
+    __shared__ int red[16];
+    __shared__ float redf[16];
+    __shared__ int redo[16];
+
+    const int t = threadIdx.x;
+    const int MS = 64;
+    const int nbase = a.nbi * a.nbj;
+    const int quad = blockIdx.x & 3, cellid = blockIdx.x >> 2;
+    const int b = cellid / nbase, base = cellid % nbase;
+    const int bi = base / a.nbj, bj = base % a.nbj;
+    const int qr = quad >> 1, qc = quad & 1;
+    const int X0 = bi * MS, Y0 = bj * MS;                 // base cell origin
+    const int x0 = X0 + qr * QS, y0 = Y0 + qc * QS;       // quadrant origin
+    const int n_pad = a.nbi * MS, m_pad = a.nbj * MS;
+    const int64_t P = (int64_t)a.n * a.m;
+    const float thr = a.negate ? -a.thresh : a.thresh;
+    fill_neg1(a, QT);
+
+    // ---- 1. the quadrant's own (QS+1)^2 window into LDS; max / flags over the base cell's whole (MS+1)^2 window in registers
+    for (int idx = t; idx < QW * QW; idx += QT) {
+        const int r = idx / QW, c = idx % QW;
+        window_elem(a, b, x0 + r, y0 + c, n_pad, m_pad, P, &v[r * QPITCH + c], &fm[r * QPITCH + c]);
+    }
+    float wmax = -INFINITY;
+    int wflag = 0;
+    for (int idx = t; idx < (MS + 1) * (MS + 1); idx += QT) {
+        const int r = idx / (MS + 1), c = idx % (MS + 1);
+        float val;
+        uint8_t f;
+        window_elem(a, b, X0 + r, Y0 + c, n_pad, m_pad, P, &val, &f);
+        wmax = fmaxf(wmax, val);
+        wflag |= f;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        wmax = fmaxf(wmax, __shfl_xor(wmax, d, 64));
+        wflag |= __shfl_xor(wflag, d, 64);
+    }
+    if ((t & 63) == 0) {
+        redf[t >> 6] = wmax;
+        redo[t >> 6] = wflag;
+    }
+    __syncthreads();
+    float tmax = -INFINITY;
+    int tflag = 0;
+#pragma unroll
+    for (int w = 0; w < QT / 64; ++w) {
+        tmax = fmaxf(tmax, redf[w]);
+        tflag |= redo[w];
+    }
+    const bool top_split = (a.larger ? (tmax > thr) : (tmax < thr)) || tflag != 0;
+    const int rank = 3 - (qr + 2 * qc);
+    const int cnt_slot = (b * nbase + (nbase - 1 - base)) * 4 + rank;
+    if (!top_split) {
+        // the base cell is one leaf (level 6): every in-image pixel gets local id 0 relative to the cell's first count slot
+        const int r = t >> 5, c = t & 31;
+        const int gr = x0 + r, gc = y0 + c;
+        if (gr < a.n && gc < a.m) {
+            const int64_t p = b * P + (int64_t)gr * a.m + gc;
+            a.local_id[p] = 0;
+            a.level[p] = 6;
+        }
+        if (t == 0) a.cnt[cnt_slot] = (rank == 0 && X0 < a.n && Y0 < a.m) ? 1 : 0;
+        return;
+    }
+
+    // ---- 2. window-max pyramid of the quadrant; level l has (QS >> l)^2 cells of size 2^l, l = 1 .. 5
+    int lbase = 0, prev_base = 0;
+    for (int l = 1; l <= 5; ++l) {
+        const int nc = QS >> l;
+        for (int idx = t; idx < nc * nc; idx += QT) {
+            const int i = idx / nc, j = idx % nc;
+            float mx;
+            uint8_t fo;
+            if (l == 1) {
+                mx = -INFINITY;
+                fo = 0;
+#pragma unroll
+                for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+                    for (int dc = 0; dc < 3; ++dc) {
+                        const int o = (2 * i + dr) * QPITCH + 2 * j + dc;
+                        mx = fmaxf(mx, v[o]);
+                        fo |= fm[o];
+                    }
+            } else {
+                // (a level-l window is the union of its four children's windows: they overlap in the rows / columns the
+                // children share and reach the same extra row and column)
+                const int pc = nc * 2;
+                const int o = prev_base + (2 * i) * pc + 2 * j;
+                mx = fmaxf(fmaxf(D[o], D[o + 1]), fmaxf(D[o + pc], D[o + pc + 1]));
+                fo = Fp[o] | Fp[o + 1] | Fp[o + pc] | Fp[o + pc + 1];
+            }
+            D[lbase + idx] = mx;
+            Fp[lbase + idx] = fo;
+            split[lbase + idx] = ((a.larger ? (mx > thr) : (mx < thr)) || fo != 0) ? 1 : 0;
+        }
+        __syncthreads();
+        prev_base = lbase;
+        lbase += nc * nc;
+    }
+
+    // ---- 3. leaf level of this thread's pixel, head flags in DFS (reversed Morton) order
+    const int r = t >> 5, c = t & 31;
+    flags[t] = 0;
+    __syncthreads();
+    int leaf = 0, off = lbase;
+    for (int l = 5; l >= 1; --l) {
+        const int nc = QS >> l;
+        off -= nc * nc;
+        if (!split[off + (r >> l) * nc + (c >> l)]) {
+            leaf = l;
+            break;
+        }
+    }
+    const int sz = 1 << leaf;
+    const int r0 = r & ~(sz - 1), c0 = c & ~(sz - 1);
+    bool valid = (x0 + r0 < a.n) && (y0 + c0 < a.m);
+    if (leaf == 0 && (fm[r * QPITCH + c] & 1)) valid = false;
+    if (valid && r == r0 && c == c0) flags[QS * QS - 1 - (int)morton_rc(r, c)] = 1;
+    __syncthreads();
+
+    // ---- 4. exclusive scan over the QS^2 keys (one per thread)
+    const int f = flags[t];
+    int total;
+    const int ex = qt_block_excl_scan(f, red, &total);
+    __syncthreads();
+    flags[t] = ex;
+    __syncthreads();
+
+    // ---- 5. local leaf id (relative to the quadrant's count slot) and level of this thread's pixel
+    const int gr = x0 + r, gc = y0 + c;
+    if (gr < a.n && gc < a.m) {
+        const int id = valid ? flags[QS * QS - 1 - (int)morton_rc(r0, c0)] : -1;
+        const int64_t p = b * P + (int64_t)gr * a.m + gc;
+        a.local_id[p] = id;
+        a.level[p] = (uint8_t)leaf;
+    }
+    if (t == 0) a.cnt[cnt_slot] = total;
+}
+
 // positional encoding + size feature of a node (add_positional_encoding and the size channel, model/graph_functions.py:366-389,
 // :599-607): centroid / image extent, pixel count / size_norm
 __device__ __forceinline__ void node_features(int4 cl, int i, int n, int m, float size_norm, float* __restrict__ feat,
@@ -204,7 +375,7 @@ __device__ __forceinline__ void node_features(int4 cl, int i, int n, int m, floa
     npix[i] = np_;
 }
 
-__global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const int32_t* __restrict__ offs_in, int raw,
+__global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const int32_t* __restrict__ offs_in, int raw, int quads,
                                   int B, int n, int m, int MS, int nbj, int nbase,
                                   int32_t* __restrict__ labels, const uint8_t* __restrict__ level,
                                   int32_t* __restrict__ cell, int32_t* __restrict__ node_off, float size_norm,
@@ -217,8 +388,11 @@ __global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const in
     __shared__ int soffs[1025];
     __shared__ int red[8];
     const int32_t* offs = offs_in;
+    // quads != 0: the counts come per 32 x 32 quadrant of a 64 x 64 base cell (k_quadtree_stage1q), four slots per base cell in
+    // DFS order; a pixel of level 6 (its base cell is one leaf) counts from the cell's first slot
+    const int per = quads ? 4 : 1;
     if (raw) {
-        const int len = B * nbase;
+        const int len = B * nbase * per;
         int carry = 0;
         for (int c0 = 0; c0 < len; c0 += 256) {
             const int i = c0 + (int)threadIdx.x;
@@ -234,7 +408,7 @@ __global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const in
     }
     const int64_t P = (int64_t)n * m;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx <= B) node_off[idx] = offs[idx * nbase];
+    if (idx <= B) node_off[idx] = offs[idx * nbase * per];
     if (idx >= B * P) return;
     const int b = (int)(idx / P);
     const int p = (int)(idx % P);
@@ -243,7 +417,12 @@ __global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const in
     const int id = local_id[idx];
     int lab = -1;
     if (id >= 0) {
-        lab = id + offs[b * nbase + (nbase - 1 - base)];
+        int slot = b * nbase + (nbase - 1 - base);
+        if (quads) {
+            const int rank = level[idx] >= 6 ? 0 : 3 - (((r % MS) >> 5) + 2 * ((c % MS) >> 5));
+            slot = slot * 4 + rank;
+        }
+        lab = id + offs[slot];
         const int s = 1 << level[idx];
         if ((r & (s - 1)) == 0 && (c & (s - 1)) == 0) {
             int4 cl = make_int4(r, c, s, b);
@@ -354,12 +533,14 @@ __global__ void k_node_features(const int32_t* __restrict__ cell, int Ncap, cons
 extern "C" int qt_quadtree_stage1(const float* src, int src_rows, int src_cols, const float* nodeval,
                                   int nodeval_stride, const int32_t* old_labels, int B, int n, int m, int max_size, float thresh,
                                   int condition, const uint8_t* mask, const uint8_t* hir, int32_t* local_id,
-                                  uint8_t* level, int32_t* cnt, void* stream) {
+                                  uint8_t* level, int32_t* cnt, int quads, int32_t* fill_neg1_ptr, int fill_len, void* stream) {
     QT_ARG(B > 0 && n > 0 && m > 0, "empty image batch");
     QT_ARG(max_size >= 2 && max_size <= 64 && (max_size & (max_size - 1)) == 0, "max_size must be a power of two in [2, 64]");
     QT_ARG(condition >= 0 && condition <= 3, "unknown condition");
     QT_ARG((src != nullptr) != (nodeval != nullptr && old_labels != nullptr), "give either src or nodeval+old_labels");
     QT_ARG(local_id && level && cnt, "null output");
+    QT_ARG(!quads || max_size == 64, "quads: one workgroup per 32 x 32 quadrant needs max_size == 64");
+    QT_ARG(fill_len >= 0 && (fill_len == 0 || fill_neg1_ptr), "fill_len without a buffer");
     Stage1Args a;
     a.src = src;
     a.src_rows = src_rows;
@@ -383,24 +564,30 @@ extern "C" int qt_quadtree_stage1(const float* src, int src_rows, int src_cols, 
     a.local_id = local_id;
     a.level = level;
     a.cnt = cnt;
-    hipLaunchKernelGGL(k_quadtree_stage1, dim3(B * a.nbi * a.nbj), dim3(S1T), 0, (hipStream_t)stream, a);
+    a.fill = fill_len > 0 ? fill_neg1_ptr : nullptr;
+    a.fill_len = fill_len;
+    if (quads)
+        hipLaunchKernelGGL(k_quadtree_stage1q, dim3(4 * B * a.nbi * a.nbj), dim3(QT), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(k_quadtree_stage1, dim3(B * a.nbi * a.nbj), dim3(S1T), 0, (hipStream_t)stream, a);
     QT_LAUNCHED();
     return QT_OK;
 }
 
 extern "C" int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_offsets, int B, int n, int m,
                                   int max_size, int32_t* labels, const uint8_t* level, int32_t* cell,
-                                  int32_t* node_off, float size_norm, float* feat, float* npix, int raw_counts,
+                                  int32_t* node_off, float size_norm, float* feat, float* npix, int raw_counts, int quads,
                                   const int32_t* old_labels, const uint8_t* old_level, int32_t* fwd_src, int32_t* bwd_src,
                                   void* stream) {
     QT_ARG(local_id && cnt_offsets && labels && level && cell && node_off, "null pointer");
     QT_ARG((!fwd_src && !bwd_src) || (old_labels && old_level), "fwd_src / bwd_src need the old mesh's labels and levels");
     QT_ARG((feat == nullptr) == (npix == nullptr), "give both feat and npix or neither");
     const int nbi = qt_cdiv(n, max_size), nbj = qt_cdiv(m, max_size);
-    QT_ARG(!raw_counts || (int64_t)B * nbi * nbj <= 1024, "raw_counts: at most 1024 base cells (scan them with qt_scan_i32 instead)");
+    QT_ARG(!quads || max_size == 64, "quads needs max_size == 64");
+    QT_ARG(!raw_counts || (int64_t)B * nbi * nbj * (quads ? 4 : 1) <= 1024, "raw_counts: at most 1024 counts (scan them with qt_scan_i32 instead)");
     const int64_t total = (int64_t)B * n * m;
     hipLaunchKernelGGL(k_quadtree_stage3, dim3(qt_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, local_id,
-                       cnt_offsets, raw_counts, B, n, m, max_size, nbj, nbi * nbj, labels, level, cell, node_off, size_norm, feat, npix,
+                       cnt_offsets, raw_counts, quads, B, n, m, max_size, nbj, nbi * nbj, labels, level, cell, node_off, size_norm, feat, npix,
                        old_labels, old_level, fwd_src, bwd_src);
     QT_LAUNCHED();
     return QT_OK;

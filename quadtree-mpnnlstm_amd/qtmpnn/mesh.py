@@ -227,19 +227,29 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     i32 = dict(dtype=torch.int32, device=device)
     local_id = torch.empty(B, n, m, **i32)
     level = torch.empty(B, n, m, dtype=torch.uint8, device=device)
-    cnt = torch.empty(B * nbase, **i32)
-    offs = torch.empty(B * nbase + 1, **i32)
-    tmp = torch.empty(B * nbase // 1024 + 8, **i32)
+    # 64 x 64 base cells are decomposed by four workgroups each (one per quadrant): leaf counts per quadrant, in DFS order
+    quads = int(max_size == 64 and os.environ.get('QT_NO_STAGE1_QUADS') != '1')
+    ncnt = B * nbase * (4 if quads else 1)
+    cnt = torch.empty(ncnt, **i32)
+    offs = torch.empty(ncnt + 1, **i32)
+    tmp = torch.empty(ncnt // 1024 + 8, **i32)
+    direct = src is None and os.environ.get('QT_NO_DIRECT_SRC') != '1'
+    # bwd_src (per OLD node: the new node under its single pixel) is completed by stage 3, which writes only the entries of old
+    # nodes whose head pixel carries their label; stage 1 fills it with -1 first, so an entry nobody writes reads "no direct row"
+    bwd_src = torch.empty(max(old.N, 1), **i32) if direct else None
+    fill_len = bwd_src.numel() if direct else 0
     if src is not None:
         _lib.call('qt_quadtree_stage1', ptr(src), src.shape[1], src.shape[2], None, 0, None, B, n, m, max_size,
-                  float(thresh), CONDITIONS.index(condition), ptr(mk), ptr(hr), ptr(local_id), ptr(level), ptr(cnt))
+                  float(thresh), CONDITIONS.index(condition), ptr(mk), ptr(hr), ptr(local_id), ptr(level), ptr(cnt), quads,
+                  None, 0)
     else:
         _lib.call('qt_quadtree_stage1', None, 0, 0, ptr(nodeval), nodeval.stride(0) if nodeval.numel() > 1 else 1,
                   ptr(old.labels), B, n, m, max_size,
-                  float(thresh), CONDITIONS.index(condition), ptr(mk), ptr(hr), ptr(local_id), ptr(level), ptr(cnt))
-    fused_scan = static and B * nbase <= 1024 and os.environ.get('QT_NO_FUSED_SCAN') != '1'   # stage 3 scans the counts itself
+                  float(thresh), CONDITIONS.index(condition), ptr(mk), ptr(hr), ptr(local_id), ptr(level), ptr(cnt), quads,
+                  ptr(bwd_src), fill_len)
+    fused_scan = static and ncnt <= 1024 and os.environ.get('QT_NO_FUSED_SCAN') != '1'   # stage 3 scans the counts itself
     if not fused_scan:
-        _lib.call('qt_scan_i32', ptr(cnt), ptr(offs), B * nbase, ptr(tmp))
+        _lib.call('qt_scan_i32', ptr(cnt), ptr(offs), ncnt, ptr(tmp))
     N = B * n * m if static else int(offs[-1].item())     # dynamic mode: the one host sync of a mesh build
 
     ms = Mesh()
@@ -255,14 +265,14 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     ms.npix = torch.empty(N, device=device)
     size_norm = size_norm if size_norm is not None else (max_size / 2) ** 2
     old_lab = old_lvl = None
-    if src is None and os.environ.get('QT_NO_DIRECT_SRC') != '1':
+    if direct:
         import weakref
         ms.built_from = weakref.ref(old)
-        ms.fwd_src = torch.empty(max(N, 1), **i32)
-        ms.bwd_src = torch.empty(max(old.N, 1), **i32)
+        ms.fwd_src = torch.empty(max(N, 1), **i32)         # (stage 3 writes every valid node's entry)
+        ms.bwd_src = bwd_src
         old_lab, old_lvl = old.labels, old.level
     _lib.call('qt_quadtree_stage3', ptr(local_id), ptr(cnt if fused_scan else offs), B, n, m, max_size, ptr(ms.labels), ptr(level),
-              ptr(ms.cell), ptr(ms.node_off), float(size_norm), ptr(ms.posfeat), ptr(ms.npix), int(fused_scan),
+              ptr(ms.cell), ptr(ms.node_off), float(size_norm), ptr(ms.posfeat), ptr(ms.npix), int(fused_scan), quads,
               ptr(old_lab), ptr(old_lvl), ptr(ms.fwd_src), ptr(ms.bwd_src))
     nd = None
     if static:

@@ -132,3 +132,77 @@ def test_dense_mapping_compatibility():
     back = unflatten(flat, mesh, g['labels'].shape, mask)
     inside = (lab >= 0).view(*g['labels'].shape)
     close(back[:, inside], torch.einsum('np,snc->spc', dense, flat).reshape(3, *g['labels'].shape, 2)[:, inside], atol=1e-6)
+
+
+@pytest.mark.parametrize('shape,masked', [((64, 64), False), ((100, 100), True), ((64, 128), False), ((128, 128), True), ((80, 150), True)])
+def test_stage1_four_workgroups_per_base_cell_equals_one(shape, masked, monkeypatch):
+    """qt_quadtree_stage1 with one workgroup per 32 x 32 quadrant of a 64 x 64 base cell (the default: leaf counts per quadrant in
+    DFS order, k_quadtree_stage1q) against one workgroup per base cell: labels, levels, cells, node offsets, CSR bit for bit --
+    image sizes that are no multiples of 64 or 32 (quadrants partly or wholly outside the image), land mask + high-interest
+    region, base cells that do not split at all (one level-6 leaf), meshes decided by node values of an old mesh, static mode."""
+    from qtmpnn import synthetic
+    from qtmpnn.mesh import build_mesh
+    n, m = shape
+    rng = np.random.default_rng(n * 1000 + m)
+    img = np.zeros((3, n, m), np.float32)
+    img[0, n // 3:n // 3 + 9, m // 2:m // 2 + 13] = rng.random((9, 13)).astype(np.float32)          # mostly empty: whole base cells
+    img[1] = (rng.random((n, m)) < 0.03).astype(np.float32)                                            # scattered pixels
+    img[2] = rng.random((n, m)).astype(np.float32) * 0.2                                               # noise around the threshold
+    mask = hir = None
+    if masked:
+        mask = np.zeros((n, m), bool)
+        mask[n // 2:n // 2 + 7, 3:m // 3] = True
+        hir = np.zeros((n, m), bool)
+        hir[5:9, m - 12:m - 2] = True
+    src = torch.from_numpy(img).to(dev())
+
+    def build(quads, static, prev=None):
+        monkeypatch.setenv('QT_NO_STAGE1_QUADS', '0' if quads else '1')
+        if prev is None:
+            return build_mesh(src=src, thresh=0.1, mask=mask, high_interest_region=hir, static=static)
+        return build_mesh(prev=prev, thresh=0.1, mask=mask, high_interest_region=hir, static=static)
+    for static in (False, True):
+        a, b = build(True, static), build(False, static)
+        nv = a.n_valid
+        assert nv == b.n_valid and a.N == b.N
+        for name in ('labels', 'level', 'node_off'):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+        assert torch.equal(a.cell[:nv], b.cell[:nv]) and torch.equal(a.rowptr[:nv + 1], b.rowptr[:nv + 1])
+        E = int(a.rowptr[nv])
+        assert torch.equal(a.col[:E], b.col[:E]) and torch.equal(a.nrm[:E], b.nrm[:E])
+        # a mesh decided by node values on the old mesh (the re-mesh of the rollout), both ways
+        val = torch.rand(a.N, 4, device=dev()) * 0.2
+        a2, b2 = build(True, static, (val[:, 0], a)), build(False, static, (val[:, 0], b))
+        assert a2.n_valid == b2.n_valid and torch.equal(a2.labels, b2.labels) and torch.equal(a2.level, b2.level)
+        assert torch.equal(a2.fwd_src[:a2.n_valid], b2.fwd_src[:b2.n_valid]) and torch.equal(a2.bwd_src[:nv], b2.bwd_src[:nv])
+
+
+def test_direct_row_index_of_a_remesh_is_complete():
+    """bwd_src (per OLD node the new node under its single pixel, -1 otherwise) is filled with -1 before the mesh build writes
+    the entries it owns, so no entry is ever an uninitialised row index; the state transfer through the direct index equals the
+    general path (labels -> rows) in both directions, on a masked mesh."""
+    from qtmpnn import ops
+    from qtmpnn.mesh import build_mesh
+    rng = np.random.default_rng(5)
+    img = (rng.random((2, 64, 64)) * 0.3).astype(np.float32)
+    mask = np.zeros((64, 64), bool)
+    mask[20:31, 8:40] = True
+    old = build_mesh(src=torch.from_numpy(img).to(dev()), thresh=0.15, mask=mask)
+    val = torch.rand(old.N, 4, device=dev()) * 0.3
+    new = build_mesh(prev=(val[:, 0], old), thresh=0.15, mask=mask)
+    bs = new.bwd_src[:old.N]
+    assert int(bs.min()) >= -1 and int(bs.max()) < new.N and int(new.fwd_src[:new.N].min()) >= -1 and int(new.fwd_src[:new.N].max()) < old.N
+    single_old = (old.npix == 1)
+    assert bool((bs[~single_old] == -1).all())                  # multi-pixel old nodes take the general path
+    state = torch.randn(old.N, 8, device=dev(), requires_grad=True)
+    out = ops.remesh_transfer(state, old, new)
+    g = torch.randn_like(out)
+    (gs,) = torch.autograd.grad(out, state, g)
+    keep_f, keep_b, new.fwd_src, new.bwd_src = new.fwd_src, new.bwd_src, None, None
+    built, new.built_from = new.built_from, None
+    try:
+        out2 = ops.remesh_transfer(state, old, new)
+        (gs2,) = torch.autograd.grad(out2, state, g)
+    finally:
+        new.fwd_src, new.bwd_src, new.built_from = keep_f, keep_b, built
+    assert torch.equal(out, out2) and torch.equal(gs, gs2)
