@@ -124,16 +124,43 @@ __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* _
                             uint32_t* __restrict__ tail_info) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= qt_rows(n_dev, Ncap)) return;
-    const float di = dis[i];
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    // The edges beyond the fourth again, per CLIP, as {column relative to the clip's first node, weight}: the clip-resident
+    // recurrence kernel (chebclip.hip) copies a clip's pool into LDS once per launch.  A row reserves its run with one atomic add
+    // on the clip's counter (zeroed by k_edges_count) -- issued here, before the edge loop, so that its round trip overlaps the
+    // loop's own loads -- and the loop writes the run as it goes.  The order of the runs varies from build to build, the
+    // contents of a run (CSR order) do not.  A clip with more than QT_TAIL_CAP tail edges keeps the rows that did not fit on the
+    // CSR walk (base 0xffff).  The counters sit QT_TAIL_CNT_STRIDE ints (one 128-byte line) apart: side by side in one line, the
+    // ~3500 atomic adds of a 32-clip mesh serialised on that line and the launch took 32 us instead of 8.
+    uint32_t info = 0;
+    int2* run = nullptr;
+    int r0 = 0;
+    if (tail_info) {
+        const int cnt = min(e1 - e0 - 4, 0xffff);
+        if (cnt > 0) {
+            const int clip = cell[4 * (int64_t)i + 3];
+            r0 = node_off[clip];
+            const int base = atomicAdd(&tail_cnt[QT_TAIL_CNT_STRIDE * clip], cnt);
+            if (base + cnt <= QT_TAIL_CAP) {
+                run = tail_pool + (int64_t)clip * QT_TAIL_CAP + base;
+                info = (uint32_t)base | ((uint32_t)cnt << 16);
+            } else {
+                info = 0xffffu | ((uint32_t)cnt << 16);
+            }
+        }
+    }
+    const float di = dis[i];
     int c4[4] = {i, i, i, i};              // (an unused slot re-reads the row itself with weight 0)
     float w4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int e = e0; e < e1; ++e) {
-        const float v = -(di * w[e] * dis[col[e]]);
+        const int cj = col[e];
+        const float v = -(di * w[e] * dis[cj]);
         nrm[e] = v;
         if (e - e0 < 4) {
-            c4[e - e0] = col[e];
+            c4[e - e0] = cj;
             w4[e - e0] = v;
+        } else if (run && e - e0 - 4 < 0xffff) {
+            run[e - e0 - 4] = make_int2(cj - r0, __float_as_int(v));
         }
     }
     if (ell) {
@@ -143,29 +170,7 @@ __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* _
         ell[2 * (int64_t)i] = make_int4(c4[0], c4[1], c4[2], c4[3]);
         ell[2 * (int64_t)i + 1] = make_int4(__float_as_int(w4[0]), __float_as_int(w4[1]), __float_as_int(w4[2]), __float_as_int(w4[3]));
     }
-    if (tail_info) {
-        // The edges beyond the fourth again, per CLIP, as {column relative to the clip's first node, weight}: the clip-resident
-        // recurrence kernel (chebclip.hip) copies a clip's pool into LDS once per launch.  A row reserves its run with one atomic
-        // add on the clip's counter (zeroed by k_edges_count), so the order of the runs varies from build to build, the contents
-        // of a run (CSR order) do not.  A clip with more than QT_TAIL_CAP tail edges keeps the rows that did not fit on the CSR
-        // walk (base 0xffff).  The counters sit QT_TAIL_CNT_STRIDE ints (one 128-byte line) apart: side by side in one line, the
-        // ~3500 atomic adds of a 32-clip mesh serialised on that line and the launch took 32 us instead of 8.
-        uint32_t info = 0;
-        const int cnt = min(e1 - e0 - 4, 0xffff);
-        if (cnt > 0) {
-            const int clip = cell[4 * (int64_t)i + 3];
-            const int r0 = node_off[clip];
-            const int base = atomicAdd(&tail_cnt[QT_TAIL_CNT_STRIDE * clip], cnt);
-            if (base + cnt <= QT_TAIL_CAP) {
-                int2* dst = tail_pool + (int64_t)clip * QT_TAIL_CAP + base;
-                for (int j = 0; j < cnt; ++j) dst[j] = make_int2(col[e0 + 4 + j] - r0, __float_as_int(nrm[e0 + 4 + j]));
-                info = (uint32_t)base | ((uint32_t)cnt << 16);
-            } else {
-                info = 0xffffu | ((uint32_t)cnt << 16);
-            }
-        }
-        tail_info[i] = info;
-    }
+    if (tail_info) tail_info[i] = info;
 }
 
 }  // namespace
