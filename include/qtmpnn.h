@@ -161,6 +161,16 @@ int qt_remesh(const float* const* src_parts, const int* widths, const int* lds, 
               single-pixel nodes then read their source row through it (same rows, two dependent loads instead of three) */,
               void* stream);
 
+/* qt_remesh for frames of at most 64 x 64 pixels, clip-resident (csrc/remeshclip.hip): one workgroup per (clip, 4-channel slice)
+ * stages the clip's source rows in LDS, gathers the pixel values from there and sums them up a 64 x 64 pyramid; every
+ * destination node is written once by the thread that owns its head pixel.  Same arguments as qt_remesh minus the per-node
+ * records (cell, N, n_dev, direct), plus the source mesh's node offsets (B + 1; qt_quadtree_stage3 writes them). */
+int qt_remesh_clip_rows(void);
+int qt_remesh_clip(const float* const* src_parts, const int* widths, const int* lds, int nparts,
+                   const int32_t* src_labels, const float* src_npix, int src_inv, const int32_t* src_node_off,
+                   const int32_t* labels, const uint8_t* level, const float* npix, int mean, int B, int n, int m,
+                   float* const* out_parts, const int* out_widths, int nout, void* stream);
+
 /* masked MSE, model/mpnnlstm.py:243-246: partial[b*ntile + tile] = sum over the tile's unmasked pixels of
  * (out[labels[p]] - y[p])^2 ; y (B, n*m).  Pixels with label < 0 are the masked ones. */
 int qt_sse(const float* out, int out_stride, const int32_t* labels, const float* y, int64_t y_clip_stride,

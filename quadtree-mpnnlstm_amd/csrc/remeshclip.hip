@@ -1,0 +1,191 @@
+// Clip-resident mesh -> mesh state transfer (the re-mesh of model/seq2seq.py:434-491: unflatten on the old mesh + flatten on
+// the new one, :440-442 + :474-477, fused; its backward is the same op with the meshes swapped).
+//
+//   out[new node i] = (mean ? 1 / npix[i] : 1) * sum over the pixels p of node i of  S[src_label[p]] (* 1 / src_npix[..] if src_inv)
+//
+// The general kernels (transfer.hip: k_pool_nodes for nodes up to 4 x 4 pixels, k_pool for the bigger ones) walk
+// index -> label -> row chains through L2 / HBM for every node and channel chunk, 41 - 52 us per transfer of the benchmark's
+// 68 state channels.  For frames of at most 64 x 64 pixels a clip's whole transfer of one 4-channel column slice fits a
+// workgroup's LDS, like the Chebyshev recurrences of chebclip.hip:
+//   * the source slice of the clip (<= 4096 rows x 16 B = 64 KB) is staged once (pre-scaled by 1 / src_npix for the backward);
+//   * every thread owns one 2 x 2 pixel block (Morton order): pixel value = staged row of the pixel's source node, an LDS gather;
+//   * a sum pyramid over the 64 x 64 frame (level-1 sums in registers, levels 2 .. 6 through 22 KB of LDS) -- a quadtree leaf
+//     of level L is exactly one level-L entry, so every destination node is written once, deterministically, by the thread
+//     that owns its head pixel.
+// No per-node cell record, no direct-index side array, no pixel loops of data-dependent length, no atomics.  Summation order:
+// (top-left + top-right) + (bottom-left + bottom-right) at every level.
+#include "qt_common.h"
+
+namespace {
+
+constexpr int RC_T = 1024;          // threads = 2 x 2 pixel blocks of a 64 x 64 frame
+constexpr int RC_ROWS = 4096;       // source rows of a clip that fit
+
+struct RcArgs {
+    const float* part[8];           // source state as up to 8 matrices side by side (row strides part_ld, float4 prefix part_end)
+    int part_ld[8], part_end[8];
+    float* opart[8];                // the result likewise, dense rows (widths opart_w, float4 prefix opart_end)
+    int opart_w[8], opart_end[8];
+    const int32_t* src_labels;      // (B, n, m) source mesh
+    const float* src_npix;
+    const int32_t* src_off;         // (B + 1) first node of every clip of the source mesh
+    const int32_t* labels;          // (B, n, m) destination mesh
+    const uint8_t* level;
+    const float* npix;
+    int src_inv, mean, B, n, m;
+};
+
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ unsigned compact_bits(unsigned v) {       // even bits of v -> low half
+    v &= 0x55555555u;
+    v = (v | (v >> 1)) & 0x33333333u;
+    v = (v | (v >> 2)) & 0x0F0F0F0Fu;
+    v = (v | (v >> 4)) & 0x00FF00FFu;
+    return v;
+}
+// Workgroup barrier that waits for this wave's LDS traffic only (not for its global loads / stores)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(RC_T) void k_remesh_clip(RcArgs a) {
+    __shared__ float4 A[RC_ROWS];                 // the clip's source slice
+    __shared__ float4 L1[1024], L2[256], L3[64], L4[16], L5[4], L6[1];
+    const int t = threadIdx.x;
+    const int b = (int)blockIdx.x % a.B, ch = (int)blockIdx.x / a.B;
+    int sp = 0, op = 0;
+    while (ch >= a.part_end[sp]) ++sp;
+    while (ch >= a.opart_end[op]) ++op;
+    const float* src = a.part[sp] + (ch - (sp ? a.part_end[sp - 1] : 0)) * 4;
+    const int lds = a.part_ld[sp];
+    float* dst = a.opart[op] + (ch - (op ? a.opart_end[op - 1] : 0)) * 4;
+    const int ldd = a.opart_w[op];
+    const int r0s = a.src_off[b];
+    const int nrs = min(a.src_off[b + 1] - r0s, RC_ROWS);
+    const int P = a.n * a.m;
+
+    // ---- one memory phase: the source slice (4 rows per thread) and the labels / levels of this thread's 2 x 2 pixels
+    float4 x[4];
+    float sc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int lr = min(t + RC_T * u, nrs - 1);
+        x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sc[u] = 1.0f;
+        if (nrs > 0) {
+            x[u] = *reinterpret_cast<const float4*>(src + (int64_t)(r0s + lr) * lds);
+            if (a.src_inv) sc[u] = a.src_npix[r0s + lr];
+        }
+    }
+    const int br = (int)compact_bits((unsigned)t), bc = (int)compact_bits((unsigned)t >> 1);     // t = spread(br) | spread(bc) << 1
+    int lab[4], sl[4], lv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 2 * br + (q >> 1), c = 2 * bc + (q & 1);
+        lab[q] = sl[q] = -1;
+        lv[q] = 0;
+        if (r < a.n && c < a.m) {
+            const int64_t p = (int64_t)b * P + (int64_t)r * a.m + c;
+            lab[q] = a.labels[p];
+            sl[q] = a.src_labels[p];
+            lv[q] = a.level[p];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (t + RC_T * u < nrs) A[t + RC_T * u] = a.src_inv ? mul4(x[u], 1.0f / sc[u]) : x[u];
+    lds_barrier();
+
+    // ---- pixel values, single-pixel nodes, 2 x 2 sums
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool ok = lab[q] >= 0 && sl[q] >= 0;
+        v[q] = A[ok ? ((sl[q] - r0s) & (RC_ROWS - 1)) : 0];
+        if (!ok) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (lab[q] >= 0 && lv[q] == 0) *reinterpret_cast<float4*>(dst + (int64_t)lab[q] * ldd) = v[q];
+    const float4 s1 = add4(add4(v[0], v[1]), add4(v[2], v[3]));
+    const int L = lab[0] >= 0 ? lv[0] : 0;          // a node of level >= 1 has its head at a block's first pixel
+    float oscale = 1.0f;
+    if (L >= 1 && a.mean) oscale = 1.0f / a.npix[lab[0]];          // (requested before the pyramid, used after it)
+    L1[t] = s1;
+    lds_barrier();
+    // ---- sum pyramid: entry j of level k = the four level-(k-1) entries 4j .. 4j+3 (Morton order: child = row bit | col bit << 1)
+    if (t < 256) L2[t] = add4(add4(L1[4 * t], L1[4 * t + 2]), add4(L1[4 * t + 1], L1[4 * t + 3]));
+    lds_barrier();
+    if (t < 64) L3[t] = add4(add4(L2[4 * t], L2[4 * t + 2]), add4(L2[4 * t + 1], L2[4 * t + 3]));
+    lds_barrier();
+    if (t < 16) L4[t] = add4(add4(L3[4 * t], L3[4 * t + 2]), add4(L3[4 * t + 1], L3[4 * t + 3]));
+    lds_barrier();
+    if (t < 4) L5[t] = add4(add4(L4[4 * t], L4[4 * t + 2]), add4(L4[4 * t + 1], L4[4 * t + 3]));
+    lds_barrier();
+    if (t < 1) L6[0] = add4(add4(L5[0], L5[2]), add4(L5[1], L5[3]));
+    lds_barrier();
+    // ---- every node of level >= 1 is written by the thread that owns its head pixel (the block's first pixel, aligned to 2^L)
+    if (L >= 1 && ((2 * br) & ((1 << L) - 1)) == 0 && ((2 * bc) & ((1 << L) - 1)) == 0) {
+        float4 s;
+        switch (L) {
+            case 1: s = s1; break;
+            case 2: s = L2[t >> 2]; break;
+            case 3: s = L3[t >> 4]; break;
+            case 4: s = L4[t >> 6]; break;
+            case 5: s = L5[t >> 8]; break;
+            default: s = L6[0]; break;
+        }
+        *reinterpret_cast<float4*>(dst + (int64_t)lab[0] * ldd) = mul4(s, oscale);
+    }
+}
+
+}  // namespace
+
+extern "C" int qt_remesh_clip_rows(void) { return RC_ROWS; }
+
+extern "C" int qt_remesh_clip(const float* const* src_parts, const int* widths, const int* lds, int nparts,
+                              const int32_t* src_labels, const float* src_npix, int src_inv, const int32_t* src_node_off,
+                              const int32_t* labels, const uint8_t* level, const float* npix, int mean, int B, int n, int m,
+                              float* const* out_parts, const int* out_widths, int nout, void* stream) {
+    QT_ARG(src_parts && widths && lds && nparts >= 1 && nparts <= 8 && src_labels && src_node_off && labels && level && B > 0,
+           "bad arguments");
+    QT_ARG(n >= 1 && m >= 1 && n <= 64 && m <= 64, "the clip-resident transfer serves frames of at most 64 x 64 pixels");
+    QT_ARG(out_parts && out_widths && nout >= 1 && nout <= 8, "bad output parts");
+    QT_ARG(!mean || npix, "mean pooling needs npix");
+    QT_ARG(!src_inv || src_npix, "src_inv needs src_npix");
+    RcArgs a = {};
+    int c4 = 0;
+    for (int i = 0; i < nparts; ++i) {
+        QT_ARG(src_parts[i] && widths[i] > 0 && widths[i] % 4 == 0 && lds[i] % 4 == 0 && lds[i] >= widths[i] &&
+               ((uintptr_t)src_parts[i] & 15) == 0, "source parts must be 16-byte aligned with widths / strides that are multiples of 4");
+        a.part[i] = src_parts[i];
+        a.part_ld[i] = lds[i];
+        c4 += widths[i] / 4;
+        a.part_end[i] = c4;
+    }
+    for (int i = nparts; i < 8; ++i) { a.part[i] = nullptr; a.part_ld[i] = 0; a.part_end[i] = 1 << 30; }
+    int o4 = 0;
+    for (int i = 0; i < nout; ++i) {
+        QT_ARG(out_parts[i] && out_widths[i] > 0 && out_widths[i] % 4 == 0 && ((uintptr_t)out_parts[i] & 15) == 0,
+               "output parts must be 16-byte aligned with widths that are multiples of 4");
+        a.opart[i] = out_parts[i];
+        a.opart_w[i] = out_widths[i];
+        o4 += out_widths[i] / 4;
+        a.opart_end[i] = o4;
+    }
+    for (int i = nout; i < 8; ++i) { a.opart[i] = nullptr; a.opart_w[i] = 0; a.opart_end[i] = 1 << 30; }
+    QT_ARG(o4 == c4, "the output parts must add up to the source width");
+    a.src_labels = src_labels;
+    a.src_npix = src_npix;
+    a.src_off = src_node_off;
+    a.labels = labels;
+    a.level = level;
+    a.npix = npix;
+    a.src_inv = src_inv;
+    a.mean = mean;
+    a.B = B;
+    a.n = n;
+    a.m = m;
+    hipLaunchKernelGGL(k_remesh_clip, dim3(B * c4), dim3(RC_T), 0, (hipStream_t)stream, a);
+    QT_LAUNCHED();
+    return QT_OK;
+}

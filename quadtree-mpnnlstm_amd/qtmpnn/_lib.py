@@ -32,6 +32,8 @@ _SIGNATURES = {
     'qt_sse_rollout': [_I, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64, _I, _I, _I, _P, _P],
     'qt_sse_rollout_bwd': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     'qt_remesh': [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
+    'qt_remesh_clip_rows': [],
+    'qt_remesh_clip': [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P],
     'qt_sse': [_P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
     'qt_spmm': [_P, _P, _P, _I, _P, _I, _P, _F, _P, _F, _P, _F, _P, _P],
     'qt_spmm1': [_P, _P, _P, _P, _I, _P, _P, _I, _F, _P, _I, _F, _P, _I, _F, _P, _I, _I, _I, _P, _I, _P, _P],
@@ -77,7 +79,7 @@ _SIGNATURES = {
     'qt_head_fwd': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P],
     'qt_head_bwd': [_P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
 }
-_PLAIN = {'qt_abi_version', 'qt_cheb_clip_rows', 'qt_tail_cap', 'qt_num_cus', 'qt_lstm_fused_blocks', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_lstm_dgrad_blocks', 'qt_attn_blocks'}  # return a value, not an error code
+_PLAIN = {'qt_abi_version', 'qt_cheb_clip_rows', 'qt_remesh_clip_rows', 'qt_tail_cap', 'qt_num_cus', 'qt_lstm_fused_blocks', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_lstm_dgrad_blocks', 'qt_attn_blocks'}  # return a value, not an error code
 
 _lib = None
 

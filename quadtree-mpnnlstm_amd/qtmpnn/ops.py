@@ -1265,6 +1265,9 @@ def gather_pixels(val, mesh):
     return _Gather.apply(val, mesh)
 
 
+_CLIP_REMESH = os.environ.get('QT_NO_CLIP_REMESH') != '1'      # (A/B switch: 1 = the general node / tile kernels everywhere)
+
+
 def _remesh_raw(dst, src, parts, outs, src_inv, mean):
     """outs (dense (dst.N, w) matrices, side by side) = per-node reduction over dst's pixels of [parts...][src.labels[p]]
     (qt_remesh)."""
@@ -1275,6 +1278,11 @@ def _remesh_raw(dst, src, parts, outs, src_inv, mean):
     lds = (ctypes.c_int * n)(*[_ld(t) for t in parts])
     optrs = (ctypes.c_void_p * no)(*[t.data_ptr() for t in outs])
     owidths = (ctypes.c_int * no)(*[t.shape[1] for t in outs])
+    if _CLIP_REMESH and dst.n <= 64 and dst.m <= 64 and getattr(src, 'node_off', None) is not None:
+        # frames of at most 64 x 64 pixels: a clip's transfer of one 4-channel slice runs inside one workgroup's LDS
+        _lib.call('qt_remesh_clip', ptrs, widths, lds, n, ptr(src.labels), ptr(src.npix), int(src_inv), ptr(src.node_off),
+                  ptr(dst.labels), ptr(dst.level), ptr(dst.npix), int(mean), dst.B, dst.n, dst.m, optrs, owidths, no)
+        return
     # the direct row index of the single-pixel nodes, when one mesh of the pair was decomposed from the other
     direct = None
     if dst.built_from is not None and dst.built_from() is src:

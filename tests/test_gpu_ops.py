@@ -81,6 +81,47 @@ def test_remesh_transfer_vs_oracle():
     assert torch.equal(torch.cat([ga, gb], dim=1), gv)
 
 
+@pytest.mark.parametrize('shape,B', [((64, 64), 3), ((48, 64), 2), ((24, 32), 1), ((64, 40), 2)])
+def test_clip_resident_remesh_equals_general_kernels(shape, B):
+    """csrc/remeshclip.hip (a clip's transfer of one 4-channel slice inside one workgroup's LDS: staged source rows, LDS gathers,
+    a 64 x 64 sum pyramid) against the general node / tile kernels of transfer.hip, forward and backward (the transposed transfer:
+    sums scaled by 1 / source pixel count): frames smaller than 64 x 64, a land mask, cells from 1 x 1 to the whole frame, several
+    source and output parts with row-strided views.  Same sums in another association: 1e-6 relative."""
+    from qtmpnn import ops
+    from qtmpnn.mesh import build_mesh
+    n, m = shape
+    rng = np.random.default_rng(n + m + B)
+    img_a = np.zeros((B, n, m), np.float32)
+    img_b = np.zeros((B, n, m), np.float32)
+    for b in range(B):
+        img_a[b, rng.integers(0, n - 6):, :][:5, rng.integers(0, m - 8):][:, :7] = 1.0           # a few fine patches
+        img_b[b] = (rng.random((n, m)) < 0.02 + 0.1 * b).astype(np.float32)
+    img_b[-1] = 0.0                                                     # last clip of the new mesh: unsplit base cells (level 6 / 5)
+    mask = np.zeros((n, m), bool)
+    mask[n // 2:n // 2 + 5, 2:m // 2] = True
+    old = build_mesh(src=torch.from_numpy(img_a).to(dev()), thresh=0.5, mask=mask)
+    new = build_mesh(src=torch.from_numpy(img_b).to(dev()), thresh=0.5, mask=mask)
+    assert int(new.level.max()) >= (5 if min(n, m) >= 48 else 3) and int(old.level.min()) == 0
+    torch.manual_seed(0)
+    wide = torch.randn(old.N, 40, device=dev())
+    parts = [wide[:, 4:8].requires_grad_(True), torch.randn(old.N, 16, device=dev(), requires_grad=True), wide[:, 12:24].requires_grad_(True)]
+    gouts = [torch.randn(new.N, w, device=dev()) for w in (4, 8, 20)]
+
+    def run():
+        outs = ops.remesh_transfer(parts, old, new, [4, 8, 20])
+        grads = torch.autograd.grad(outs, parts, gouts)
+        return [o.detach() for o in outs] + list(grads)
+    assert ops._CLIP_REMESH
+    fast = run()
+    prev, ops._CLIP_REMESH = ops._CLIP_REMESH, False
+    try:
+        ref = run()
+    finally:
+        ops._CLIP_REMESH = prev
+    for a, r in zip(fast, ref):
+        close(a, r, rtol=1e-6, atol=1e-6 * float(r.abs().max()))
+
+
 @pytest.mark.parametrize('n_conv', [1, 2, 3])
 def test_graphconv_stack_vs_oracle(n_conv):
     """Composed Chebyshev polynomial (one kernel pass) == the oracle's sequential ChebConv stack, fwd + grads."""
