@@ -171,6 +171,11 @@ int qt_remesh_clip(const float* const* src_parts, const int* widths, const int* 
                    const int32_t* labels, const uint8_t* level, const float* npix, int mean, int B, int n, int m,
                    float* const* out_parts, const int* out_widths, int nout, void* stream);
 
+/* qt_pool from an image for frames of at most 64 x 64 pixels, clip-resident: one workgroup per (clip, frame, channel) sums the
+ * frame up a 64 x 64 pyramid in LDS (csrc/remeshclip.hip).  Arguments as qt_pool's image form. */
+int qt_pool_clip(const float* img, int S, int64_t img_clip_stride, int C, const int32_t* labels, const uint8_t* level,
+                 const float* npix, int mean, int B, int n, int m, int N, float* out, int out_stride, int out_coff, void* stream);
+
 /* masked MSE, model/mpnnlstm.py:243-246: partial[b*ntile + tile] = sum over the tile's unmasked pixels of
  * (out[labels[p]] - y[p])^2 ; y (B, n*m).  Pixels with label < 0 are the masked ones. */
 int qt_sse(const float* out, int out_stride, const int32_t* labels, const float* y, int64_t y_clip_stride,

@@ -138,6 +138,82 @@ __global__ __launch_bounds__(RC_T) void k_remesh_clip(RcArgs a) {
     }
 }
 
+// The same pyramid for image -> mesh pooling of scalar channels (flatten, model/graph_functions.py:391-419: the encoder's input
+// frames, the decoder's concat layer, the loss targets): one workgroup per (clip, frame, channel); a pixel's value comes straight
+// from the image, so nothing is staged.  img (B, S, n*m, C) with clip stride img_clip_stride; out[(s * N + node) * out_stride +
+// out_coff + c].
+struct PcArgs {
+    const float* img;
+    int64_t img_clip_stride;
+    int S, C;
+    const int32_t* labels;
+    const uint8_t* level;
+    const float* npix;
+    int mean, B, n, m, N;
+    float* out;
+    int out_stride, out_coff;
+};
+
+__global__ __launch_bounds__(RC_T) void k_pool_clip(PcArgs a) {
+    __shared__ float L1[1024], L2[256], L3[64], L4[16], L5[4], L6[1];
+    const int t = threadIdx.x;
+    const int b = (int)blockIdx.x % a.B;
+    const int sc_ = (int)blockIdx.x / a.B;
+    const int s = sc_ / a.C, c = sc_ - s * a.C;
+    const int P = a.n * a.m;
+    const float* img = a.img + (int64_t)b * a.img_clip_stride + (int64_t)s * P * a.C + c;
+    float* out = a.out + (int64_t)s * a.N * a.out_stride + a.out_coff + c;
+    const int br = (int)compact_bits((unsigned)t), bc = (int)compact_bits((unsigned)t >> 1);
+    int lab[4], lv[4];
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 2 * br + (q >> 1), cc = 2 * bc + (q & 1);
+        lab[q] = -1;
+        lv[q] = 0;
+        v[q] = 0.0f;
+        if (r < a.n && cc < a.m) {
+            const int p = r * a.m + cc;
+            lab[q] = a.labels[(int64_t)b * P + p];
+            lv[q] = a.level[(int64_t)b * P + p];
+            v[q] = img[(int64_t)p * a.C];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (lab[q] < 0) v[q] = 0.0f;
+        else if (lv[q] == 0) out[(int64_t)lab[q] * a.out_stride] = v[q];
+    }
+    const float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+    const int L = lab[0] >= 0 ? lv[0] : 0;
+    float oscale = 1.0f;
+    if (L >= 1 && a.mean) oscale = 1.0f / a.npix[lab[0]];
+    L1[t] = s1;
+    lds_barrier();
+    if (t < 256) L2[t] = (L1[4 * t] + L1[4 * t + 2]) + (L1[4 * t + 1] + L1[4 * t + 3]);
+    lds_barrier();
+    if (t < 64) L3[t] = (L2[4 * t] + L2[4 * t + 2]) + (L2[4 * t + 1] + L2[4 * t + 3]);
+    lds_barrier();
+    if (t < 16) L4[t] = (L3[4 * t] + L3[4 * t + 2]) + (L3[4 * t + 1] + L3[4 * t + 3]);
+    lds_barrier();
+    if (t < 4) L5[t] = (L4[4 * t] + L4[4 * t + 2]) + (L4[4 * t + 1] + L4[4 * t + 3]);
+    lds_barrier();
+    if (t < 1) L6[0] = (L5[0] + L5[2]) + (L5[1] + L5[3]);
+    lds_barrier();
+    if (L >= 1 && ((2 * br) & ((1 << L) - 1)) == 0 && ((2 * bc) & ((1 << L) - 1)) == 0) {
+        float sum;
+        switch (L) {
+            case 1: sum = s1; break;
+            case 2: sum = L2[t >> 2]; break;
+            case 3: sum = L3[t >> 4]; break;
+            case 4: sum = L4[t >> 6]; break;
+            case 5: sum = L5[t >> 8]; break;
+            default: sum = L6[0]; break;
+        }
+        out[(int64_t)lab[0] * a.out_stride] = sum * oscale;
+    }
+}
+
 }  // namespace
 
 extern "C" int qt_remesh_clip_rows(void) { return RC_ROWS; }
@@ -186,6 +262,21 @@ extern "C" int qt_remesh_clip(const float* const* src_parts, const int* widths, 
     a.n = n;
     a.m = m;
     hipLaunchKernelGGL(k_remesh_clip, dim3(B * c4), dim3(RC_T), 0, (hipStream_t)stream, a);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_pool_clip(const float* img, int S, int64_t img_clip_stride, int C, const int32_t* labels, const uint8_t* level,
+                            const float* npix, int mean, int B, int n, int m, int N, float* out, int out_stride, int out_coff,
+                            void* stream) {
+    QT_ARG(img && labels && level && out && S >= 1 && C >= 1 && B > 0, "bad arguments");
+    QT_ARG(n >= 1 && m >= 1 && n <= 64 && m <= 64, "the clip-resident pooling serves frames of at most 64 x 64 pixels");
+    QT_ARG(!mean || npix, "mean pooling needs npix");
+    QT_ARG(out_stride >= out_coff + C, "output row too short");
+    if (N <= 0) return QT_OK;
+    PcArgs a = {img, img_clip_stride > 0 ? img_clip_stride : (int64_t)S * n * m * C, S, C, labels, level, npix, mean, B, n, m, N,
+                out, out_stride, out_coff};
+    hipLaunchKernelGGL(k_pool_clip, dim3(B * S * C), dim3(RC_T), 0, (hipStream_t)stream, a);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -1178,6 +1178,11 @@ def head_input(O, ln_o, concat, hp, mesh, acc=None):
 # ------------------------------------------------------------------------------ mesh <-> image
 def _pool_raw(mesh, C, out, out_stride, out_coff, mean, img=None, S=1, src_val=None, src_mesh=None, src_inv=False,
               img_clip_stride=0):
+    if _CLIP_REMESH and img is not None and mesh.n <= 64 and mesh.m <= 64 and S * C <= 64:
+        # frames of at most 64 x 64 pixels, a few scalar channels: one workgroup per (clip, frame, channel), LDS pyramid
+        _lib.call('qt_pool_clip', ptr(img), S, img_clip_stride, C, ptr(mesh.labels), ptr(mesh.level), ptr(mesh.npix), int(mean),
+                  mesh.B, mesh.n, mesh.m, mesh.N, ptr(out), out_stride, out_coff)
+        return
     _lib.call('qt_pool', ptr(img), S, img_clip_stride, ptr(src_val), ptr(src_mesh.labels) if src_mesh is not None else None,
               ptr(src_mesh.npix) if src_mesh is not None else None, int(src_inv), C, ptr(mesh.labels), ptr(mesh.level),
               ptr(mesh.npix), int(mean), mesh.B, mesh.n, mesh.m, mesh.N, ptr(mesh.cell) if C >= 4 else None, ptr(mesh.n_dev),
