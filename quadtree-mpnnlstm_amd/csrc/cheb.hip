@@ -1384,7 +1384,7 @@ __global__ __launch_bounds__(256, BG ? QT_DGRAD_OCC : 2) void k_dgrad_cell(Dgrad
         }
         block_param_reduce<LPN, 11>(acc, h, sm, g.part + (int64_t)blockIdx.x * 11 * h, g.accumulate);
     }
-    __syncthreads();                                 // Bt, As complete
+    qt_lds_barrier();                                 // Bt, As complete
     f32x16 acc2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -1455,7 +1455,7 @@ __global__ __launch_bounds__(256, BG ? QT_DGRAD_OCC : 2) void k_dgrad_cell(Dgrad
     float* Cs = As;
 #pragma unroll
     for (int h2 = 0; h2 < (NT + 1) / 2; ++h2) {
-        __syncthreads();
+        qt_lds_barrier();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int nt = 2 * h2 + u;
@@ -1465,7 +1465,7 @@ __global__ __launch_bounds__(256, BG ? QT_DGRAD_OCC : 2) void k_dgrad_cell(Dgrad
                     Cs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + u * 32 + l32] = acc2[nt][r];
             }
         }
-        __syncthreads();
+        qt_lds_barrier();
 #pragma unroll
         for (int u = 0; u < BM * 16 / 256; ++u) {
             const int e = t + 256 * u;

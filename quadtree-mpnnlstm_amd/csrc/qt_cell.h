@@ -214,7 +214,7 @@ __device__ __forceinline__ void block_param_reduce(float (&acc)[NACC][4], int h,
 #pragma unroll
             for (int k = 0; k < 4; ++k) sm[(wave * LPN + lane) * NACC * 4 + a * 4 + k] = acc[a][k];
     }
-    __syncthreads();
+    qt_lds_barrier();                      // (only `sm` crosses: the rows' global stores issued before stay in flight)
     for (int idx = threadIdx.x; idx < NACC * h; idx += 256) {
         const int a = idx / h, j = idx % h;
         const int li = j >> 2, k = j & 3;

@@ -28,6 +28,21 @@ __device__ __forceinline__ int qt_rows(const int32_t* n_dev, int cap) { return n
 
 static inline int qt_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Workgroup barrier for phases that exchange data through LDS ONLY: waits for this wave's LDS operations (lgkmcnt) and not for
+// its outstanding global stores / loads (vmcnt).  __syncthreads() drains both: on gfx9 stores count in vmcnt, so a barrier
+// behind a burst of row stores waits for their round trip (~1-2 us under load) although nobody reads them in this launch.
+// QT_LDS_BARRIER=0 restores __syncthreads() (A/B builds).
+#ifndef QT_LDS_BARRIER
+#define QT_LDS_BARRIER 1
+#endif
+__device__ __forceinline__ void qt_lds_barrier() {
+#if QT_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 // Exclusive scan of one int per thread over a workgroup of up to 1024 threads (blockDim.x a multiple of 64).
 // `red` is 16 ints of LDS.  Returns the exclusive prefix; *total gets the block sum.
 __device__ __forceinline__ int qt_block_excl_scan(int v, int* red, int* total) {
