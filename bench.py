@@ -395,7 +395,10 @@ def main():
         return dt, loss, per_rank
 
     def frozen_ms(p, step, n):
-        """ms per step of `step` with the learning rate at 0 (three untimed steps first); Adam's state is zeroed afterwards."""
+        """ms per step of `step` with the learning rate at 0 (three untimed steps first); Adam's state is zeroed afterwards.
+        The caller sets the learning rate to 0 BEFORE make_graphed_step, whose two eager warm-up steps are real optimizer steps:
+        the frozen model is then the model as initialised, the same for every build and every gradient arithmetic (two real
+        steps with another rounding of the gradients end in another model, other meshes and another step time)."""
         lr = float(os.environ.get('QT_BENCH_LR', LR))
         set_lr(p.optimizer, 0.0)
         for i in range(3):
@@ -413,10 +416,15 @@ def main():
     if args.eager:
         step = lambda x, y, c: nfp.train_step(x, y, c, mask)
     else:
-        # the whole step (forward, loss, backward, clip, Adam) as ONE hipGraph; its 2 eager warm-up steps run first
+        # the whole step (forward, loss, backward, clip, Adam) as ONE hipGraph; its 2 eager warm-up steps run first (with the
+        # learning rate at 0 when the frozen phase follows: see frozen_ms)
+        if args.frozen_steps > 0:
+            set_lr(nfp.optimizer, 0.0)
         step = nfp.make_graphed_step(*pool[0], mask=mask, warmup=2)
         log('training step captured into a hipGraph')
     frozen = None
+    if args.frozen_steps > 0 and args.eager:
+        set_lr(nfp.optimizer, 0.0)
     if args.frozen_steps > 0:
         frozen = frozen_ms(nfp, step, args.frozen_steps)
         log(f'frozen model (lr = 0): {frozen:.3f} ms per step over {args.frozen_steps} steps')
@@ -461,6 +469,7 @@ def main():
                 prev = ops.set_dgrad_split_bf16(True)
                 sp = make_predictor(device, capturable=True)
                 sp.model.train()
+                set_lr(sp.optimizer, 0.0)
                 sstep = sp.make_graphed_step(*pool[0], mask=mask, warmup=2)
                 sf = frozen_ms(sp, sstep, args.frozen_steps)
                 probes['split_bf16_dgrad'] = {
