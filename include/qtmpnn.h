@@ -89,6 +89,8 @@ int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_offsets /* ex
                        int32_t* fwd_src /* (Nmax) or NULL: per node of THIS mesh the old node under its pixel if the node
                        is a single pixel, else -1: qt_remesh's `direct` index for the transfer old -> this mesh */,
                        int32_t* bwd_src /* (Nmax_old) or NULL: the same for the transposed transfer this mesh -> old */,
+                       int32_t* cell_off /* (B*nbase + 1) or NULL: first node of every base cell in label order, slot
+                       b*nbase + (nbase - 1 - base): qt_remesh_clip's source ranges for frames of several base cells */,
                        void* stream);
 
 /* exclusive scan: out[0]=0, out[i+1]=sum(in[0..i]); len+1 outputs.  tmp: (len/1024+2) int32. */
@@ -161,18 +163,21 @@ int qt_remesh(const float* const* src_parts, const int* widths, const int* lds, 
               single-pixel nodes then read their source row through it (same rows, two dependent loads instead of three) */,
               void* stream);
 
-/* qt_remesh for frames of at most 64 x 64 pixels, clip-resident (csrc/remeshclip.hip): one workgroup per (clip, 4-channel slice)
- * stages the clip's source rows in LDS, gathers the pixel values from there and sums them up a 64 x 64 pyramid; every
+/* qt_remesh tile-resident (csrc/remeshclip.hip): one workgroup per (clip, 64 x 64 tile, 4-channel slice)
+ * stages the tile's source rows in LDS (a base cell's nodes are one contiguous label range; frames of several tiles need
+ * both meshes decomposed with max_size 64), gathers the pixel values from there and sums them up a 64 x 64 pyramid; every
  * destination node is written once by the thread that owns its head pixel.  Same arguments as qt_remesh minus the per-node
  * records (cell, N, n_dev, direct), plus the source mesh's node offsets (B + 1; qt_quadtree_stage3 writes them). */
 int qt_remesh_clip_rows(void);
 int qt_remesh_clip(const float* const* src_parts, const int* widths, const int* lds, int nparts,
-                   const int32_t* src_labels, const float* src_npix, int src_inv, const int32_t* src_node_off,
+                   const int32_t* src_labels, const float* src_npix, int src_inv,
+                   const int32_t* src_cell_off /* (B*tiles + 1): first source node of every 64 x 64 tile in label order
+                   (qt_quadtree_stage3's cell_off; for one-tile frames = node_off) */,
                    const int32_t* labels, const uint8_t* level, const float* npix, int mean, int B, int n, int m,
                    float* const* out_parts, const int* out_widths, int nout, void* stream);
 
-/* qt_pool from an image for frames of at most 64 x 64 pixels, clip-resident: one workgroup per (clip, frame, channel) sums the
- * frame up a 64 x 64 pyramid in LDS (csrc/remeshclip.hip).  Arguments as qt_pool's image form. */
+/* qt_pool from an image, tile-resident: one workgroup per (clip, 64 x 64 tile, frame, channel) sums the
+ * tile up a pyramid in LDS (csrc/remeshclip.hip).  Arguments as qt_pool's image form. */
 int qt_pool_clip(const float* img, int S, int64_t img_clip_stride, int C, const int32_t* labels, const uint8_t* level,
                  const float* npix, int mean, int B, int n, int m, int N, float* out, int out_stride, int out_coff, void* stream);
 

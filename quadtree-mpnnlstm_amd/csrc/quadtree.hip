@@ -381,7 +381,7 @@ __global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const in
                                   int32_t* __restrict__ cell, int32_t* __restrict__ node_off, float size_norm,
                                   float* __restrict__ feat, float* __restrict__ npix,
                                   const int32_t* __restrict__ old_labels, const uint8_t* __restrict__ old_level,
-                                  int32_t* __restrict__ fwd_src, int32_t* __restrict__ bwd_src) {
+                                  int32_t* __restrict__ fwd_src, int32_t* __restrict__ bwd_src, int32_t* __restrict__ cell_off) {
     // raw != 0: offs_in holds the per-cell leaf COUNTS (stage 1's output) and every workgroup scans the B * nbase <= 1024 of
     // them itself in LDS -- the separate scan launch between the two stages is gone (static capacities: nobody on the host
     // needs the total)
@@ -409,6 +409,9 @@ __global__ void k_quadtree_stage3(const int32_t* __restrict__ local_id, const in
     const int64_t P = (int64_t)n * m;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx <= B) node_off[idx] = offs[idx * nbase * per];
+    // first node of every base cell, in label order (slot b * nbase + (nbase - 1 - base)): a base cell's nodes are one contiguous
+    // label range, which is what lets the clip-resident transfer (remeshclip.hip) stage one 64 x 64 tile's source rows
+    if (cell_off && idx <= (int64_t)B * nbase) cell_off[idx] = offs[idx * per];
     if (idx >= B * P) return;
     const int b = (int)(idx / P);
     const int p = (int)(idx % P);
@@ -578,7 +581,7 @@ extern "C" int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_of
                                   int max_size, int32_t* labels, const uint8_t* level, int32_t* cell,
                                   int32_t* node_off, float size_norm, float* feat, float* npix, int raw_counts, int quads,
                                   const int32_t* old_labels, const uint8_t* old_level, int32_t* fwd_src, int32_t* bwd_src,
-                                  void* stream) {
+                                  int32_t* cell_off, void* stream) {
     QT_ARG(local_id && cnt_offsets && labels && level && cell && node_off, "null pointer");
     QT_ARG((!fwd_src && !bwd_src) || (old_labels && old_level), "fwd_src / bwd_src need the old mesh's labels and levels");
     QT_ARG((feat == nullptr) == (npix == nullptr), "give both feat and npix or neither");
@@ -588,7 +591,7 @@ extern "C" int qt_quadtree_stage3(const int32_t* local_id, const int32_t* cnt_of
     const int64_t total = (int64_t)B * n * m;
     hipLaunchKernelGGL(k_quadtree_stage3, dim3(qt_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, local_id,
                        cnt_offsets, raw_counts, quads, B, n, m, max_size, nbj, nbi * nbj, labels, level, cell, node_off, size_norm, feat, npix,
-                       old_labels, old_level, fwd_src, bwd_src);
+                       old_labels, old_level, fwd_src, bwd_src, cell_off);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -5,8 +5,9 @@
 //
 // The general kernels (transfer.hip: k_pool_nodes for nodes up to 4 x 4 pixels, k_pool for the bigger ones) walk
 // index -> label -> row chains through L2 / HBM for every node and channel chunk, 41 - 52 us per transfer of the benchmark's
-// 68 state channels.  For frames of at most 64 x 64 pixels a clip's whole transfer of one 4-channel column slice fits a
-// workgroup's LDS, like the Chebyshev recurrences of chebclip.hip:
+// 68 state channels.  The transfer of one 64 x 64 tile (= base cell) of a clip and one 4-channel column slice fits a
+// workgroup's LDS -- a base cell's nodes are one contiguous label range of the DFS order, so its source rows are a range too
+// (frames of several tiles: both meshes decomposed with max_size 64; frames up to 64 x 64: any mesh, the clip is the tile):
 //   * the source slice of the clip (<= 4096 rows x 16 B = 64 KB) is staged once (pre-scaled by 1 / src_npix for the backward);
 //   * every thread owns one 2 x 2 pixel block (Morton order): pixel value = staged row of the pixel's source node, an LDS gather;
 //   * a sum pyramid over the 64 x 64 frame (level-1 sums in registers, levels 2 .. 6 through 22 KB of LDS) -- a quadtree leaf
@@ -28,11 +29,11 @@ struct RcArgs {
     int opart_w[8], opart_end[8];
     const int32_t* src_labels;      // (B, n, m) source mesh
     const float* src_npix;
-    const int32_t* src_off;         // (B + 1) first node of every clip of the source mesh
+    const int32_t* src_off;         // (B * tiles + 1) first source node of every 64 x 64 tile, label order (slot b*T + (T-1-tile))
     const int32_t* labels;          // (B, n, m) destination mesh
     const uint8_t* level;
     const float* npix;
-    int src_inv, mean, B, n, m;
+    int src_inv, mean, B, n, m, tiles_c, tiles;
 };
 
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -51,7 +52,11 @@ __global__ __launch_bounds__(RC_T) void k_remesh_clip(RcArgs a) {
     __shared__ float4 A[RC_ROWS];                 // the clip's source slice
     __shared__ float4 L1[1024], L2[256], L3[64], L4[16], L5[4], L6[1];
     const int t = threadIdx.x;
-    const int b = (int)blockIdx.x % a.B, ch = (int)blockIdx.x / a.B;
+    const int b = (int)blockIdx.x % a.B;
+    const int rest = (int)blockIdx.x / a.B;
+    const int tile = rest % a.tiles, ch = rest / a.tiles;
+    const int R0 = (tile / a.tiles_c) * 64, C0 = (tile % a.tiles_c) * 64;
+    const int slot = b * a.tiles + (a.tiles - 1 - tile);
     int sp = 0, op = 0;
     while (ch >= a.part_end[sp]) ++sp;
     while (ch >= a.opart_end[op]) ++op;
@@ -59,8 +64,8 @@ __global__ __launch_bounds__(RC_T) void k_remesh_clip(RcArgs a) {
     const int lds = a.part_ld[sp];
     float* dst = a.opart[op] + (ch - (op ? a.opart_end[op - 1] : 0)) * 4;
     const int ldd = a.opart_w[op];
-    const int r0s = a.src_off[b];
-    const int nrs = min(a.src_off[b + 1] - r0s, RC_ROWS);
+    const int r0s = a.src_off[slot];
+    const int nrs = min(a.src_off[slot + 1] - r0s, RC_ROWS);
     const int P = a.n * a.m;
 
     // ---- one memory phase: the source slice (4 rows per thread) and the labels / levels of this thread's 2 x 2 pixels
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(RC_T) void k_remesh_clip(RcArgs a) {
     int lab[4], sl[4], lv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int r = 2 * br + (q >> 1), c = 2 * bc + (q & 1);
+        const int r = R0 + 2 * br + (q >> 1), c = C0 + 2 * bc + (q & 1);
         lab[q] = sl[q] = -1;
         lv[q] = 0;
         if (r < a.n && c < a.m) {
@@ -149,7 +154,7 @@ struct PcArgs {
     const int32_t* labels;
     const uint8_t* level;
     const float* npix;
-    int mean, B, n, m, N;
+    int mean, B, n, m, N, tiles_c, tiles;
     float* out;
     int out_stride, out_coff;
 };
@@ -158,7 +163,9 @@ __global__ __launch_bounds__(RC_T) void k_pool_clip(PcArgs a) {
     __shared__ float L1[1024], L2[256], L3[64], L4[16], L5[4], L6[1];
     const int t = threadIdx.x;
     const int b = (int)blockIdx.x % a.B;
-    const int sc_ = (int)blockIdx.x / a.B;
+    const int rest = (int)blockIdx.x / a.B;
+    const int tile = rest % a.tiles, sc_ = rest / a.tiles;
+    const int R0 = (tile / a.tiles_c) * 64, C0 = (tile % a.tiles_c) * 64;
     const int s = sc_ / a.C, c = sc_ - s * a.C;
     const int P = a.n * a.m;
     const float* img = a.img + (int64_t)b * a.img_clip_stride + (int64_t)s * P * a.C + c;
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(RC_T) void k_pool_clip(PcArgs a) {
     float v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int r = 2 * br + (q >> 1), cc = 2 * bc + (q & 1);
+        const int r = R0 + 2 * br + (q >> 1), cc = C0 + 2 * bc + (q & 1);
         lab[q] = -1;
         lv[q] = 0;
         v[q] = 0.0f;
@@ -219,12 +226,12 @@ __global__ __launch_bounds__(RC_T) void k_pool_clip(PcArgs a) {
 extern "C" int qt_remesh_clip_rows(void) { return RC_ROWS; }
 
 extern "C" int qt_remesh_clip(const float* const* src_parts, const int* widths, const int* lds, int nparts,
-                              const int32_t* src_labels, const float* src_npix, int src_inv, const int32_t* src_node_off,
+                              const int32_t* src_labels, const float* src_npix, int src_inv, const int32_t* src_cell_off,
                               const int32_t* labels, const uint8_t* level, const float* npix, int mean, int B, int n, int m,
                               float* const* out_parts, const int* out_widths, int nout, void* stream) {
-    QT_ARG(src_parts && widths && lds && nparts >= 1 && nparts <= 8 && src_labels && src_node_off && labels && level && B > 0,
+    QT_ARG(src_parts && widths && lds && nparts >= 1 && nparts <= 8 && src_labels && src_cell_off && labels && level && B > 0,
            "bad arguments");
-    QT_ARG(n >= 1 && m >= 1 && n <= 64 && m <= 64, "the clip-resident transfer serves frames of at most 64 x 64 pixels");
+    QT_ARG(n >= 1 && m >= 1, "empty frame");
     QT_ARG(out_parts && out_widths && nout >= 1 && nout <= 8, "bad output parts");
     QT_ARG(!mean || npix, "mean pooling needs npix");
     QT_ARG(!src_inv || src_npix, "src_inv needs src_npix");
@@ -252,7 +259,9 @@ extern "C" int qt_remesh_clip(const float* const* src_parts, const int* widths, 
     QT_ARG(o4 == c4, "the output parts must add up to the source width");
     a.src_labels = src_labels;
     a.src_npix = src_npix;
-    a.src_off = src_node_off;
+    a.src_off = src_cell_off;
+    a.tiles_c = qt_cdiv(m, 64);
+    a.tiles = qt_cdiv(n, 64) * a.tiles_c;
     a.labels = labels;
     a.level = level;
     a.npix = npix;
@@ -261,7 +270,8 @@ extern "C" int qt_remesh_clip(const float* const* src_parts, const int* widths, 
     a.B = B;
     a.n = n;
     a.m = m;
-    hipLaunchKernelGGL(k_remesh_clip, dim3(B * c4), dim3(RC_T), 0, (hipStream_t)stream, a);
+    QT_ARG((int64_t)B * a.tiles * c4 < ((int64_t)1 << 31), "grid too large");
+    hipLaunchKernelGGL(k_remesh_clip, dim3(B * a.tiles * c4), dim3(RC_T), 0, (hipStream_t)stream, a);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -270,13 +280,15 @@ extern "C" int qt_pool_clip(const float* img, int S, int64_t img_clip_stride, in
                             const float* npix, int mean, int B, int n, int m, int N, float* out, int out_stride, int out_coff,
                             void* stream) {
     QT_ARG(img && labels && level && out && S >= 1 && C >= 1 && B > 0, "bad arguments");
-    QT_ARG(n >= 1 && m >= 1 && n <= 64 && m <= 64, "the clip-resident pooling serves frames of at most 64 x 64 pixels");
+    QT_ARG(n >= 1 && m >= 1, "empty frame");
     QT_ARG(!mean || npix, "mean pooling needs npix");
     QT_ARG(out_stride >= out_coff + C, "output row too short");
     if (N <= 0) return QT_OK;
+    const int tiles_c = qt_cdiv(m, 64), tiles = qt_cdiv(n, 64) * tiles_c;
+    QT_ARG((int64_t)B * tiles * S * C < ((int64_t)1 << 31), "grid too large");
     PcArgs a = {img, img_clip_stride > 0 ? img_clip_stride : (int64_t)S * n * m * C, S, C, labels, level, npix, mean, B, n, m, N,
-                out, out_stride, out_coff};
-    hipLaunchKernelGGL(k_pool_clip, dim3(B * S * C), dim3(RC_T), 0, (hipStream_t)stream, a);
+                tiles_c, tiles, out, out_stride, out_coff};
+    hipLaunchKernelGGL(k_pool_clip, dim3(B * tiles * S * C), dim3(RC_T), 0, (hipStream_t)stream, a);
     QT_LAUNCHED();
     return QT_OK;
 }

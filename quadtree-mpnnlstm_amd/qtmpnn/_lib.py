@@ -18,7 +18,7 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 _SIGNATURES = {
     'qt_abi_version': [],
     'qt_quadtree_stage1': [_P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P],
-    'qt_quadtree_stage3': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P, _P, _P, _P, _P],
+    'qt_quadtree_stage3': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     'qt_scan_i32': [_P, _P, _L, _P, _P],
     'qt_node_features': [_P, _I, _P, _I, _I, _F, _P, _P, _P],
     'qt_edges_blocks': [_I],

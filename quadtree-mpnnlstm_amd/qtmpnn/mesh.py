@@ -51,6 +51,7 @@ class Mesh:
         self.n_dev = None        # device int32[1] with the valid node count when N is a capacity (static mode)
         self.ell = None          # (N, 8) int32: [col x4 | nrm bits x4] of the first four edges of every row
         self.tail_cnt = self.tail_pool = self.tail_info = None     # the edges beyond the fourth, per clip (qt_edges_norm)
+        self.cell_off = None     # (B * tiles + 1) first node of every 64 x 64 tile in label order (None: no such contiguity)
         self.pixelwise = False   # every unmasked pixel is a node (thresh = -inf); unflatten then NaN-fills the mask
         self.recipe = None       # arguments that rebuild a data-independent mesh for another batch size
         self.loss_mask = None    # (n, m) u8 when the labels do not encode the mask (homogeneous preset mesh): the loss
@@ -265,6 +266,7 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     ms.npix = torch.empty(N, device=device)
     size_norm = size_norm if size_norm is not None else (max_size / 2) ** 2
     old_lab = old_lvl = None
+    cell_off = torch.empty(B * nbase + 1, **i32)
     if direct:
         import weakref
         ms.built_from = weakref.ref(old)
@@ -273,7 +275,9 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
         old_lab, old_lvl = old.labels, old.level
     _lib.call('qt_quadtree_stage3', ptr(local_id), ptr(cnt if fused_scan else offs), B, n, m, max_size, ptr(ms.labels), ptr(level),
               ptr(ms.cell), ptr(ms.node_off), float(size_norm), ptr(ms.posfeat), ptr(ms.npix), int(fused_scan), quads,
-              ptr(old_lab), ptr(old_lvl), ptr(ms.fwd_src), ptr(ms.bwd_src))
+              ptr(old_lab), ptr(old_lvl), ptr(ms.fwd_src), ptr(ms.bwd_src), ptr(cell_off))
+    # first node of every 64 x 64 tile (base cell) in label order: the tile-resident transfer stages a tile's source rows by range
+    ms.cell_off = cell_off if max_size == 64 else (ms.node_off if n <= 64 and m <= 64 else None)
     nd = None
     if static:
         ms.n_dev = ms.node_off[B:]                # view of the last entry = N
@@ -340,6 +344,7 @@ def build_homogeneous_mesh(n, m, max_size, mask, B=1, device=None, resolution=0.
     per_clip = torch.zeros(B, dtype=torch.int32, device=device).index_add_(0, base.cell[kept][:, 3].long(),
                                                                            torch.ones(ms.N, dtype=torch.int32, device=device))
     ms.node_off = torch.cat([torch.zeros(1, dtype=torch.int32, device=device), torch.cumsum(per_clip, 0, dtype=torch.int32)])
+    ms.cell_off = ms.node_off if n <= 64 and m <= 64 else None
     ms.loss_mask = mk
     ms.npix_valid = cnt[kept].contiguous()
     ms.recipe = lambda b: build_homogeneous_mesh(n, m, max_size, mask, b, device, resolution)
@@ -375,6 +380,7 @@ def build_pixel_mesh(B, n, m, mask=None, device=None, resolution=0.25):
     cell = torch.cat([rc, torch.ones(nv, 1, **i32), torch.zeros(nv, 1, **i32)], dim=1)
     ms.cell = torch.cat([cell + torch.tensor([0, 0, 0, b], **i32) for b in range(B)]).contiguous()
     ms.node_off = (torch.arange(B + 1, **i32) * nv).contiguous()
+    ms.cell_off = ms.node_off if n <= 64 and m <= 64 else None
     ms.recipe = lambda b: build_pixel_mesh(b, n, m, mask, device, resolution)
     _finish_mesh(ms, device, 1.0 / (resolution ** 2), resolution, None)          # size feature = resolution^2 (:521)
     if len(_PIXEL_MESHES) > 16:

@@ -1178,8 +1178,8 @@ def head_input(O, ln_o, concat, hp, mesh, acc=None):
 # ------------------------------------------------------------------------------ mesh <-> image
 def _pool_raw(mesh, C, out, out_stride, out_coff, mean, img=None, S=1, src_val=None, src_mesh=None, src_inv=False,
               img_clip_stride=0):
-    if _CLIP_REMESH and img is not None and mesh.n <= 64 and mesh.m <= 64 and S * C <= 64:
-        # frames of at most 64 x 64 pixels, a few scalar channels: one workgroup per (clip, frame, channel), LDS pyramid
+    if _CLIP_REMESH and img is not None and S * C <= 64:
+        # a few scalar channels: one workgroup per (clip, 64 x 64 tile, frame, channel), LDS pyramid
         _lib.call('qt_pool_clip', ptr(img), S, img_clip_stride, C, ptr(mesh.labels), ptr(mesh.level), ptr(mesh.npix), int(mean),
                   mesh.B, mesh.n, mesh.m, mesh.N, ptr(out), out_stride, out_coff)
         return
@@ -1283,9 +1283,10 @@ def _remesh_raw(dst, src, parts, outs, src_inv, mean):
     lds = (ctypes.c_int * n)(*[_ld(t) for t in parts])
     optrs = (ctypes.c_void_p * no)(*[t.data_ptr() for t in outs])
     owidths = (ctypes.c_int * no)(*[t.shape[1] for t in outs])
-    if _CLIP_REMESH and dst.n <= 64 and dst.m <= 64 and getattr(src, 'node_off', None) is not None:
-        # frames of at most 64 x 64 pixels: a clip's transfer of one 4-channel slice runs inside one workgroup's LDS
-        _lib.call('qt_remesh_clip', ptrs, widths, lds, n, ptr(src.labels), ptr(src.npix), int(src_inv), ptr(src.node_off),
+    if _CLIP_REMESH and getattr(src, 'cell_off', None) is not None:
+        # the transfer of one 64 x 64 tile and one 4-channel slice runs inside one workgroup's LDS (the source mesh's nodes of a
+        # tile are one row range: cell_off)
+        _lib.call('qt_remesh_clip', ptrs, widths, lds, n, ptr(src.labels), ptr(src.npix), int(src_inv), ptr(src.cell_off),
                   ptr(dst.labels), ptr(dst.level), ptr(dst.npix), int(mean), dst.B, dst.n, dst.m, optrs, owidths, no)
         return
     # the direct row index of the single-pixel nodes, when one mesh of the pair was decomposed from the other

@@ -81,12 +81,13 @@ def test_remesh_transfer_vs_oracle():
     assert torch.equal(torch.cat([ga, gb], dim=1), gv)
 
 
-@pytest.mark.parametrize('shape,B', [((64, 64), 3), ((48, 64), 2), ((24, 32), 1), ((64, 40), 2)])
+@pytest.mark.parametrize('shape,B', [((64, 64), 3), ((48, 64), 2), ((24, 32), 1), ((64, 40), 2), ((128, 128), 2), ((100, 150), 1)])
 def test_clip_resident_remesh_equals_general_kernels(shape, B):
     """csrc/remeshclip.hip (a clip's transfer of one 4-channel slice inside one workgroup's LDS: staged source rows, LDS gathers,
     a 64 x 64 sum pyramid) against the general node / tile kernels of transfer.hip, forward and backward (the transposed transfer:
-    sums scaled by 1 / source pixel count): frames smaller than 64 x 64, a land mask, cells from 1 x 1 to the whole frame, several
-    source and output parts with row-strided views.  Same sums in another association: 1e-6 relative."""
+    sums scaled by 1 / source pixel count): frames smaller than 64 x 64 and frames of several 64 x 64 tiles (a tile's source rows
+    are one label range: Mesh.cell_off), a land mask, cells from 1 x 1 to a whole tile, several source and output parts with
+    row-strided views.  Same sums in another association: 1e-6 relative."""
     from qtmpnn import ops
     from qtmpnn.mesh import build_mesh
     n, m = shape
@@ -112,6 +113,37 @@ def test_clip_resident_remesh_equals_general_kernels(shape, B):
         grads = torch.autograd.grad(outs, parts, gouts)
         return [o.detach() for o in outs] + list(grads)
     assert ops._CLIP_REMESH
+    fast = run()
+    prev, ops._CLIP_REMESH = ops._CLIP_REMESH, False
+    try:
+        ref = run()
+    finally:
+        ops._CLIP_REMESH = prev
+    for a, r in zip(fast, ref):
+        close(a, r, rtol=1e-6, atol=1e-6 * float(r.abs().max()))
+
+
+@pytest.mark.parametrize('shape,B,S,C', [((64, 64), 3, 4, 1), ((48, 64), 2, 1, 5), ((24, 32), 1, 2, 3), ((100, 150), 2, 2, 2)])
+def test_clip_resident_pooling_equals_general_kernels(shape, B, S, C):
+    """qt_pool_clip (image -> mesh pooling of scalar channels through a 64 x 64 LDS pyramid, one workgroup per clip, frame and
+    channel) against the general tile / node kernels: node means of (B, S, n*m, C) frames and the gradient back onto the pixels,
+    masked meshes, frames smaller than 64 x 64.  Same sums in another association: 1e-6 relative."""
+    from qtmpnn import ops
+    from qtmpnn.mesh import build_mesh
+    n, m = shape
+    rng = np.random.default_rng(n * 7 + m + C)
+    crit = (rng.random((B, n, m)) < 0.04).astype(np.float32)
+    crit[-1, : n // 2] = 0.0
+    mask = np.zeros((n, m), bool)
+    mask[3:9, m // 2:m - 2] = True
+    mesh = build_mesh(src=torch.from_numpy(crit).to(dev()), thresh=0.5, mask=mask)
+    img = torch.randn(B, S, n * m, C, device=dev(), requires_grad=True)
+    g = torch.randn(S, mesh.N, C, device=dev())
+
+    def run():
+        out = ops.pool_image(img, mesh, True)
+        (gi,) = torch.autograd.grad(out, img, g)
+        return out.detach(), gi
     fast = run()
     prev, ops._CLIP_REMESH = ops._CLIP_REMESH, False
     try:
