@@ -174,7 +174,11 @@ int qt_remesh_clip(const float* const* src_parts, const int* widths, const int* 
                    const int32_t* src_cell_off /* (B*tiles + 1): first source node of every 64 x 64 tile in label order
                    (qt_quadtree_stage3's cell_off; for one-tile frames = node_off) */,
                    const int32_t* labels, const uint8_t* level, const float* npix, int mean, int B, int n, int m,
-                   float* const* out_parts, const int* out_widths, int nout, void* stream);
+                   float* const* out_parts, const int* out_widths, int nout,
+                   const float* posfeat /* optional (N, 3) of the destination mesh: float4 chunk 0 of the result is written as
+                   (value.x, posfeat[node]) -- the decoder's next input [value | position, size], model/seq2seq.py:484-487 */,
+                   int src_first_only /* != 0: only column 0 of the source's float4 chunk 0 counts (the transposed transfer of
+                   that assembly: its gradient) */, void* stream);
 
 /* qt_pool from an image, tile-resident: one workgroup per (clip, 64 x 64 tile, frame, channel) sums the
  * tile up a pyramid in LDS (csrc/remeshclip.hip).  Arguments as qt_pool's image form. */

@@ -34,6 +34,11 @@ struct RcArgs {
     const uint8_t* level;
     const float* npix;
     int src_inv, mean, B, n, m, tiles_c, tiles;
+    // the decoder's next input assembled by the transfer itself (model/seq2seq.py:484-487: [transferred output value | position,
+    // size]): float4 chunk 0 of the result is written as (value.x, posfeat[node]) when posfeat != NULL -- and in the transposed
+    // transfer only column 0 of chunk 0 of the SOURCE counts (src_first_only): the gradient of that assembly
+    const float* posfeat;
+    int src_first_only;
 };
 
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -96,8 +101,18 @@ __global__ __launch_bounds__(RC_T) void k_remesh_clip(RcArgs a) {
         }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 4; ++u) {
+        if (a.src_first_only && ch == 0) x[u].y = x[u].z = x[u].w = 0.0f;
         if (t + RC_T * u < nrs) A[t + RC_T * u] = a.src_inv ? mul4(x[u], 1.0f / sc[u]) : x[u];
+    }
+    const bool dec = a.posfeat != nullptr && ch == 0;          // (workgroup-uniform)
+    auto put = [&](int node, float4 v) {
+        if (dec) {
+            const float* pf = a.posfeat + 3 * (int64_t)node;
+            v.y = pf[0]; v.z = pf[1]; v.w = pf[2];
+        }
+        *reinterpret_cast<float4*>(dst + (int64_t)node * ldd) = v;
+    };
     lds_barrier();
 
     // ---- pixel values, single-pixel nodes, 2 x 2 sums
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(RC_T) void k_remesh_clip(RcArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        if (lab[q] >= 0 && lv[q] == 0) *reinterpret_cast<float4*>(dst + (int64_t)lab[q] * ldd) = v[q];
+        if (lab[q] >= 0 && lv[q] == 0) put(lab[q], v[q]);
     const float4 s1 = add4(add4(v[0], v[1]), add4(v[2], v[3]));
     const int L = lab[0] >= 0 ? lv[0] : 0;          // a node of level >= 1 has its head at a block's first pixel
     float oscale = 1.0f;
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(RC_T) void k_remesh_clip(RcArgs a) {
             case 5: s = L5[t >> 8]; break;
             default: s = L6[0]; break;
         }
-        *reinterpret_cast<float4*>(dst + (int64_t)lab[0] * ldd) = mul4(s, oscale);
+        put(lab[0], mul4(s, oscale));
     }
 }
 
@@ -228,7 +243,8 @@ extern "C" int qt_remesh_clip_rows(void) { return RC_ROWS; }
 extern "C" int qt_remesh_clip(const float* const* src_parts, const int* widths, const int* lds, int nparts,
                               const int32_t* src_labels, const float* src_npix, int src_inv, const int32_t* src_cell_off,
                               const int32_t* labels, const uint8_t* level, const float* npix, int mean, int B, int n, int m,
-                              float* const* out_parts, const int* out_widths, int nout, void* stream) {
+                              float* const* out_parts, const int* out_widths, int nout, const float* posfeat, int src_first_only,
+                              void* stream) {
     QT_ARG(src_parts && widths && lds && nparts >= 1 && nparts <= 8 && src_labels && src_cell_off && labels && level && B > 0,
            "bad arguments");
     QT_ARG(n >= 1 && m >= 1, "empty frame");
@@ -270,6 +286,8 @@ extern "C" int qt_remesh_clip(const float* const* src_parts, const int* widths, 
     a.B = B;
     a.n = n;
     a.m = m;
+    a.posfeat = posfeat;
+    a.src_first_only = src_first_only;
     QT_ARG((int64_t)B * a.tiles * c4 < ((int64_t)1 << 31), "grid too large");
     hipLaunchKernelGGL(k_remesh_clip, dim3(B * a.tiles * c4), dim3(RC_T), 0, (hipStream_t)stream, a);
     QT_LAUNCHED();

@@ -496,10 +496,15 @@ class Seq2Seq(nn.Module):
             wide = (b4 is not None and b4.dim() == 2 and b4.shape == (data.shape[0], 4) and b4.is_contiguous()
                     and data.storage_offset() == b4.storage_offset() and data.stride(0) == 4)
             # the state goes across as its parts and comes back as column views of one matrix: nothing is concatenated
+            # (on the tile-resident transfer the next decoder input [value | position, size] is assembled by the same launch)
+            fold = ops._DEC_FOLD and ops.clip_remesh_ok(old, new)
             val4, *parts = ops.remesh_transfer([b4 if wide else data.expand(-1, 4).contiguous(), *hidden, *cell], old, new,
-                                               [4] + [h] * (2 * L))
+                                               [4] + [h] * (2 * L), dec_input=fold)
             val = None
         g.hidden, g.cell = list(parts[:L]), list(parts[L:])
-        g.pyg.x = ops.decoder_input(val4, new) if val is None else torch.cat([val, new.posfeat], dim=-1)
+        if val is None:
+            g.pyg.x = val4 if fold else ops.decoder_input(val4, new)
+        else:
+            g.pyg.x = torch.cat([val, new.posfeat], dim=-1)
         g.mapping, g.n_pixels_per_node = new, new.npix
         return new

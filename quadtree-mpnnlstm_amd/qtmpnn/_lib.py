@@ -34,7 +34,7 @@ _SIGNATURES = {
     'qt_remesh': [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     'qt_remesh_clip_rows': [],
     'qt_pool_clip': [_P, _I, _L, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
-    'qt_remesh_clip': [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P],
+    'qt_remesh_clip': [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P],
     'qt_sse': [_P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
     'qt_spmm': [_P, _P, _P, _I, _P, _I, _P, _F, _P, _F, _P, _F, _P, _P],
     'qt_spmm1': [_P, _P, _P, _P, _I, _P, _P, _I, _F, _P, _I, _F, _P, _I, _F, _P, _I, _I, _I, _P, _I, _P, _P],

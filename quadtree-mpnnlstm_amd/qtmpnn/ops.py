@@ -1273,7 +1273,7 @@ def gather_pixels(val, mesh):
 _CLIP_REMESH = os.environ.get('QT_NO_CLIP_REMESH') != '1'      # (A/B switch: 1 = the general node / tile kernels everywhere)
 
 
-def _remesh_raw(dst, src, parts, outs, src_inv, mean):
+def _remesh_raw(dst, src, parts, outs, src_inv, mean, posfeat=None, first_only=False):
     """outs (dense (dst.N, w) matrices, side by side) = per-node reduction over dst's pixels of [parts...][src.labels[p]]
     (qt_remesh)."""
     import ctypes
@@ -1287,8 +1287,10 @@ def _remesh_raw(dst, src, parts, outs, src_inv, mean):
         # the transfer of one 64 x 64 tile and one 4-channel slice runs inside one workgroup's LDS (the source mesh's nodes of a
         # tile are one row range: cell_off)
         _lib.call('qt_remesh_clip', ptrs, widths, lds, n, ptr(src.labels), ptr(src.npix), int(src_inv), ptr(src.cell_off),
-                  ptr(dst.labels), ptr(dst.level), ptr(dst.npix), int(mean), dst.B, dst.n, dst.m, optrs, owidths, no)
+                  ptr(dst.labels), ptr(dst.level), ptr(dst.npix), int(mean), dst.B, dst.n, dst.m, optrs, owidths, no,
+                  ptr(posfeat), int(first_only))
         return
+    assert posfeat is None and not first_only, 'the decoder-input assembly is part of the tile-resident transfer only'
     # the direct row index of the single-pixel nodes, when one mesh of the pair was decomposed from the other
     direct = None
     if dst.built_from is not None and dst.built_from() is src:
@@ -1307,14 +1309,17 @@ class _Remesh(Function):
     of one 272-byte-pitch matrix the same parts cost the gate kernels 5 % more)."""
 
     @staticmethod
-    def forward(ctx, old, new, out_widths, *vals):
+    def forward(ctx, old, new, out_widths, dec_input, *vals):
+        # dec_input: the first output part (4 wide) comes back as the decoder's next input [value | position, size]
+        # (model/seq2seq.py:484-487), assembled by the transfer kernel; its gradient counts column 0 only
         parts = [_rows(v.float())[0] for v in vals]
         C = sum(t.shape[1] for t in parts)
         assert sum(out_widths) == C and len(parts) <= 8 and len(out_widths) <= 8
+        assert not dec_input or (out_widths[0] == 4 and parts[0].shape[1] == 4)
         outs = [parts[0].new_empty(new.N, w) for w in out_widths]
         if new.N > 0:
-            _remesh_raw(new, old, parts, outs, False, True)
-        ctx.old, ctx.new, ctx.in_widths, ctx.out_widths = old, new, [t.shape[1] for t in parts], out_widths
+            _remesh_raw(new, old, parts, outs, False, True, posfeat=new.posfeat if dec_input else None)
+        ctx.old, ctx.new, ctx.in_widths, ctx.out_widths, ctx.dec = old, new, [t.shape[1] for t in parts], out_widths, dec_input
         ctx.set_materialize_grads(False)
         return tuple(outs)
 
@@ -1325,13 +1330,22 @@ class _Remesh(Function):
         parts = [_rows(g)[0] if g is not None else ref.new_zeros(new.N, w) for g, w in zip(gs, ctx.out_widths)]
         gvals = [ref.new_empty(old.N, w) for w in ctx.in_widths]
         if old.N > 0:
-            _remesh_raw(old, new, parts, gvals, True, False)
-        return (None, None, None, *gvals)
+            _remesh_raw(old, new, parts, gvals, True, False, first_only=ctx.dec)
+        return (None, None, None, None, *gvals)
 
 
-def remesh_transfer(vals, old, new, out_widths=None):
+_DEC_FOLD = os.environ.get('QT_NO_DEC_FOLD') != '1'           # (A/B switch)
+
+
+def clip_remesh_ok(old, new):
+    """True when the transfer old -> new (and its backward) runs on the tile-resident kernel (both meshes keep cell_off)."""
+    return _CLIP_REMESH and getattr(old, 'cell_off', None) is not None and getattr(new, 'cell_off', None) is not None
+
+
+def remesh_transfer(vals, old, new, out_widths=None, dec_input=False):
     """vals: one (N_old, C) matrix or a list of column parts (widths multiples of 4); returns the transferred state as
-    one matrix (out_widths None) or as the list of its column parts."""
+    one matrix (out_widths None) or as the list of its column parts.  dec_input (needs clip_remesh_ok): the first part
+    (4 wide) comes back as [transferred value | new.posfeat], the decoder's next input."""
     single = not isinstance(vals, (list, tuple))
     vals = [vals] if single else list(vals)
     win = [v.shape[1] for v in vals]
@@ -1349,11 +1363,11 @@ def remesh_transfer(vals, old, new, out_widths=None):
     outs = []
     if groups is None:       # e.g. 9 parts into one matrix: across in runs of 8 with their own widths, regrouped afterwards
         for a in range(0, len(vals), 8):
-            outs += _Remesh.apply(old, new, tuple(win[a:a + 8]), *vals[a:a + 8])
+            outs += _Remesh.apply(old, new, tuple(win[a:a + 8]), dec_input and a == 0, *vals[a:a + 8])
         outs = torch.split(concat_cols(outs, new), wout, dim=1)
     else:
         for i0, i1, o0, o1 in groups:
-            outs += _Remesh.apply(old, new, tuple(wout[o0:o1]), *vals[i0:i1])
+            outs += _Remesh.apply(old, new, tuple(wout[o0:o1]), dec_input and i0 == 0 and o0 == 0, *vals[i0:i1])
     return outs[0] if out_widths is None else list(outs)
 
 

@@ -123,6 +123,31 @@ def test_clip_resident_remesh_equals_general_kernels(shape, B):
         close(a, r, rtol=1e-6, atol=1e-6 * float(r.abs().max()))
 
 
+def test_transfer_assembles_the_next_decoder_input():
+    """remesh_transfer(..., dec_input=True): the first 4-wide part comes back as [transferred value | position, size] of the new
+    mesh (model/seq2seq.py:484-487) from the transfer launch itself == remesh_transfer + ops.decoder_input, bit for bit, values
+    and gradients (only column 0 of that part carries a gradient back)."""
+    from qtmpnn import ops
+    old, _ = _mesh_64(31, noise=0.03, B=2)
+    new, _ = _mesh_64(33, noise=0.0, B=2)
+    assert ops.clip_remesh_ok(old, new)
+    torch.manual_seed(2)
+    v4 = torch.randn(old.N, 4, device=dev(), requires_grad=True)
+    hs = [torch.randn(old.N, 16, device=dev(), requires_grad=True) for _ in range(2)]
+    gx, gh = torch.randn(new.N, 4, device=dev()), [torch.randn(new.N, 16, device=dev()) for _ in range(2)]
+
+    def run(fold):
+        x, *parts = ops.remesh_transfer([v4, *hs], old, new, [4, 16, 16], dec_input=fold)
+        if not fold:
+            x = ops.decoder_input(x, new)
+        grads = torch.autograd.grad([x, *parts], [v4, *hs], [gx, *gh])
+        return [x.detach(), *[p.detach() for p in parts], *grads]
+    a, b = run(True), run(False)
+    for u, w in zip(a, b):
+        assert torch.equal(u, w)
+    assert torch.equal(a[0][:, 1:], new.posfeat) and bool((a[3][:, 1:] == 0).all())
+
+
 @pytest.mark.parametrize('shape,B,S,C', [((64, 64), 3, 4, 1), ((48, 64), 2, 1, 5), ((24, 32), 1, 2, 3), ((100, 150), 2, 2, 2)])
 def test_clip_resident_pooling_equals_general_kernels(shape, B, S, C):
     """qt_pool_clip (image -> mesh pooling of scalar channels through a 64 x 64 LDS pyramid, one workgroup per clip, frame and

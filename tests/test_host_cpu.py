@@ -67,7 +67,7 @@ def test_bad_arguments_fail_loudly_without_gpu():
         'qt_compose_step_fwd': (None,) * 4 + (3, 1, 3, 4, 16, None, None, None),
         'qt_remesh': (None, None, None, 0, None, None, 0, None, None, None, 1, 1, 64, 64, 4, None, None, None, None, 0, None, None),
         'qt_pool_clip': (None, 1, 0, 1, None, None, None, 1, 1, 64, 64, 4, None, 1, 0, None),
-        'qt_remesh_clip': (None, None, None, 0, None, None, 0, None, None, None, None, 1, 1, 64, 64, None, None, 0, None),
+        'qt_remesh_clip': (None, None, None, 0, None, None, 0, None, None, None, None, 1, 1, 64, 64, None, None, 0, None, 0, None),
         'qt_attn_fwd': (None,) * 6 + (0, None, 8, 8, 4, None, 1.0, 0, None, None, None, 1, 0, 0, 0, 0, None),
         'qt_proj_group': (None, 0, 0, 1, 4, None, None, None, 0, 1, 1, 4, None, 0, 0, 0, 4, None, None),
         'qt_wgrad_groups': (1, None, None, None, None, None, None, 4, 4, 4, 4, 0, 1, 0, 0, 0, None, None),
