@@ -1,4 +1,4 @@
-"""Phase timeline of k_cheb_clip from in-kernel wall_clock64 stamps (diagnostics build tools/micro/libqt_clip_timing.so,
+"""Phase timeline of k_cheb_clip from in-kernel wall_clock64 stamps (diagnostics build: `make -C quadtree-mpnnlstm_amd/csrc timing`,
 -DQT_CLIP_TIMING): start | counter barrier | ELL unpacked | pool filled + barrier | hop 1 | hop 2 | ..."""
 import ctypes, os, sys
 ROOT = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
