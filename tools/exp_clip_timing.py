@@ -1,5 +1,5 @@
 """Phase timeline of k_cheb_clip from in-kernel wall_clock64 stamps (diagnostics build: `make -C quadtree-mpnnlstm_amd/csrc timing`,
--DQT_CLIP_TIMING): start | counter barrier | ELL unpacked | pool filled + barrier | hop 1 | hop 2 | ..."""
+-DQT_CLIP_TIMING): start | prologue loads issued | ELL unpacked, first plane written | barrier passed | hop 1 | hop 2 | ..."""
 import ctypes, os, sys
 ROOT = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'quadtree-mpnnlstm_amd'))
@@ -34,7 +34,7 @@ for K, widths, bwd in [(5, (4, 16), False), (5, (4, 16), True), (5, (16,), False
     t0 = t[:, 0].min()
     t = (t[:, :n] - t0) / 100.0
     print(f'K={K} widths={widths} {"bwd" if bwd else "fwd"}: {nwg} workgroups, span {float(t[:, n - 1].max()):.2f} us')
-    names = ['start', 'cnt barrier', 'ELL unpacked', 'pool+barrier'] + [f'hop {i + 1}' for i in range(K - 1)]
+    names = ['start', 'loads issued', 'unpacked', 'barrier'] + [f'hop {i + 1}' for i in range(K - 1)]
     for i, nm in enumerate(names):
         c = t[:, i]
         print(f'   {nm:13s} median {float(c.median()):6.2f}  min {float(c.min()):6.2f}  max {float(c.max()):6.2f} us')
