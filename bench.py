@@ -221,6 +221,8 @@ def gemm_mfma(nfp, batch, mask, reps=20):
     N, h, K, Ca, Cab = mesh.N, HIDDEN, 5, 4, HIDDEN
     nv = mesh.n_valid
     Kt = K * (Ca + Cab) + 4
+    from qtmpnn import ops
+    sm = int(ops._clip_resident(mesh, [Ca, Cab], K))          # the plane layout of the real launch (slice-major from k_cheb_clip)
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
     X, H, TX, TH = rnd(N, Ca), rnd(N, Cab), rnd(K - 1, N, Ca), rnd(K - 1, N, Cab)
@@ -231,7 +233,7 @@ def gemm_mfma(nfp, batch, mask, reps=20):
     Hn, Cn, gates = (torch.empty(N, w, device=dev) for w in (h, h, 4 * h))
     fn = lambda: _lib.call('qt_dense_lstm', ptr(X), Ca, ptr(TX), ptr(H), Cab, ptr(TH), K, Ca, Cab, ptr(W), ptr(WT), ptr(S), 4,
                            ptr(W[K * (Ca + Cab):]), h, N, ptr(mesh.n_dev), ptr(Cp), h, ptr(wc), ptr(b), ptr(ln), None, ptr(Hn),
-                           ptr(Cn), ptr(gates))
+                           ptr(Cn), ptr(gates), sm)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):

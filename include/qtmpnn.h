@@ -231,7 +231,10 @@ int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* nrm, int N,
  *   node_off (B + 1): first node of each clip (device; qt_quadtree_stage3 writes it); ell, tail_cnt / tail_pool / tail_info:
  *   required, from qt_edges_norm (the first four edges of a row in registers, the rest from the clip's pool copied to LDS).
  *   N: plane stride in rows (the capacity in static mode; the valid rows come from node_off).
- * qt_cheb_clip_fwd: T_k = 2 L^ T_{k-1} - T_{k-2} (T_0 = Z = [za | zb], T_1 = L^ Z) -> Ta (K - 1, N, Ca), Tb (K - 1, N, Cb).
+ * qt_cheb_clip_fwd: T_k = 2 L^ T_{k-1} - T_{k-2} (T_0 = Z = [za | zb], T_1 = L^ Z) -> Ta, Tb: K - 1 planes each, stored
+ *   SLICE-major -- plane k as (C / 4, N, 4): a workgroup owns one 4-channel slice, so consecutive rows of its slice are
+ *   contiguous and its stores coalesce (row-major (N, C) planes cost a forward launch 7 - 9 % more).  The consumers take the
+ *   layout through their planes_sm flag (qt_dense2, qt_dense_lstm, qt_wgrad, qt_wgrad_group).
  * qt_cheb_clip_bwd: Clenshaw on the gradient planes Ga (K, N, Ca), Gb (K, N, Cb): plane 0 is overwritten with
  *   A_0 + L^ b_1 - b_2, b_k = A_k + 2 L^ b_{k+1} - b_{k+2}; planes 1 .. K - 1 are left as given (the b_k stay in LDS). */
 int qt_cheb_clip_rows(void);
@@ -263,7 +266,8 @@ int qt_dense2(const float* a0, int lda0, const float* a_rest, const float* a0b, 
               const float* W, const float* WT /* optional: [W ; Ws]^T, (Kb*(Cb+Cbb), K) row-major; W may then be NULL */,
               const float* S, int Ks, const float* Ws, int Kb, int Cb, int Cbb, int N,
               const int32_t* n_dev, int act, const float* res, int res_stride, const float* drop, float* out, float* outb,
-              void* stream);
+              int planes_sm /* != 0: the INPUT planes 1 .. Ka-1 (a_rest / a_restb) are stored slice-major, (plane, 4-channel
+              slice, N, 4), as qt_cheb_clip_fwd writes them; plane 0 stays row-major */, void* stream);
 
 /* Data-gradient product as a split-bf16 GEMM (gradients only): out planes (Kb, N, Cb) [| outb (Kb, N, Cbb)] = A (N rows of K floats,
  * row stride lda) @ B, B^T given as the two bf16 terms Whi + Wlo (Kb (Cb + Cbb), K) of qt_split_bf16 -- for the data gradient of
@@ -279,13 +283,13 @@ int qt_dense_sb(const float* A, int lda, int K, const void* Whi, const void* Wlo
 int qt_wgrad_blocks(int N);
 int qt_wgrad(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb, int Ka, int Ca, int Cab,
              const float* S, int Ks, const float* G, int Co, int N, const int32_t* n_dev, int accumulate, float* part,
-             void* stream);      /* planes in two parts as in qt_dense2 (Cab == 0: one part) */
+             int planes_sm, void* stream);      /* planes in two parts and planes_sm as in qt_dense2 (Cab == 0: one part) */
 /* qt_wgrad for up to 16 uses of one weight (the rollout steps of a pass) in ONE launch: host arrays of nseg device
  * pointers / capacities, shared (Ka, Ca, Ks, Co).  part: (qt_wgrad_group_blocks(nseg, N), Ka*Ca + Ks, Co), overwritten. */
 int qt_wgrad_group_blocks(int nseg, const int* N);
 int qt_wgrad_group(int nseg, const float* const* a0, const int* lda0, const float* const* a_rest, const float* const* a0b,
                    const int* lda0b, const float* const* a_restb, const float* const* S, const float* const* G, const int* N,
-                   const int32_t* const* n_dev, int Ka, int Ca, int Cab, int Ks, int Co, float* part, void* stream);
+                   const int32_t* const* n_dev, int Ka, int Ca, int Cab, int Ks, int Co, float* part, int planes_sm, void* stream);
 /* qt_wgrad_group for the Gn weights of qt_proj_group at once: use s multiplies [A_g | S]^T (A_g = a0[s] + g gsA, Cin columns, row
  * stride lda0[s]) with the gradient rows G[s] + g gsG (Co columns, row stride ldg; gpl > 0: stored as Co / gpl planes (N[s], gpl),
  * row stride ldg); per_node != 0: gsA / gsG count floats per node of the use (group stride = gs x N[s]: head-major arrays of uses with
@@ -328,7 +332,7 @@ int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, const float* a
                   const float* W, const float* WT /* optional transpose, as in qt_dense2 */, const float* S, int Ks,
                   const float* Ws, int h, int N, const int32_t* n_dev, const float* Cprev, int ld_c,
                   const float* wc, const float* b, const float* ln, float* O, float* Hn, float* Cn,
-                  float* gates, void* stream);
+                  float* gates, int planes_sm /* as in qt_dense2 */, void* stream);
 /* gO, gHn, gCn may each be NULL (that output was not used: zero gradient).  part: (nblk, 11*h) partial sums [g_wc(3h) | g_b(4h) | g_ln(4h)], nblk = qt_lstm_bwd_blocks(N, h) */
 int qt_lstm_bwd_blocks(int N, int h);
 int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,   /* row strides */

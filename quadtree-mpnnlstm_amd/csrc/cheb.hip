@@ -289,6 +289,9 @@ struct PlaneSrc {
     const float* S;
     int Ka, Ca, Cab, Ks, N;
     int lda0, lda0b;        // row strides of plane 0 (column views of wider matrices are passed as they are)
+    int sm;                 // planes 1 .. Ka-1 are stored SLICE-major: (plane, 4-channel slice, N, 4) -- the layout the clip-resident
+                            // recurrence writes (consecutive rows of a slice are contiguous: coalesced stores there, and a quad of a
+                            // row is reached at slice base + row * 4 here)
 };
 
 struct GemmArgs {
@@ -357,11 +360,21 @@ __device__ __forceinline__ void build_quad_table(const PlaneSrc& A, const float*
         if (k < kc) {
             const int pl = k / ct, c = k - pl * ct;
             if (c < A.Ca) {
-                qptr[Q] = (pl == 0 ? A.a0 : A.a_rest + (int64_t)(pl - 1) * A.N * A.Ca) + c;
-                qstr[Q] = pl == 0 ? A.lda0 : A.Ca;
+                if (pl > 0 && A.sm) {
+                    qptr[Q] = A.a_rest + ((int64_t)(pl - 1) * (A.Ca / 4) + c / 4) * A.N * 4;
+                    qstr[Q] = 4;
+                } else {
+                    qptr[Q] = (pl == 0 ? A.a0 : A.a_rest + (int64_t)(pl - 1) * A.N * A.Ca) + c;
+                    qstr[Q] = pl == 0 ? A.lda0 : A.Ca;
+                }
             } else {
-                qptr[Q] = (pl == 0 ? A.a0b : A.a_restb + (int64_t)(pl - 1) * A.N * A.Cab) + (c - A.Ca);
-                qstr[Q] = pl == 0 ? A.lda0b : A.Cab;
+                if (pl > 0 && A.sm) {
+                    qptr[Q] = A.a_restb + ((int64_t)(pl - 1) * (A.Cab / 4) + (c - A.Ca) / 4) * A.N * 4;
+                    qstr[Q] = 4;
+                } else {
+                    qptr[Q] = (pl == 0 ? A.a0b : A.a_restb + (int64_t)(pl - 1) * A.N * A.Cab) + (c - A.Ca);
+                    qstr[Q] = pl == 0 ? A.lda0b : A.Cab;
+                }
             }
         } else {
             qptr[Q] = A.S + (k - kc);
@@ -1214,7 +1227,7 @@ struct WgradGroup {
     const float* G[MAXSEG];
     const int32_t* n_dev[MAXSEG];
     int N[MAXSEG], zend[MAXSEG], lda0[MAXSEG], lda0b[MAXSEG];
-    int nseg, Ka, Ca, Cab, Ks, Co, rows;
+    int nseg, Ka, Ca, Cab, Ks, Co, rows, sm;
     float* part;
     // Gn weights per use (the stacks of one layer, qt_proj_group): grid y = (group, column tile); group g reads plane 0 at
     // a0 + g gsA and the gradient rows at G + g gsG (row stride ldg), and owns slab (z, g) of part
@@ -1228,7 +1241,7 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad_group(WgradGroup w) {
     const int zl = blockIdx.z - (s ? w.zend[s - 1] : 0);
     PlaneSrc A;
     A.a0 = w.a0[s]; A.a_rest = w.a_rest[s]; A.a0b = w.a0b[s]; A.a_restb = w.a_restb[s]; A.S = w.S[s];
-    A.Ka = w.Ka; A.Ca = w.Ca; A.Cab = w.Cab; A.Ks = w.Ks; A.N = w.N[s]; A.lda0 = w.lda0[s]; A.lda0b = w.lda0b[s];
+    A.Ka = w.Ka; A.Ca = w.Ca; A.Cab = w.Cab; A.Ks = w.Ks; A.N = w.N[s]; A.lda0 = w.lda0[s]; A.lda0b = w.lda0b[s]; A.sm = w.sm;
     const int M = w.Ka * (w.Ca + w.Cab) + w.Ks;
     const int64_t rbeg = (int64_t)zl * w.rows;
     const int64_t rend = min((int64_t)qt_rows(w.n_dev[s], w.N[s]), rbeg + w.rows);
@@ -1571,11 +1584,21 @@ __global__ __launch_bounds__(4 * TR, 2) void k_cell_bwd_fused(CellBwdFusedArgs f
         if (k < kc) {
             const int pl = k / ct, c = k - pl * ct;
             if (c < A.Ca) {
-                qptr[Q] = (pl == 0 ? A.a0 : A.a_rest + (int64_t)(pl - 1) * A.N * A.Ca) + c;
-                qstr[Q] = pl == 0 ? A.lda0 : A.Ca;
+                if (pl > 0 && A.sm) {
+                    qptr[Q] = A.a_rest + ((int64_t)(pl - 1) * (A.Ca / 4) + c / 4) * A.N * 4;
+                    qstr[Q] = 4;
+                } else {
+                    qptr[Q] = (pl == 0 ? A.a0 : A.a_rest + (int64_t)(pl - 1) * A.N * A.Ca) + c;
+                    qstr[Q] = pl == 0 ? A.lda0 : A.Ca;
+                }
             } else {
-                qptr[Q] = (pl == 0 ? A.a0b : A.a_restb + (int64_t)(pl - 1) * A.N * A.Cab) + (c - A.Ca);
-                qstr[Q] = pl == 0 ? A.lda0b : A.Cab;
+                if (pl > 0 && A.sm) {
+                    qptr[Q] = A.a_restb + ((int64_t)(pl - 1) * (A.Cab / 4) + (c - A.Ca) / 4) * A.N * 4;
+                    qstr[Q] = 4;
+                } else {
+                    qptr[Q] = (pl == 0 ? A.a0b : A.a_restb + (int64_t)(pl - 1) * A.N * A.Cab) + (c - A.Ca);
+                    qstr[Q] = pl == 0 ? A.lda0b : A.Cab;
+                }
             }
         } else {
             qptr[Q] = A.S + (k - kc);
@@ -1747,7 +1770,7 @@ __global__ __launch_bounds__(4 * TR, 2) void k_cell_bwd_fused(CellBwdFusedArgs f
 
 // shared argument checks / operand setup of the node-feature operand
 static int plane_src(PlaneSrc* A, const char* fn, const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b,
-                     const float* a_restb, int Ka, int Ca, int Cab, const float* S, int Ks, int N) {
+                     const float* a_restb, int Ka, int Ca, int Cab, const float* S, int Ks, int N, int sm = 0) {
     const bool ok = a0 && Ka >= 1 && Ca >= 1 && Cab >= 0 && (Ka == 1 || a_rest) && (Cab == 0 || (a0b && (Ka == 1 || a_restb))) &&
                     (Ks == 0 || S) && Ca % 4 == 0 && Cab % 4 == 0 && Ks % 4 == 0 && lda0 % 4 == 0 && lda0b % 4 == 0 && (Ka * (Ca + Cab) + Ks) / 4 <= MAXQ &&
                     (((uintptr_t)a0 | (uintptr_t)a_rest | (uintptr_t)a0b | (uintptr_t)a_restb | (uintptr_t)S) & 15) == 0;
@@ -1759,6 +1782,7 @@ static int plane_src(PlaneSrc* A, const char* fn, const float* a0, int lda0, con
     A->a0 = a0; A->a_rest = a_rest; A->a0b = Cab ? a0b : nullptr; A->a_restb = Cab ? a_restb : nullptr; A->S = S;
     A->Ka = Ka; A->Ca = Ca; A->Cab = Cab; A->Ks = Ks; A->N = N;
     A->lda0 = lda0 > 0 ? lda0 : Ca; A->lda0b = lda0b > 0 ? lda0b : Cab;
+    A->sm = sm != 0;
     return QT_OK;
 }
 
@@ -1873,7 +1897,7 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
                          int Ca, int Cab,
                          const float* W, const float* WT, const float* S, int Ks, const float* Ws, int Kb, int Cb, int Cbb, int N,
                          const int32_t* n_dev, int act, const float* res, int res_stride, const float* drop, float* out,
-                         float* outb, void* stream) {
+                         float* outb, int planes_sm, void* stream) {
     QT_ARG((W || WT) && out && Kb >= 1 && Cb >= 1 && Cbb >= 0 && (Cbb == 0 || outb), "bad arguments");
     QT_ARG((Ks == 0) || Ws || WT, "Ws missing");
     QT_ARG(Ks == 0 || WT || Ws == W + (int64_t)Ka * (Ca + Cab) * Kb * (Cb + Cbb), "Ws must follow W contiguously ([W ; Ws] is one matrix)");
@@ -1882,7 +1906,7 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
     QT_ARG((((uintptr_t)W | (uintptr_t)WT) & 15) == 0, "W / WT must be 16-byte aligned");
     QT_ARG(act != QT_ACT_TANH_RES || res, "QT_ACT_TANH_RES needs res");
     GemmArgs g = {};
-    if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N)) return rc;
+    if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N, planes_sm)) return rc;
     if (N <= 0) return QT_OK;
     g.B = W; g.BT = WT; g.M = N; g.K = Ka * (Ca + Cab) + Ks; g.NB = Kb * (Cb + Cbb);
     g.outb = outb; g.Cbb = Cbb;
@@ -1963,7 +1987,7 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
                         const float* Ws, int Kb, int Cb, int N, const int32_t* n_dev, int act, const float* res,
                         int res_stride, const float* drop, float* out, void* stream) {
     return qt_dense2(a0, 0, a_rest, nullptr, 0, nullptr, Ka, Ca, 0, W, nullptr, S, Ks, Ws, Kb, Cb, 0, N, n_dev, act, res, res_stride, drop, out,
-                     nullptr, stream);
+                     nullptr, 0, stream);
 }
 
 extern "C" int qt_lstm_dgrad_blocks(int N) { return N <= 0 ? 0 : qt_cdiv(N, BM); }
@@ -2070,14 +2094,14 @@ extern "C" int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, con
                              int Ka, int Ca, int Cab, const float* W, const float* WT, const float* S, int Ks,
                              const float* Ws, int h, int N, const int32_t* n_dev, const float* Cprev, int ld_c,
                              const float* wc, const float* b, const float* ln, float* O, float* Hn, float* Cn,
-                             float* gates, void* stream) {
+                             float* gates, int planes_sm, void* stream) {
     QT_ARG((W || WT) && wc && b && Hn && Cn && gates, "bad arguments");
     QT_ARG(h == 8 || h == 16 || h == 32, "the fused gate GEMM + cell covers hidden sizes 8, 16 and 32 (qt_dense + qt_lstm_fwd otherwise)");
     QT_ARG((Ks == 0) || Ws || WT, "Ws missing");
     QT_ARG(Ks == 0 || WT || Ws == W + (int64_t)Ka * (Ca + Cab) * 4 * h, "Ws must follow W contiguously ([W ; Ws] is one matrix)");
     QT_ARG((((uintptr_t)W | (uintptr_t)WT | (uintptr_t)Cprev) & 15) == 0 && ld_c % 4 == 0, "operands must be 16-byte aligned");
     GemmArgs g = {};
-    if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N)) return rc;
+    if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N, planes_sm)) return rc;
     if (N <= 0) return QT_OK;
     g.B = W; g.BT = WT; g.M = N; g.K = Ka * (Ca + Cab) + Ks; g.NB = 4 * h;
     g.Kb = 1; g.Cb = 4 * h; g.act = QT_ACT_NONE; g.res = nullptr; g.res_stride = 0; g.drop = nullptr; g.out = nullptr;
@@ -2123,10 +2147,10 @@ extern "C" int qt_wgrad_blocks(int N) { return N > 0 ? qt_cdiv(N, WGRAD_ROWS) : 
 extern "C" int qt_wgrad(const float* a0, int lda0, const float* a_rest, const float* a0b, int lda0b, const float* a_restb, int Ka,
                         int Ca, int Cab,
                         const float* S, int Ks, const float* G, int Co, int N, const int32_t* n_dev, int accumulate,
-                        float* part, void* stream) {
+                        float* part, int planes_sm, void* stream) {
     QT_ARG(G && part && Co >= 1 && Co % 4 == 0 && ((uintptr_t)G & 15) == 0, "bad arguments");
     GemmArgs g = {};
-    if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N)) return rc;
+    if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N, planes_sm)) return rc;
     if (N <= 0) return QT_OK;
     g.B = G; g.M = Ka * (Ca + Cab) + Ks; g.K = N; g.NB = Co;
     g.Kb = 1; g.Cb = Co; g.act = QT_ACT_NONE; g.res = nullptr; g.res_stride = 0; g.drop = nullptr; g.out = part;
@@ -2148,8 +2172,9 @@ extern "C" int qt_wgrad_group_blocks(int nseg, const int* N) {
 static int wgrad_group_launch(const char* fn, int nseg, const float* const* a0, const int* lda0, const float* const* a_rest,
                               const float* const* a0b, const int* lda0b, const float* const* a_restb, const float* const* S,
                               const float* const* G, const int* N, const int32_t* const* n_dev, int Ka, int Ca, int Cab, int Ks,
-                              int Co, int ldg, int gpl, int Gn, int64_t gsA, int64_t gsG, int per_node, float* part, void* stream) {
+                              int Co, int ldg, int gpl, int Gn, int64_t gsA, int64_t gsG, int per_node, float* part, void* stream, int sm = 0) {
     WgradGroup w;
+    w.sm = sm != 0;
     int z = 0, k = 0;
     for (int i = 0; i < nseg; ++i) {
         if (N[i] <= 0) continue;
@@ -2185,13 +2210,14 @@ static int wgrad_group_launch(const char* fn, int nseg, const float* const* a0, 
 
 extern "C" int qt_wgrad_group(int nseg, const float* const* a0, const int* lda0, const float* const* a_rest,
                               const float* const* a0b, const int* lda0b, const float* const* a_restb, const float* const* S, const float* const* G, const int* N,
-                              const int32_t* const* n_dev, int Ka, int Ca, int Cab, int Ks, int Co, float* part, void* stream) {
+                              const int32_t* const* n_dev, int Ka, int Ca, int Cab, int Ks, int Co, float* part, int planes_sm,
+                              void* stream) {
     QT_ARG(nseg >= 1 && nseg <= MAXSEG && a0 && G && N && n_dev && part, "1..16 uses per launch");
     QT_ARG(Ka >= 1 && Ca >= 1 && Cab >= 0 && Co >= 1 && (Ka == 1 || a_rest) && (Ks == 0 || S) && (Cab == 0 || (a0b && (Ka == 1 || a_restb))),
            "bad arguments");
     QT_ARG(Co % 4 == 0, "Co must be a multiple of 4 (float4 operands)");
     return wgrad_group_launch(__func__, nseg, a0, lda0, a_rest, a0b, lda0b, a_restb, S, G, N, n_dev, Ka, Ca, Cab, Ks, Co, Co, 0, 1, 0, 0, 0,
-                              part, stream);
+                              part, stream, planes_sm);
 }
 
 // qt_wgrad_group for the Gn weights of qt_proj_group at once: use s multiplies [A_g | S]^T (A_g = a0[s] + g gsA, Cin columns,

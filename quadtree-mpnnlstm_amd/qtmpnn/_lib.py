@@ -38,22 +38,22 @@ _SIGNATURES = {
     'qt_sse': [_P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
     'qt_spmm': [_P, _P, _P, _I, _P, _I, _P, _F, _P, _F, _P, _F, _P, _P],
     'qt_spmm1': [_P, _P, _P, _P, _I, _P, _P, _I, _F, _P, _I, _F, _P, _I, _F, _P, _I, _I, _I, _P, _I, _P, _P],
-    'qt_dense2': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P],
+    'qt_dense2': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P],
     'qt_spmm2': [_P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _F, _F, _F, _P, _P],
     'qt_cheb_clip_rows': [],
     'qt_cheb_clip_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P],
     'qt_cheb_clip_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P],
     'qt_dense': [_P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P],
     'qt_wgrad_blocks': [_I],
-    'qt_wgrad': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P],
+    'qt_wgrad': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P],
     'qt_colsum': [_P, _I, _L, _P, _P],
     'qt_lstm_fwd': [_P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P],
     'qt_lstm_bwd_blocks': [_I, _I],
     'qt_lstm_bwd': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P],
     'qt_sse_bwd': [_P, _I, _P, _P, _P, _I, _P, _I, _P, _P],
     'qt_wgrad_group_blocks': [_I, _P],
-    'qt_wgrad_group': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
-    'qt_dense_lstm': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    'qt_wgrad_group': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
+    'qt_dense_lstm': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'qt_decoder_input': [_P, _I, _P, _I, _P, _P, _P],
     'qt_concat': [_P, _P, _P, _I, _I, _P, _P, _P],
     'qt_act_bwd': [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P],

@@ -277,7 +277,8 @@ def _clip_resident(mesh, widths, K):
 
 
 def clip_planes(mesh, Zs, TZs, K):
-    """TZs[i] (K - 1, N, C_i) <- T_1 .. T_{K-1} of the recurrence on the parts Zs, all hops in ONE launch (qt_cheb_clip_fwd)."""
+    """TZs[i] <- T_1 .. T_{K-1} of the recurrence on the parts Zs, all hops in ONE launch (qt_cheb_clip_fwd).  The planes are
+    written SLICE-major: TZs[i] (allocated (K - 1, N, C_i)) then holds (K - 1, C_i / 4, N, 4)."""
     two = len(Zs) > 1
     _lib.call('qt_cheb_clip_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off),
               ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_info), mesh.B, Zs[0].shape[0], K, Zs[0].shape[1], ptr(Zs[0]), _ld(Zs[0]), ptr(TZs[0]),
@@ -296,15 +297,23 @@ def _cheb_planes(Zs, mesh, K):
     N = Zs[0].shape[0]
     TZs = [Z.new_empty(max(K - 1, 1), N, Z.shape[1]) for Z in Zs]
     if _clip_resident(mesh, [Z.shape[1] for Z in Zs], K):
-        clip_planes(mesh, Zs, TZs, K)
-        return TZs
+        clip_planes(mesh, Zs, TZs, K)          # (these planes are stored slice-major: see planes_rowmajor)
+        return TZs, 1
     for k in range(1, K):
         if k == 1:
             spmm2(mesh, Zs, 1.0, None, 0.0, None, 0.0, [T[0] for T in TZs])
         else:
             spmm2(mesh, [T[k - 2] for T in TZs], 2.0, Zs if k == 2 else [T[k - 3] for T in TZs], -1.0, None, 0.0,
                   [T[k - 1] for T in TZs])
-    return TZs
+    return TZs, 0
+
+
+def planes_rowmajor(T, sm):
+    """(K - 1, N, C) row-major view / copy of a plane tensor of _cheb_planes (sm: stored as (K - 1, C / 4, N, 4))."""
+    if not sm:
+        return T
+    Km, N, C = T.shape
+    return T.view(Km, C // 4, N, 4).permute(0, 2, 1, 3).reshape(Km, N, C)
 
 
 def _w_t(W, acc):
@@ -345,7 +354,7 @@ def _dgrad_weight(W, K, Cs, live, acc):
     return Wb, skinny
 
 
-def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, gTs_pre=None, w_fused=False):
+def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, gTs_pre=None, w_fused=False, sm=0):
     """(gZ parts, gW) of Y = [T_0 .. T_{K-1} | S] W from G = dL/dY (N, Co).  w_fused: this use's weight-gradient partials are
     already in acc.wslab (qt_lstm_bwd_fused; G is then None)."""
     N = Zs[0].shape[0]
@@ -375,7 +384,7 @@ def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, g
                 _lib.call('qt_dense2', ptr(G), 0, None, None, 0, None, 1, Co, 0, ptr(Wb) if skinny else None,
                           None if skinny else ptr(Wb), None, 0, None, K, Cl[0],
                           Cl[1] if len(Cl) > 1 else 0, N, ptr(mesh.n_dev), ACT_NONE, None, 0, None, ptr(gTs[0]),
-                          ptr(gTs[1]) if len(Cl) > 1 else None)
+                          ptr(gTs[1]) if len(Cl) > 1 else None, 0)
         # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
         if _clip_resident(mesh, Cl, K):         # all hops in one launch; only plane 0 (= gZ) is rewritten
             clip_clenshaw(mesh, gTs, K)
@@ -403,13 +412,13 @@ def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, g
                 nblk = _lib.value('qt_wgrad_blocks', N)
                 part = Zs[0].new_empty(nblk, W.shape[0], Co)
                 _lib.call('qt_wgrad', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(S), ksp, ptr(G), Co, N,
-                          ptr(mesh.n_dev), 0, ptr(part))
+                          ptr(mesh.n_dev), 0, ptr(part), sm)
                 _lib.call('qt_colsum', ptr(part), nblk, W.numel(), ptr(gW))
         else:
             # deferred: the weight gradient is off the critical path, so all uses of this pass (<= 16 per launch) are
             # reduced together by the last backward -- one long launch instead of one short one per rollout step
             if not w_fused:
-                acc.pending.append((Zs, TZs, S, G, N, mesh.n_dev))
+                acc.pending.append((Zs, TZs, S, G, N, mesh.n_dev, sm))
             if acc.leave(use_idx):
                 gW = _wgrad_group(acc.pending, W, K, Cs, ksp, Co) if acc.pending else None
                 acc.pending = []
@@ -439,14 +448,14 @@ class _ChebPoly(Function):
         Co = W.shape[1]
         ksp = (Ks + 3) // 4 * 4
         assert W.shape[0] == K * sum(Cs) + ksp, f'weight rows {W.shape[0]} != {K}*{sum(Cs)}+{ksp}'
-        TZs = _cheb_planes(Zs, mesh, K)
+        TZs, sm = _cheb_planes(Zs, mesh, K)
         S = mesh.cheb_ones(Ks) if Ks else None
         Y = Zs[0].new_empty(N, Co)
         drop = _c(drop)
         _lib.call('qt_dense2', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(W), ptr(_w_t(W, acc)), ptr(S), ksp,
                   ptr(W[K * sum(Cs):]) if Ks else None, 1, Co, 0, N, ptr(mesh.n_dev), act, ptr(res), _row_stride(res), ptr(drop),
-                  ptr(Y), None)
-        ctx.mesh, ctx.K, ctx.Ks, ctx.act, ctx.acc, ctx.nz = mesh, K, Ks, act, acc, len(Zs)
+                  ptr(Y), None, sm)
+        ctx.mesh, ctx.K, ctx.Ks, ctx.act, ctx.acc, ctx.nz, ctx.sm = mesh, K, Ks, act, acc, len(Zs), sm
         ctx.use_idx = acc.enter() if acc is not None else 0
         ctx.save_for_backward(*Zs, *TZs, W, Y if act != ACT_NONE else None, res, drop)
         return Y
@@ -472,7 +481,7 @@ class _ChebPoly(Function):
                 _lib.call('qt_act_bwd', ptr(gin), ptr(Y), ptr(res), _row_stride(res), ptr(drop), act, N,
                           ptr(mesh.n_dev), Co, ptr(G), ptr(gres))
         gZs, gW = _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, ctx.acc, ctx.use_idx,
-                                 list(ctx.needs_input_grad[:nz]), ctx.needs_input_grad[2])
+                                 list(ctx.needs_input_grad[:nz]), ctx.needs_input_grad[2], sm=ctx.sm)
         gZa = gZs[0] if gZs is not None else None
         gZb = gZs[1] if gZs is not None and nz > 1 else None
         return gZa, gZb, gW, gres, None, None, None, None, None, None
@@ -483,6 +492,8 @@ def _wgrad_group(uses, W, K, Cs, ksp, Co):
     uses = [u for u in uses if u[4] > 0]
     if not uses:
         return torch.zeros_like(W)
+    sm = uses[0][6]
+    assert all(u[6] == sm for u in uses), 'the uses of one weight must share the layout of their planes'
     two = len(Cs) > 1
     chunks = [uses[i:i + 16] for i in range(0, len(uses), 16)]
     counts = []
@@ -499,7 +510,7 @@ def _wgrad_group(uses, W, K, Cs, ksp, Co):
                   pa(lambda u: u[0][1]) if two else None, ip(*[_ld(u[0][1]) for u in ch]) if two else None,
                   pa(lambda u: u[1][1]) if two else None,
                   pa(lambda u: u[2]), pa(lambda u: u[3]), Ns, pa(lambda u: u[5]), K, Cs[0], Cs[1] if two else 0, ksp, Co,
-                  ptr(part[off:]))
+                  ptr(part[off:]), sm)
         off += nb
     gW = torch.empty_like(W)
     _lib.call('qt_colsum', ptr(part), part.shape[0], W.numel(), ptr(gW))
@@ -1058,16 +1069,16 @@ class _GateCell(Function):
         h = W.shape[1] // 4
         ksp = (Ks + 3) // 4 * 4
         assert W.shape[0] == K * sum(Cs) + ksp, f'weight rows {W.shape[0]} != {K}*{sum(Cs)}+{ksp}'
-        TZs = _cheb_planes(Zs, mesh, K)
+        TZs, sm = _cheb_planes(Zs, mesh, K)
         S = mesh.cheb_ones(Ks) if Ks else None
         Cprev, ld_c = _rows(Cprev)
         Hn, Cn = (Zs[0].new_empty(N, h) for _ in range(2))
         gates = Zs[0].new_empty(N, 4 * h)
         _lib.call('qt_dense_lstm', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(W), ptr(_w_t(W, acc_w)), ptr(S), ksp,
                   ptr(W[K * sum(Cs):]) if Ks else None, h, N, ptr(mesh.n_dev), ptr(Cprev), ld_c, ptr(wc), ptr(b), ptr(ln),
-                  None, ptr(Hn), ptr(Cn), ptr(gates))
+                  None, ptr(Hn), ptr(Cn), ptr(gates), sm)
         ctx.save_for_backward(*Zs, *TZs, W, gates, Cprev, wc, ln)
-        ctx.mesh, ctx.K, ctx.Ks, ctx.acc_w, ctx.acc_p, ctx.nz = mesh, K, Ks, acc_w, acc_p, len(Zs)
+        ctx.mesh, ctx.K, ctx.Ks, ctx.acc_w, ctx.acc_p, ctx.nz, ctx.sm = mesh, K, Ks, acc_w, acc_p, len(Zs), sm
         ctx.use_w = acc_w.enter() if acc_w is not None else 0
         ctx.use_p = acc_p.enter() if acc_p is not None else 0
         ctx.set_materialize_grads(False)
@@ -1095,7 +1106,7 @@ class _GateCell(Function):
             # the bench shape the persistent launch takes 71 us against 47 + 21 us for this launch plus its share of the
             # deferred weight gradient -- fp32 MFMA issues on the vector pipe, so its 18 us of MFMA time, the cell arithmetic
             # and the memory phases add up instead of overlapping; 9.17 vs 8.98 ms per step.
-            if (os.environ.get('QT_WGRAD_FUSION') == '1' and ctx.needs_input_grad[2] and ctx.acc_w is not None
+            if (os.environ.get('QT_WGRAD_FUSION') == '1' and not ctx.sm and ctx.needs_input_grad[2] and ctx.acc_w is not None
                     and W.shape[0] <= 128 and NB <= (128 if h == 16 else 64)):
                 ksp = (ctx.Ks + 3) // 4 * 4
                 S = ctx.mesh.cheb_ones(ctx.Ks) if ctx.Ks else None
@@ -1104,7 +1115,7 @@ class _GateCell(Function):
                 w_fused = True
         gG, gCp, gwc, gb, gln = _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, ctx.mesh, ctx.acc_p, ctx.use_p, dgrad)
         gZs, gW = _cheb_backward(Zs, TZs, W, gG, ctx.mesh, K, ctx.Ks, ctx.acc_w, ctx.use_w, need, ctx.needs_input_grad[2],
-                                 gTs_pre=planes, w_fused=w_fused)
+                                 gTs_pre=planes, w_fused=w_fused, sm=ctx.sm)
         gZa = gZs[0] if gZs is not None else None
         gZb = gZs[1] if gZs is not None and nz > 1 else None
         return gZa, gZb, gW, gCp, gwc, gb, gln, None, None, None, None, None

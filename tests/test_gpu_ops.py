@@ -583,7 +583,7 @@ def test_proj_group_and_grouped_weight_gradient_equal_dense_calls():
     for h in range(G):
         Y = torch.empty(N, co, device=dev())
         _lib.call('qt_dense2', ptr(A[h]), 0, None, None, 0, None, 1, cin, 0, ptr(W[h]), None, ptr(ones), 4, ptr(W[h][cin:]), 1, co, 0, N, None,
-                  0, None, 0, None, ptr(Y), None)
+                  0, None, 0, None, ptr(Y), None, 0)
         assert torch.equal(P[h].permute(1, 0, 2).reshape(N, co), Y), h
     # data gradient: gA_g = gP_g W_g[:cin]^T from the planes of gP (the forward weight's rows are the transposed operand)
     gP = torch.randn_like(P)
@@ -751,11 +751,12 @@ def test_clip_resident_recurrence_equals_per_hop_launches(K, widths, B):
     ops.clip_planes(mesh, Zs, fused, K)
     prev, ops._CLIP_CHEB = ops._CLIP_CHEB, False          # one qt_spmm2 launch per hop
     try:
-        ref = ops._cheb_planes(Zs, mesh, K)
+        ref, sm = ops._cheb_planes(Zs, mesh, K)
+        assert sm == 0
     finally:
         ops._CLIP_CHEB = prev
-    for a, r in zip(fused, ref):
-        assert torch.equal(a, r)
+    for a, r in zip(fused, ref):            # (the fused launch stores its planes slice-major)
+        assert torch.equal(ops.planes_rowmajor(a, 1), r)
     # backward: Clenshaw on random gradient planes
     G = [torch.randn(K, N, w, device=dev()) for w in widths]
     Gf = [g.clone() for g in G]
@@ -783,12 +784,14 @@ def test_clip_resident_recurrence_static_capacities():
     Z = torch.randn(mesh.N, 16, device=dev())
     Zs = torch.full((sm.N, 16), float('nan'), device=dev())
     Zs[:nv] = Z
-    ref = ops._cheb_planes([Z], mesh, 4)[0]
+    planes, layout = ops._cheb_planes([Z], mesh, 4)
+    ref = ops.planes_rowmajor(planes[0], layout)
     got = torch.full((3, sm.N, 16), 7.0, device=dev())
     from qtmpnn import _lib
     from qtmpnn._lib import ptr
     _lib.call('qt_cheb_clip_fwd', ptr(sm.rowptr), ptr(sm.col), ptr(sm.nrm), ptr(sm.ell), ptr(sm.node_off), ptr(sm.tail_cnt),
               ptr(sm.tail_pool), ptr(sm.tail_info), sm.B, sm.N, 4, 16, ptr(Zs), 16, ptr(got), 0, None, 0, None)
+    got = ops.planes_rowmajor(got, 1)
     assert torch.equal(got[:, :nv], ref)
     assert bool((got[:, nv:] == 7.0).all())
 

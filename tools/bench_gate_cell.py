@@ -46,7 +46,8 @@ def shape(name, K, Ca, Cab):
     wc, b, ln = 0.1 * torch.randn(3, h, device=dev), 0.1 * torch.randn(4, h, device=dev), torch.randn(4, h, device=dev)
     Hn, Cn, gates = (torch.zeros(CAP, w, device=dev) for w in (h, h, 4 * h))
     fwd = lambda: _lib.call('qt_dense_lstm', ptr(X), Ca, ptr(TX), ptr(Hh), Cab, ptr(TH), K, Ca, Cab, ptr(W), ptr(WT), ptr(S), 4,
-                            ptr(W[K * (Ca + Cab):]), h, CAP, ptr(nvalid), ptr(Cp), h, ptr(wc), ptr(b), ptr(ln), None, ptr(Hn), ptr(Cn), ptr(gates))
+                            ptr(W[K * (Ca + Cab):]), h, CAP, ptr(nvalid), ptr(Cp), h, ptr(wc), ptr(b), ptr(ln), None, ptr(Hn), ptr(Cn), ptr(gates),
+                            int(os.environ.get('QT_PLANES_SM', '0')))
     us = graph_time(fwd)
     flops = 2.0 * N * Kt * 4 * h
     byts = 4.0 * N * (Kt + h + 6 * h)

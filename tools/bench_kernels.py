@@ -27,7 +27,7 @@ G = torch.randn(N, Co, device=dev); Wt = torch.randn(Co, K * C, device=dev); gT 
 bwd = lambda: _lib.call('qt_dense', ptr(G), None, 1, Co, ptr(Wt), None, 0, None, K, C, N, None, 0, None, 0, None, ptr(gT))
 print('gemm bwd-data (N x 64)(64 x 100) us', round(timeit(bwd), 2))
 nblk = _lib.value('qt_wgrad_blocks', N); part = torch.zeros(nblk, K * C + 4, Co, device=dev)
-wg = lambda: _lib.call('qt_wgrad', ptr(Z), 0, ptr(TZ), None, 0, None, K, C, 0, ptr(S), 4, ptr(G), Co, N, None, 1, ptr(part))
+wg = lambda: _lib.call('qt_wgrad', ptr(Z), 0, ptr(TZ), None, 0, None, K, C, 0, ptr(S), 4, ptr(G), Co, N, None, 1, ptr(part), 0)
 print('wgrad us', round(timeit(wg), 2))
 out = torch.empty(N, C, device=dev); p_ = torch.randn(N, C, device=dev)
 print('spmm C=20 us', round(timeit(lambda: spmm(mesh, Z, 2.0, p_, -1.0, None, 0.0, out, C)), 2))
@@ -41,5 +41,5 @@ print('gemm fwd interleaved A (N x 100 rows contiguous) us', round(timeit(densei
 gTi = torch.empty(N, K * C, device=dev)
 bwdi = lambda: _lib.call('qt_dense', ptr(G), None, 1, Co, ptr(Wt), None, 0, None, 1, K * C, N, None, 0, None, 0, None, ptr(gTi))
 print('gemm bwd-data interleaved out us', round(timeit(bwdi), 2))
-wgi = lambda: _lib.call('qt_wgrad', ptr(Zi), 0, None, None, 0, None, 1, K * C, 0, ptr(S), 4, ptr(G), Co, N, None, 1, ptr(part))
+wgi = lambda: _lib.call('qt_wgrad', ptr(Zi), 0, None, None, 0, None, 1, K * C, 0, ptr(S), 4, ptr(G), Co, N, None, 1, ptr(part), 0)
 print('wgrad interleaved A us', round(timeit(wgi), 2))
