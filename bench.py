@@ -96,9 +96,9 @@ def spmm_roofline(nfp, batch, mask, reps=10):
         records.append(('fwd', ms, tuple(z.shape[1] for z in Zs), False, False, K))
         orig_fwd(ms, Zs, TZs, K)
 
-    def spy_bwd(ms, Gs, K):
-        records.append(('bwd', ms, tuple(g.shape[2] for g in Gs), False, False, K))
-        orig_bwd(ms, Gs, K)
+    def spy_bwd(ms, Gs, K, sm=0):
+        records.append(('bwd', ms, tuple(g.shape[2] for g in Gs), bool(sm), False, K))      # (has_p slot: the planes' layout)
+        orig_bwd(ms, Gs, K, sm)
     qmesh.spmm2 = ops.spmm2 = spy_spmm
     ops.clip_planes, ops.clip_clenshaw = spy_fwd, spy_bwd
     try:
@@ -130,7 +130,7 @@ def spmm_roofline(nfp, batch, mask, reps=10):
                 fn = lambda: orig_fwd(ms, Zs, TZs, K)
             else:
                 Gs = [torch.randn(K, ms.N, c, device=dev) for c in Cs]
-                fn = lambda: orig_bwd(ms, Gs, K)
+                fn = lambda: orig_bwd(ms, Gs, K, int(has_p))
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 fn()

@@ -244,7 +244,9 @@ int qt_cheb_clip_fwd(const int32_t* rowptr, const int32_t* col, const float* nrm
                      int Cb, const float* zb, int ldb, float* Tb, void* stream);
 int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* node_off,
                      const int32_t* tail_cnt, const int32_t* tail_pool, const int32_t* tail_info,
-                     int B, int N, int K, int Ca, float* Ga, int Cb, float* Gb, void* stream);
+                     int B, int N, int K, int Ca, float* Ga, int Cb, float* Gb,
+                     int planes_sm /* != 0: planes 1 .. K-1 of Ga / Gb are slice-major (written so by qt_lstm_bwd_dgrad / qt_dense2) */,
+                     void* stream);
 
 /* qt_dense: out planes = act( [A planes | S] @ [W ; Ws] ), the gate GEMM.
  *   A: Ka planes, plane k at a0 (k == 0) or a_rest + (k-1)*N*Ca, each (N, Ca)   (T_0 = Z stays in the caller's tensor)
@@ -266,8 +268,9 @@ int qt_dense2(const float* a0, int lda0, const float* a_rest, const float* a0b, 
               const float* W, const float* WT /* optional: [W ; Ws]^T, (Kb*(Cb+Cbb), K) row-major; W may then be NULL */,
               const float* S, int Ks, const float* Ws, int Kb, int Cb, int Cbb, int N,
               const int32_t* n_dev, int act, const float* res, int res_stride, const float* drop, float* out, float* outb,
-              int planes_sm /* != 0: the INPUT planes 1 .. Ka-1 (a_rest / a_restb) are stored slice-major, (plane, 4-channel
-              slice, N, 4), as qt_cheb_clip_fwd writes them; plane 0 stays row-major */, void* stream);
+              int planes_sm /* bit 0: the INPUT planes 1 .. Ka-1 (a_rest / a_restb) are stored slice-major, (plane, 4-channel
+              slice, N, 4), as qt_cheb_clip_fwd writes them; bit 1: the OUTPUT planes 1 .. Kb-1 are written slice-major, as
+              qt_cheb_clip_bwd reads them; plane 0 is row-major either way */, void* stream);
 
 /* Data-gradient product as a split-bf16 GEMM (gradients only): out planes (Kb, N, Cb) [| outb (Kb, N, Cbb)] = A (N rows of K floats,
  * row stride lda) @ B, B^T given as the two bf16 terms Whi + Wlo (Kb (Cb + Cbb), K) of qt_split_bf16 -- for the data gradient of
@@ -353,6 +356,7 @@ int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, int ld_gh, c
                       const float* gates, const float* Cprev, int ld_c, const float* wc, const float* ln,
                       int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
                       const float* Wrows, const void* Whi, const void* Wlo, int Kb, int Cb, int Cbb, float* out, float* outb,
+                      int out_sm /* != 0: the data-gradient planes 1 .. Kb-1 leave slice-major (as qt_cheb_clip_bwd reads them) */,
                       void* stream);
 /* x (n fp32) -> hi, lo (n bf16 each) with x ~ hi + lo (hi = round(x), lo = round(x - hi)) */
 int qt_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream);

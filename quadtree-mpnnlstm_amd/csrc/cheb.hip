@@ -307,6 +307,7 @@ struct GemmArgs {
     float* out;
     float* outb;        // forward: second column part of every output plane, (Kb, M, Cbb); Cbb == 0: none
     int Cbb;
+    int out_sm;         // output planes 1 .. Kb-1 slice-major (plane_piece)
     int64_t row0_step;  // wgrad: rows per block
     const int32_t* n_dev;  // valid node rows on the device (NULL: A.N)
     int accumulate;        // wgrad: add into part instead of overwriting (sums several uses of one weight)
@@ -350,6 +351,14 @@ typedef float qt_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 gload4(const float* p) {
     const qt_v4f v = *(const __attribute__((address_space(1))) qt_v4f*)p;
     return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// float4 piece (plane pl, row i, channel ch) of an OUTPUT plane set of width C: row-major (planes, M, C) -- or, with sm, planes
+// 1.. slice-major (C / 4, M, 4), the layout the clip-resident Clenshaw launch reads with coalesced loads (plane 0 stays row-major:
+// it becomes the gradient matrix of the layer's input)
+__device__ __forceinline__ float* plane_piece(float* base, int pl, int64_t i, int ch, int C, int64_t M, int sm, int ld) {
+    if (sm && pl > 0) return base + (((int64_t)pl * (C >> 2) + (ch >> 2)) * M + i) * 4;
+    return base + (int64_t)pl * M * C + i * ld + ch;
 }
 
 // Quad table: quad Q of a node row lives at qptr[Q] + row * qstr[Q] (plane Q*4/Ca of the operand, or S).
@@ -575,9 +584,9 @@ __global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : (NT == 3 ? 3 : QT
             const int ct = g.Cb + g.Cbb;
             const int pl = j / ct, ch = j - pl * ct;              // Cb, Cbb % 4 == 0: a float4 never straddles two parts
             if (ch < g.Cb)
-                *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * (g.ldo ? g.ldo : g.Cb) + ch) = v;
+                *reinterpret_cast<float4*>(plane_piece(g.out, pl, i, ch, g.Cb, g.M, g.out_sm, g.ldo ? g.ldo : g.Cb)) = v;
             else
-                *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + i * g.Cbb + (ch - g.Cb)) = v;
+                *reinterpret_cast<float4*>(plane_piece(g.outb, pl, i, ch - g.Cb, g.Cbb, g.M, g.out_sm, g.Cbb)) = v;
         }
     }
     QT_STAMP(5);
@@ -825,9 +834,9 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g) {
     const int ct = g.Cb + g.Cbb;
     const int pl = j / ct, ch = j - pl * ct;
     if (ch < g.Cb)
-        *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + row * g.Cb + ch) = v;
+        *reinterpret_cast<float4*>(plane_piece(g.out, pl, row, ch, g.Cb, g.M, g.out_sm, g.Cb)) = v;
     else
-        *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + row * g.Cbb + (ch - g.Cb)) = v;
+        *reinterpret_cast<float4*>(plane_piece(g.outb, pl, row, ch - g.Cb, g.Cbb, g.M, g.out_sm, g.Cbb)) = v;
 }
 
 // ---- bf16x3 variant of the forward / data-gradient GEMM -------------------------------------------------------------
@@ -963,9 +972,9 @@ __global__ __launch_bounds__(256) void k_gemm_fwd3(GemmArgs g) {
             const int ct = g.Cb + g.Cbb;
             const int pl = j / ct, ch = j - pl * ct;
             if (ch < g.Cb)
-                *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+                *reinterpret_cast<float4*>(plane_piece(g.out, pl, i, ch, g.Cb, g.M, g.out_sm, g.Cb)) = v;
             else
-                *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + i * g.Cbb + (ch - g.Cb)) = v;
+                *reinterpret_cast<float4*>(plane_piece(g.outb, pl, i, ch - g.Cb, g.Cbb, g.M, g.out_sm, g.Cbb)) = v;
         }
     }
 }
@@ -1066,9 +1075,9 @@ __global__ __launch_bounds__(256, 4) void k_gemm_sb(GemmArgs g, const __bf16* __
             const int ct = g.Cb + g.Cbb;
             const int pl = j / ct, ch = j - pl * ct;
             if (ch < g.Cb)
-                *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+                *reinterpret_cast<float4*>(plane_piece(g.out, pl, i, ch, g.Cb, g.M, g.out_sm, g.Cb)) = v;
             else
-                *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + i * g.Cbb + (ch - g.Cb)) = v;
+                *reinterpret_cast<float4*>(plane_piece(g.outb, pl, i, ch - g.Cb, g.Cbb, g.M, g.out_sm, g.Cbb)) = v;
         }
     }
 }
@@ -1315,6 +1324,7 @@ struct DgradCellArgs {
     int M, NB, Kb, Cb, Cbb;
     float *out, *outb;
     const int32_t* n_dev;
+    int out_sm;             // output planes 1 .. Kb-1 slice-major (plane_piece)
 };
 
 // BG: the right operand (the weight rows, <= 32 KB, L1 / L2 resident) is read straight from global memory by the lanes that
@@ -1331,7 +1341,7 @@ __global__ __launch_bounds__(256, BG ? QT_DGRAD_OCC : 2) void k_dgrad_cell(Dgrad
     using namespace qtcell;
     constexpr int BNT = 32 * NT, K = 16 * LPN, PITCH = K + 4, RP = 256 / LPN;
     __shared__ __attribute__((aligned(16))) float Bt[BG ? 4 : BNT * PITCH];
-    __shared__ __attribute__((aligned(16))) float As[128 * (PITCH > 64 ? PITCH : 64)];
+    __shared__ __attribute__((aligned(16))) float As[128 * (PITCH > 68 ? PITCH : 68)];       // (>= 128 x 68: the epilogue's staging tile)
     __shared__ float sm[4 * LPN * 11 * 4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l32 = lane & 31, half = lane >> 5;
@@ -1464,8 +1474,12 @@ __global__ __launch_bounds__(256, BG ? QT_DGRAD_OCC : 2) void k_dgrad_cell(Dgrad
         }
     }
     }
-    // epilogue as in k_gemm_fwd: the tile goes through LDS (As is free now) so that rows leave as float4 pieces
+    // epilogue as in k_gemm_fwd: the tile goes through LDS (As is free now) so that rows leave as float4 pieces.  The staging
+    // tile has a pitch of 68 floats (As holds 128 x 68): with slice-major output planes a wave stores 64 consecutive ROWS of one
+    // 4-channel piece -- 1 KB contiguous in that slice's array -- and reads them from LDS at a 272-byte stride, which the 64
+    // banks take without conflicts (a 256-byte stride would hit one bank group 16 times).
     float* Cs = As;
+    constexpr int CP = 68;
 #pragma unroll
     for (int h2 = 0; h2 < (NT + 1) / 2; ++h2) {
         qt_lds_barrier();
@@ -1475,24 +1489,26 @@ __global__ __launch_bounds__(256, BG ? QT_DGRAD_OCC : 2) void k_dgrad_cell(Dgrad
             if (nt < NT) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    Cs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + u * 32 + l32] = acc2[nt][r];
+                    Cs[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + u * 32 + l32] = acc2[nt][r];
             }
         }
         qt_lds_barrier();
 #pragma unroll
         for (int u = 0; u < BM * 16 / 256; ++u) {
             const int e = t + 256 * u;
-            const int row = e >> 4, c4 = (e & 15) * 4;
+            // row-major planes: 16 consecutive lanes take the 16 pieces of one row (64-byte runs per plane); slice-major planes:
+            // 128 consecutive threads take the 128 rows of one piece
+            const int row = g.out_sm ? (e & 127) : (e >> 4), c4 = (g.out_sm ? (e >> 7) : (e & 15)) * 4;
             const int64_t i = i0 + row;
             const int j = h2 * 64 + c4;
             if (i >= rows || j >= g.NB) continue;
-            const float4 v = *reinterpret_cast<const float4*>(&Cs[row * 64 + c4]);
+            const float4 v = *reinterpret_cast<const float4*>(&Cs[row * CP + c4]);
             const int ct = g.Cb + g.Cbb;
             const int pl = j / ct, ch = j - pl * ct;
             if (ch < g.Cb)
-                *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+                *reinterpret_cast<float4*>(plane_piece(g.out, pl, i, ch, g.Cb, g.M, g.out_sm, g.Cb)) = v;
             else
-                *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + i * g.Cbb + (ch - g.Cb)) = v;
+                *reinterpret_cast<float4*>(plane_piece(g.outb, pl, i, ch - g.Cb, g.Cbb, g.M, g.out_sm, g.Cbb)) = v;
         }
     }
 }
@@ -1742,9 +1758,9 @@ __global__ __launch_bounds__(4 * TR, 2) void k_cell_bwd_fused(CellBwdFusedArgs f
                     const int ct = g.Cb + g.Cbb;
                     const int pl = j / ct, ch = j - pl * ct;
                     if (ch < g.Cb)
-                        *reinterpret_cast<float4*>(g.out + (int64_t)pl * g.M * g.Cb + i * g.Cb + ch) = v;
+                        *reinterpret_cast<float4*>(plane_piece(g.out, pl, i, ch, g.Cb, g.M, g.out_sm, g.Cb)) = v;
                     else
-                        *reinterpret_cast<float4*>(g.outb + (int64_t)pl * g.M * g.Cbb + i * g.Cbb + (ch - g.Cb)) = v;
+                        *reinterpret_cast<float4*>(plane_piece(g.outb, pl, i, ch - g.Cb, g.Cbb, g.M, g.out_sm, g.Cbb)) = v;
                 }
             }
         }
@@ -1906,7 +1922,8 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
     QT_ARG((((uintptr_t)W | (uintptr_t)WT) & 15) == 0, "W / WT must be 16-byte aligned");
     QT_ARG(act != QT_ACT_TANH_RES || res, "QT_ACT_TANH_RES needs res");
     GemmArgs g = {};
-    if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N, planes_sm)) return rc;
+    if (int rc = plane_src(&g.A, __func__, a0, lda0, a_rest, a0b, lda0b, a_restb, Ka, Ca, Cab, S, Ks, N, planes_sm & 1)) return rc;
+    g.out_sm = (planes_sm >> 1) & 1;
     if (N <= 0) return QT_OK;
     g.B = W; g.BT = WT; g.M = N; g.K = Ka * (Ca + Cab) + Ks; g.NB = Kb * (Cb + Cbb);
     g.outb = outb; g.Cbb = Cbb;
@@ -1996,7 +2013,7 @@ extern "C" int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, i
                                  const float* gates, const float* Cprev, int ld_c, const float* wc, const float* ln, int N,
                                  const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
                                  const float* Wrows, const void* Whi, const void* Wlo, int Kb, int Cb, int Cbb, float* out,
-                                 float* outb, void* stream) {
+                                 float* outb, int out_sm, void* stream) {
     QT_ARG(gates && wc && gG && part && Wrows && out, "null pointer");
     QT_ARG((Whi == nullptr) == (Wlo == nullptr) && (((uintptr_t)Whi | (uintptr_t)Wlo) & 15) == 0, "Whi / Wlo come as a 16-byte aligned pair");
     QT_ARG(h == 8 || h == 16, "fused for hidden sizes 8 and 16 (others: qt_lstm_bwd + qt_dense2)");
@@ -2013,6 +2030,7 @@ extern "C" int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, i
     g.gG = gG; g.gCprev = gCprev; g.part = part; g.accumulate = accumulate;
     g.BT = Wrows; g.M = N; g.NB = NB; g.Kb = Kb; g.Cb = Cb; g.Cbb = Cbb; g.out = out; g.outb = outb; g.n_dev = n_dev;
     g.BThi = (const __bf16*)Whi; g.BTlo = (const __bf16*)Wlo;
+    g.out_sm = out_sm != 0;
     const dim3 grid(qt_cdiv(N, BM));
     // 32-column MFMA tiles: as many as the output planes need (K' C = 80 or 96 columns take three, not four)
     if (h == 16) {

@@ -58,6 +58,7 @@ struct ClipArgs {
     const uint32_t* tail_info;     // (N) per row: pool base | count << 16; 0 = at most four edges; base 0xffff = walk the CSR
     int B, K, nsa;                 // nsa: 4-channel slices of part a (part b's follow)
     int Ncap;                      // plane stride in rows (the capacity in static mode)
+    int bwd_sm;                    // backward: the gradient planes 1 .. K-1 are slice-major (plane 0 is always row-major)
     ClipPart a, b;
 #ifdef QT_CLIP_TIMING
     long long* dbg;                // diagnostics build (tools/exp_clip_timing.py): 16 stamps per workgroup
@@ -130,6 +131,11 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
     const int K = g.K;
     const unsigned pstride = (unsigned)g.Ncap * (unsigned)C;      // (K * Ncap * C < 2^31: checked by the host entry -- 32-bit offsets)
 
+    // element offset of this slice's float4 of (gradient plane k, row): row-major (K, Ncap, C), or planes 1.. slice-major
+    auto grad_off = [&](int k, unsigned row) -> unsigned {
+        if (g.bwd_sm && k > 0) return (unsigned)k * pstride + ((unsigned)(ch >> 2) * (unsigned)g.Ncap + row) * 4u;
+        return (unsigned)k * pstride + row * (unsigned)C + ch;
+    };
     // Prologue, ONE memory phase: the first four edges of this thread's rows (kept in registers for every hop), the rows'
     // tail descriptors, their first operand and the clip's tail pool -- all requested before anything is used.  Rows past the
     // clip's count are clamped to its last row (valid loads, results discarded), so no load sits behind a branch.
@@ -147,8 +153,7 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
         if constexpr (!BWD) {
             first[u] = ld4g(pt.z + (rowc[u] * (unsigned)pt.ld + ch));
         } else {
-            const unsigned off = rowc[u] * (unsigned)C + ch;
-            first[u] = ld4g(pt.planes + ((unsigned)(K - 1) * pstride + off));
+            first[u] = ld4g(pt.planes + grad_off(K - 1, rowc[u]));
         }
     }
     {
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
     CL_STAMP(2);
     if constexpr (BWD) {       // A_{K-2} of the rows: needed at the end of the first hop's groups (requested here, not in the prologue:
 #pragma unroll                 // its registers would sit beside the ELL vectors' and spill)
-        for (int u = 0; u < CL_RPT; ++u) nxt[u] = ld4g(pt.planes + ((unsigned)(K - 2) * pstride + rowc[u] * (unsigned)C + ch));
+        for (int u = 0; u < CL_RPT; ++u) nxt[u] = ld4g(pt.planes + grad_off(K - 2, rowc[u]));
     }
     lds_barrier();
     CL_STAMP(3);
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
             return [=, &nxt, &rowc](int u, float4& r) {
                 const float4 ak = nxt[u];                      // A_k of this row; its A_{k-1} is requested as soon as A_k is consumed
                 r.x += 1.0f * ak.x; r.y += 1.0f * ak.y; r.z += 1.0f * ak.z; r.w += 1.0f * ak.w;
-                if (k > 0) nxt[u] = ld4g(pt.planes + ((unsigned)(k - 1) * pstride + rowc[u] * (unsigned)C + ch));
+                if (k > 0) nxt[u] = ld4g(pt.planes + grad_off(k - 1, rowc[u]));
             };
         };
         // b_k stays in LDS; the last hop (k = 0) writes the result over A_0 in global memory
@@ -323,8 +328,9 @@ struct ClipMesh {       // the mesh operands both entry points share
 };
 
 static int clip_launch(bool bwd, const ClipMesh& m, int Ncap, int K, int Ca, const float* za, int lda, float* Pa, int Cb,
-                       const float* zb, int ldb, float* Pb, void* stream) {
+                       const float* zb, int ldb, float* Pb, void* stream, int bwd_sm = 0) {
     ClipArgs g;
+    g.bwd_sm = bwd_sm != 0;
     g.rowptr = m.rowptr;
     g.col = m.col;
     g.nrm = m.nrm;
@@ -372,14 +378,15 @@ extern "C" int qt_cheb_clip_fwd(const int32_t* rowptr, const int32_t* col, const
 
 extern "C" int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell,
                                 const int32_t* node_off, const int32_t* tail_cnt, const int32_t* tail_pool,
-                                const int32_t* tail_info, int B, int N, int K, int Ca, float* Ga, int Cb, float* Gb, void* stream) {
+                                const int32_t* tail_info, int B, int N, int K, int Ca, float* Ga, int Cb, float* Gb, int planes_sm,
+                                void* stream) {
     CLIP_MESH_ARGS_OK;
     QT_ARG(Ga && Ca > 0 && Ca % 4 == 0 && Cb >= 0 && Cb % 4 == 0 && (Cb == 0 || Gb), "bad operands");
     QT_ARG((((uintptr_t)Ga | (uintptr_t)Gb | (uintptr_t)ell | (uintptr_t)tail_pool) & 15) == 0, "operands must be 16-byte aligned");
     QT_ARG((int64_t)K * N * max(Ca, Cb) < ((int64_t)1 << 31), "planes too large for 32-bit offsets");
     if (N <= 0) return QT_OK;
     const ClipMesh m = {rowptr, col, nrm, ell, node_off, tail_cnt, tail_pool, tail_info, B};
-    clip_launch(true, m, N, K, Ca, nullptr, 0, Ga, Cb, nullptr, 0, Gb, stream);
+    clip_launch(true, m, N, K, Ca, nullptr, 0, Ga, Cb, nullptr, 0, Gb, stream, planes_sm);
     QT_LAUNCHED();
     return QT_OK;
 }

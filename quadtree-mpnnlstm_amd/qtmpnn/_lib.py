@@ -42,7 +42,7 @@ _SIGNATURES = {
     'qt_spmm2': [_P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _F, _F, _F, _P, _P],
     'qt_cheb_clip_rows': [],
     'qt_cheb_clip_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P],
-    'qt_cheb_clip_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P],
+    'qt_cheb_clip_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     'qt_dense': [_P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P],
     'qt_wgrad_blocks': [_I],
     'qt_wgrad': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P],
@@ -63,7 +63,7 @@ _SIGNATURES = {
     'qt_attn_bwd': [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I,
                     _I, _I, _L, _L, _L, _L, _P],
     'qt_lstm_dgrad_blocks': [_I],
-    'qt_lstm_bwd_dgrad': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    'qt_lstm_bwd_dgrad': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P],
     'qt_split_bf16': [_P, _L, _P, _P, _P],
     'qt_flat_adam': [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P],
     'qt_proj_group': [_P, _I, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _P, _I, _L, _I, _I, _P, _P],

@@ -285,11 +285,13 @@ def clip_planes(mesh, Zs, TZs, K):
               Zs[1].shape[1] if two else 0, ptr(Zs[1]) if two else None, _ld(Zs[1]) if two else 0, ptr(TZs[1]) if two else None)
 
 
-def clip_clenshaw(mesh, Gs, K):
-    """Gs[i] (K, N, C_i) gradient planes: plane 0 <- A_0 + L^ b_1 - b_2 (Clenshaw), all hops in ONE launch (qt_cheb_clip_bwd)."""
+def clip_clenshaw(mesh, Gs, K, sm=0):
+    """Gs[i] (K, N, C_i) gradient planes: plane 0 <- A_0 + L^ b_1 - b_2 (Clenshaw), all hops in ONE launch (qt_cheb_clip_bwd).
+    sm: planes 1 .. K-1 are stored slice-major (written so by the data-gradient kernels on request)."""
     two = len(Gs) > 1
     _lib.call('qt_cheb_clip_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off),
-              ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_info), mesh.B, Gs[0].shape[1], K, Gs[0].shape[2], ptr(Gs[0]), Gs[1].shape[2] if two else 0, ptr(Gs[1]) if two else None)
+              ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_info), mesh.B, Gs[0].shape[1], K, Gs[0].shape[2], ptr(Gs[0]),
+              Gs[1].shape[2] if two else 0, ptr(Gs[1]) if two else None, int(sm))
 
 
 def _cheb_planes(Zs, mesh, K):
@@ -369,8 +371,10 @@ def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, g
         # launches of its cells then carry H's 16 channels alone, and the data-gradient GEMM is narrower)
         live = [i for i, f in enumerate(need) if f]
         Cl = [Cs[i] for i in live]
+        clip = _clip_resident(mesh, Cl, K)
+        gsm = 0                                # the gradient planes 1.. leave the GEMM slice-major when the fused Clenshaw reads them
         if gTs_pre is not None:
-            gTs = gTs_pre                      # already computed together with G (qt_lstm_bwd_dgrad)
+            gTs, gsm = gTs_pre                 # already computed together with G (qt_lstm_bwd_dgrad)
         else:
             Wb, skinny = _dgrad_weight(W, K, Cs, live, acc)
             gTs = [Zs[0].new_empty(K, N, c) for c in Cl]
@@ -381,13 +385,14 @@ def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, g
                 _lib.call('qt_dense_sb', ptr(G), 0, Co, ptr(split[0]), ptr(split[1]), K, Cl[0], Cl[1] if len(Cl) > 1 else 0, N,
                           ptr(mesh.n_dev), ptr(gTs[0]), ptr(gTs[1]) if len(Cl) > 1 else None)
             else:
+                gsm = int(clip)
                 _lib.call('qt_dense2', ptr(G), 0, None, None, 0, None, 1, Co, 0, ptr(Wb) if skinny else None,
                           None if skinny else ptr(Wb), None, 0, None, K, Cl[0],
                           Cl[1] if len(Cl) > 1 else 0, N, ptr(mesh.n_dev), ACT_NONE, None, 0, None, ptr(gTs[0]),
-                          ptr(gTs[1]) if len(Cl) > 1 else None, 0)
+                          ptr(gTs[1]) if len(Cl) > 1 else None, 2 * gsm)
         # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
-        if _clip_resident(mesh, Cl, K):         # all hops in one launch; only plane 0 (= gZ) is rewritten
-            clip_clenshaw(mesh, gTs, K)
+        if clip:                                # all hops in one launch; only plane 0 (= gZ) is rewritten
+            clip_clenshaw(mesh, gTs, K, gsm)
             K_hops = 0
         else:
             K_hops = K
@@ -1007,12 +1012,13 @@ class _LstmCell(Function):
 
 def _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, mesh, acc, use_idx, dgrad=None):
     """(gG, gCprev, g_wc, g_b, g_ln) of the cell; the parameter gradients are None until the pass's last backward.
-    dgrad = (Wrows, K, [part widths], [plane tensors (K, N, c)]): the data gradient of the gate GEMM, gG @ Wrows^T, is
-    computed by the same launch (qt_lstm_bwd_dgrad) into the given planes."""
+    dgrad = (Wrows, K, [part widths], [plane tensors (K, N, c)], out_sm): the data gradient of the gate GEMM, gG @ Wrows^T, is
+    computed by the same launch (qt_lstm_bwd_dgrad) into the given planes (out_sm: planes 1.. slice-major); a tuple in the
+    fifth place instead selects the opt-in launch that also accumulates the weight gradient (qt_lstm_bwd_fused)."""
     N, h = gates.shape[0], gates.shape[1] // 4
     (gHn, ld_gh), (gCn, ld_gc) = _rows(gHn), _rows(gCn)
     (gO, ld_go), (Cprev, ld_c) = _rows(gO), _rows(Cprev)
-    fused_w = dgrad is not None and len(dgrad) > 4
+    fused_w = dgrad is not None and isinstance(dgrad[4], tuple)
     gG = None if (fused_w and N > 0) else torch.empty_like(gates)
     gCp = gates.new_empty(N, h) if Cprev is not None else None
     # (one slab row per workgroup of whichever kernel serves a use: k_lstm_bwd, k_dgrad_cell or the persistent fused launch)
@@ -1024,7 +1030,7 @@ def _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, mesh, acc, use_idx, dgrad
     else:
         nblk = rows_of(max(mesh.B * mesh.P, N))      # one slab for every use of the pass, whichever kernel serves it
         part = acc.slab(gates, nblk, 11 * h)
-    if N > 0 and dgrad is not None and len(dgrad) > 4:
+    if N > 0 and fused_w:
         Wrows, K, Cl, planes, (Zs, TZs, S, ksp, Cs, wslab) = dgrad
         gG = None                                   # the gate gradients stay inside the launch
         _lib.call('qt_lstm_bwd_fused', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Cprev), ld_c,
@@ -1032,12 +1038,12 @@ def _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, mesh, acc, use_idx, dgrad
                   ptr(Wrows), K, Cl[0], Cl[1] if len(Cl) > 1 else 0, ptr(planes[0]), ptr(planes[1]) if len(Cl) > 1 else None,
                   *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(S), ksp, ptr(wslab), wslab.shape[0])
     elif N > 0 and dgrad is not None:
-        Wrows, K, Cl, planes = dgrad[:4]
+        Wrows, K, Cl, planes, out_sm = dgrad
         split = Wrows.__dict__.get('_qt_split') if hasattr(Wrows, '__dict__') else None
         _lib.call('qt_lstm_bwd_dgrad', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Cprev), ld_c,
                   ptr(wc), ptr(ln), N, ptr(mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part), 0 if acc is None else 1,
                   ptr(Wrows), ptr(split[0]) if split else None, ptr(split[1]) if split else None, K, Cl[0],
-                  Cl[1] if len(Cl) > 1 else 0, ptr(planes[0]), ptr(planes[1]) if len(Cl) > 1 else None)
+                  Cl[1] if len(Cl) > 1 else 0, ptr(planes[0]), ptr(planes[1]) if len(Cl) > 1 else None, int(out_sm))
     elif N > 0:
         if acc is None and nblk > _lib.value('qt_lstm_bwd_blocks', N, h):
             part.zero_()
@@ -1101,7 +1107,8 @@ class _GateCell(Function):
             # the cell backward and the data gradient of the gate GEMM in one launch: gG feeds the MFMA loop from LDS
             Wb, _ = _dgrad_weight(W, K, Cs, live, ctx.acc_w)
             planes = [Zs[0].new_empty(K, N, Cs[i]) for i in live]
-            dgrad = (Wb, K, [Cs[i] for i in live], planes)
+            osm = int(_clip_resident(ctx.mesh, [Cs[i] for i in live], K))      # planes 1.. slice-major for the fused Clenshaw
+            dgrad = (Wb, K, [Cs[i] for i in live], planes, osm)
             # ... and, on request, the weight gradient too (qt_lstm_bwd_fused: gG never leaves the launch).  OFF by default: at
             # the bench shape the persistent launch takes 71 us against 47 + 21 us for this launch plus its share of the
             # deferred weight gradient -- fp32 MFMA issues on the vector pipe, so its 18 us of MFMA time, the cell arithmetic
@@ -1111,11 +1118,12 @@ class _GateCell(Function):
                 ksp = (ctx.Ks + 3) // 4 * 4
                 S = ctx.mesh.cheb_ones(ctx.Ks) if ctx.Ks else None
                 wslab = ctx.acc_w.weight_slab(W, W.shape[0], W.shape[1])
-                dgrad = dgrad + ((Zs, TZs, S, ksp, Cs, wslab),)
+                dgrad = dgrad[:4] + ((Zs, TZs, S, ksp, Cs, wslab),)
+                osm = 0
                 w_fused = True
         gG, gCp, gwc, gb, gln = _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, ctx.mesh, ctx.acc_p, ctx.use_p, dgrad)
         gZs, gW = _cheb_backward(Zs, TZs, W, gG, ctx.mesh, K, ctx.Ks, ctx.acc_w, ctx.use_w, need, ctx.needs_input_grad[2],
-                                 gTs_pre=planes, w_fused=w_fused, sm=ctx.sm)
+                                 gTs_pre=None if planes is None else (planes, osm), w_fused=w_fused, sm=ctx.sm)
         gZa = gZs[0] if gZs is not None else None
         gZb = gZs[1] if gZs is not None and nz > 1 else None
         return gZa, gZb, gW, gCp, gwc, gb, gln, None, None, None, None, None

@@ -769,6 +769,15 @@ def test_clip_resident_recurrence_equals_per_hop_launches(K, widths, B):
     for a, r, g0 in zip(Gf, Gr, G):
         assert torch.equal(a[0], r[0])
         assert torch.equal(a[1:], g0[1:])                          # the fused launch leaves planes 1 .. K-1 as given
+    # the same with planes 1 .. K-1 stored slice-major, (C / 4, N, 4) each -- what the data-gradient kernels write on request
+    Gs = []
+    for g0, w in zip(G, widths):
+        t = g0.clone()
+        t[1:] = g0[1:].view(K - 1, N, w // 4, 4).permute(0, 2, 1, 3).reshape(K - 1, N, w)
+        Gs.append(t)
+    ops.clip_clenshaw(mesh, Gs, K, sm=1)
+    for a, r in zip(Gs, Gr):
+        assert torch.equal(a[0], r[0])
 
 
 def test_clip_resident_recurrence_static_capacities():
