@@ -43,7 +43,8 @@ extern "C" {
 
 /* tail edges (edges 5, 6, .. of a row) kept per clip for the clip-resident recurrence kernel: pool entries per clip */
 #define QT_TAIL_CAP 4080
-#define QT_TAIL_CNT_STRIDE 32 /* ints between the per-clip tail counters (one 128-byte line each) */
+#define QT_TAIL_CNT_STRIDE 32 /* ints between the per-clip tail counters (one 128-byte line each): [0] tail edges, [1] rows with a tail */
+#define QT_TAIL_REC_CAP 4096 /* records (rows with more than four edges) per clip = the most rows a clip-resident clip can have */
 
 #define QT_ACT_NONE 0
 #define QT_ACT_RELU 1
@@ -124,10 +125,16 @@ int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, con
                   again as [col x4 | nrm bits x4] (an unused slot = the row itself with weight 0; a complemented last column
                   flags more than four edges): qt_spmm2 then reaches its gathers without the row pointer */,
                   const int32_t* cell, const int32_t* node_off /* (B + 1) */, int32_t* tail_cnt /* (B * QT_TAIL_CNT_STRIDE), zeroed by qt_edges_count */,
-                  int32_t* tail_pool /* (B, QT_TAIL_CAP, 2) */, int32_t* tail_info /* (N) */, void* stream);
+                  int32_t* tail_pool /* (B, QT_TAIL_CAP, 2) */, int32_t* tail_info /* (N) */,
+                  int32_t* tail_rec /* optional (B, QT_TAIL_REC_CAP, 8) */, void* stream);
 /* tail_info != NULL (then the four arrays before it are required): the edges beyond the fourth of every row, per clip, as
  * {column - node_off[clip], weight bits} runs in tail_pool; tail_info[i] = run base | edge count << 16 (0: at most four edges;
- * base 0xffff: the clip's pool was full, the row stays on the CSR arrays).  Read by qt_cheb_clip_fwd / _bwd. */
+ * base 0xffff: the clip's pool was full, the row stays on the CSR arrays).
+ * tail_rec != NULL (needs tail_info and ell): one 32-byte record per row with more than four edges, clip c's records in the
+ * order their rows' atomic adds on tail_cnt[QT_TAIL_CNT_STRIDE c + 1] arrive (at most QT_TAIL_REC_CAP are kept):
+ *   {lc01, lc23, w0, w1}, {w2, w3, info, row - node_off[c]}: lc = the first four columns relative to the clip, as
+ *   (column << 4) | (next column << 20); w = their weights' bits; info = the row's tail_info word.
+ * qt_cheb_clip_fwd / _bwd read tail_cnt, tail_pool and tail_rec: thread j of a clip's workgroup takes record j. */
 int qt_tail_cap(void);
 
 /* ---------------------------------------------------------------- mesh <-> image transfers
@@ -228,8 +235,9 @@ int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* nrm, int N,
  * for block-diagonal meshes whose clips hold at most qt_cheb_clip_rows() nodes each (4096: a 64 x 64 frame).  One workgroup per
  * (clip, 4-channel column slice) keeps two slice planes in LDS; gathers are LDS reads, hops are separated by a workgroup barrier.
  * Replaces K - 1 qt_spmm2 calls of PyG ChebConv.forward's recurrence (model/model.py:53,96); bit-identical planes.
- *   node_off (B + 1): first node of each clip (device; qt_quadtree_stage3 writes it); ell, tail_cnt / tail_pool / tail_info:
- *   required, from qt_edges_norm (the first four edges of a row in registers, the rest from the clip's pool copied to LDS).
+ *   node_off (B + 1): first node of each clip (device; qt_quadtree_stage3 writes it); ell, tail_cnt / tail_pool / tail_rec:
+ *   required, from qt_edges_norm (the first four edges of a row in registers, the rest from the clip's pool copied to LDS;
+ *   a row with more than four edges is finished by the thread that holds its record, not by the row's owner).
  *   N: plane stride in rows (the capacity in static mode; the valid rows come from node_off).
  * qt_cheb_clip_fwd: T_k = 2 L^ T_{k-1} - T_{k-2} (T_0 = Z = [za | zb], T_1 = L^ Z) -> Ta, Tb: K - 1 planes each, stored
  *   SLICE-major -- plane k as (C / 4, N, 4): a workgroup owns one 4-channel slice, so consecutive rows of its slice are
@@ -238,12 +246,16 @@ int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* nrm, int N,
  * qt_cheb_clip_bwd: Clenshaw on the gradient planes Ga (K, N, Ca), Gb (K, N, Cb): plane 0 is overwritten with
  *   A_0 + L^ b_1 - b_2, b_k = A_k + 2 L^ b_{k+1} - b_{k+2}; planes 1 .. K - 1 are left as given (the b_k stay in LDS). */
 int qt_cheb_clip_rows(void);
+/* Channels per workgroup of the two launches below: 0 (default) = automatic -- 2 when B * (Ca + Cb) / 2 workgroups fit the
+ * CUs in one round (a hop is bound by the CU's LDS, so half-width slices on twice the CUs are faster), else 4; 2 or 4 pins it
+ * (diagnostics, parity tests of both widths: the planes are the same bit for bit).  Returns the previous setting. */
+int qt_cheb_clip_width(int w);
 int qt_cheb_clip_fwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* node_off,
-                     const int32_t* tail_cnt, const int32_t* tail_pool, const int32_t* tail_info,
+                     const int32_t* tail_cnt, const int32_t* tail_pool, const int32_t* tail_rec,
                      int B, int N, int K, int Ca, const float* za, int lda, float* Ta,
                      int Cb, const float* zb, int ldb, float* Tb, void* stream);
 int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* node_off,
-                     const int32_t* tail_cnt, const int32_t* tail_pool, const int32_t* tail_info,
+                     const int32_t* tail_cnt, const int32_t* tail_pool, const int32_t* tail_rec,
                      int B, int N, int K, int Ca, float* Ga, int Cb, float* Gb,
                      int planes_sm /* != 0: planes 1 .. K-1 of Ga / Gb are slice-major (written so by qt_lstm_bwd_dgrad / qt_dense2) */,
                      void* stream);

@@ -31,13 +31,10 @@ namespace {
 #ifndef QT_CLIP_T
 #define QT_CLIP_T 1024
 #endif
-#ifndef QT_CLIP_GR
-#define QT_CLIP_GR 1
-#endif
-constexpr int CL_ROWS = 4096;              // rows of a clip that fit: 2 planes x 4096 x 16 B = 128 KB
+constexpr int CL_ROWS = QT_TAIL_REC_CAP;   // rows of a clip that fit: 2 planes x 4096 x 16 B = 128 KB
 constexpr int CL_T = QT_CLIP_T;            // threads per workgroup
-constexpr int CL_RPT = CL_ROWS / CL_T;     // rows per thread (8 registers per row for all hops: packed ELL columns, weights, tail
-                                           // descriptor, row number; the backward 4 more for the prefetched A_k)
+constexpr int CL_RPT = CL_ROWS / CL_T;     // rows per thread (6 registers per row for all hops: packed ELL columns, weights; the
+                                           // backward 4 more for the prefetched A_k)
 constexpr int CL_TAIL = QT_TAIL_CAP;       // LDS pool of tail edges (edges 5, 6, .. of a row) per clip: 8 B each, ~32 KB
 
 struct ClipPart {
@@ -53,10 +50,12 @@ struct ClipArgs {
     const float* nrm;
     const int4* ell;
     const int32_t* node_off;       // (B + 1) first node of every clip (device): the valid rows of clip c are [off[c], off[c + 1])
-    const int32_t* tail_cnt;       // (B * QT_TAIL_CNT_STRIDE) tail edges of every clip in the pool (may exceed the capacity: see tail_info)
+    const int32_t* tail_cnt;       // (B * QT_TAIL_CNT_STRIDE): [0] tail edges of the clip in the pool (may exceed the capacity: see the
+                                   // records' info word), [1] rows with a tail = records of the clip
     const int2* tail_pool;         // (B, CL_TAIL) {local column, weight bits}
-    const uint32_t* tail_info;     // (N) per row: pool base | count << 16; 0 = at most four edges; base 0xffff = walk the CSR
-    int B, K, nsa;                 // nsa: 4-channel slices of part a (part b's follow)
+    const int4* tail_rec;          // (B, CL_ROWS, 2 x int4) one record per row with more than four edges (qt_edges_norm):
+                                   // {lc01, lc23, w0, w1}, {w2, w3, info, local row}; info = pool base | tail edges << 16, base 0xffff: walk the CSR
+    int B, K, nsa;                 // nsa: slices of part a (part b's follow)
     int Ncap;                      // plane stride in rows (the capacity in static mode)
     int bwd_sm;                    // backward: the gradient planes 1 .. K-1 are slice-major (plane 0 is always row-major)
     ClipPart a, b;
@@ -70,90 +69,153 @@ struct ClipArgs {
 #define CL_STAMP(i) do {} while (0)
 #endif
 
-__device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// the W channels of a slice row: a plain struct (independent registers: as one ext_vector value the 4-register tuples' alignment
+// cost the W = 4 kernels ~25 more registers and spills); memory accesses go through the matching vector type
+template <int W> struct fvec {
+    float v[W];
+    __device__ __forceinline__ float& operator[](int i) { return v[i]; }
+    __device__ __forceinline__ const float& operator[](int i) const { return v[i]; }
+};
+template <int W> using fraw = float __attribute__((ext_vector_type(W)));
+template <int W> __device__ __forceinline__ fvec<W> vload(const void* p) {
+    const fraw<W> r = *reinterpret_cast<const fraw<W>*>(p);
+    fvec<W> o;
+#pragma unroll
+    for (int i = 0; i < W; ++i) o.v[i] = r[i];
+    return o;
+}
+template <int W> __device__ __forceinline__ void vstore(void* p, const fvec<W>& a) {
+    fraw<W> r;
+#pragma unroll
+    for (int i = 0; i < W; ++i) r[i] = a.v[i];
+    *reinterpret_cast<fraw<W>*>(p) = r;
+}
+template <int W> __device__ __forceinline__ fvec<W> ldg(const float* p) { return vload<W>(p); }
+template <int W> __device__ __forceinline__ fvec<W> vzero() {
+    fvec<W> z;
+#pragma unroll
+    for (int i = 0; i < W; ++i) z.v[i] = 0.0f;
+    return z;
+}
 
 // Workgroup barrier between two hops: only LDS is shared between the threads, so the barrier waits for this wave's LDS
 // operations (lgkmcnt) and NOT for its global stores / prefetches (vmcnt), which __syncthreads() would also drain.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// LDS rows are addressed by BYTE offset inside a plane (row * 16 < 65536: two offsets per register)
-__device__ __forceinline__ float4 lds_row(const char* plane, unsigned byte_off) { return *reinterpret_cast<const float4*>(plane + byte_off); }
+// LDS rows are addressed by row * 16 (< 65536: two offsets per register); a slice row is 4 W bytes
+template <int W> __device__ __forceinline__ fvec<W> lds_row(const char* plane, unsigned off16) {
+    return vload<W>(plane + off16 * (unsigned)W / 4u);
+}
+
+// acc += w f, one fused multiply-add per channel.  Spelled with the intrinsic: left to the contraction pass, the vector form of
+// w0 f0 + w1 f1 was fused the other way round in half the lanes -- 1 ulp away from k_spmm's chain ((0 + w0 f0) + w1 f1) + ...
+template <int W> __device__ __forceinline__ void vfma(fvec<W>& a, float w, const fvec<W>& f) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) a[i] = __builtin_fmaf(w, f[i], a[i]);
+}
+
+// The first four edges of a row: the gathers are issued together, then the chain in ELL order
+template <int W>
+__device__ __forceinline__ fvec<W> gather_head(const char* __restrict__ P, unsigned l01, unsigned l23, const float (&w)[4]) {
+    fvec<W> f[4];
+    f[0] = lds_row<W>(P, l01 & 0xffffu);
+    f[1] = lds_row<W>(P, l01 >> 16);
+    f[2] = lds_row<W>(P, l23 & 0xffffu);
+    f[3] = lds_row<W>(P, l23 >> 16);
+    fvec<W> a = vzero<W>();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vfma<W>(a, w[e], f[e]);
+    return a;
+}
 
 // The tail of a row with more than four edges, from the LDS copy of the clip's pool.  Four pool entries and their four
 // gathers are in flight per trip; the accumulation order is the CSR order, as in k_spmm.
-__device__ __forceinline__ void gather_tail_lds(float4& a, const char* __restrict__ P, const int2* __restrict__ TE, unsigned info) {
+template <int W>
+__device__ __forceinline__ void gather_tail_lds(fvec<W>& a, const char* __restrict__ P, const int2* __restrict__ TE, unsigned info) {
     const unsigned base = info & 0xffffu, cnt = info >> 16;
     for (unsigned j0 = 0; j0 < cnt; j0 += 4) {
         int2 e[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) e[v] = TE[base + min(j0 + v, cnt - 1)];
-        float4 f[4];
+        fvec<W> f[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) f[v] = lds_row(P, (unsigned)e[v].x << 4);
+        for (int v = 0; v < 4; ++v) f[v] = lds_row<W>(P, (unsigned)e[v].x << 4);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            if (j0 + v < cnt) {
-                const float we = __int_as_float(e[v].y);
-                a.x += we * f[v].x; a.y += we * f[v].y; a.z += we * f[v].z; a.w += we * f[v].w;
-            }
-        }
+        for (int v = 0; v < 4; ++v)
+            if (j0 + v < cnt) vfma<W>(a, __int_as_float(e[v].y), f[v]);
     }
 }
 
 // (pool full -- a clip with more than CL_TAIL tail edges: the row walks the CSR arrays instead; correct, slow, rare)
-__device__ __forceinline__ void gather_tail_csr(float4& a, const char* __restrict__ P, unsigned row, int r0,
+template <int W>
+__device__ __forceinline__ void gather_tail_csr(fvec<W>& a, const char* __restrict__ P, unsigned row, int r0,
                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                 const float* __restrict__ nrm) {
     const int e0 = rowptr[row] + 4, e1 = rowptr[row + 1];
     for (int e = e0; e < e1; ++e) {
         const unsigned cj = (unsigned)((col[e] - r0) & (CL_ROWS - 1)) << 4;
-        const float we = nrm[e];
-        const float4 f = lds_row(P, cj);
-        a.x += we * f.x; a.y += we * f.y; a.z += we * f.z; a.w += we * f.w;
+        vfma<W>(a, nrm[e], lds_row<W>(P, cj));
     }
 }
 
-template <bool BWD>
+// W: channels per workgroup.  The hops are bound by the CU's own work (vector issue, LDS), not by memory: with W = 4 the
+// benchmark's 32 clips x 4 .. 5 slices occupy 128 .. 160 of the 256 CUs; W = 2 (8-byte slice rows, twice the workgroups) is
+// taken when B * C / 2 workgroups still fit the CUs in one round (clip_launch).  Same arithmetic per channel either way.
+template <bool BWD, int W>
 __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
-    __shared__ __attribute__((aligned(16))) char Pl[2 * CL_ROWS * 16];
+    using V = fvec<W>;
+    __shared__ __attribute__((aligned(16))) char Pl[2 * CL_ROWS * 4 * W];
     __shared__ int2 TE[CL_TAIL];
     const int t = threadIdx.x;
     const int c = (int)blockIdx.x % g.B, s = (int)blockIdx.x / g.B;
     const bool second = s >= g.nsa;
     const ClipPart& pt = second ? g.b : g.a;
     const int C = pt.C;
-    const int ch = 4 * (second ? s - g.nsa : s);
+    const int ch = W * (second ? s - g.nsa : s);
     const int r0 = g.node_off[c];
     const int nr = min(g.node_off[c + 1] - r0, CL_ROWS);
     if (nr <= 0) return;                                   // (workgroup-uniform)
     const int ntail = min(g.tail_cnt[QT_TAIL_CNT_STRIDE * c], CL_TAIL);
+    const int ntr = min(g.tail_cnt[QT_TAIL_CNT_STRIDE * c + 1], CL_ROWS);
     CL_STAMP(0);
     const int K = g.K;
     const unsigned pstride = (unsigned)g.Ncap * (unsigned)C;      // (K * Ncap * C < 2^31: checked by the host entry -- 32-bit offsets)
 
-    // element offset of this slice's float4 of (gradient plane k, row): row-major (K, Ncap, C), or planes 1.. slice-major
+    // element offset of this slice's channels of (gradient plane k, row): row-major (K, Ncap, C), or planes 1.. slice-major
     auto grad_off = [&](int k, unsigned row) -> unsigned {
-        if (g.bwd_sm && k > 0) return (unsigned)k * pstride + ((unsigned)(ch >> 2) * (unsigned)g.Ncap + row) * 4u;
+        if (g.bwd_sm && k > 0) return (unsigned)k * pstride + ((unsigned)(ch >> 2) * (unsigned)g.Ncap + row) * 4u + (unsigned)(ch & 3);
         return (unsigned)k * pstride + row * (unsigned)C + ch;
     };
-    // Prologue, ONE memory phase: the first four edges of this thread's rows (kept in registers for every hop), the rows'
-    // tail descriptors, their first operand and the clip's tail pool -- all requested before anything is used.  Rows past the
+    // Rows with MORE than four edges (big cells beside small ones: 3 - 4 % of the rows of the benchmark's meshes) are not
+    // finished by the thread that owns them.  Handled in place -- every thread checking its rows for a tail -- nearly every
+    // wave walked the tail loop in every one of its row trips for one or two active lanes: 10 of 24 us of a K = 5 launch.
+    // The mesh build leaves the clip's tail rows as a compact list of records instead, and record j goes to the row SLOT nr + j:
+    // the slots past the clip's nr rows are idle anyway, and there are enough of them -- a row with a tail is a cell of at
+    // least four pixels (a one-pixel cell has at most four neighbours), which frees three slots of the n x m <= 4096.  The
+    // thread that owns slot nr + j runs that row entirely (first four edges from the record, then the pool entries, then the
+    // row's finish), so the tail loop runs in the two or three waves that hold records, with every lane busy; the row's own
+    // thread still writes the first plane and gathers, but stores nothing.  Records that found no slot (never, see above) are
+    // re-read from memory in every hop by the loop at the end of `hop`.
+    const int nslot = min(ntr, CL_ROWS - nr);
+    // Prologue, ONE memory phase: the first four edges of this thread's rows (kept in registers for every hop) or the records
+    // of its slots, the rows' first operand and the clip's tail pool -- all requested before anything is used.  Rows past the
     // clip's count are clamped to its last row (valid loads, results discarded), so no load sits behind a branch.
     unsigned rowc[CL_RPT];
     int4 c4[CL_RPT], wb[CL_RPT];
-    unsigned tinfo[CL_RPT];                 // per row: pool base | tail edge count << 16 (0: none; base 0xffff: walk the CSR)
-    float4 first[CL_RPT];
-    float4 nxt[CL_RPT];
+    V first[CL_RPT];
+    V nxt[CL_RPT];
 #pragma unroll
     for (int u = 0; u < CL_RPT; ++u) {
-        rowc[u] = (unsigned)(r0 + min(t + CL_T * u, nr - 1));
-        c4[u] = g.ell[2 * rowc[u]];
-        wb[u] = g.ell[2 * rowc[u] + 1];
-        tinfo[u] = g.tail_info[rowc[u]];
+        const int i = t + CL_T * u;
+        rowc[u] = (unsigned)(r0 + min(i, nr - 1));
+        const bool isrec = i >= nr && i - nr < nslot;
+        const int4* src = isrec ? g.tail_rec + 2 * ((int64_t)c * CL_ROWS + (i - nr)) : g.ell + 2 * (int64_t)rowc[u];
+        c4[u] = src[0];
+        wb[u] = src[1];
         if constexpr (!BWD) {
-            first[u] = ld4g(pt.z + (rowc[u] * (unsigned)pt.ld + ch));
+            first[u] = ldg<W>(pt.z + (rowc[u] * (unsigned)pt.ld + ch));
         } else {
-            first[u] = ld4g(pt.planes + grad_off(K - 1, rowc[u]));
+            first[u] = ldg<W>(pt.planes + grad_off(K - 1, rowc[u]));
         }
     }
     {
@@ -169,94 +231,110 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
     CL_STAMP(1);
     unsigned lc[CL_RPT][2];
     float w[CL_RPT][4];
+    unsigned tinfo[CL_RPT];                 // record slots: pool base | tail edge count << 16 (base 0xffff: walk the CSR); 0 otherwise
+    unsigned mine = 0;                      // bit u: this thread finishes row u (its own row without a tail, or a record's row)
     bool tails = false;
 #pragma unroll
     for (int u = 0; u < CL_RPT; ++u) {
-        const bool ok = t + CL_T * u < nr;
-        if (c4[u].w < 0) c4[u].w = ~c4[u].w;
-        if (!ok) tinfo[u] = 0;
-        tails |= tinfo[u] != 0;
-        lc[u][0] = ((unsigned)((c4[u].x - r0) & (CL_ROWS - 1)) << 4) | ((unsigned)((c4[u].y - r0) & (CL_ROWS - 1)) << 20);
-        lc[u][1] = ((unsigned)((c4[u].z - r0) & (CL_ROWS - 1)) << 4) | ((unsigned)((c4[u].w - r0) & (CL_ROWS - 1)) << 20);
-        w[u][0] = __int_as_float(wb[u].x);
-        w[u][1] = __int_as_float(wb[u].y);
-        w[u][2] = __int_as_float(wb[u].z);
-        w[u][3] = __int_as_float(wb[u].w);
-        if (ok) *reinterpret_cast<float4*>(Pl + (t + CL_T * u) * 16) = first[u];
+        const int i = t + CL_T * u;
+        const bool ok = i < nr;
+        if (ok) vstore<W>(Pl + i * (4 * W), first[u]);
+        if (i >= nr && i - nr < nslot) {    // a record: {lc01, lc23, w0, w1}, {w2, w3, info, local row}
+            lc[u][0] = (unsigned)c4[u].x;
+            lc[u][1] = (unsigned)c4[u].y;
+            w[u][0] = __int_as_float(c4[u].z);
+            w[u][1] = __int_as_float(c4[u].w);
+            w[u][2] = __int_as_float(wb[u].x);
+            w[u][3] = __int_as_float(wb[u].y);
+            tinfo[u] = (unsigned)wb[u].z;
+            rowc[u] = (unsigned)r0 + ((unsigned)wb[u].w & (CL_ROWS - 1));
+            mine |= 1u << u;
+            tails = true;
+        } else {
+            const bool tail = c4[u].w < 0;  // (the ELL array flags a row with more edges by complementing its last column)
+            if (tail) c4[u].w = ~c4[u].w;
+            if (ok && !tail) mine |= 1u << u;
+            lc[u][0] = ((unsigned)((c4[u].x - r0) & (CL_ROWS - 1)) << 4) | ((unsigned)((c4[u].y - r0) & (CL_ROWS - 1)) << 20);
+            lc[u][1] = ((unsigned)((c4[u].z - r0) & (CL_ROWS - 1)) << 4) | ((unsigned)((c4[u].w - r0) & (CL_ROWS - 1)) << 20);
+            w[u][0] = __int_as_float(wb[u].x);
+            w[u][1] = __int_as_float(wb[u].y);
+            w[u][2] = __int_as_float(wb[u].z);
+            w[u][3] = __int_as_float(wb[u].w);
+            tinfo[u] = 0;
+        }
     }
     CL_STAMP(2);
     if constexpr (BWD) {       // A_{K-2} of the rows: needed at the end of the first hop's groups (requested here, not in the prologue:
 #pragma unroll                 // its registers would sit beside the ELL vectors' and spill)
-        for (int u = 0; u < CL_RPT; ++u) nxt[u] = ld4g(pt.planes + grad_off(K - 2, rowc[u]));
+        for (int u = 0; u < CL_RPT; ++u) nxt[u] = ldg<W>(pt.planes + grad_off(K - 2, rowc[u]));
     }
     lds_barrier();
     CL_STAMP(3);
     int stamp = 4;
     (void)stamp;
     // One hop with the gathered plane at byte offset CO of Pl (compile-time: the hop loops below are unrolled by two, so the plane
-    // offsets are instruction immediates).  GR rows at a time: their 4 GR gathers AND their own old values (OWN: the plane
-    // being overwritten) are requested together, so a hop is CL_RPT / GR LDS round trips per wave, not two per row (one per gather group and
-    // one per own-row read, as the first version had it: 3.6 us per hop with 0.7 us of gather work in it).  Then the rare tails,
-    // then `fin(u, alpha * acc [+ beta * own])` stores row u.
-    constexpr int GR = QT_CLIP_GR;
-    constexpr unsigned PLANE = (unsigned)CL_ROWS * 16u;
+    // offsets are instruction immediates).  Per row: its four gathers AND its own old value (OWN: the plane being overwritten) are
+    // requested together -- one LDS round trip (the first version took two per row: 3.6 us per hop with 0.7 us of gather work
+    // in it) -- then the tail of a record's row,  r = alpha * acc;  addend(r) (backward: + A_k of the row);  r += beta * own;
+    // fin(row, r) stores the row.
+    constexpr unsigned PLANE = (unsigned)CL_ROWS * 4u * W;
     auto hop = [&](auto co_tag, auto own_tag, float alpha, float beta, auto&& addend, auto&& fin) {
         constexpr unsigned CO = decltype(co_tag)::value;
         constexpr bool OWN = decltype(own_tag)::value;
         const char* Pc = Pl + CO;
         char* Pn = Pl + (CO ^ PLANE);
+        auto finish = [&](const V& acc, const V& own, V& nx, char* slot, unsigned grow, bool live) {
+            V r;
+#pragma unroll
+            for (int i = 0; i < W; ++i) r[i] = alpha * acc[i];
+            addend(nx, grow, r);                               // (backward: + A_k of the row)
+            if constexpr (OWN) {
+#pragma unroll
+                for (int i = 0; i < W; ++i) r[i] = __builtin_fmaf(beta, own[i], r[i]);
+            }
+            if (live) fin(grow, r, slot);
+        };
         // (the packed column offsets and the row numbers are made opaque once per hop: otherwise the loop-invariant unpacked LDS
         // addresses -- one per gather -- and 64-bit row addresses are kept in registers across the hops, and the kernel spills)
 #pragma unroll
         for (int u = 0; u < CL_RPT; ++u) asm volatile("" : "+v"(lc[u][0]), "+v"(lc[u][1]), "+v"(rowc[u]));
 #pragma unroll
-        for (int u0 = 0; u0 < CL_RPT; u0 += GR) {
-            float4 f[GR][4], own[GR];
+        for (int u = 0; u < CL_RPT; ++u) {
+            V f[4], own = vzero<W>();
+            f[0] = lds_row<W>(Pc, lc[u][0] & 0xffffu);
+            f[1] = lds_row<W>(Pc, lc[u][0] >> 16);
+            f[2] = lds_row<W>(Pc, lc[u][1] & 0xffffu);
+            f[3] = lds_row<W>(Pc, lc[u][1] >> 16);
+            char* slot = Pn + (rowc[u] - (unsigned)r0) * (4u * W);
+            if constexpr (OWN) own = vload<W>(slot);
+            V acc = vzero<W>();                                // (the same chain of fused multiply-adds as k_spmm)
 #pragma unroll
-            for (int v = 0; v < GR; ++v) {
-                const unsigned (&l)[2] = lc[u0 + v];
-                f[v][0] = lds_row(Pc, l[0] & 0xffffu);
-                f[v][1] = lds_row(Pc, l[0] >> 16);
-                f[v][2] = lds_row(Pc, l[1] & 0xffffu);
-                f[v][3] = lds_row(Pc, l[1] >> 16);
+            for (int e = 0; e < 4; ++e) vfma<W>(acc, w[u][e], f[e]);
+            if (tails && tinfo[u]) {
+                if ((tinfo[u] & 0xffffu) != 0xffffu)
+                    gather_tail_lds<W>(acc, Pc, TE, tinfo[u]);
+                else
+                    gather_tail_csr<W>(acc, Pc, rowc[u], r0, g.rowptr, g.col, g.nrm);
             }
-            if constexpr (OWN) {
-#pragma unroll
-                for (int v = 0; v < GR; ++v) own[v] = lds_row(Pn, (unsigned)(t + CL_T * (u0 + v)) * 16u);
-            }
-            float4 acc[GR];
-#pragma unroll
-            for (int v = 0; v < GR; ++v) {
-                const float (&ww)[4] = w[u0 + v];
-                float ax = 0.0f, ay = 0.0f, az = 0.0f, aw = 0.0f;      // (same fused multiply-adds in the same order as k_spmm)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ax += ww[e] * f[v][e].x; ay += ww[e] * f[v][e].y; az += ww[e] * f[v][e].z; aw += ww[e] * f[v][e].w;
-                }
-                acc[v] = make_float4(ax, ay, az, aw);
-            }
-            if (tails) {
-#pragma unroll
-                for (int v = 0; v < GR; ++v) {
-                    if (tinfo[u0 + v]) {
-                        if ((tinfo[u0 + v] & 0xffffu) != 0xffffu)
-                            gather_tail_lds(acc[v], Pc, TE, tinfo[u0 + v]);
-                        else
-                            gather_tail_csr(acc[v], Pc, rowc[u0 + v], r0, g.rowptr, g.col, g.nrm);
-                    }
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < GR; ++v) {
-                const int u = u0 + v;
-                float4 r = make_float4(alpha * acc[v].x, alpha * acc[v].y, alpha * acc[v].z, alpha * acc[v].w);
-                addend(u, r);                                  // (backward: + A_k of the row)
-                if constexpr (OWN) {
-                    r.x += beta * own[v].x; r.y += beta * own[v].y; r.z += beta * own[v].z; r.w += beta * own[v].w;
-                }
-                if (t + CL_T * u < nr) fin(u, r, reinterpret_cast<float4*>(Pn + (unsigned)(t + CL_T * u) * 16u));
-            }
+            finish(acc, own, nxt[u], slot, rowc[u], (mine >> u) & 1u);      // (loads unconditional, the stores predicated)
             __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int j = nslot + t; j < ntr; j += CL_T) {          // (records without a slot: re-read in every hop; see above)
+            const int4* rp = g.tail_rec + 2 * ((int64_t)c * CL_ROWS + j);
+            const int4 q0 = rp[0], q1 = rp[1];
+            const float qw[4] = {__int_as_float(q0.z), __int_as_float(q0.w), __int_as_float(q1.x), __int_as_float(q1.y)};
+            const unsigned lrow = (unsigned)q1.w & (CL_ROWS - 1), info = (unsigned)q1.z;
+            V nx = vzero<W>();
+            if constexpr (BWD) nx = addend.load((unsigned)r0 + lrow);
+            V acc = gather_head<W>(Pc, (unsigned)q0.x, (unsigned)q0.y, qw);
+            if ((info & 0xffffu) != 0xffffu)
+                gather_tail_lds<W>(acc, Pc, TE, info);
+            else
+                gather_tail_csr<W>(acc, Pc, (unsigned)r0 + lrow, r0, g.rowptr, g.col, g.nrm);
+            char* slot = Pn + lrow * (4u * W);
+            V own = vzero<W>();
+            if constexpr (OWN) own = vload<W>(slot);
+            finish(acc, own, nx, slot, (unsigned)r0 + lrow, true);
         }
         lds_barrier();
         CL_STAMP(stamp++);
@@ -265,18 +343,20 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
     using Co1 = std::integral_constant<unsigned, PLANE>;
     using Yes = std::true_type;
     using No = std::false_type;
-    auto none = [](int, float4&) {};
     if constexpr (!BWD) {
         // T_1 = L^ T_0;  T_k = 2 L^ T_{k-1} - T_{k-2}: the owner of a row reads its old value and overwrites it (nobody else reads
         // that plane during the hop)
+        auto none = [](V&, unsigned, V&) {};
         auto store = [&](int k) {
             // planes leave SLICE-major, (plane, 4-channel slice, N, 4): this workgroup's rows are contiguous, its stores coalesce
             // (row-major planes: 16-byte pieces 4 C bytes apart, 21.3 vs 19.5 us per K = 5 launch); the GEMMs that read the
             // planes reach a row's quad at slice base + 4 row (PlaneSrc.sm)
-            float* outp = pt.planes + ((unsigned)(k - 1) * pstride + (unsigned)(ch >> 2) * (unsigned)g.Ncap * 4u);
-            return [=, &rowc](int u, const float4& r, float4* own) {
-                *own = r;
-                *reinterpret_cast<float4*>(outp + rowc[u] * 4u) = r;
+            float* outp = pt.planes + ((unsigned)(k - 1) * pstride + (unsigned)(ch >> 2) * (unsigned)g.Ncap * 4u + (unsigned)(ch & 3));
+            return [=](unsigned grow, const V& r, char* own) {
+                vstore<W>(own, r);
+#ifndef QT_EXP_CLIP_NOSTORE         // (timing experiment)
+                vstore<W>(outp + grow * 4u, r);
+#endif
             };
         };
         hop(Co0{}, No{}, 1.0f, 0.0f, none, store(1));
@@ -286,21 +366,27 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
         }
     } else {
         // Clenshaw on the gradient planes A_0 .. A_{K-1}: b_{K-1} = A_{K-1}; b_k = A_k + 2 L^ b_{k+1} - b_{k+2};
-        // out = A_0 + L^ b_1 - b_2 (written over A_0).  A_k is this thread's own row of plane k, requested during the hop before.
-        auto add_ak = [&](int k) {
-            return [=, &nxt, &rowc](int u, float4& r) {
-                const float4 ak = nxt[u];                      // A_k of this row; its A_{k-1} is requested as soon as A_k is consumed
-                r.x += 1.0f * ak.x; r.y += 1.0f * ak.y; r.z += 1.0f * ak.z; r.w += 1.0f * ak.w;
-                if (k > 0) nxt[u] = ld4g(pt.planes + grad_off(k - 1, rowc[u]));
-            };
+        // out = A_0 + L^ b_1 - b_2 (written over A_0).  A_k is the row's own entry of plane k, requested during the hop before.
+        struct AddAk {
+            const float* planes;
+            decltype(grad_off)& off;
+            int k;
+            __device__ __forceinline__ V load(unsigned grow) const { return ldg<W>(planes + off(k, grow)); }
+            __device__ __forceinline__ void operator()(V& nx, unsigned grow, V& r) const {
+                const V ak = nx;                              // A_k of this row; its A_{k-1} is requested as soon as A_k is consumed
+#pragma unroll
+                for (int i = 0; i < W; ++i) r[i] += 1.0f * ak[i];
+                if (k > 0) nx = ldg<W>(planes + off(k - 1, grow));
+            }
         };
+        auto add_ak = [&](int k) { return AddAk{pt.planes, grad_off, k}; };
         // b_k stays in LDS; the last hop (k = 0) writes the result over A_0 in global memory
         auto put = [&](int k) {
-            return [=, &rowc](int u, const float4& r, float4* own) {
+            return [=](unsigned grow, const V& r, char* own) {
                 if (k == 0)
-                    *reinterpret_cast<float4*>(pt.planes + (rowc[u] * (unsigned)C + ch)) = r;
+                    vstore<W>(pt.planes + (grow * (unsigned)C + ch), r);
                 else
-                    *own = r;
+                    vstore<W>(own, r);
             };
         };
         int k = K - 2;
@@ -323,12 +409,27 @@ extern "C" void qt_clip_timing_buffer(long long* p) { g_clip_dbg = p; }
 struct ClipMesh {       // the mesh operands both entry points share
     const int32_t *rowptr, *col;
     const float* nrm;
-    const int32_t *ell, *node_off, *tail_cnt, *tail_pool, *tail_info;
+    const int32_t *ell, *node_off, *tail_cnt, *tail_pool, *tail_rec;
     int B;
 };
 
+// Slice width: 0 = automatic (2 when the launch's B * C / 2 workgroups fit the CUs in one round, else 4); qt_cheb_clip_width(w)
+// pins it (diagnostics and the parity tests of both widths).
+static int g_clip_width = 0;
+extern "C" int qt_num_cus(void);
+extern "C" int qt_cheb_clip_width(int w) {
+    const int old = g_clip_width;
+    if (w == 0 || w == 2 || w == 4) g_clip_width = w;
+    return old;
+}
+
 static int clip_launch(bool bwd, const ClipMesh& m, int Ncap, int K, int Ca, const float* za, int lda, float* Pa, int Cb,
                        const float* zb, int ldb, float* Pb, void* stream, int bwd_sm = 0) {
+    // forward: half-width slices whenever they still fit the CUs in one round (K = 5, 16 channels, 32 clips: 16.8 -> 15.2 us);
+    // backward only when even they leave half the CUs idle: its A_k loads and the final store move 8 of every 16 bytes at
+    // W = 2 (the same shape backward: 19.1 us at W = 4, 21.0 at W = 2; 4 channels: 13.2 vs 11.5)
+    const int half = m.B * ((Ca + Cb) / 2);
+    const int W = g_clip_width ? g_clip_width : (half <= (bwd ? qt_num_cus() / 2 : qt_num_cus()) ? 2 : 4);
     ClipArgs g;
     g.bwd_sm = bwd_sm != 0;
     g.rowptr = m.rowptr;
@@ -338,39 +439,43 @@ static int clip_launch(bool bwd, const ClipMesh& m, int Ncap, int K, int Ca, con
     g.node_off = m.node_off;
     g.tail_cnt = m.tail_cnt;
     g.tail_pool = reinterpret_cast<const int2*>(m.tail_pool);
-    g.tail_info = reinterpret_cast<const uint32_t*>(m.tail_info);
+    g.tail_rec = reinterpret_cast<const int4*>(m.tail_rec);
     g.B = m.B;
     g.K = K;
-    g.nsa = Ca / 4;
+    g.nsa = Ca / W;
     g.Ncap = Ncap;
 #ifdef QT_CLIP_TIMING
     g.dbg = g_clip_dbg;
 #endif
     g.a = ClipPart{za, Pa, Ca, lda ? lda : Ca};
     g.b = ClipPart{zb, Pb, Cb, ldb ? ldb : Cb};
-    const int grid = m.B * (Ca / 4 + Cb / 4);
-    if (bwd)
-        hipLaunchKernelGGL(k_cheb_clip<true>, dim3(grid), dim3(CL_T), 0, (hipStream_t)stream, g);
+    const int grid = m.B * ((Ca + Cb) / W);
+    if (bwd && W == 2)
+        hipLaunchKernelGGL((k_cheb_clip<true, 2>), dim3(grid), dim3(CL_T), 0, (hipStream_t)stream, g);
+    else if (bwd)
+        hipLaunchKernelGGL((k_cheb_clip<true, 4>), dim3(grid), dim3(CL_T), 0, (hipStream_t)stream, g);
+    else if (W == 2)
+        hipLaunchKernelGGL((k_cheb_clip<false, 2>), dim3(grid), dim3(CL_T), 0, (hipStream_t)stream, g);
     else
-        hipLaunchKernelGGL(k_cheb_clip<false>, dim3(grid), dim3(CL_T), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL((k_cheb_clip<false, 4>), dim3(grid), dim3(CL_T), 0, (hipStream_t)stream, g);
     return 0;
 }
 
 #define CLIP_MESH_ARGS_OK                                                                                                        \
-    QT_ARG(rowptr && col && nrm && ell && node_off && tail_cnt && tail_pool && tail_info && B > 0 && K >= 2,                    \
-           "bad arguments (the ELL side array and the tail pool of qt_edges_norm are required)")
+    QT_ARG(rowptr && col && nrm && ell && node_off && tail_cnt && tail_pool && tail_rec && B > 0 && K >= 2,                     \
+           "bad arguments (the ELL side array, the tail pool and the tail-row records of qt_edges_norm are required)")
 
 extern "C" int qt_cheb_clip_fwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell,
                                 const int32_t* node_off, const int32_t* tail_cnt, const int32_t* tail_pool,
-                                const int32_t* tail_info, int B, int N, int K, int Ca, const float* za, int lda, float* Ta, int Cb,
+                                const int32_t* tail_rec, int B, int N, int K, int Ca, const float* za, int lda, float* Ta, int Cb,
                                 const float* zb, int ldb, float* Tb, void* stream) {
     CLIP_MESH_ARGS_OK;
     QT_ARG(za && Ta && Ca > 0 && Ca % 4 == 0 && Cb >= 0 && Cb % 4 == 0 && (Cb == 0 || (zb && Tb)), "bad operands");
     QT_ARG((lda | ldb) % 4 == 0, "row strides must be multiples of 4");
-    QT_ARG((((uintptr_t)za | (uintptr_t)Ta | (uintptr_t)zb | (uintptr_t)Tb | (uintptr_t)ell | (uintptr_t)tail_pool) & 15) == 0, "operands must be 16-byte aligned");
+    QT_ARG((((uintptr_t)za | (uintptr_t)Ta | (uintptr_t)zb | (uintptr_t)Tb | (uintptr_t)ell | (uintptr_t)tail_pool | (uintptr_t)tail_rec) & 15) == 0, "operands must be 16-byte aligned");
     QT_ARG((int64_t)K * N * max(Ca, Cb) < ((int64_t)1 << 31) && (int64_t)N * max(max(lda, ldb), 4) < ((int64_t)1 << 31), "planes too large for 32-bit offsets");
     if (N <= 0) return QT_OK;
-    const ClipMesh m = {rowptr, col, nrm, ell, node_off, tail_cnt, tail_pool, tail_info, B};
+    const ClipMesh m = {rowptr, col, nrm, ell, node_off, tail_cnt, tail_pool, tail_rec, B};
     clip_launch(false, m, N, K, Ca, za, lda, Ta, Cb, zb, ldb, Tb, stream);
     QT_LAUNCHED();
     return QT_OK;
@@ -378,14 +483,14 @@ extern "C" int qt_cheb_clip_fwd(const int32_t* rowptr, const int32_t* col, const
 
 extern "C" int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell,
                                 const int32_t* node_off, const int32_t* tail_cnt, const int32_t* tail_pool,
-                                const int32_t* tail_info, int B, int N, int K, int Ca, float* Ga, int Cb, float* Gb, int planes_sm,
+                                const int32_t* tail_rec, int B, int N, int K, int Ca, float* Ga, int Cb, float* Gb, int planes_sm,
                                 void* stream) {
     CLIP_MESH_ARGS_OK;
     QT_ARG(Ga && Ca > 0 && Ca % 4 == 0 && Cb >= 0 && Cb % 4 == 0 && (Cb == 0 || Gb), "bad operands");
-    QT_ARG((((uintptr_t)Ga | (uintptr_t)Gb | (uintptr_t)ell | (uintptr_t)tail_pool) & 15) == 0, "operands must be 16-byte aligned");
+    QT_ARG((((uintptr_t)Ga | (uintptr_t)Gb | (uintptr_t)ell | (uintptr_t)tail_pool | (uintptr_t)tail_rec) & 15) == 0, "operands must be 16-byte aligned");
     QT_ARG((int64_t)K * N * max(Ca, Cb) < ((int64_t)1 << 31), "planes too large for 32-bit offsets");
     if (N <= 0) return QT_OK;
-    const ClipMesh m = {rowptr, col, nrm, ell, node_off, tail_cnt, tail_pool, tail_info, B};
+    const ClipMesh m = {rowptr, col, nrm, ell, node_off, tail_cnt, tail_pool, tail_rec, B};
     clip_launch(true, m, N, K, Ca, nullptr, 0, Ga, Cb, nullptr, 0, Gb, stream, planes_sm);
     QT_LAUNCHED();
     return QT_OK;

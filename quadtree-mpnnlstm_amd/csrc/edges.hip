@@ -51,7 +51,10 @@ __global__ __launch_bounds__(ET) void k_edges_count(const int32_t* __restrict__ 
                                                     int32_t* __restrict__ tail_cnt, int B) {
     __shared__ int red[16];
     const int idx = blockIdx.x * ET + threadIdx.x;
-    if (tail_cnt && idx < B) tail_cnt[QT_TAIL_CNT_STRIDE * idx] = 0;      // the per-clip tail-edge counters k_edges_nrm adds to (two launches later)
+    if (tail_cnt && idx < B) {           // the per-clip counters k_edges_nrm adds to (two launches later): tail edges, rows with a tail
+        tail_cnt[QT_TAIL_CNT_STRIDE * idx] = 0;
+        tail_cnt[QT_TAIL_CNT_STRIDE * idx + 1] = 0;
+    }
     int cnt = 0;
     if (idx < 4 * qt_rows(n_dev, Ncap)) {
         const int4 cl = reinterpret_cast<const int4*>(cell)[idx >> 2];
@@ -121,7 +124,7 @@ __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* _
                             const float* __restrict__ dis, int Ncap, const int32_t* __restrict__ n_dev,
                             float* __restrict__ nrm, int4* __restrict__ ell, const int32_t* __restrict__ cell,
                             const int32_t* __restrict__ node_off, int32_t* __restrict__ tail_cnt, int2* __restrict__ tail_pool,
-                            uint32_t* __restrict__ tail_info) {
+                            uint32_t* __restrict__ tail_info, int4* __restrict__ tail_rec) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= qt_rows(n_dev, Ncap)) return;
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
@@ -132,8 +135,13 @@ __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* _
     // contents of a run (CSR order) do not.  A clip with more than QT_TAIL_CAP tail edges keeps the rows that did not fit on the
     // CSR walk (base 0xffff).  The counters sit QT_TAIL_CNT_STRIDE ints (one 128-byte line) apart: side by side in one line, the
     // ~3500 atomic adds of a 32-clip mesh serialised on that line and the launch took 32 us instead of 8.
+    // A row with a tail also takes one slot of its clip's list of RECORDS (second counter of the clip's line): the row's first
+    // four edges as the kernel wants them (columns relative to the clip, packed), its pool descriptor and its own number in the
+    // clip -- chebclip.hip hands record j to thread j, so the tail loops run in a few full waves instead of one or two lanes
+    // of every wave.  Order of the records: as the atomics arrive; their contents do not depend on it.
     uint32_t info = 0;
     int2* run = nullptr;
+    int4* rec = nullptr;
     int r0 = 0;
     if (tail_info) {
         const int cnt = min(e1 - e0 - 4, 0xffff);
@@ -146,6 +154,10 @@ __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* _
                 info = (uint32_t)base | ((uint32_t)cnt << 16);
             } else {
                 info = 0xffffu | ((uint32_t)cnt << 16);
+            }
+            if (tail_rec) {
+                const int slot = atomicAdd(&tail_cnt[QT_TAIL_CNT_STRIDE * clip + 1], 1);
+                if (slot < QT_TAIL_REC_CAP) rec = tail_rec + 2 * ((int64_t)clip * QT_TAIL_REC_CAP + slot);
             }
         }
     }
@@ -171,6 +183,14 @@ __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* _
         ell[2 * (int64_t)i + 1] = make_int4(__float_as_int(w4[0]), __float_as_int(w4[1]), __float_as_int(w4[2]), __float_as_int(w4[3]));
     }
     if (tail_info) tail_info[i] = info;
+    if (rec) {
+        const int c3 = c4[3] < 0 ? ~c4[3] : c4[3];
+        const unsigned M = QT_TAIL_REC_CAP - 1;
+        rec[0] = make_int4((int)((((unsigned)(c4[0] - r0) & M) << 4) | (((unsigned)(c4[1] - r0) & M) << 20)),
+                           (int)((((unsigned)(c4[2] - r0) & M) << 4) | (((unsigned)(c3 - r0) & M) << 20)),
+                           __float_as_int(w4[0]), __float_as_int(w4[1]));
+        rec[1] = make_int4(__float_as_int(w4[2]), __float_as_int(w4[3]), (int)info, i - r0);
+    }
 }
 
 }  // namespace
@@ -203,15 +223,16 @@ extern "C" int qt_tail_cap(void) { return QT_TAIL_CAP; }
 
 extern "C" int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, const float* dis, int N,
                              const int32_t* n_dev, float* nrm, int32_t* ell, const int32_t* cell, const int32_t* node_off,
-                             int32_t* tail_cnt, int32_t* tail_pool, int32_t* tail_info, void* stream) {
+                             int32_t* tail_cnt, int32_t* tail_pool, int32_t* tail_info, int32_t* tail_rec, void* stream) {
     QT_ARG(rowptr && col && w && dis && nrm, "null pointer");
     QT_ARG(((uintptr_t)ell & 15) == 0, "ell must be 16-byte aligned");
     QT_ARG(!tail_info || (cell && node_off && tail_cnt && tail_pool && ((uintptr_t)tail_pool & 15) == 0),
            "tail_info needs cell, node_off, tail_cnt (zeroed by qt_edges_count) and a 16-byte aligned tail_pool");
+    QT_ARG(!tail_rec || (tail_info && ell && ((uintptr_t)tail_rec & 15) == 0), "tail_rec needs tail_info, ell and 16-byte alignment");
     if (N <= 0) return QT_OK;
     hipLaunchKernelGGL(k_edges_nrm, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, w, dis, N, n_dev, nrm,
                        reinterpret_cast<int4*>(ell), cell, node_off, tail_cnt, reinterpret_cast<int2*>(tail_pool),
-                       reinterpret_cast<uint32_t*>(tail_info));
+                       reinterpret_cast<uint32_t*>(tail_info), reinterpret_cast<int4*>(tail_rec));
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -50,7 +50,7 @@ class Mesh:
         self._E = None
         self.n_dev = None        # device int32[1] with the valid node count when N is a capacity (static mode)
         self.ell = None          # (N, 8) int32: [col x4 | nrm bits x4] of the first four edges of every row
-        self.tail_cnt = self.tail_pool = self.tail_info = None     # the edges beyond the fourth, per clip (qt_edges_norm)
+        self.tail_cnt = self.tail_pool = self.tail_info = self.tail_rec = None     # the edges beyond the fourth, per clip (qt_edges_norm)
         self.cell_off = None     # (B * tiles + 1) first node of every 64 x 64 tile in label order (None: no such contiguity)
         self.pixelwise = False   # every unmasked pixel is a node (thresh = -inf); unflatten then NaN-fills the mask
         self.recipe = None       # arguments that rebuild a data-independent mesh for another batch size
@@ -310,6 +310,7 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
     ms.tail_cnt = torch.empty(B * 32, **i32)                 # (QT_TAIL_CNT_STRIDE ints apart: one cache line per clip's counter)
     ms.tail_pool = torch.empty(B, tcap, 2, **i32)
     ms.tail_info = torch.empty(N, **i32)
+    ms.tail_rec = torch.empty(B, 4096, 8, **i32)             # (B, QT_TAIL_REC_CAP, 8): one record per row with more than four edges
     _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4), ptr(sums), ptr(ms.tail_cnt), B)
     emax = 4 * B * n * m                          # every directed edge owns >= 1 of the 4*P pixel adjacencies
     ms.col = torch.empty(emax, **i32)
@@ -319,7 +320,7 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
               ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis))
     ms.ell = torch.empty(N, 8, **i32)             # first four edges per row as two 16-byte vectors (k_spmm's fast path)
     _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm), ptr(ms.ell), ptr(ms.cell),
-              ptr(ms.node_off), ptr(ms.tail_cnt), ptr(ms.tail_pool), ptr(ms.tail_info))
+              ptr(ms.node_off), ptr(ms.tail_cnt), ptr(ms.tail_pool), ptr(ms.tail_info), ptr(ms.tail_rec))
 
 
 def build_homogeneous_mesh(n, m, max_size, mask, B=1, device=None, resolution=0.25):

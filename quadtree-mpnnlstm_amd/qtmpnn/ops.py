@@ -272,7 +272,7 @@ def _clip_resident(mesh, widths, K):
     diagonal mesh fits the kernel's LDS planes (n x m <= 4096 nodes), rows are float4 slices, the ELL side array exists."""
     if not _CLIP_ROWS:
         _CLIP_ROWS.append(_lib.value('qt_cheb_clip_rows'))
-    return (_CLIP_CHEB and K >= max(_CLIP_MIN_K, 2) and mesh.N > 0 and mesh.ell is not None and mesh.tail_info is not None and mesh.n * mesh.m <= _CLIP_ROWS[0]
+    return (_CLIP_CHEB and K >= max(_CLIP_MIN_K, 2) and mesh.N > 0 and mesh.ell is not None and mesh.tail_rec is not None and mesh.n * mesh.m <= _CLIP_ROWS[0]
             and len(widths) <= 2 and all(w % 4 == 0 for w in widths) and getattr(mesh, 'node_off', None) is not None)
 
 
@@ -281,7 +281,7 @@ def clip_planes(mesh, Zs, TZs, K):
     written SLICE-major: TZs[i] (allocated (K - 1, N, C_i)) then holds (K - 1, C_i / 4, N, 4)."""
     two = len(Zs) > 1
     _lib.call('qt_cheb_clip_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off),
-              ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_info), mesh.B, Zs[0].shape[0], K, Zs[0].shape[1], ptr(Zs[0]), _ld(Zs[0]), ptr(TZs[0]),
+              ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_rec), mesh.B, Zs[0].shape[0], K, Zs[0].shape[1], ptr(Zs[0]), _ld(Zs[0]), ptr(TZs[0]),
               Zs[1].shape[1] if two else 0, ptr(Zs[1]) if two else None, _ld(Zs[1]) if two else 0, ptr(TZs[1]) if two else None)
 
 
@@ -290,7 +290,7 @@ def clip_clenshaw(mesh, Gs, K, sm=0):
     sm: planes 1 .. K-1 are stored slice-major (written so by the data-gradient kernels on request)."""
     two = len(Gs) > 1
     _lib.call('qt_cheb_clip_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off),
-              ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_info), mesh.B, Gs[0].shape[1], K, Gs[0].shape[2], ptr(Gs[0]),
+              ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_rec), mesh.B, Gs[0].shape[1], K, Gs[0].shape[2], ptr(Gs[0]),
               Gs[1].shape[2] if two else 0, ptr(Gs[1]) if two else None, int(sm))
 
 

@@ -728,12 +728,23 @@ def test_spmm_two_row_strided_parts_equal_one_matrix():
     assert torch.equal(torch.cat([oa, ob], dim=1), ref)
 
 
+@pytest.fixture
+def clip_width(request):
+    """Pin the slice width of the clip-resident launches (0 = the library's own choice) for one test."""
+    from qtmpnn import _lib
+    prev = _lib.value('qt_cheb_clip_width', request.param)
+    yield request.param
+    _lib.value('qt_cheb_clip_width', prev)
+
+
+@pytest.mark.parametrize('clip_width', [4, 2, 0], indirect=True)
 @pytest.mark.parametrize('K,widths,B', [(5, (4, 16), 3), (3, (16, 4), 2), (5, (16,), 1), (2, (8,), 2), (3, (32,), 2)])
-def test_clip_resident_recurrence_equals_per_hop_launches(K, widths, B):
+def test_clip_resident_recurrence_equals_per_hop_launches(K, widths, B, clip_width):
     """csrc/chebclip.hip (all hops of a ChebConv recurrence in one launch, a clip's rows in LDS) against one qt_spmm2 launch per
     hop: forward planes T_1 .. T_{K-1} and the Clenshaw backward, bit for bit; row-strided column views as Z; a mesh with big
     cells beside small ones (rows with more than four edges take the CSR tail); static capacities (node counts on the device,
-    capacity rows poisoned with NaN) give the same valid rows."""
+    capacity rows poisoned with NaN) give the same valid rows.  Both slice widths of the kernel (4 and 2 channels per
+    workgroup) and the automatic choice."""
     from qtmpnn import _lib, ops
     from qtmpnn._lib import ptr
     from qtmpnn.mesh import spmm2
@@ -799,7 +810,7 @@ def test_clip_resident_recurrence_static_capacities():
     from qtmpnn import _lib
     from qtmpnn._lib import ptr
     _lib.call('qt_cheb_clip_fwd', ptr(sm.rowptr), ptr(sm.col), ptr(sm.nrm), ptr(sm.ell), ptr(sm.node_off), ptr(sm.tail_cnt),
-              ptr(sm.tail_pool), ptr(sm.tail_info), sm.B, sm.N, 4, 16, ptr(Zs), 16, ptr(got), 0, None, 0, None)
+              ptr(sm.tail_pool), ptr(sm.tail_rec), sm.B, sm.N, 4, 16, ptr(Zs), 16, ptr(got), 0, None, 0, None)
     got = ops.planes_rowmajor(got, 1)
     assert torch.equal(got[:, :nv], ref)
     assert bool((got[:, nv:] == 7.0).all())

@@ -7,6 +7,9 @@ import os, sys
 ROOT = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'quadtree-mpnnlstm_amd'))
 import numpy as np, torch
+from qtmpnn import _lib
+if os.environ.get('QT_LIB'):
+    _lib.LIB_PATH = os.path.join(ROOT, 'tools', 'micro', os.environ['QT_LIB'])
 from qtmpnn import ops, synthetic
 from qtmpnn.mesh import build_mesh, spmm2
 
@@ -52,6 +55,13 @@ for K, widths in [(5, (4, 16)), (5, (16,)), (3, (4, 16)), (3, (16,)), (3, (16, 4
             spmm2(mesh, [g[k + 1] for g in G], 2.0, [g[k] for g in G], 1.0, [g[k + 2] for g in G] if k + 2 < K else None, -1.0, [g[k] for g in G])
         spmm2(mesh, [g[1] for g in G], 1.0, [g[0] for g in G], 1.0, [g[2] for g in G] if K > 2 else None, -1.0, [g[0] for g in G])
     t_hf, t_hb = timeit(hops_fwd), timeit(hops_bwd)
+    from qtmpnn import _lib
+    per_w = {}
+    for wd in (4, 2):
+        _lib.value('qt_cheb_clip_width', wd)
+        per_w[wd] = (timeit(lambda: ops.clip_planes(mesh, Zs, TZ, K)), timeit(lambda: ops.clip_clenshaw(mesh, G, K)))
+    _lib.value('qt_cheb_clip_width', 0)
+    print(f'   slice width 4: {per_w[4][0]:6.2f} / {per_w[4][1]:6.2f} us   width 2: {per_w[2][0]:6.2f} / {per_w[2][1]:6.2f} us   (automatic below)')
     t_cf, t_cb = timeit(lambda: ops.clip_planes(mesh, Zs, TZ, K)), timeit(lambda: ops.clip_clenshaw(mesh, G, K))
     nv, C = mesh.n_valid, sum(widths)
     idx = 4.0 * (nv + 1) + 8.0 * mesh.E
