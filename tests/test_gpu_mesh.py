@@ -206,3 +206,40 @@ def test_direct_row_index_of_a_remesh_is_complete():
     finally:
         new.fwd_src, new.bwd_src, new.built_from = keep_f, keep_b, built
     assert torch.equal(out, out2) and torch.equal(gs, gs2)
+
+
+@pytest.mark.parametrize('noise,static', [(0.0, False), (0.05, False), (0.05, True)])
+def test_tail_row_records(noise, static):
+    """qt_edges_norm's tail_rec array (what csrc/chebclip.hip runs the rows with more than four edges from): clip c holds exactly
+    one record per such row -- its first four CSR edges (columns relative to the clip, packed as the kernel keeps them; weights =
+    nrm), its tail_info word and its row number -- and rows + records fit the kernel's 4096 row slots (a row with a tail is a
+    cell of at least two pixels)."""
+    from qtmpnn import synthetic
+    from qtmpnn.mesh import build_mesh
+    B = 3
+    img = np.stack([synthetic.make_clip(20 + i, n_frames=1, pixel_noise=noise)[0, ..., 0] for i in range(B)])
+    mesh = build_mesh(src=torch.from_numpy(img).to(dev()), thresh=0.1, static=static)
+    off = mesh.node_off.cpu().numpy()
+    rp, col, nrm = mesh.rowptr.cpu().numpy(), mesh.col.cpu().numpy(), mesh.nrm.cpu().numpy()
+    rec = mesh.tail_rec.cpu().numpy().view(np.uint32)
+    tinfo = mesh.tail_info.cpu().numpy().view(np.uint32)
+    tcnt = mesh.tail_cnt.cpu().numpy()
+    total = 0
+    for c in range(B):
+        r0, nr = int(off[c]), int(off[c + 1] - off[c])
+        T = int(tcnt[32 * c + 1])
+        deg = rp[r0 + 1:r0 + nr + 1] - rp[r0:r0 + nr]
+        assert T == int((deg > 4).sum()) and nr + T <= 4096
+        rows = set()
+        for j in range(T):
+            ent = rec[c, j]
+            r = int(ent[7])
+            assert r not in rows and 0 <= r < nr and deg[r] > 4
+            rows.add(r)
+            e0 = int(rp[r0 + r])
+            cols = [int(col[e0 + k]) - r0 for k in range(4)]
+            assert [(int(ent[0]) >> 4) & 4095, int(ent[0]) >> 20, (int(ent[1]) >> 4) & 4095, int(ent[1]) >> 20] == cols
+            assert ent[2:6].view(np.float32).tolist() == [float(np.float32(nrm[e0 + k])) for k in range(4)]
+            assert int(ent[6]) == int(tinfo[r0 + r]) != 0
+        total += T
+    assert total > 0
