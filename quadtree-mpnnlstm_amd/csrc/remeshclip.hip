@@ -39,6 +39,8 @@ struct RcArgs {
     // transfer only column 0 of chunk 0 of the SOURCE counts (src_first_only): the gradient of that assembly
     const float* posfeat;
     int src_first_only;
+    int ride;                       // 1: chunk 0 is the decoder input's scalar (posfeat or src_first_only, and more chunks follow): it has no
+                                    // workgroups of its own, the workgroups of chunk 1 carry its column 0 along
 };
 
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -53,13 +55,31 @@ __device__ __forceinline__ unsigned compact_bits(unsigned v) {       // even bit
 // Workgroup barrier that waits for this wave's LDS traffic only (not for its global loads / stores)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(RC_T) void k_remesh_clip(RcArgs a) {
-    __shared__ float4 A[RC_ROWS];                 // the clip's source slice
-    __shared__ float4 L1[1024], L2[256], L3[64], L4[16], L5[4], L6[1];
+// Pairwise sums over lane groups of four, in the pyramid's order: lane 4j holds child 0 .. lane 4j+3 child 3 of entry j (Morton
+// order, child = row bit | col bit << 1) -> every lane of the group gets (c0 + c2) + (c1 + c3) (a + b = b + a bit for bit, so
+// the four lanes hold the same bits).  sh = log2 of the distance between the children: 0, 2, 4 for levels 2, 3, 4.
+__device__ __forceinline__ float quad_sum(float v, int sh) {
+    const float a = v + __shfl_xor(v, 2 << sh, 64);
+    return a + __shfl_xor(a, 1 << sh, 64);
+}
+__device__ __forceinline__ float4 quad_sum4(float4 v, int sh) {
+    return make_float4(quad_sum(v.x, sh), quad_sum(v.y, sh), quad_sum(v.z, sh), quad_sum(v.w, sh));
+}
+
+// 64 KB + 16 KB of LDS and <= 64 registers: TWO workgroups per CU.  The first version kept the whole pyramid in LDS (86 KB, one
+// workgroup per CU, seven barriers) and the benchmark's 17 chunks x 32 clips = 544 workgroups ran in three rounds over the 256
+// CUs; now levels 1 .. 4 are lane-group sums in registers (a wave's 64 threads are exactly one level-4 entry), levels 5 and 6
+// are formed from the sixteen level-4 entries by the few threads that need them, and the decoder input's scalar chunk RIDES with
+// chunk 1 (ride): 16 x 32 = 512 workgroups, all resident at once.
+__global__ __launch_bounds__(RC_T, 2) void k_remesh_clip(RcArgs a) {
+    __shared__ float4 A[RC_ROWS];                 // the clip's source slice; after the gathers its first 16 entries = the level-4 sums
+    __shared__ float A0[RC_ROWS];                 // the rider: column 0 of chunk 0; likewise
     const int t = threadIdx.x;
     const int b = (int)blockIdx.x % a.B;
     const int rest = (int)blockIdx.x / a.B;
-    const int tile = rest % a.tiles, ch = rest / a.tiles;
+    const int tile = rest % a.tiles;
+    const int ch = rest / a.tiles + a.ride;
+    const bool ride = a.ride && ch == 1;          // (workgroup-uniform) this workgroup also transfers column 0 of chunk 0
     const int R0 = (tile / a.tiles_c) * 64, C0 = (tile % a.tiles_c) * 64;
     const int slot = b * a.tiles + (a.tiles - 1 - tile);
     int sp = 0, op = 0;
@@ -75,14 +95,16 @@ __global__ __launch_bounds__(RC_T) void k_remesh_clip(RcArgs a) {
 
     // ---- one memory phase: the source slice (4 rows per thread) and the labels / levels of this thread's 2 x 2 pixels
     float4 x[4];
-    float sc[4];
+    float x0[4], sc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int lr = min(t + RC_T * u, nrs - 1);
         x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        x0[u] = 0.0f;
         sc[u] = 1.0f;
         if (nrs > 0) {
             x[u] = *reinterpret_cast<const float4*>(src + (int64_t)(r0s + lr) * lds);
+            if (ride) x0[u] = a.part[0][(int64_t)(r0s + lr) * a.part_ld[0]];
             if (a.src_inv) sc[u] = a.src_npix[r0s + lr];
         }
     }
@@ -100,61 +122,92 @@ __global__ __launch_bounds__(RC_T) void k_remesh_clip(RcArgs a) {
             lv[q] = a.level[p];
         }
     }
+    const bool first_only = a.src_first_only && ch == 0;       // (the scalar chunk on its own: a transfer of that chunk alone)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        if (a.src_first_only && ch == 0) x[u].y = x[u].z = x[u].w = 0.0f;
-        if (t + RC_T * u < nrs) A[t + RC_T * u] = a.src_inv ? mul4(x[u], 1.0f / sc[u]) : x[u];
+        if (first_only) x[u].y = x[u].z = x[u].w = 0.0f;
+        if (t + RC_T * u < nrs) {
+            const float inv = a.src_inv ? 1.0f / sc[u] : 1.0f;
+            A[t + RC_T * u] = a.src_inv ? mul4(x[u], inv) : x[u];
+            if (ride) A0[t + RC_T * u] = a.src_inv ? x0[u] * inv : x0[u];
+        }
     }
-    const bool dec = a.posfeat != nullptr && ch == 0;          // (workgroup-uniform)
+    const bool dec = a.posfeat != nullptr;          // chunk 0 of the result = [value | position, size] of the node
+    float* dst0 = a.opart[0];
+    const int ldd0 = a.opart_w[0];
     auto put = [&](int node, float4 v) {
-        if (dec) {
+        if (dec && ch == 0) {
             const float* pf = a.posfeat + 3 * (int64_t)node;
             v.y = pf[0]; v.z = pf[1]; v.w = pf[2];
         }
         *reinterpret_cast<float4*>(dst + (int64_t)node * ldd) = v;
     };
+    auto put0 = [&](int node, float v) {            // the rider's result row: (value, position, size) or (gradient, 0, 0, 0)
+        float4 o = make_float4(v, 0.0f, 0.0f, 0.0f);
+        if (dec) {
+            const float* pf = a.posfeat + 3 * (int64_t)node;
+            o.y = pf[0]; o.z = pf[1]; o.w = pf[2];
+        }
+        *reinterpret_cast<float4*>(dst0 + (int64_t)node * ldd0) = o;
+    };
     lds_barrier();
 
     // ---- pixel values, single-pixel nodes, 2 x 2 sums
     float4 v[4];
+    float v0[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const bool ok = lab[q] >= 0 && sl[q] >= 0;
-        v[q] = A[ok ? ((sl[q] - r0s) & (RC_ROWS - 1)) : 0];
-        if (!ok) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int row = ok ? ((sl[q] - r0s) & (RC_ROWS - 1)) : 0;
+        v[q] = A[row];
+        v0[q] = ride ? A0[row] : 0.0f;
+        if (!ok) {
+            v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            v0[q] = 0.0f;
+        }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        if (lab[q] >= 0 && lv[q] == 0) put(lab[q], v[q]);
-    const float4 s1 = add4(add4(v[0], v[1]), add4(v[2], v[3]));
+        if (lab[q] >= 0 && lv[q] == 0) {
+            put(lab[q], v[q]);
+            if (ride) put0(lab[q], v0[q]);
+        }
     const int L = lab[0] >= 0 ? lv[0] : 0;          // a node of level >= 1 has its head at a block's first pixel
     float oscale = 1.0f;
     if (L >= 1 && a.mean) oscale = 1.0f / a.npix[lab[0]];          // (requested before the pyramid, used after it)
-    L1[t] = s1;
-    lds_barrier();
-    // ---- sum pyramid: entry j of level k = the four level-(k-1) entries 4j .. 4j+3 (Morton order: child = row bit | col bit << 1)
-    if (t < 256) L2[t] = add4(add4(L1[4 * t], L1[4 * t + 2]), add4(L1[4 * t + 1], L1[4 * t + 3]));
-    lds_barrier();
-    if (t < 64) L3[t] = add4(add4(L2[4 * t], L2[4 * t + 2]), add4(L2[4 * t + 1], L2[4 * t + 3]));
-    lds_barrier();
-    if (t < 16) L4[t] = add4(add4(L3[4 * t], L3[4 * t + 2]), add4(L3[4 * t + 1], L3[4 * t + 3]));
-    lds_barrier();
-    if (t < 4) L5[t] = add4(add4(L4[4 * t], L4[4 * t + 2]), add4(L4[4 * t + 1], L4[4 * t + 3]));
-    lds_barrier();
-    if (t < 1) L6[0] = add4(add4(L5[0], L5[2]), add4(L5[1], L5[3]));
+    // ---- sum pyramid, (top-left + bottom-left) + (top-right + bottom-right) at every level as before: levels 1 .. 4 in registers
+    const float4 s1 = add4(add4(v[0], v[1]), add4(v[2], v[3]));
+    const float4 s2 = quad_sum4(s1, 0), s3 = quad_sum4(s2, 2), s4 = quad_sum4(s3, 4);
+    float r1 = 0.0f, r2 = 0.0f, r3 = 0.0f, r4 = 0.0f;
+    if (ride) {
+        r1 = (v0[0] + v0[1]) + (v0[2] + v0[3]);
+        r2 = quad_sum(r1, 0); r3 = quad_sum(r2, 2); r4 = quad_sum(r3, 4);
+    }
+    lds_barrier();                                  // every gather done: A / A0 are free
+    if ((t & 63) == 0) {
+        A[t >> 6] = s4;
+        A0[t >> 6] = r4;
+    }
     lds_barrier();
     // ---- every node of level >= 1 is written by the thread that owns its head pixel (the block's first pixel, aligned to 2^L)
     if (L >= 1 && ((2 * br) & ((1 << L) - 1)) == 0 && ((2 * bc) & ((1 << L) - 1)) == 0) {
         float4 s;
+        float r;
+        auto l5 = [&](int j) { return add4(add4(A[4 * j], A[4 * j + 2]), add4(A[4 * j + 1], A[4 * j + 3])); };
+        auto l50 = [&](int j) { return (A0[4 * j] + A0[4 * j + 2]) + (A0[4 * j + 1] + A0[4 * j + 3]); };
         switch (L) {
-            case 1: s = s1; break;
-            case 2: s = L2[t >> 2]; break;
-            case 3: s = L3[t >> 4]; break;
-            case 4: s = L4[t >> 6]; break;
-            case 5: s = L5[t >> 8]; break;
-            default: s = L6[0]; break;
+            case 1: s = s1; r = r1; break;
+            case 2: s = s2; r = r2; break;
+            case 3: s = s3; r = r3; break;
+            case 4: s = s4; r = r4; break;
+            case 5: s = l5(t >> 8); r = ride ? l50(t >> 8) : 0.0f; break;
+            default:
+                s = add4(add4(l5(0), l5(2)), add4(l5(1), l5(3)));
+                r = ride ? (l50(0) + l50(2)) + (l50(1) + l50(3)) : 0.0f;
+                break;
         }
         put(lab[0], mul4(s, oscale));
+        if (ride) put0(lab[0], r * oscale);
     }
 }
 
@@ -288,8 +341,9 @@ extern "C" int qt_remesh_clip(const float* const* src_parts, const int* widths, 
     a.m = m;
     a.posfeat = posfeat;
     a.src_first_only = src_first_only;
+    a.ride = (posfeat || src_first_only) && c4 > 1 && widths[0] == 4 && out_widths[0] == 4 ? 1 : 0;
     QT_ARG((int64_t)B * a.tiles * c4 < ((int64_t)1 << 31), "grid too large");
-    hipLaunchKernelGGL(k_remesh_clip, dim3(B * a.tiles * c4), dim3(RC_T), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_remesh_clip, dim3(B * a.tiles * (c4 - a.ride)), dim3(RC_T), 0, (hipStream_t)stream, a);
     QT_LAUNCHED();
     return QT_OK;
 }
