@@ -559,7 +559,10 @@ class _ScalarCheb3(Function):
         N = Y.shape[0]
         gin = _c(gY.float())
         G = torch.empty_like(gin)
-        gres = torch.empty_like(res) if ctx.needs_input_grad[1] else None
+        # (qt_act_bwd writes whole rows of the residual's ROW STRIDE -- column 0 = gY[:, 0], the rest 0 -- so a column view of a
+        # wider matrix gets a buffer of that stride and its gradient is the matching column view)
+        gbuf = res.new_empty(N, _row_stride(res)) if ctx.needs_input_grad[1] else None
+        gres = gbuf
         if N > 0:
             _lib.call('qt_act_bwd', ptr(gin), ptr(Y), ptr(res), _row_stride(res), ptr(drop), ACT_TANH_RES, N, ptr(mesh.n_dev), 4,
                       ptr(G), ptr(gres))
@@ -567,7 +570,7 @@ class _ScalarCheb3(Function):
             g = G.data_ptr()
             _spmm1(mesh, g, 4, 1.0, g + 4, 4)
             _spmm1(mesh, g + 4, 4, 2.0, g + 8, 4, p=g, ldp=4, beta=-1.0)
-        return G, gres, None, None
+        return G, (gbuf[:, :res.shape[1]] if gbuf is not None else None), None, None
 
 
 def scalar_cheb3(U, res, drop, mesh):

@@ -959,3 +959,30 @@ def test_flat_adam_equals_clip_grad_norm_plus_torch_adam(capturable):
         for gr in ob.param_groups:
             gr['lr'] = float(sched.get_last_lr()[0])
     assert int(oa.state[pa]['step']) == 5
+
+
+def test_scalar_cheb3_residual_as_column_view():
+    """ops.scalar_cheb3 (the decoder head's one-output-channel ChebConv on single columns, model/seq2seq.py:121,174-186) with
+    the residual operand given as a column view of a wider matrix (row stride 4, one column): same Y, dU and d res as with a
+    contiguous (N, 1) residual -- the backward used to size the residual's gradient buffer by the view's shape while the kernel
+    writes rows of the view's stride."""
+    from qtmpnn import ops
+    mesh, _ = _mesh_64(40, noise=0.0, B=2)
+    N = mesh.N
+    torch.manual_seed(3)
+    U0 = torch.randn(N, 4, device=dev())
+    U0[:, 3] = 0
+    X0 = torch.randn(N, 4, device=dev())
+    drop = (torch.rand(N, device=dev()) > 0.2).float() / 0.8
+    gy = torch.randn(N, 4, device=dev())
+    gy[:, 1:] = 0
+    outs = []
+    for view in (True, False):
+        U = U0.clone().requires_grad_(True)
+        X = (X0.clone() if view else X0[:, :1].clone()).requires_grad_(True)
+        Y = ops.scalar_cheb3(U, X[:, :1], drop, mesh)
+        gU, gX = torch.autograd.grad(Y, [U, X], gy)
+        outs.append((Y.detach(), gU, gX[:, :1], gX))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    assert bool((outs[0][3][:, 1:] == 0).all())
