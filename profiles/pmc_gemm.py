@@ -59,9 +59,14 @@ def main(d, pat):
     out['wave_stall_frac'] = {'waiting_on_memory_or_barrier': round(tot_wait / tot_wave, 3),
                               'issue_stalled_mfma_dependency_or_pipe': round(tot_stall / tot_wave, 3),
                               'issuing': round(tot_act / tot_wave, 3)}
-    out['reading'] = ('the fp32 MFMA pipe is busy for about a third of the launch and no wave class is saturated: 1.8 units of '
-                      '32 rows per wave leave no steady state, so the launch is the sum of its phases (operand latency, MFMA chain, '
-                      'cell arithmetic on the same vector pipe, store drain) rather than their maximum -- see DESIGN.md section 6')
+    busy = out.get('mfma_busy_frac', 0.0)
+    if busy > 0:
+        out['reading'] = (f'the fp32 MFMA pipe is busy for {busy:.2f} of the launch and no wave class is saturated: the launch is the sum of '
+                          'its phases (operand latency, MFMA chain, cell arithmetic on the same vector pipe, store drain) rather than their '
+                          'maximum -- see DESIGN.md section 6')
+    else:
+        out['reading'] = ('no MFMA work: waves wait on LDS / barriers / the prologue\'s loads for more than half of the launch and issue '
+                          'vector instructions for the rest (a wave64 instruction occupies a SIMD for 4 cycles) -- see DESIGN.md section 6')
     print(json.dumps(out, indent=1))
 
 
