@@ -362,14 +362,17 @@ int qt_lstm_bwd(const float* gO, int ld_go, const float* gHn, int ld_gh, const f
  * part: (qt_lstm_dgrad_blocks(N), 11 h) partial sums as in qt_lstm_bwd (one row per 128-node workgroup).
  * Whi / Wlo (optional pair, bf16 (Kb (Cb + Cbb), 4h) from qt_split_bf16(Wrows)): the data gradient then runs as a split-bf16
  * product on bf16 MFMA (gG and W as two bf16 terms each, three products: relative error ~2^-16, gradients only) instead of
- * fp32 MFMA; NULL: exact fp32, bit for bit qt_lstm_bwd + qt_dense2. */
+ * fp32 MFMA; NULL: exact fp32, bit for bit qt_lstm_bwd + qt_dense2.
+ * gHn2 (optional, row stride ld_gh2): a second gradient of H', added to gHn on load; add0 (optional, (N, Cb) dense): added to
+ * output plane 0 of part a -- the two sums autograd otherwise makes with elementwise launches when H' feeds the next layer AND
+ * the next time step, and when the cell's input is also the head's residual operand (model/seq2seq.py:152-186). */
 int qt_lstm_dgrad_blocks(int N);
 int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, int ld_gh, const float* gCn, int ld_gc,
                       const float* gates, const float* Cprev, int ld_c, const float* wc, const float* ln,
                       int N, const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
                       const float* Wrows, const void* Whi, const void* Wlo, int Kb, int Cb, int Cbb, float* out, float* outb,
                       int out_sm /* != 0: the data-gradient planes 1 .. Kb-1 leave slice-major (as qt_cheb_clip_bwd reads them) */,
-                      void* stream);
+                      const float* gHn2, int ld_gh2, const float* add0, void* stream);
 /* x (n fp32) -> hi, lo (n bf16 each) with x ~ hi + lo (hi = round(x), lo = round(x - hi)) */
 int qt_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream);
 
@@ -419,9 +422,11 @@ int qt_spmm1(const int32_t* rowptr, const int32_t* col, const float* nrm, const 
              float* out, int ldo, int pad4, int act, const float* res, int ldr, const float* drop, void* stream);
 
 /* backward of the qt_dense epilogue activations: G = gY * act'(Y) (QT_ACT_RELU, QT_ACT_TANH_RES with res / drop as in
- * qt_dense); gres (N, res_stride) or NULL receives the gradient of the residual operand (column 0 = gY[:, 0], rest 0). */
+ * qt_dense); gres (N, res_stride) or NULL receives the gradient of the residual operand (column 0 = gY[:, 0], rest 0).
+ * gY2 (optional, laid out like gY): a second gradient of Y, added to gY on load (Y with two consumers: the decoder's output goes
+ * to the loss and, re-meshed, into the next step's input, model/seq2seq.py:380-398). */
 int qt_act_bwd(const float* gY, const float* Y, const float* res, int res_stride, const float* drop, int act, int N,
-               const int32_t* n_dev, int Co, float* G, float* gres, void* stream);
+               const int32_t* n_dev, int Co, float* G, float* gres, const float* gY2, void* stream);
 
 /* ---------------------------------------------------------------- edge-softmax attention (TransformerConv)
  * torch_geometric TransformerConv(heads=1, concat=False, beta=False, edge_dim=2, root_weight=True) as configured by

@@ -1325,6 +1325,11 @@ struct DgradCellArgs {
     float *out, *outb;
     const int32_t* n_dev;
     int out_sm;             // output planes 1 .. Kb-1 slice-major (plane_piece)
+    // Two gradient sums that autograd would otherwise make with separate elementwise launches (a tensor with two consumers):
+    const float* gHn2;      // optional second gradient of H' (the state goes to the next time step AND to the next layer): added on load
+    int ld_gh2;
+    const float* add0;      // optional (N, Cb): added to output plane 0 of part a (the decoder input is also the head's residual
+                            // operand: that gradient rides into the Clenshaw recurrence as part of A_0)
 };
 
 // BG: the right operand (the weight rows, <= 32 KB, L1 / L2 resident) is read straight from global memory by the lanes that
@@ -1386,6 +1391,11 @@ __global__ __launch_bounds__(256, BG ? QT_DGRAD_OCC : 2) void k_dgrad_cell(Dgrad
                 if (g.gHn) gyh = ld4(g.gHn + node * g.ld_gh + j0);
                 if (g.gCn) gyc = ld4(g.gCn + node * g.ld_gc + j0);
                 if (g.gO) go_in = ld4(g.gO + node * g.ld_go + j0);
+                if (g.gHn2) {
+                    const F4 h2 = ld4(g.gHn2 + node * g.ld_gh2 + j0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) gyh.v[k] += h2.v[k];
+                }
             }
 #ifdef QT_EXP_DG_NOCELL
             CellBwdOut o;
@@ -1502,13 +1512,18 @@ __global__ __launch_bounds__(256, BG ? QT_DGRAD_OCC : 2) void k_dgrad_cell(Dgrad
             const int64_t i = i0 + row;
             const int j = h2 * 64 + c4;
             if (i >= rows || j >= g.NB) continue;
-            const float4 v = *reinterpret_cast<const float4*>(&Cs[row * CP + c4]);
+            float4 v = *reinterpret_cast<const float4*>(&Cs[row * CP + c4]);
             const int ct = g.Cb + g.Cbb;
             const int pl = j / ct, ch = j - pl * ct;
-            if (ch < g.Cb)
+            if (ch < g.Cb) {
+                if (pl == 0 && g.add0) {
+                    const float4 e = *reinterpret_cast<const float4*>(g.add0 + i * g.Cb + ch);
+                    v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+                }
                 *reinterpret_cast<float4*>(plane_piece(g.out, pl, i, ch, g.Cb, g.M, g.out_sm, g.Cb)) = v;
-            else
+            } else {
                 *reinterpret_cast<float4*>(plane_piece(g.outb, pl, i, ch - g.Cb, g.Cbb, g.M, g.out_sm, g.Cbb)) = v;
+            }
         }
     }
 }
@@ -2013,8 +2028,9 @@ extern "C" int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, i
                                  const float* gates, const float* Cprev, int ld_c, const float* wc, const float* ln, int N,
                                  const int32_t* n_dev, int h, float* gG, float* gCprev, float* part, int accumulate,
                                  const float* Wrows, const void* Whi, const void* Wlo, int Kb, int Cb, int Cbb, float* out,
-                                 float* outb, int out_sm, void* stream) {
+                                 float* outb, int out_sm, const float* gHn2, int ld_gh2, const float* add0, void* stream) {
     QT_ARG(gates && wc && gG && part && Wrows && out, "null pointer");
+    QT_ARG((!gHn2 || (ld_gh2 >= h && ld_gh2 % 4 == 0)) && (((uintptr_t)gHn2 | (uintptr_t)add0) & 15) == 0, "bad second gradient / plane-0 addend");
     QT_ARG((Whi == nullptr) == (Wlo == nullptr) && (((uintptr_t)Whi | (uintptr_t)Wlo) & 15) == 0, "Whi / Wlo come as a 16-byte aligned pair");
     QT_ARG(h == 8 || h == 16, "fused for hidden sizes 8 and 16 (others: qt_lstm_bwd + qt_dense2)");
     QT_ARG(Kb >= 1 && Cb >= 4 && Cb % 4 == 0 && Cbb >= 0 && Cbb % 4 == 0 && (Cbb == 0 || outb), "bad output planes");
@@ -2031,6 +2047,7 @@ extern "C" int qt_lstm_bwd_dgrad(const float* gO, int ld_go, const float* gHn, i
     g.BT = Wrows; g.M = N; g.NB = NB; g.Kb = Kb; g.Cb = Cb; g.Cbb = Cbb; g.out = out; g.outb = outb; g.n_dev = n_dev;
     g.BThi = (const __bf16*)Whi; g.BTlo = (const __bf16*)Wlo;
     g.out_sm = out_sm != 0;
+    g.gHn2 = gHn2; g.ld_gh2 = ld_gh2; g.add0 = add0;
     const dim3 grid(qt_cdiv(N, BM));
     // 32-column MFMA tiles: as many as the output planes need (K' C = 80 or 96 columns take three, not four)
     if (h == 16) {

@@ -159,14 +159,14 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ gZ, 
 // the residual operand, gres (N, rs): column 0 = gY[:, 0], the rest 0.  One launch instead of ~8 elementwise tensor ops.
 __global__ void k_act_bwd(const float* __restrict__ gY, const float* __restrict__ Y, const float* __restrict__ res, int rs,
                           const float* __restrict__ drop, int act, int Ncap, const int32_t* __restrict__ n_dev, int Co,
-                          float* __restrict__ G, float* __restrict__ gres) {
+                          float* __restrict__ G, float* __restrict__ gres, const float* __restrict__ gY2) {
     // 32-bit thread index and division (the launcher checks N * Co < 2^31): a 64-bit division by a run-time value is a
     // ~100-instruction routine per thread
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned row = idx / (unsigned)Co;
     if ((int)row >= qt_rows(n_dev, Ncap)) return;
     const int c = (int)(idx - row * (unsigned)Co);
-    const float g = gY[idx], y = Y[idx];
+    const float g = gY2 ? gY[idx] + gY2[idx] : gY[idx], y = Y[idx];      // (gY2: the gradient of Y's second consumer, same layout)
     float o;
     if (act == QT_ACT_RELU) {
         o = y > 0.0f ? g : 0.0f;
@@ -292,13 +292,13 @@ extern "C" int qt_head_bwd(const float* gZ, const float* gZb, const float* O, in
 }
 
 extern "C" int qt_act_bwd(const float* gY, const float* Y, const float* res, int res_stride, const float* drop, int act, int N,
-                          const int32_t* n_dev, int Co, float* G, float* gres, void* stream) {
+                          const int32_t* n_dev, int Co, float* G, float* gres, const float* gY2, void* stream) {
     QT_ARG(gY && Y && G && Co >= 1, "null pointer");
     QT_ARG(act == QT_ACT_RELU || (act == QT_ACT_TANH_RES && res && res_stride >= 1 && res_stride <= Co), "bad activation arguments");
     QT_ARG((int64_t)N * Co + 256 < ((int64_t)1 << 31), "N * Co too large for 32-bit thread indices");
     if (N <= 0) return QT_OK;
     hipLaunchKernelGGL(k_act_bwd, dim3(qt_cdiv((int64_t)N * Co, 256)), dim3(256), 0, (hipStream_t)stream, gY, Y, res, res_stride,
-                       drop, act, N, n_dev, Co, G, gres);
+                       drop, act, N, n_dev, Co, G, gres, gY2);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -412,8 +412,12 @@ class GConvLSTM(nn.Module):
             out.append(PackedCell(W, K, Ks, wc, b, ln, ops.GradAcc(), acc_p))
         return out
 
-    def step(self, X, mesh, H, C, pk):
-        """One cell update with packed weights `pk`; pk.ln = (4, h) LayerNorm parameters fused onto H', C' or None."""
+    def step(self, X, mesh, H, C, pk, alias_h=False, pass_x=False):
+        """One cell update with packed weights `pk`; pk.ln = (4, h) LayerNorm parameters fused onto H', C' or None.
+        alias_h / pass_x: return H' / X once more after (O, H', C') -- see ops.gate_cell."""
+        if pk.W is None and (alias_h or pass_x):
+            out = tuple(self.step(X, mesh, H, C, pk))
+            return out + ((out[1],) if alias_h else ()) + ((X,) if pass_x else ())
         if pk.W is None and pk.multi is not None:
             Hz = H if H is not None else X.new_zeros(X.shape[0], self.out_channels)     # conv_h(0) is not 0 (biases)
             c0 = self.conv_x_i.convolutions[0]
@@ -435,7 +439,7 @@ class GConvLSTM(nn.Module):
                 return x
             G = torch.cat([stack(f'conv_x_{g}', X) + stack(f'conv_h_{g}', Hz) for g in self.GATES], dim=1)
             return ops.lstm_cell(G, C, pk.wc, pk.b, pk.ln, mesh, pk.acc_p)
-        return ops.gate_cell(X, H, pk.W, C, pk.wc, pk.b, pk.ln, mesh, pk.K, pk.Ks, pk.acc_w, pk.acc_p)
+        return ops.gate_cell(X, H, pk.W, C, pk.wc, pk.b, pk.ln, mesh, pk.K, pk.Ks, pk.acc_w, pk.acc_p, alias_h, pass_x)
 
     def forward(self, X, edge_index, edge_weight=None, H=None, C=None):
         pad = (-X.shape[1]) % 4

@@ -199,14 +199,22 @@ class Decoder(nn.Module):
         return (torch.rand(steps, rows, device=device) < keep).float() / keep
 
     def run(self, X, mesh, concat_layers, H, C, pk, drop=None):
-        """One decoder step on packed weights; X (N, 4k) padded input, H / C per-layer lists."""
+        """One decoder step on packed weights; X (N, 4k) padded input, H / C per-layer lists.  Leaves `state_output`: the output
+        once more (same values) for the state update of the rollout, or None."""
         assert self.concat_layers_dim == 1
-        hs, cs, inp = [], [], X
+        self.state_output = None
+        hs, cs, inp, Xres = [], [], X, X
+        last = len(self.rnns) - 1
         for i, rnn in enumerate(self.rnns):
-            out, h, c = rnn.step(inp, mesh, H[i], C[i], pk['rnns'][i])
+            # H' of a lower layer has two consumers (the next layer now, this layer at the next step) and so has X (layer 0 and
+            # the head's residual): the cell hands both out a second time and sums their gradients inside its backward launch
+            res = rnn.step(inp, mesh, H[i], C[i], pk['rnns'][i], alias_h=i < last, pass_x=i == 0)
+            out, h, c = res[:3]
             hs.append(h)
             cs.append(c)
-            inp = h
+            inp = res[3] if i < last else h
+            if i == 0:
+                Xres = res[-1]
         if concat_layers is None:
             # beyond-reference: HEAD crashes here (fc_out1 expects hidden+1 channels, seq2seq.py:115,164);
             # the decoder's current input value is used as the 1-channel concat (what :471,484 intended)
@@ -224,10 +232,15 @@ class Decoder(nn.Module):
             # fc_out2 has ONE output channel: its three coefficient columns are applied first (a 16 -> 4 product) and the
             # Chebyshev recurrence then runs on single columns -- 4 bytes per row and neighbour instead of z's 64-byte rows
             U = ops.cheb_poly(z, pk['fc2c'], mesh, 1, 1, acc=pk['acc2'])                     # (N, 4) = z [w_0 w_1 w_2 0] + [b 0 0 0]
-            y = ops.scalar_cheb3(U, X, drop, mesh)[:, :1]
+            # (the output has two consumers -- the loss, and the next step's input through the re-mesh: the second one takes the
+            # alias `state_output`, so that the two gradients are summed inside the head's backward launch)
+            Y, Y2 = ops.scalar_cheb3(U, Xres, drop, mesh, alias=True)
+            y = Y[:, :1]
+            if not self.binary:
+                self.state_output = Y2[:, :1]
         else:
             # the head GEMM writes float4 rows; column 0 is the prediction (the rest is tanh(0) + X[:, 0], never read as data)
-            y = ops.cheb_poly(z, pk['fc2'], mesh, self.fc_out2.K, 1, ops.ACT_TANH_RES, res=X, drop=drop, acc=pk['acc2'])[:, :1]
+            y = ops.cheb_poly(z, pk['fc2'], mesh, self.fc_out2.K, 1, ops.ACT_TANH_RES, res=Xres, drop=drop, acc=pk['acc2'])[:, :1]
         if self.binary:
             y = torch.sigmoid(y)
         return y, hs, cs
@@ -236,6 +249,7 @@ class Decoder(nn.Module):
         pad = (-X.shape[1]) % 4
         Xp = nn.functional.pad(X, (0, pad)) if pad else X
         y, hs, cs = self.run(Xp, edge_index, concat_layers, H, C, packed if packed is not None else self.pack(Xp.shape[1]))
+        self.state_output = None
         return y, torch.stack(hs), torch.stack(cs)
 
 
@@ -422,6 +436,8 @@ class Seq2Seq(nn.Module):
             output, hidden, cell = self.decoder.run(g.pyg.x, mesh, concat_t, g.hidden, g.cell, dec_pack,
                                                     None if drops is None else drops[si, :mesh.N])
             outputs.append(output)
+            if self.decoder.state_output is not None:
+                output, self.decoder.state_output = self.decoder.state_output, None       # (the copy for the state update)
             output_mappings.append(mesh)
             teacher_force = random.random() < teacher_forcing_ratio
             if t == steps[-1]:

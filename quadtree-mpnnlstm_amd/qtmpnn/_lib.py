@@ -57,14 +57,14 @@ _SIGNATURES = {
     'qt_dense_lstm': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     'qt_decoder_input': [_P, _I, _P, _I, _P, _P, _P],
     'qt_concat': [_P, _P, _P, _I, _I, _P, _P, _P],
-    'qt_act_bwd': [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P],
+    'qt_act_bwd': [_P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P],
     'qt_attn_blocks': [_I, _I],
     'qt_attn_edge_attrs': [_P, _P, _P, _I, _P, _P, _P, _P],
     'qt_attn_fwd': [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _P, _I, _I, _L, _L, _L, _P],
     'qt_attn_bwd': [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _F, ctypes.c_uint32, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I,
                     _I, _I, _L, _L, _L, _L, _P],
     'qt_lstm_dgrad_blocks': [_I],
-    'qt_lstm_bwd_dgrad': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P],
+    'qt_lstm_bwd_dgrad': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P],
     'qt_split_bf16': [_P, _L, _P, _P, _P],
     'qt_flat_adam': [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P],
     'qt_proj_group': [_P, _I, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _P, _I, _L, _I, _I, _P, _P],

@@ -484,7 +484,7 @@ class _ChebPoly(Function):
                 gres = torch.empty_like(res)
             if N > 0:
                 _lib.call('qt_act_bwd', ptr(gin), ptr(Y), ptr(res), _row_stride(res), ptr(drop), act, N,
-                          ptr(mesh.n_dev), Co, ptr(G), ptr(gres))
+                          ptr(mesh.n_dev), Co, ptr(G), ptr(gres), None)
         gZs, gW = _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, ctx.acc, ctx.use_idx,
                                  list(ctx.needs_input_grad[:nz]), ctx.needs_input_grad[2], sm=ctx.sm)
         gZa = gZs[0] if gZs is not None else None
@@ -537,7 +537,7 @@ class _ScalarCheb3(Function):
     model/seq2seq.py:174-186 through PyG's ChebConv; the same sum, associated differently).  Returns (N, 4): column 0 = y."""
 
     @staticmethod
-    def forward(ctx, U, res, drop, mesh):
+    def forward(ctx, U, res, drop, mesh, alias=False):
         assert U.dim() == 2 and U.shape[1] == 4 and U.is_contiguous() and U.dtype == torch.float32
         N = U.shape[0]
         res, ldr = _rows(res)
@@ -549,15 +549,25 @@ class _ScalarCheb3(Function):
         _spmm1(mesh, b1.data_ptr(), 1, 1.0, Y.data_ptr(), 4, p=u, ldp=4, beta=1.0, q=u + 8, ldq=4, gamma=-1.0, pad4=1,
                act=ACT_TANH_RES, res=res, ldr=ldr, drop=drop)
         ctx.save_for_backward(Y, res, drop)
-        ctx.mesh = mesh
+        ctx.mesh, ctx.alias = mesh, alias
+        if alias:
+            # Y once more for its second consumer (the same storage, but NOT a view of Y: the consumer looks at `_base`): both
+            # gradients then arrive here and qt_act_bwd adds them on load, instead of an elementwise launch of autograd's
+            ctx.set_materialize_grads(False)
+            return Y, Y.new_empty(0).set_(Y.untyped_storage(), Y.storage_offset(), Y.shape, Y.stride())
         return Y
 
     @staticmethod
-    def backward(ctx, gY):
+    def backward(ctx, gY, gY2=None):
         Y, res, drop = ctx.saved_tensors
         mesh = ctx.mesh
         N = Y.shape[0]
+        if gY is None:
+            gY, gY2 = gY2, None
+        if gY is None:
+            return (None,) * 5
         gin = _c(gY.float())
+        gin2 = _c(gY2.float()) if gY2 is not None else None
         G = torch.empty_like(gin)
         # (qt_act_bwd writes whole rows of the residual's ROW STRIDE -- column 0 = gY[:, 0], the rest 0 -- so a column view of a
         # wider matrix gets a buffer of that stride and its gradient is the matching column view)
@@ -565,16 +575,17 @@ class _ScalarCheb3(Function):
         gres = gbuf
         if N > 0:
             _lib.call('qt_act_bwd', ptr(gin), ptr(Y), ptr(res), _row_stride(res), ptr(drop), ACT_TANH_RES, N, ptr(mesh.n_dev), 4,
-                      ptr(G), ptr(gres))
+                      ptr(G), ptr(gres), ptr(gin2))
             # G[:, 0] = g = dL/dy_pre;  gu_1 = L^ g -> column 1;  gu_2 = 2 L^ gu_1 - g -> column 2  (L^ symmetric)
             g = G.data_ptr()
             _spmm1(mesh, g, 4, 1.0, g + 4, 4)
             _spmm1(mesh, g + 4, 4, 2.0, g + 8, 4, p=g, ldp=4, beta=-1.0)
-        return G, (gbuf[:, :res.shape[1]] if gbuf is not None else None), None, None
+        return G, (gbuf[:, :res.shape[1]] if gbuf is not None else None), None, None, None
 
 
-def scalar_cheb3(U, res, drop, mesh):
-    return _ScalarCheb3.apply(U, res, drop, mesh)
+def scalar_cheb3(U, res, drop, mesh, alias=False):
+    """alias=True: returns (Y, Y again) -- see _ScalarCheb3.forward."""
+    return _ScalarCheb3.apply(U, res, drop, mesh, alias)
 
 
 def pad_bias_rows(W, Ks):
@@ -1013,15 +1024,21 @@ class _LstmCell(Function):
         return (*res, None, None)
 
 
-def _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, mesh, acc, use_idx, dgrad=None):
+def _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, mesh, acc, use_idx, dgrad=None, gHn2=None, add0=None):
     """(gG, gCprev, g_wc, g_b, g_ln) of the cell; the parameter gradients are None until the pass's last backward.
+    gHn2: a second gradient of H' (added to gHn: by qt_lstm_bwd_dgrad on load, else here); add0: (N, c) added to plane 0 of
+    the first part of `dgrad`'s planes (qt_lstm_bwd_dgrad only: the caller checks that this launch serves the use).
     dgrad = (Wrows, K, [part widths], [plane tensors (K, N, c)], out_sm): the data gradient of the gate GEMM, gG @ Wrows^T, is
     computed by the same launch (qt_lstm_bwd_dgrad) into the given planes (out_sm: planes 1.. slice-major); a tuple in the
     fifth place instead selects the opt-in launch that also accumulates the weight gradient (qt_lstm_bwd_fused)."""
     N, h = gates.shape[0], gates.shape[1] // 4
-    (gHn, ld_gh), (gCn, ld_gc) = _rows(gHn), _rows(gCn)
-    (gO, ld_go), (Cprev, ld_c) = _rows(gO), _rows(Cprev)
     fused_w = dgrad is not None and isinstance(dgrad[4], tuple)
+    if gHn2 is not None and (dgrad is None or fused_w or N == 0):
+        gHn, gHn2 = (gHn2 if gHn is None else gHn + gHn2), None          # (the other launches take one gradient of H')
+    assert add0 is None or (dgrad is not None and not fused_w)
+    (gHn, ld_gh), (gCn, ld_gc) = _rows(gHn), _rows(gCn)
+    (gHn2, ld_gh2) = _rows(gHn2)
+    (gO, ld_go), (Cprev, ld_c) = _rows(gO), _rows(Cprev)
     gG = None if (fused_w and N > 0) else torch.empty_like(gates)
     gCp = gates.new_empty(N, h) if Cprev is not None else None
     # (one slab row per workgroup of whichever kernel serves a use: k_lstm_bwd, k_dgrad_cell or the persistent fused launch)
@@ -1046,7 +1063,8 @@ def _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, mesh, acc, use_idx, dgrad
         _lib.call('qt_lstm_bwd_dgrad', ptr(gO), ld_go, ptr(gHn), ld_gh, ptr(gCn), ld_gc, ptr(gates), ptr(Cprev), ld_c,
                   ptr(wc), ptr(ln), N, ptr(mesh.n_dev), h, ptr(gG), ptr(gCp), ptr(part), 0 if acc is None else 1,
                   ptr(Wrows), ptr(split[0]) if split else None, ptr(split[1]) if split else None, K, Cl[0],
-                  Cl[1] if len(Cl) > 1 else 0, ptr(planes[0]), ptr(planes[1]) if len(Cl) > 1 else None, int(out_sm))
+                  Cl[1] if len(Cl) > 1 else 0, ptr(planes[0]), ptr(planes[1]) if len(Cl) > 1 else None, int(out_sm),
+                  ptr(gHn2), ld_gh2, ptr(add0))
     elif N > 0:
         if acc is None and nblk > _lib.value('qt_lstm_bwd_blocks', N, h):
             part.zero_()
@@ -1069,7 +1087,7 @@ class _GateCell(Function):
     gate O is returned as a column view of the saved gate activations.  Backward = the two backward passes."""
 
     @staticmethod
-    def forward(ctx, Za, Zb, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w, acc_p):
+    def forward(ctx, Za, Zb, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w, acc_p, alias_h=False, pass_x=False):
         _lib.require_cuda(Za, 'node features')
         Zs = _zparts(Za, Zb)
         W, wc, b, ln = _c(W.float()), _c(wc), _c(b), _c(ln)
@@ -1091,10 +1109,23 @@ class _GateCell(Function):
         ctx.use_w = acc_w.enter() if acc_w is not None else 0
         ctx.use_p = acc_p.enter() if acc_p is not None else 0
         ctx.set_materialize_grads(False)
-        return gates[:, 3 * h:], Hn, Cn
+        ctx.extras = (alias_h, pass_x)
+        # alias_h: H' again as a second output (the same storage) for a second consumer; pass_x: Za again as an output (for a
+        # consumer that would otherwise read Za itself).  A tensor with two consumers costs an elementwise gradient sum per use
+        # in autograd; this way both gradients arrive HERE and the backward launch adds them where it reads / writes anyway.
+        out = (gates[:, 3 * h:], Hn, Cn)
+        if alias_h:
+            out += (Hn.view_as(Hn),)
+        if pass_x:
+            out += (Za.view_as(Za),)
+        return out
 
     @staticmethod
-    def backward(ctx, gO, gHn, gCn):
+    def backward(ctx, gO, gHn, gCn, *gextra):
+        alias_h, pass_x = ctx.extras
+        gextra = list(gextra)
+        gHn2 = gextra.pop(0) if alias_h else None
+        gXp = gextra.pop(0) if pass_x else None
         nz = ctx.nz
         saved = ctx.saved_tensors
         Zs, TZs = list(saved[:nz]), list(saved[nz:2 * nz])
@@ -1124,24 +1155,35 @@ class _GateCell(Function):
                 dgrad = dgrad[:4] + ((Zs, TZs, S, ksp, Cs, wslab),)
                 osm = 0
                 w_fused = True
-        gG, gCp, gwc, gb, gln = _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, ctx.mesh, ctx.acc_p, ctx.use_p, dgrad)
+        # (the pass-through gradient of Za rides into plane 0 of part a when the fused launch writes that plane)
+        add0 = None
+        if gXp is not None and dgrad is not None and not w_fused and live and live[0] == 0 and N > 0:
+            add0 = _c(gXp.float())
+            assert add0.shape == (N, Cs[0])
+        gG, gCp, gwc, gb, gln = _lstm_backward(gO, gHn, gCn, gates, Cprev, wc, ln, ctx.mesh, ctx.acc_p, ctx.use_p, dgrad,
+                                               gHn2=gHn2, add0=add0)
         gZs, gW = _cheb_backward(Zs, TZs, W, gG, ctx.mesh, K, ctx.Ks, ctx.acc_w, ctx.use_w, need, ctx.needs_input_grad[2],
                                  gTs_pre=None if planes is None else (planes, osm), w_fused=w_fused, sm=ctx.sm)
         gZa = gZs[0] if gZs is not None else None
         gZb = gZs[1] if gZs is not None and nz > 1 else None
-        return gZa, gZb, gW, gCp, gwc, gb, gln, None, None, None, None, None
+        if gXp is not None and add0 is None and need[0]:
+            gZa = gXp if gZa is None else gZa + gXp
+        return gZa, gZb, gW, gCp, gwc, gb, gln, None, None, None, None, None, None, None
 
 
-def gate_cell(X, H, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w=None, acc_p=None):
+def gate_cell(X, H, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w=None, acc_p=None, alias_h=False, pass_x=False):
     """(O, LayerNorm_h(H'), LayerNorm_c(C')) of one GConvLSTM update from Z = [X | H] (H may be None) and the packed
-    gate weights W; X and H are passed as they are (column views of wider matrices included), never concatenated."""
+    gate weights W; X and H are passed as they are (column views of wider matrices included), never concatenated.
+    alias_h / pass_x: further outputs -- H' once more (for its second consumer) / X once more (for a second consumer of X):
+    the same values; on the fused path the same storage, with both gradients summed inside the backward launch."""
     C = X.shape[1] + (H.shape[1] if H is not None else 0)
     if W.shape[0] == K * C + Ks and Ks % 4:
         W = pad_bias_rows(W, Ks)
     if W.shape[1] in (32, 64, 128) and X.is_cuda:
-        return _GateCell.apply(X, H, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w, acc_p)
+        return _GateCell.apply(X, H, W, Cprev, wc, b, ln, mesh, K, Ks, acc_w, acc_p, alias_h, pass_x)
     G = cheb_poly((X, H), W, mesh, K, Ks, acc=acc_w)
-    return lstm_cell(G, Cprev, wc, b, ln, mesh, acc_p)
+    out = lstm_cell(G, Cprev, wc, b, ln, mesh, acc_p)
+    return tuple(out) + ((out[1],) if alias_h else ()) + ((X,) if pass_x else ())
 
 
 def lstm_cell(G, Cprev, wc, b, ln, mesh, acc=None):

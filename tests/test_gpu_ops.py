@@ -986,3 +986,30 @@ def test_scalar_cheb3_residual_as_column_view():
     for a, b in zip(outs[0][:3], outs[1][:3]):
         assert torch.equal(a, b)
     assert bool((outs[0][3][:, 1:] == 0).all())
+
+
+@pytest.mark.parametrize('h', [16, 8])
+def test_gate_cell_second_consumers_sum_inside_the_backward_launch(h):
+    """ops.gate_cell(alias_h=True, pass_x=True): H' and X handed out a second time for their second consumers (the decoder's
+    layer-0 state feeds layer 1 AND the next step; the decoder input is also the head's residual, model/seq2seq.py:152-186).
+    Same values as using H' / X twice, and the same gradients: the fused backward launch adds the second gradient of H' on
+    load and the pass-through gradient of X into plane 0 (tolerance: the sums are associated differently)."""
+    from qtmpnn import ops
+    mesh, _ = _mesh_64(7, noise=0.02, B=2)
+    N, K, Ks = mesh.N, 3, 1
+    torch.manual_seed(5)
+    X0, H0, C0 = torch.randn(N, 4, device=dev()), torch.randn(N, h, device=dev()), torch.randn(N, h, device=dev())
+    W0 = 0.2 * torch.randn(K * (4 + h) + 4, 4 * h, device=dev())
+    wc0, b0, ln0 = 0.1 * torch.randn(3, h, device=dev()), 0.1 * torch.randn(4, h, device=dev()), torch.randn(4, h, device=dev())
+    w1, w2, w3, w4 = (torch.randn(N, c, device=dev()) for c in (h, h, 4, h))
+    res = []
+    for alias in (True, False):
+        X, H, C, W = (t.clone().requires_grad_(True) for t in (X0, H0, C0, W0))
+        out = ops.gate_cell(X, H, W, C, wc0, b0, ln0, mesh, K, Ks, alias_h=alias, pass_x=alias)
+        O, Hn, Cn = out[:3]
+        Hn2, Xp = (out[3], out[4]) if alias else (Hn, X)
+        assert Hn2.data_ptr() == Hn.data_ptr() and Xp.data_ptr() == X.data_ptr()
+        loss = (Hn * w1).sum() + (Hn2 * w2).sum() + (Xp * w3).sum() + (Cn * w4).sum() + O.sum()
+        res.append(torch.autograd.grad(loss, [X, H, C, W]))
+    for a, b in zip(*res):
+        close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))

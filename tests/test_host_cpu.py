@@ -59,7 +59,7 @@ def test_bad_arguments_fail_loudly_without_gpu():
     assert lib.qt_lstm_fwd(None, None, 0, None, 0, None, None, None, 1, None, 16, None, None, None, None, None) == -1
     # every entry point refuses NULL / inconsistent arguments with an error code and a message naming itself -- no launch
     null_calls = {
-        'qt_lstm_bwd_dgrad': (None, 0, None, 0, None, 0, None, None, 0, None, None, 4, None, 16, None, None, None, 0, None, None, None, 3, 16, 0, None, None, 0, None),
+        'qt_lstm_bwd_dgrad': (None, 0, None, 0, None, 0, None, None, 0, None, None, 4, None, 16, None, None, None, 0, None, None, None, 3, 16, 0, None, None, 0, None, 0, None, None),
         'qt_lstm_bwd_fused': (None, 0, None, 0, None, 0, None, None, 0, None, None, 4, None, 16, None, None, 0, None, 3, 16, 0, None, None,
                               None, 0, None, None, 0, None, 3, 16, 0, None, 0, None, 0, None),
         'qt_flat_adam': (None, None, None, None, 0, None, None, 0.0, 0.9, 0.999, 1e-8, 10.0, None, None),

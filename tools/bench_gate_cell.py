@@ -71,7 +71,8 @@ def shape(name, K, Ca, Cab):
     _lib.call('qt_split_bf16', ptr(Wb), Wb.numel(), ptr(whi), ptr(wlo))
     bwd = lambda: _lib.call('qt_lstm_bwd_dgrad', ptr(gO), h, ptr(gH), h, ptr(gC), h, ptr(gates), ptr(Cp), h, ptr(wc), ptr(ln), CAP,
                             ptr(nvalid), h, ptr(gG), ptr(gCp), ptr(part), 1, ptr(Wb), ptr(whi), ptr(wlo), K, live[0], live[1] if len(live) > 1 else 0,
-                            ptr(planes[0]), ptr(planes[1]) if len(live) > 1 else None, int(os.environ.get('QT_PLANES_SM', '0')))
+                            ptr(planes[0]), ptr(planes[1]) if len(live) > 1 else None, int(os.environ.get('QT_PLANES_SM', '0')),
+                            None, 0, None)
     part.zero_()
     us = graph_time(bwd)
     NB = K * sum(live)
