@@ -49,6 +49,7 @@ extern "C" {
 #define QT_ACT_NONE 0
 #define QT_ACT_RELU 1
 #define QT_ACT_TANH_RES 2 /* y = tanh(drop * acc) + res */
+#define QT_ACT_RELU_BWD 3 /* y = acc where res > 0, else 0: the backward of QT_ACT_RELU applied to a data-gradient product (qt_dense2) */
 
 const char* qt_last_error(void);
 int qt_abi_version(void);
@@ -282,7 +283,11 @@ int qt_dense2(const float* a0, int lda0, const float* a_rest, const float* a0b, 
               const int32_t* n_dev, int act, const float* res, int res_stride, const float* drop, float* out, float* outb,
               int planes_sm /* bit 0: the INPUT planes 1 .. Ka-1 (a_rest / a_restb) are stored slice-major, (plane, 4-channel
               slice, N, 4), as qt_cheb_clip_fwd writes them; bit 1: the OUTPUT planes 1 .. Kb-1 are written slice-major, as
-              qt_cheb_clip_bwd reads them; plane 0 is row-major either way */, void* stream);
+              qt_cheb_clip_bwd reads them; plane 0 is row-major either way */,
+              const float* post_W, float* post_out /* optional pair, only with 16 output columns and W: a second product in the
+              epilogue, post_out (N, 4) = [act(out) | 1 0 0 0] @ post_W (20, 4) -- the decoder head's fc_out1 -> coefficient
+              columns of fc_out2 in one launch; same bits as a second qt_dense2 call on the stored rows */,
+              void* stream);
 
 /* Data-gradient product as a split-bf16 GEMM (gradients only): out planes (Kb, N, Cb) [| outb (Kb, N, Cbb)] = A (N rows of K floats,
  * row stride lda) @ B, B^T given as the two bf16 terms Whi + Wlo (Kb (Cb + Cbb), K) of qt_split_bf16 -- for the data gradient of

@@ -308,6 +308,10 @@ struct GemmArgs {
     float* outb;        // forward: second column part of every output plane, (Kb, M, Cbb); Cbb == 0: none
     int Cbb;
     int out_sm;         // output planes 1 .. Kb-1 slice-major (plane_piece)
+    // k_gemm_skinny<64> with NB = 16: a second product in the epilogue, post_out (M, 4) = [act(out) | 1 0 0 0] @ post_W (NB + 4, 4)
+    // (the decoder head: fc_out1's 16 channels -> the three coefficient columns of fc_out2, seq2seq.py:115-121)
+    const float* post_W;
+    float* post_out;
     int64_t row0_step;  // wgrad: rows per block
     const int32_t* n_dev;  // valid node rows on the device (NULL: A.N)
     int accumulate;        // wgrad: add into part instead of overwriting (sums several uses of one weight)
@@ -782,6 +786,7 @@ template <int RPB>
 __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g) {
     __shared__ const float* qptr[MAXQ];
     __shared__ int qstr[MAXQ];
+    __shared__ float hs[RPB == 64 ? 64 * 17 : 1];       // (post product: the 64 x 16 output tile, pitch 17)
     const int t = threadIdx.x;
     const int64_t rows = qt_rows(g.n_dev, g.M);
     const int64_t row0 = (int64_t)blockIdx.x * RPB;
@@ -822,10 +827,42 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g) {
         for (int u = 0; u < QT_SKINNY_INFLIGHT; ++u)
             if (Q + u < nquad) step(aq[u], Q + u);
     }
-    if (!ok) return;
+    const bool post = RPB == 64 && g.post_W != nullptr;       // (uniform; the host guarantees NB == 16: all four waves are here)
+    if (!ok && !post) return;
     float4 v = acc;
     if (g.act == QT_ACT_RELU) {
         v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+    }
+    if (g.act == QT_ACT_RELU_BWD && ok) {          // G = v * relu'(Y): k_act_bwd's arithmetic, Y = g.res (M, res_stride)
+        const float4 y = *reinterpret_cast<const float4*>(g.res + row * g.res_stride + j);
+        v.x = y.x > 0.0f ? v.x : 0.0f; v.y = y.y > 0.0f ? v.y : 0.0f; v.z = y.z > 0.0f ? v.z : 0.0f; v.w = y.w > 0.0f ? v.w : 0.0f;
+    }
+    if constexpr (RPB == 64) {
+        if (post) {
+            // the second product, by wave 0 from the tile in LDS: the same fused multiply-adds in the same order as a k_gemm_skinny<256>
+            // launch on the stored rows (quads 0 .. 3 of the row, then the bias quad (1, 0, 0, 0))
+            float* h = &hs[(t & 63) * 17 + j];
+            h[0] = v.x; h[1] = v.y; h[2] = v.z; h[3] = v.w;
+            __syncthreads();
+            if (t < 64 && ok) {
+                float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* r = &hs[t * 17];
+#pragma unroll
+                for (int Q = 0; Q <= 4; ++Q) {
+                    const float4 a = Q < 4 ? make_float4(r[4 * Q], r[4 * Q + 1], r[4 * Q + 2], r[4 * Q + 3]) : make_float4(1.f, 0.f, 0.f, 0.f);
+                    const float4 w0 = *reinterpret_cast<const float4*>(g.post_W + (4 * Q + 0) * 4);
+                    const float4 w1 = *reinterpret_cast<const float4*>(g.post_W + (4 * Q + 1) * 4);
+                    const float4 w2 = *reinterpret_cast<const float4*>(g.post_W + (4 * Q + 2) * 4);
+                    const float4 w3 = *reinterpret_cast<const float4*>(g.post_W + (4 * Q + 3) * 4);
+                    u.x = fmaf(a.x, w0.x, u.x); u.y = fmaf(a.x, w0.y, u.y); u.z = fmaf(a.x, w0.z, u.z); u.w = fmaf(a.x, w0.w, u.w);
+                    u.x = fmaf(a.y, w1.x, u.x); u.y = fmaf(a.y, w1.y, u.y); u.z = fmaf(a.y, w1.z, u.z); u.w = fmaf(a.y, w1.w, u.w);
+                    u.x = fmaf(a.z, w2.x, u.x); u.y = fmaf(a.z, w2.y, u.y); u.z = fmaf(a.z, w2.z, u.z); u.w = fmaf(a.z, w2.w, u.w);
+                    u.x = fmaf(a.w, w3.x, u.x); u.y = fmaf(a.w, w3.y, u.y); u.z = fmaf(a.w, w3.z, u.z); u.w = fmaf(a.w, w3.w, u.w);
+                }
+                *reinterpret_cast<float4*>(g.post_out + row * 4) = u;
+            }
+            if (!ok) return;
+        }
     }
     if (g.act == QT_ACT_TANH_RES) {
         const float d = g.drop ? g.drop[row] : 1.0f, rs = g.res[row * g.res_stride];
@@ -1928,8 +1965,12 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
                          int Ca, int Cab,
                          const float* W, const float* WT, const float* S, int Ks, const float* Ws, int Kb, int Cb, int Cbb, int N,
                          const int32_t* n_dev, int act, const float* res, int res_stride, const float* drop, float* out,
-                         float* outb, int planes_sm, void* stream) {
+                         float* outb, int planes_sm, const float* post_W, float* post_out, void* stream) {
     QT_ARG((W || WT) && out && Kb >= 1 && Cb >= 1 && Cbb >= 0 && (Cbb == 0 || outb), "bad arguments");
+    QT_ARG((post_W == nullptr) == (post_out == nullptr) && (!post_W || (W && Kb * (Cb + Cbb) == 16 && (((uintptr_t)post_W | (uintptr_t)post_out) & 15) == 0)),
+           "the second product needs 16 output columns, W (not WT) and 16-byte aligned post_W (20, 4) / post_out (N, 4)");
+    QT_ARG(act != QT_ACT_RELU_BWD || (res && res_stride >= Kb * (Cb + Cbb) && res_stride % 4 == 0 && W && Kb * (Cb + Cbb) <= 16 && Kb * (Cb + Cbb) > 4),
+           "QT_ACT_RELU_BWD: res = the forward output (N, res_stride), 8 .. 16 output columns, W (not WT)");
     QT_ARG((Ks == 0) || Ws || WT, "Ws missing");
     QT_ARG(Ks == 0 || WT || Ws == W + (int64_t)Ka * (Ca + Cab) * Kb * (Cb + Cbb), "Ws must follow W contiguously ([W ; Ws] is one matrix)");
     QT_ARG(act == QT_ACT_NONE || (Kb == 1 && Cbb == 0), "activation needs one undivided output plane");
@@ -1946,11 +1987,12 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
     g.dbg = g_dbg;
 #endif
     g.Kb = Kb; g.Cb = Cb; g.act = act; g.res = res; g.res_stride = res_stride; g.drop = drop; g.out = out; g.row0_step = 0; g.n_dev = n_dev; g.accumulate = 0;
+    g.post_W = post_W; g.post_out = post_out;
     // default: exact fp32 MFMA (bit-for-bit a k-ordered fmaf chain).  QT_GEMM_BF16X3=1 opts into the bf16x3 split
     // kernels (fp32-level error, ~8 % faster on these memory/latency-shaped GEMMs: measured 27.7 vs 30.1 us).
     static const bool exact_fp32 = getenv("QT_GEMM_BF16X3") == nullptr;
     static const bool no_skinny = getenv("QT_GEMM_NO_SKINNY") != nullptr;
-    if (!no_skinny && g.NB <= 16 && W) {       // (wide outputs of short reductions measured slower here: 24.5 vs 14.5 us)
+    if ((!no_skinny || post_W || act == QT_ACT_RELU_BWD) && g.NB <= 16 && W) {       // (wide outputs of short reductions measured slower here: 24.5 vs 14.5 us)
         if (g.NB <= 4)
             hipLaunchKernelGGL((k_gemm_skinny<256>), dim3(qt_cdiv(N, 256), 1, 1), dim3(256), 0, (hipStream_t)stream, g);
         else
@@ -2019,7 +2061,7 @@ extern "C" int qt_dense(const float* a0, const float* a_rest, int Ka, int Ca, co
                         const float* Ws, int Kb, int Cb, int N, const int32_t* n_dev, int act, const float* res,
                         int res_stride, const float* drop, float* out, void* stream) {
     return qt_dense2(a0, 0, a_rest, nullptr, 0, nullptr, Ka, Ca, 0, W, nullptr, S, Ks, Ws, Kb, Cb, 0, N, n_dev, act, res, res_stride, drop, out,
-                     nullptr, 0, stream);
+                     nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int qt_lstm_dgrad_blocks(int N) { return N <= 0 ? 0 : qt_cdiv(N, BM); }

@@ -227,11 +227,11 @@ class Decoder(nn.Module):
             y = self.fc_out2(torch.relu(self.fc_out1(torch.cat(z, dim=1), mesh, packed=p1)), mesh, packed=p2)
             y = torch.tanh(y if drop is None else y * drop.unsqueeze(1)) + X[:, :1]
             return (torch.sigmoid(y) if self.binary else y), hs, cs
-        z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'])
         if pk.get('fc2c') is not None:
-            # fc_out2 has ONE output channel: its three coefficient columns are applied first (a 16 -> 4 product) and the
-            # Chebyshev recurrence then runs on single columns -- 4 bytes per row and neighbour instead of z's 64-byte rows
-            U = ops.cheb_poly(z, pk['fc2c'], mesh, 1, 1, acc=pk['acc2'])                     # (N, 4) = z [w_0 w_1 w_2 0] + [b 0 0 0]
+            # fc_out2 has ONE output channel: its three coefficient columns are applied first (a 16 -> 4 product, in the epilogue
+            # of fc_out1's launch) and the Chebyshev recurrence then runs on single columns -- 4 bytes per row and neighbour
+            # instead of z's 64-byte rows;  U (N, 4) = z [w_0 w_1 w_2 0] + [b 0 0 0]
+            z, U = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'], post=(pk['fc2c'], pk['acc2']))
             # (the output has two consumers -- the loss, and the next step's input through the re-mesh: the second one takes the
             # alias `state_output`, so that the two gradients are summed inside the head's backward launch)
             Y, Y2 = ops.scalar_cheb3(U, Xres, drop, mesh, alias=True)
@@ -239,6 +239,7 @@ class Decoder(nn.Module):
             if not self.binary:
                 self.state_output = Y2[:, :1]
         else:
+            z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'])
             # the head GEMM writes float4 rows; column 0 is the prediction (the rest is tanh(0) + X[:, 0], never read as data)
             y = ops.cheb_poly(z, pk['fc2'], mesh, self.fc_out2.K, 1, ops.ACT_TANH_RES, res=Xres, drop=drop, acc=pk['acc2'])[:, :1]
         if self.binary:

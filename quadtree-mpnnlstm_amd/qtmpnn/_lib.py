@@ -38,7 +38,7 @@ _SIGNATURES = {
     'qt_sse': [_P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
     'qt_spmm': [_P, _P, _P, _I, _P, _I, _P, _F, _P, _F, _P, _F, _P, _P],
     'qt_spmm1': [_P, _P, _P, _P, _I, _P, _P, _I, _F, _P, _I, _F, _P, _I, _F, _P, _I, _I, _I, _P, _I, _P, _P],
-    'qt_dense2': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P],
+    'qt_dense2': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     'qt_spmm2': [_P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _F, _F, _F, _P, _P],
     'qt_cheb_clip_rows': [],
     'qt_cheb_clip_width': [_I],

@@ -11,7 +11,8 @@ from . import _lib
 from ._lib import ptr
 from .mesh import spmm, spmm2
 
-ACT_NONE, ACT_RELU, ACT_TANH_RES = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_TANH_RES, ACT_RELU_BWD = 0, 1, 2, 3
+_HEAD_FUSE = os.environ.get('QT_NO_HEAD_FUSE') != '1'      # (A/B switch: 1 = the decoder head's two products as two launches each way)
 
 # Arithmetic of the backward pass's gate-GEMM data gradient (gG W^T).  False (default): exact fp32 products on the fp32 MFMA,
 # like every other product of the path and like the reference (model/model.py:394-463 is fp32 throughout).  True: the opt-in
@@ -389,7 +390,7 @@ def _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, acc, use_idx, need_gZ, need_gW, g
                 _lib.call('qt_dense2', ptr(G), 0, None, None, 0, None, 1, Co, 0, ptr(Wb) if skinny else None,
                           None if skinny else ptr(Wb), None, 0, None, K, Cl[0],
                           Cl[1] if len(Cl) > 1 else 0, N, ptr(mesh.n_dev), ACT_NONE, None, 0, None, ptr(gTs[0]),
-                          ptr(gTs[1]) if len(Cl) > 1 else None, 2 * gsm)
+                          ptr(gTs[1]) if len(Cl) > 1 else None, 2 * gsm, None, None)
         # Clenshaw: b_k = A_k + 2 L^ b_{k+1} - b_{k+2}, in place;  gZ = A_0 + L^ b_1 - b_2
         if clip:                                # all hops in one launch; only plane 0 (= gZ) is rewritten
             clip_clenshaw(mesh, gTs, K, gsm)
@@ -445,7 +446,10 @@ class _ChebPoly(Function):
     """
 
     @staticmethod
-    def forward(ctx, Za, Zb, W, res, drop, mesh, K, Ks, act, acc):
+    def forward(ctx, Za, Zb, W, res, drop, mesh, K, Ks, act, acc, W2=None, acc2=None):
+        """W2 (Co + 4, 4), Co = 16: a second product in the same launch, U = [Y | 1 0 0 0] @ W2 (an ordinary K = 1 cheb_poly
+        with one bias row on the 16 output channels: the decoder head's fc_out1 -> coefficient columns of fc_out2); returns
+        (Y, U).  Its backward is fused the other way round: gU @ W2^T and Y's ReLU gradient in one launch."""
         _lib.require_cuda(Za, 'node features')
         Zs, W = _zparts(Za, Zb), _c(W.float())
         N = Zs[0].shape[0]
@@ -457,23 +461,55 @@ class _ChebPoly(Function):
         S = mesh.cheb_ones(Ks) if Ks else None
         Y = Zs[0].new_empty(N, Co)
         drop = _c(drop)
-        _lib.call('qt_dense2', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(W), ptr(_w_t(W, acc)), ptr(S), ksp,
+        U = None
+        if W2 is not None:
+            W2 = _c(W2.float())
+            assert Co == 16 and W2.shape == (Co + 4, 4) and act in (ACT_NONE, ACT_RELU), (Co, W2.shape, act)
+            U = Y.new_empty(N, 4)
+        _lib.call('qt_dense2', *_plane_args(Zs, TZs), K, Cs[0], Cs[1] if len(Cs) > 1 else 0, ptr(W),
+                  None if W2 is not None else ptr(_w_t(W, acc)), ptr(S), ksp,
                   ptr(W[K * sum(Cs):]) if Ks else None, 1, Co, 0, N, ptr(mesh.n_dev), act, ptr(res), _row_stride(res), ptr(drop),
-                  ptr(Y), None, sm)
+                  ptr(Y), None, sm, ptr(W2), ptr(U))
         ctx.mesh, ctx.K, ctx.Ks, ctx.act, ctx.acc, ctx.nz, ctx.sm = mesh, K, Ks, act, acc, len(Zs), sm
         ctx.use_idx = acc.enter() if acc is not None else 0
-        ctx.save_for_backward(*Zs, *TZs, W, Y if act != ACT_NONE else None, res, drop)
+        ctx.acc2 = acc2
+        ctx.use_idx2 = acc2.enter() if (W2 is not None and acc2 is not None) else 0
+        ctx.save_for_backward(*Zs, *TZs, W, Y if (act != ACT_NONE or W2 is not None) else None, res, drop, W2)
+        if W2 is not None:
+            ctx.set_materialize_grads(False)
+            return Y, U
         return Y
 
     @staticmethod
-    def backward(ctx, gY):
+    def backward(ctx, gY, gU=None):
         nz = ctx.nz
         saved = ctx.saved_tensors
         Zs, TZs = list(saved[:nz]), list(saved[nz:2 * nz])
-        W, Y, res, drop = saved[2 * nz:]
+        W, Y, res, drop, W2 = saved[2 * nz:]
         mesh, K, Ks, act = ctx.mesh, ctx.K, ctx.Ks, ctx.act
         N = Zs[0].shape[0]
         Co = W.shape[1]
+        gW2 = None
+        if W2 is not None:
+            # the second product's backward: its weight gradient is deferred like any other (Z = Y, one plane), its data gradient
+            # gU @ W2[:Co]^T lands in this op's own incoming gradient -- with Y's ReLU gradient applied by the same launch
+            if gU is None:
+                gU = Y.new_zeros(N, 4)
+            gU = _c(gU.float())
+            _, gW2 = _cheb_backward([Y], [Y.new_empty(1, 0, Co)], W2, gU, mesh, 1, 1, ctx.acc2, ctx.use_idx2, False,
+                                    ctx.needs_input_grad[10])
+            Wb2, _ = _dgrad_weight(W2, 1, [Co], [0], ctx.acc2)               # (4, Co): W2[:Co]^T
+            G = Y.new_empty(N, Co)
+            fuse = act == ACT_RELU and gY is None
+            if N > 0:
+                _lib.call('qt_dense2', ptr(gU), 0, None, None, 0, None, 1, 4, 0, ptr(Wb2), None, None, 0, None, 1, Co, 0, N,
+                          ptr(mesh.n_dev), ACT_RELU_BWD if fuse else ACT_NONE, ptr(Y) if fuse else None, Co if fuse else 0, None,
+                          ptr(G), None, 0, None, None)
+            if fuse:
+                act = ACT_NONE                      # (done)
+            elif gY is not None:
+                G = G + gY.float()
+            gY = G
         G = _c(gY.float())
         gres = None
         if act != ACT_NONE:
@@ -489,7 +525,7 @@ class _ChebPoly(Function):
                                  list(ctx.needs_input_grad[:nz]), ctx.needs_input_grad[2], sm=ctx.sm)
         gZa = gZs[0] if gZs is not None else None
         gZb = gZs[1] if gZs is not None and nz > 1 else None
-        return gZa, gZb, gW, gres, None, None, None, None, None, None
+        return gZa, gZb, gW, gres, None, None, None, None, None, None, gW2, None
 
 
 def _wgrad_group(uses, W, K, Cs, ksp, Co):
@@ -594,13 +630,23 @@ def pad_bias_rows(W, Ks):
     return torch.nn.functional.pad(W, (0, 0, 0, pad)) if pad else W
 
 
-def cheb_poly(Z, W, mesh, K, Ks, act=ACT_NONE, res=None, drop=None, acc=None):
+def cheb_poly(Z, W, mesh, K, Ks, act=ACT_NONE, res=None, drop=None, acc=None, post=None):
     """Z: one (N, C) matrix or a pair (Za, Zb) standing for [Za | Zb].  W: ((K*C + Ks [padded to a multiple of 4]), Co).
-    acc: GradAcc shared by all uses of W in this pass."""
+    acc: GradAcc shared by all uses of W in this pass.  post = (W2 (Co + 1 [padded to Co + 4], 4), acc2): returns (Y, U) with
+    U = cheb_poly(Y, W2, mesh, 1, 1, acc=acc2) computed by the same launch (Co = 16 on the GPU; else two calls)."""
     Za, Zb = Z if isinstance(Z, (tuple, list)) else (Z, None)
     C = Za.shape[1] + (Zb.shape[1] if Zb is not None else 0)
     if W.shape[0] == K * C + Ks and Ks % 4:
         W = pad_bias_rows(W, Ks)
+    if post is not None:
+        W2, acc2 = post
+        Co = W.shape[1]
+        if W2.shape[0] == Co + 1:
+            W2 = pad_bias_rows(W2, 1)
+        if _HEAD_FUSE and Co == 16 and W2.shape == (Co + 4, 4) and act in (ACT_NONE, ACT_RELU) and Za.is_cuda:
+            return _ChebPoly.apply(Za, Zb, W, res, drop, mesh, K, Ks, act, acc, W2, acc2)
+        Y = _ChebPoly.apply(Za, Zb, W, res, drop, mesh, K, Ks, act, acc)
+        return Y, _ChebPoly.apply(Y, None, W2, None, None, mesh, 1, 1, ACT_NONE, acc2)
     return _ChebPoly.apply(Za, Zb, W, res, drop, mesh, K, Ks, act, acc)
 
 

@@ -583,7 +583,7 @@ def test_proj_group_and_grouped_weight_gradient_equal_dense_calls():
     for h in range(G):
         Y = torch.empty(N, co, device=dev())
         _lib.call('qt_dense2', ptr(A[h]), 0, None, None, 0, None, 1, cin, 0, ptr(W[h]), None, ptr(ones), 4, ptr(W[h][cin:]), 1, co, 0, N, None,
-                  0, None, 0, None, ptr(Y), None, 0)
+                  0, None, 0, None, ptr(Y), None, 0, None, None)
         assert torch.equal(P[h].permute(1, 0, 2).reshape(N, co), Y), h
     # data gradient: gA_g = gP_g W_g[:cin]^T from the planes of gP (the forward weight's rows are the transposed operand)
     gP = torch.randn_like(P)
@@ -1013,3 +1013,31 @@ def test_gate_cell_second_consumers_sum_inside_the_backward_launch(h):
         res.append(torch.autograd.grad(loss, [X, H, C, W]))
     for a, b in zip(*res):
         close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+
+
+def test_head_products_in_one_launch_each_way():
+    """ops.cheb_poly(post=...): the decoder head's fc_out1 (K = 3, 20 -> 16, ReLU) and the coefficient columns of fc_out2
+    (16 -> 4, model/seq2seq.py:115-121,160-186) as ONE launch forward (second product in the epilogue) and the second product's
+    data gradient + the ReLU gradient as ONE launch backward -- against the two cheb_poly calls they replace: Y, U and every
+    gradient bit for bit (the same fused multiply-adds in the same order)."""
+    from qtmpnn import ops
+    mesh, _ = _mesh_64(9, noise=0.02, B=2)
+    N = mesh.N
+    torch.manual_seed(2)
+    Za0, Zb0 = torch.randn(N, 16, device=dev()), torch.randn(N, 4, device=dev())
+    W10 = 0.2 * torch.randn(3 * 20 + 1, 16, device=dev())
+    W20 = 0.3 * torch.randn(16 + 1, 4, device=dev())
+    gU = torch.randn(N, 4, device=dev())
+    res = []
+    for fuse in (True, False):
+        prev, ops._HEAD_FUSE = ops._HEAD_FUSE, fuse
+        try:
+            Za, Zb, W1, W2 = (t.clone().requires_grad_(True) for t in (Za0, Zb0, W10, W20))
+            acc1, acc2 = ops.GradAcc(), ops.GradAcc()
+            Y, U = ops.cheb_poly((Za, Zb), W1, mesh, 3, 1, ops.ACT_RELU, acc=acc1, post=(W2, acc2))
+            grads = torch.autograd.grad(U, [Za, Zb, W1, W2], gU)
+        finally:
+            ops._HEAD_FUSE = prev
+        res.append((Y.detach(), U.detach(), *grads))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

@@ -28,7 +28,7 @@ def shape(name, K, Ca, Cab, Co, Kb=1, Cb=None, Cbb=0, ks=4, act=0):
     out = torch.empty(Kb, N, Cb, device=dev); outb = torch.empty(Kb, N, Cbb, device=dev) if Cbb else None
     res = torch.randn(N, 4, device=dev)
     fn = lambda: _lib.call('qt_dense2', ptr(Za), 0, ptr(TZa), ptr(Zb), 0, ptr(TZb), K, Ca, Cab, ptr(W), None, ptr(S), ks,
-                           ptr(W[K * (Ca + Cab):]) if ks else None, Kb, Cb, Cbb, N, None, act, ptr(res), 4, None, ptr(out), ptr(outb))
+                           ptr(W[K * (Ca + Cab):]) if ks else None, Kb, Cb, Cbb, N, None, act, ptr(res), 4, None, ptr(out), ptr(outb), 0, None, None)
     print(f'{name:34s} {timeit(fn):7.2f} us')
     return out
 shape('fc1 fwd  (N x 64)(64 x 16) relu', 3, 16, 4, 16, act=1)
