@@ -68,7 +68,7 @@ def make_predictor(device, capturable=False):
     return nfp
 
 
-def spmm_roofline(nfp, batch, mask, reps=10):
+def spmm_roofline(nfp, batch, mask, reps=10, traffic_files=('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_spmm.json')):
     """Roofline of the message-aggregate kernels, measured live with HIP events on the launch stream.
 
     One extra (untimed) eager forward + backward records every message-aggregate launch of the real workload: the clip-resident
@@ -77,12 +77,14 @@ def spmm_roofline(nfp, batch, mask, reps=10):
     hipGraph, so that the device and not the host call is timed) between two events on the replay stream with same-shaped
     operands, and the per-launch averages are summed: the figure covers exactly the launch mix of one training step.
 
-    Algorithmic bytes.  The unit of work is one message-aggregate hop, SURVEY.md 8(d): 4(N+1) + 8E' + 8NC
-    bytes (index arrays + every feature row read once + every output row written once); a launch is priced at that figure x the
-    hops it processes (`achieved`, `frac`: 1 hop for k_spmm, K - 1 for a clip-resident launch).  `fused_own_bytes` is the
-    stricter count for the fused launches: what THEY must move through HBM -- index arrays once, Z once and K - 1 planes out
-    (forward: 4(N+1) + 8E' + 4NC K), or K gradient planes in and one out (backward: 4(N+1) + 8E' + 4NC (K + 1)); the
-    intermediate planes of a fused recurrence are never re-read from HBM.  `traffic` (PMC) is what actually crossed the fabric."""
+    Algorithmic bytes.  A per-hop launch moves SURVEY.md 8(d)'s 4(N+1) + 8E' + 8NC bytes (index arrays +
+    every feature row read once + every output row written once).  A fused launch (all K - 1 hops) is priced on what IT must
+    move through HBM -- index arrays once, Z once and K - 1 planes out (forward: 4(N+1) + 8E' + 4NC K), or K gradient planes in
+    and one out (backward: 4(N+1) + 8E' + 4NC (K + 1)); the intermediate planes of a fused recurrence are never re-read from
+    HBM.  `achieved` / `frac` use these per-launch bytes; `equivalent_unfused` keeps the hops x per-hop pricing of rounds 1 - 3
+    for comparison; `traffic` (PMC) is what actually crossed the fabric.  Works for any workload / frame size (tools/
+    bench_configs.py calls it for the 128x128 and 256x256 configurations, whose hops are per-hop k_spmm launches or tile-
+    resident launches)."""
     import torch
     from qtmpnn import mesh as qmesh, ops
     records = []
@@ -171,12 +173,17 @@ def spmm_roofline(nfp, batch, mask, reps=10):
         pk['us'] += us
         pk['bytes'] += by
     n = len(records)
-    achieved = tot['hop_bytes'] / (tot['us'] * 1e-6) / 1e9          # SURVEY 8(d)'s per-hop figure x the hops a launch processes
-    own = tot['bytes'] / (tot['us'] * 1e-6) / 1e9                   # the fused launches' own compulsory bytes (stricter)
+    # `achieved` / `frac`: the bytes a launch MUST move through HBM (algorithmic, per launch) / its measured duration.  A fused
+    # launch is priced on its own compulsory bytes -- index arrays + Z once + K - 1 planes out (backward: K planes in, one
+    # out) --, NOT on hops x the per-hop figure: the intermediate planes of a fused recurrence never cross HBM, and crediting
+    # them overstated the fraction by 1.4 - 1.65 x (round-3 advisor finding).  The per-hop pricing stays as
+    # `equivalent_unfused` (what the same hops would have moved as K - 1 separate launches: comparable with rounds 1 - 2).
+    unfused = tot['hop_bytes'] / (tot['us'] * 1e-6) / 1e9
+    achieved = tot['bytes'] / (tot['us'] * 1e-6) / 1e9
     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes over this same command (they cannot be collected
     # in-process); the newest committed record is quoted and named
     traffic = source = None
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_spmm.json'):
+    for name in traffic_files:
         pmc = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pmc):
             traffic, source = json.load(open(pmc))['traffic_bytes_per_launch'], 'profiles/' + name
@@ -186,18 +193,25 @@ def spmm_roofline(nfp, batch, mask, reps=10):
              {'launches_per_step': v['launches'], 'avg_launch_us': round(v['us'] / v['launches'], 2),
               'avg_bytes_per_launch': round(v['bytes'] / v['launches']),
               'achieved_gbs': round(v['bytes'] / (v['us'] * 1e-6) / 1e9, 1)} for k, v in per_kind.items()}
-    return {'bound': 'hbm', 'kernel': 'k_cheb_clip (clip-resident multi-hop message aggregate)' if fused else 'k_spmm',
-            'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': source,
-            'launches_per_step': n, 'hops_per_step': tot['hops'], 'avg_launch_us': round(tot['us'] / n, 2),
-            'us_per_step': round(tot['us'], 1), 'avg_bytes_per_launch': round(tot['hop_bytes'] / n),
-            'avg_us_per_hop': round(tot['us'] / max(tot['hops'], 1), 2), 'kernels': kinds,
-            'fused_own_bytes': {'achieved': round(own, 1), 'frac': round(own / HBM_PEAK_GBS, 4),
-                                'avg_bytes_per_launch': round(tot['bytes'] / n),
-                                'note': 'the stricter count: a fused launch priced on the bytes IT must move (index arrays + Z '
-                                        'once + K-1 planes out; backward K planes in + one out), not on hops x the per-hop figure'},
-            'bytes_formula': "per hop 4(N+1) + 8E' + 8NC (SURVEY 8(d)); fused K-1 hops: forward 4(N+1) + 8E' + 4NC K, "
-                             "backward 4(N+1) + 8E' + 4NC (K+1)"}
+    rec = {'bound': 'hbm', 'kernel': 'k_cheb_clip (clip-resident multi-hop message aggregate)' if fused else 'k_spmm',
+           'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+           'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': source,
+           'launches_per_step': n, 'hops_per_step': tot['hops'], 'avg_launch_us': round(tot['us'] / n, 2),
+           'us_per_step': round(tot['us'], 1), 'avg_bytes_per_launch': round(tot['bytes'] / n),
+           'avg_us_per_hop': round(tot['us'] / max(tot['hops'], 1), 2), 'kernels': kinds,
+           'equivalent_unfused': {'achieved': round(unfused, 1), 'frac': round(unfused / HBM_PEAK_GBS, 4),
+                                  'avg_bytes_per_launch': round(tot['hop_bytes'] / n),
+                                  'note': "SURVEY 8(d)'s per-hop figure x the hops a launch processes: what K - 1 separate "
+                                          'launches would have moved; a fused launch never re-reads its intermediate planes, so '
+                                          'this is NOT HBM traffic (rounds 1-3 reported it as `frac`)'},
+           'bytes_formula': "per launch: k_spmm (one hop) 4(N+1) + 8E' + 8NC (SURVEY 8(d)); fused K-1 hops: forward "
+                            "4(N+1) + 8E' + 4NC K, backward 4(N+1) + 8E' + 4NC (K+1)"}
+    if fused:
+        rec['limiter'] = ('not HBM: one CU\'s vector issue + LDS per workgroup (SQ counters: profiles/r03_pmc_clip_sq.json); '
+                          '`bound` names the roof the contract prices against')
+    if traffic:
+        rec['traffic_gbs'] = round(traffic / (tot['us'] / n * 1e-6) / 1e9, 1)
+    return rec
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= the fp32 vector rate)
@@ -319,11 +333,12 @@ def main():
     import torch
     import torch.distributed as dist
     from qtmpnn import ops, synthetic
-    from qtmpnn.dist import broadcast_parameters, init_from_env
+    from qtmpnn.dist import HostBarrier, broadcast_parameters, init_from_env
 
     # QT_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box); the real runs use RCCL
     rank, world, local = init_from_env(os.environ.get('QT_DIST_BACKEND', 'nccl'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    side = HostBarrier()                 # (collective: every rank, right after init)
     device = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     assert not ops.DGRAD_SPLIT_BF16, 'the headline is the exact-fp32 step: unset QT_DGRAD_SPLIT_BF16'
@@ -351,19 +366,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    hb_count = [0]
-
-    def host_barrier(poll=0.05):
-        """All ranks meet through the rendezvous store, polling on the HOST: a rank that waits here for rank 0's seconds of
-        single-rank work sits in no RCCL collective (nothing for the watchdog to time, no GPU spin)."""
-        if world == 1:
-            return
-        store = dist.distributed_c10d._get_default_store()
-        hb_count[0] += 1
-        key = f'qt_bench_hb{hb_count[0]}'
-        store.add(key, 1)
-        while int(store.add(key, 0)) < world:
-            time.sleep(poll)
+    def host_barrier():
+        """All ranks meet on the HOST (gloo side group created at init, qtmpnn.dist.HostBarrier): a rank that waits here for
+        rank 0's seconds of single-rank work sits in no RCCL collective (nothing for the watchdog to time, no GPU spin)."""
+        side.wait()
 
     def set_lr(opt, v):
         g = opt.param_groups[0]
@@ -491,6 +497,7 @@ def main():
         global_batch = args.batch * world
         frames = global_batch * (T_IN + T_OUT) * args.steps
         srt = sorted(windows)
+        med_ms = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
         line = {
             'metric': 'frames/sec (train fwd+bwd), 64x64 MovingMNIST in=10/out=10', 'value': round(frames / dt, 1),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -507,7 +514,7 @@ def main():
                        'final_loss': round(final_loss, 6)},
             'frozen_ms_per_step': None if frozen is None else round(frozen, 3),
             'window_ms_per_step': [round(w, 3) for w in windows],
-            'median_ms_per_step': round(srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2]), 3),
+            'median_ms_per_step': round(med_ms, 3), 'median_value': round(global_batch * (T_IN + T_OUT) / med_ms * 1e3, 1),
             'spread_ms_per_step': round(srt[-1] - srt[0], 3),
             'rank_ms_per_step': {'min': round(min(per_rank) / args.steps * 1e3, 3), 'max': round(max(per_rank) / args.steps * 1e3, 3)},
         }

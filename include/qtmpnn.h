@@ -42,7 +42,9 @@ extern "C" {
 #define QT_COND_MIN_SMALLER 3
 
 /* tail edges (edges 5, 6, .. of a row) kept per clip for the clip-resident recurrence kernel: pool entries per clip */
+#ifndef QT_TAIL_CAP /* (a test build shrinks it to force the pool-overflow path: csrc/Makefile, target smallcaps) */
 #define QT_TAIL_CAP 4080
+#endif
 #define QT_TAIL_CNT_STRIDE 32 /* ints between the per-clip tail counters (one 128-byte line each): [0] tail edges, [1] rows with a tail */
 #define QT_TAIL_REC_CAP 4096 /* records (rows with more than four edges) per clip = the most rows a clip-resident clip can have */
 
@@ -247,19 +249,19 @@ int qt_spmm2(const int32_t* rowptr, const int32_t* col, const float* nrm, int N,
  * qt_cheb_clip_bwd: Clenshaw on the gradient planes Ga (K, N, Ca), Gb (K, N, Cb): plane 0 is overwritten with
  *   A_0 + L^ b_1 - b_2, b_k = A_k + 2 L^ b_{k+1} - b_{k+2}; planes 1 .. K - 1 are left as given (the b_k stay in LDS). */
 int qt_cheb_clip_rows(void);
-/* Channels per workgroup of the two launches below: 0 (default) = automatic -- 2 when B * (Ca + Cb) / 2 workgroups fit the
- * CUs in one round (a hop is bound by the CU's LDS, so half-width slices on twice the CUs are faster), else 4; 2 or 4 pins it
- * (diagnostics, parity tests of both widths: the planes are the same bit for bit).  Returns the previous setting. */
-int qt_cheb_clip_width(int w);
+/* width: channels per workgroup of the two launches below: 0 = automatic -- 2 when B * (Ca + Cb) / 2 workgroups fit the CUs in
+ * one round (a hop is bound by the CU's LDS, so half-width slices on twice the CUs are faster), else 4; 2 or 4 pins it
+ * (diagnostics, parity tests of both widths: the planes are the same bit for bit).  An argument, not a library switch: the
+ * library keeps no mutable global state besides the thread-local error string. */
 int qt_cheb_clip_fwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* node_off,
                      const int32_t* tail_cnt, const int32_t* tail_pool, const int32_t* tail_rec,
                      int B, int N, int K, int Ca, const float* za, int lda, float* Ta,
-                     int Cb, const float* zb, int ldb, float* Tb, void* stream);
+                     int Cb, const float* zb, int ldb, float* Tb, int width, void* stream);
 int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* node_off,
                      const int32_t* tail_cnt, const int32_t* tail_pool, const int32_t* tail_rec,
                      int B, int N, int K, int Ca, float* Ga, int Cb, float* Gb,
                      int planes_sm /* != 0: planes 1 .. K-1 of Ga / Gb are slice-major (written so by qt_lstm_bwd_dgrad / qt_dense2) */,
-                     void* stream);
+                     int width, void* stream);
 
 /* qt_dense: out planes = act( [A planes | S] @ [W ; Ws] ), the gate GEMM.
  *   A: Ka planes, plane k at a0 (k == 0) or a_rest + (k-1)*N*Ca, each (N, Ca)   (T_0 = Z stays in the caller's tensor)

@@ -114,20 +114,6 @@ template <int W> __device__ __forceinline__ void vfma(fvec<W>& a, float w, const
     for (int i = 0; i < W; ++i) a[i] = __builtin_fmaf(w, f[i], a[i]);
 }
 
-// The first four edges of a row: the gathers are issued together, then the chain in ELL order
-template <int W>
-__device__ __forceinline__ fvec<W> gather_head(const char* __restrict__ P, unsigned l01, unsigned l23, const float (&w)[4]) {
-    fvec<W> f[4];
-    f[0] = lds_row<W>(P, l01 & 0xffffu);
-    f[1] = lds_row<W>(P, l01 >> 16);
-    f[2] = lds_row<W>(P, l23 & 0xffffu);
-    f[3] = lds_row<W>(P, l23 >> 16);
-    fvec<W> a = vzero<W>();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) vfma<W>(a, w[e], f[e]);
-    return a;
-}
-
 // The tail of a row with more than four edges, from the LDS copy of the clip's pool.  Four pool entries and their four
 // gathers are in flight per trip; the accumulation order is the CSR order, as in k_spmm.
 template <int W>
@@ -146,7 +132,8 @@ __device__ __forceinline__ void gather_tail_lds(fvec<W>& a, const char* __restri
     }
 }
 
-// (pool full -- a clip with more than CL_TAIL tail edges: the row walks the CSR arrays instead; correct, slow, rare)
+// (pool full -- a clip with more than CL_TAIL tail edges: the row walks the CSR arrays instead; correct, slow, rare.  Forced
+// by the small-caps test build: tests/test_gpu_ops.py::test_clip_resident_pool_overflow_walks_the_csr)
 template <int W>
 __device__ __forceinline__ void gather_tail_csr(fvec<W>& a, const char* __restrict__ P, unsigned row, int r0,
                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
@@ -194,8 +181,9 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
     // least four pixels (a one-pixel cell has at most four neighbours), which frees three slots of the n x m <= 4096.  The
     // thread that owns slot nr + j runs that row entirely (first four edges from the record, then the pool entries, then the
     // row's finish), so the tail loop runs in the two or three waves that hold records, with every lane busy; the row's own
-    // thread still writes the first plane and gathers, but stores nothing.  Records that found no slot (never, see above) are
-    // re-read from memory in every hop by the loop at the end of `hop`.
+    // thread still writes the first plane and gathers, but stores nothing.  Every record finds a slot: rows + rows with a tail
+    // <= pixels <= CL_ROWS (tests/test_gpu_mesh.py::test_tail_row_records checks it on every mesh it builds; round 3 carried a
+    // per-hop re-read loop for slot-less records that no mesh could reach -- removed).
     const int nslot = min(ntr, CL_ROWS - nr);
     // Prologue, ONE memory phase: the first four edges of this thread's rows (kept in registers for every hop) or the records
     // of its slots, the rows' first operand and the clip's tail pool -- all requested before anything is used.  Rows past the
@@ -319,23 +307,6 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
             finish(acc, own, nxt[u], slot, rowc[u], (mine >> u) & 1u);      // (loads unconditional, the stores predicated)
             __builtin_amdgcn_sched_barrier(0);
         }
-        for (int j = nslot + t; j < ntr; j += CL_T) {          // (records without a slot: re-read in every hop; see above)
-            const int4* rp = g.tail_rec + 2 * ((int64_t)c * CL_ROWS + j);
-            const int4 q0 = rp[0], q1 = rp[1];
-            const float qw[4] = {__int_as_float(q0.z), __int_as_float(q0.w), __int_as_float(q1.x), __int_as_float(q1.y)};
-            const unsigned lrow = (unsigned)q1.w & (CL_ROWS - 1), info = (unsigned)q1.z;
-            V nx = vzero<W>();
-            if constexpr (BWD) nx = addend.load((unsigned)r0 + lrow);
-            V acc = gather_head<W>(Pc, (unsigned)q0.x, (unsigned)q0.y, qw);
-            if ((info & 0xffffu) != 0xffffu)
-                gather_tail_lds<W>(acc, Pc, TE, info);
-            else
-                gather_tail_csr<W>(acc, Pc, (unsigned)r0 + lrow, r0, g.rowptr, g.col, g.nrm);
-            char* slot = Pn + lrow * (4u * W);
-            V own = vzero<W>();
-            if constexpr (OWN) own = vload<W>(slot);
-            finish(acc, own, nx, slot, (unsigned)r0 + lrow, true);
-        }
         lds_barrier();
         CL_STAMP(stamp++);
     };
@@ -371,7 +342,6 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
             const float* planes;
             decltype(grad_off)& off;
             int k;
-            __device__ __forceinline__ V load(unsigned grow) const { return ldg<W>(planes + off(k, grow)); }
             __device__ __forceinline__ void operator()(V& nx, unsigned grow, V& r) const {
                 const V ak = nx;                              // A_k of this row; its A_{k-1} is requested as soon as A_k is consumed
 #pragma unroll
@@ -413,23 +383,18 @@ struct ClipMesh {       // the mesh operands both entry points share
     int B;
 };
 
-// Slice width: 0 = automatic (2 when the launch's B * C / 2 workgroups fit the CUs in one round, else 4); qt_cheb_clip_width(w)
-// pins it (diagnostics and the parity tests of both widths).
-static int g_clip_width = 0;
+// Slice width (the `width` argument of both entry points): 0 = automatic (2 when the launch's B * C / 2 workgroups fit the CUs in
+// one round, else 4); 2 or 4 pins it (diagnostics and the parity tests of both widths).  No library-global switch: the ABI keeps
+// no mutable state besides the thread-local error string.
 extern "C" int qt_num_cus(void);
-extern "C" int qt_cheb_clip_width(int w) {
-    const int old = g_clip_width;
-    if (w == 0 || w == 2 || w == 4) g_clip_width = w;
-    return old;
-}
 
 static int clip_launch(bool bwd, const ClipMesh& m, int Ncap, int K, int Ca, const float* za, int lda, float* Pa, int Cb,
-                       const float* zb, int ldb, float* Pb, void* stream, int bwd_sm = 0) {
+                       const float* zb, int ldb, float* Pb, void* stream, int width, int bwd_sm = 0) {
     // forward: half-width slices whenever they still fit the CUs in one round (K = 5, 16 channels, 32 clips: 16.8 -> 15.2 us);
     // backward only when even they leave half the CUs idle: its A_k loads and the final store move 8 of every 16 bytes at
     // W = 2 (the same shape backward: 19.1 us at W = 4, 21.0 at W = 2; 4 channels: 13.2 vs 11.5)
     const int half = m.B * ((Ca + Cb) / 2);
-    const int W = g_clip_width ? g_clip_width : (half <= (bwd ? qt_num_cus() / 2 : qt_num_cus()) ? 2 : 4);
+    const int W = width ? width : (half <= (bwd ? qt_num_cus() / 2 : qt_num_cus()) ? 2 : 4);
     ClipArgs g;
     g.bwd_sm = bwd_sm != 0;
     g.rowptr = m.rowptr;
@@ -468,15 +433,16 @@ static int clip_launch(bool bwd, const ClipMesh& m, int Ncap, int K, int Ca, con
 extern "C" int qt_cheb_clip_fwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell,
                                 const int32_t* node_off, const int32_t* tail_cnt, const int32_t* tail_pool,
                                 const int32_t* tail_rec, int B, int N, int K, int Ca, const float* za, int lda, float* Ta, int Cb,
-                                const float* zb, int ldb, float* Tb, void* stream) {
+                                const float* zb, int ldb, float* Tb, int width, void* stream) {
     CLIP_MESH_ARGS_OK;
+    QT_ARG(width == 0 || width == 2 || width == 4, "width must be 0 (automatic), 2 or 4");
     QT_ARG(za && Ta && Ca > 0 && Ca % 4 == 0 && Cb >= 0 && Cb % 4 == 0 && (Cb == 0 || (zb && Tb)), "bad operands");
     QT_ARG((lda | ldb) % 4 == 0, "row strides must be multiples of 4");
     QT_ARG((((uintptr_t)za | (uintptr_t)Ta | (uintptr_t)zb | (uintptr_t)Tb | (uintptr_t)ell | (uintptr_t)tail_pool | (uintptr_t)tail_rec) & 15) == 0, "operands must be 16-byte aligned");
     QT_ARG((int64_t)K * N * max(Ca, Cb) < ((int64_t)1 << 31) && (int64_t)N * max(max(lda, ldb), 4) < ((int64_t)1 << 31), "planes too large for 32-bit offsets");
     if (N <= 0) return QT_OK;
     const ClipMesh m = {rowptr, col, nrm, ell, node_off, tail_cnt, tail_pool, tail_rec, B};
-    clip_launch(false, m, N, K, Ca, za, lda, Ta, Cb, zb, ldb, Tb, stream);
+    clip_launch(false, m, N, K, Ca, za, lda, Ta, Cb, zb, ldb, Tb, stream, width);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -484,14 +450,15 @@ extern "C" int qt_cheb_clip_fwd(const int32_t* rowptr, const int32_t* col, const
 extern "C" int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell,
                                 const int32_t* node_off, const int32_t* tail_cnt, const int32_t* tail_pool,
                                 const int32_t* tail_rec, int B, int N, int K, int Ca, float* Ga, int Cb, float* Gb, int planes_sm,
-                                void* stream) {
+                                int width, void* stream) {
     CLIP_MESH_ARGS_OK;
+    QT_ARG(width == 0 || width == 2 || width == 4, "width must be 0 (automatic), 2 or 4");
     QT_ARG(Ga && Ca > 0 && Ca % 4 == 0 && Cb >= 0 && Cb % 4 == 0 && (Cb == 0 || Gb), "bad operands");
     QT_ARG((((uintptr_t)Ga | (uintptr_t)Gb | (uintptr_t)ell | (uintptr_t)tail_pool | (uintptr_t)tail_rec) & 15) == 0, "operands must be 16-byte aligned");
     QT_ARG((int64_t)K * N * max(Ca, Cb) < ((int64_t)1 << 31), "planes too large for 32-bit offsets");
     if (N <= 0) return QT_OK;
     const ClipMesh m = {rowptr, col, nrm, ell, node_off, tail_cnt, tail_pool, tail_rec, B};
-    clip_launch(true, m, N, K, Ca, nullptr, 0, Ga, Cb, nullptr, 0, Gb, stream, planes_sm);
+    clip_launch(true, m, N, K, Ca, nullptr, 0, Ga, Cb, nullptr, 0, Gb, stream, width, planes_sm);
     QT_LAUNCHED();
     return QT_OK;
 }

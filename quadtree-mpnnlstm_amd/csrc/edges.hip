@@ -51,9 +51,11 @@ __global__ __launch_bounds__(ET) void k_edges_count(const int32_t* __restrict__ 
                                                     int32_t* __restrict__ tail_cnt, int B) {
     __shared__ int red[16];
     const int idx = blockIdx.x * ET + threadIdx.x;
-    if (tail_cnt && idx < B) {           // the per-clip counters k_edges_nrm adds to (two launches later): tail edges, rows with a tail
-        tail_cnt[QT_TAIL_CNT_STRIDE * idx] = 0;
-        tail_cnt[QT_TAIL_CNT_STRIDE * idx + 1] = 0;
+    if (tail_cnt) {                      // the per-clip counters k_edges_nrm adds to (two launches later): tail edges, rows with a tail
+        for (int c = idx; c < B; c += (int)gridDim.x * ET) {      // (grid-stride: any number of clips)
+            tail_cnt[QT_TAIL_CNT_STRIDE * c] = 0;
+            tail_cnt[QT_TAIL_CNT_STRIDE * c + 1] = 0;
+        }
     }
     int cnt = 0;
     if (idx < 4 * qt_rows(n_dev, Ncap)) {
@@ -200,7 +202,7 @@ extern "C" int qt_edges_blocks(int N) { return N > 0 ? qt_cdiv(4 * (int64_t)N + 
 extern "C" int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, const int32_t* n_dev, int n, int m,
                               int32_t* cnt4, int32_t* sums, int32_t* tail_cnt, int B, void* stream) {
     QT_ARG(labels && cell && cnt4 && sums, "null pointer");
-    QT_ARG(!tail_cnt || (B > 0 && B <= ET), "tail_cnt: 1 .. 1024 clips");
+    QT_ARG(!tail_cnt || B > 0, "tail_cnt needs the number of clips");
     if (N <= 0) return QT_OK;
     hipLaunchKernelGGL(k_edges_count, dim3(qt_edges_blocks(N)), dim3(ET), 0, (hipStream_t)stream, labels, cell, N, n_dev, n, m,
                        cnt4, sums, tail_cnt, B);

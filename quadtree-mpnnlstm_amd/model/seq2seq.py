@@ -199,10 +199,12 @@ class Decoder(nn.Module):
         return (torch.rand(steps, rows, device=device) < keep).float() / keep
 
     def run(self, X, mesh, concat_layers, H, C, pk, drop=None):
-        """One decoder step on packed weights; X (N, 4k) padded input, H / C per-layer lists.  Leaves `state_output`: the output
-        once more (same values) for the state update of the rollout, or None."""
+        """One decoder step on packed weights; X (N, 4k) padded input, H / C per-layer lists.  Returns (y, hs, cs, state_y):
+        state_y is the output once more (same values, same storage, a second autograd alias) for the state update of the
+        rollout -- the head's backward launch then sums the two gradients -- or None when there is no such alias (the caller
+        uses y itself)."""
         assert self.concat_layers_dim == 1
-        self.state_output = None
+        state_y = None
         hs, cs, inp, Xres = [], [], X, X
         last = len(self.rnns) - 1
         for i, rnn in enumerate(self.rnns):
@@ -226,31 +228,30 @@ class Decoder(nn.Module):
             p1, p2 = pk.get('heads') or (None, None)
             y = self.fc_out2(torch.relu(self.fc_out1(torch.cat(z, dim=1), mesh, packed=p1)), mesh, packed=p2)
             y = torch.tanh(y if drop is None else y * drop.unsqueeze(1)) + X[:, :1]
-            return (torch.sigmoid(y) if self.binary else y), hs, cs
+            return (torch.sigmoid(y) if self.binary else y), hs, cs, None
         if pk.get('fc2c') is not None:
             # fc_out2 has ONE output channel: its three coefficient columns are applied first (a 16 -> 4 product, in the epilogue
             # of fc_out1's launch) and the Chebyshev recurrence then runs on single columns -- 4 bytes per row and neighbour
             # instead of z's 64-byte rows;  U (N, 4) = z [w_0 w_1 w_2 0] + [b 0 0 0]
             z, U = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'], post=(pk['fc2c'], pk['acc2']))
             # (the output has two consumers -- the loss, and the next step's input through the re-mesh: the second one takes the
-            # alias `state_output`, so that the two gradients are summed inside the head's backward launch)
+            # alias `state_y`, so that the two gradients are summed inside the head's backward launch)
             Y, Y2 = ops.scalar_cheb3(U, Xres, drop, mesh, alias=True)
             y = Y[:, :1]
             if not self.binary:
-                self.state_output = Y2[:, :1]
+                state_y = Y2[:, :1]
         else:
             z = ops.cheb_poly(z, pk['fc1'], mesh, self.fc_out1.K, 1, ops.ACT_RELU, acc=pk['acc1'])
             # the head GEMM writes float4 rows; column 0 is the prediction (the rest is tanh(0) + X[:, 0], never read as data)
             y = ops.cheb_poly(z, pk['fc2'], mesh, self.fc_out2.K, 1, ops.ACT_TANH_RES, res=Xres, drop=drop, acc=pk['acc2'])[:, :1]
         if self.binary:
             y = torch.sigmoid(y)
-        return y, hs, cs
+        return y, hs, cs, state_y
 
     def forward(self, X, edge_index, edge_weight, concat_layers, H, C, packed=None):
         pad = (-X.shape[1]) % 4
         Xp = nn.functional.pad(X, (0, pad)) if pad else X
-        y, hs, cs = self.run(Xp, edge_index, concat_layers, H, C, packed if packed is not None else self.pack(Xp.shape[1]))
-        self.state_output = None
+        y, hs, cs, _ = self.run(Xp, edge_index, concat_layers, H, C, packed if packed is not None else self.pack(Xp.shape[1]))
         return y, torch.stack(hs), torch.stack(cs)
 
 
@@ -434,11 +435,11 @@ class Seq2Seq(nn.Module):
                 cl = concat_layers[:, t].reshape(mesh.B, 1, mesh.P, 1)
                 concat_t = ops.pool_image(cl, mesh, True)[0]
                 g.concat_layers = concat_t
-            output, hidden, cell = self.decoder.run(g.pyg.x, mesh, concat_t, g.hidden, g.cell, dec_pack,
-                                                    None if drops is None else drops[si, :mesh.N])
+            output, hidden, cell, state_y = self.decoder.run(g.pyg.x, mesh, concat_t, g.hidden, g.cell, dec_pack,
+                                                             None if drops is None else drops[si, :mesh.N])
             outputs.append(output)
-            if self.decoder.state_output is not None:
-                output, self.decoder.state_output = self.decoder.state_output, None       # (the copy for the state update)
+            if state_y is not None:
+                output = state_y                                                           # (the alias for the state update)
             output_mappings.append(mesh)
             teacher_force = random.random() < teacher_forcing_ratio
             if t == steps[-1]:

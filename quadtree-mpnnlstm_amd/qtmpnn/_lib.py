@@ -41,9 +41,8 @@ _SIGNATURES = {
     'qt_dense2': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     'qt_spmm2': [_P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _F, _F, _F, _P, _P],
     'qt_cheb_clip_rows': [],
-    'qt_cheb_clip_width': [_I],
-    'qt_cheb_clip_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P],
-    'qt_cheb_clip_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
+    'qt_cheb_clip_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
+    'qt_cheb_clip_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P],
     'qt_dense': [_P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P],
     'qt_wgrad_blocks': [_I],
     'qt_wgrad': [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P],
@@ -81,7 +80,7 @@ _SIGNATURES = {
     'qt_head_fwd': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P],
     'qt_head_bwd': [_P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
 }
-_PLAIN = {'qt_abi_version', 'qt_cheb_clip_rows', 'qt_cheb_clip_width', 'qt_remesh_clip_rows', 'qt_tail_cap', 'qt_num_cus', 'qt_lstm_fused_blocks', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_lstm_dgrad_blocks', 'qt_attn_blocks'}  # return a value, not an error code
+_PLAIN = {'qt_abi_version', 'qt_cheb_clip_rows', 'qt_remesh_clip_rows', 'qt_tail_cap', 'qt_num_cus', 'qt_lstm_fused_blocks', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_lstm_dgrad_blocks', 'qt_attn_blocks'}  # return a value, not an error code
 
 _lib = None
 

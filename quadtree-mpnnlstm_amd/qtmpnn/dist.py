@@ -28,6 +28,23 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+class HostBarrier:
+    """A barrier the ranks wait in on the HOST: a gloo side group over the same rendezvous (public API only --
+    `dist.new_group(backend='gloo')` + `dist.barrier(group=...)`; round 3 polled the private default store).  A rank that waits
+    here for another rank's seconds of single-rank work sits in no RCCL collective: nothing for the watchdog to time, no
+    GPU spin.  Create it right after init_process_group, on every rank (new_group is itself collective)."""
+
+    def __init__(self, timeout_s=1800):
+        import datetime
+        self.group = None
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            self.group = dist.new_group(backend='gloo', timeout=datetime.timedelta(seconds=timeout_s))
+
+    def wait(self):
+        if self.group is not None:
+            dist.barrier(group=self.group)
+
+
 def shard_range(n_items, rank, world):
     """Contiguous shard [lo, hi) of n_items clips for `rank` (equal sizes; n_items % world == 0)."""
     assert n_items % world == 0, f'{n_items} clips do not split evenly over {world} ranks'

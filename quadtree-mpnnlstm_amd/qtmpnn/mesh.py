@@ -305,12 +305,15 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
     nblk = _lib.value('qt_edges_blocks', N)
     cnt4 = torch.empty(nblk * 1024, **i32)
     sums = torch.empty(nblk + 1, **i32)
-    # per-clip pool of the edges beyond a row's fourth (qt_edges_norm fills it; the clip-resident recurrence kernel reads it)
-    tcap = _lib.value('qt_tail_cap')
-    ms.tail_cnt = torch.empty(B * 32, **i32)                 # (QT_TAIL_CNT_STRIDE ints apart: one cache line per clip's counter)
-    ms.tail_pool = torch.empty(B, tcap, 2, **i32)
-    ms.tail_info = torch.empty(N, **i32)
-    ms.tail_rec = torch.empty(B, 4096, 8, **i32)             # (B, QT_TAIL_REC_CAP, 8): one record per row with more than four edges
+    # per-clip pool of the edges beyond a row's fourth (qt_edges_norm fills it; the clip-resident recurrence kernel reads it):
+    # only for meshes whose clips fit that kernel's LDS planes (frames up to 64 x 64) -- bigger frames never take it, and
+    # their rows' atomic adds on a few per-clip counters (B = 1: one cache line) would only slow qt_edges_norm down
+    if n * m <= _lib.value('qt_cheb_clip_rows'):
+        tcap = _lib.value('qt_tail_cap')
+        ms.tail_cnt = torch.empty(B * 32, **i32)             # (QT_TAIL_CNT_STRIDE ints apart: one cache line per clip's counter)
+        ms.tail_pool = torch.empty(B, tcap, 2, **i32)
+        ms.tail_info = torch.empty(N, **i32)
+        ms.tail_rec = torch.empty(B, 4096, 8, **i32)         # (B, QT_TAIL_REC_CAP, 8): one record per row with more than four edges
     _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4), ptr(sums), ptr(ms.tail_cnt), B)
     emax = 4 * B * n * m                          # every directed edge owns >= 1 of the 4*P pixel adjacencies
     ms.col = torch.empty(emax, **i32)

@@ -277,22 +277,23 @@ def _clip_resident(mesh, widths, K):
             and len(widths) <= 2 and all(w % 4 == 0 for w in widths) and getattr(mesh, 'node_off', None) is not None)
 
 
-def clip_planes(mesh, Zs, TZs, K):
+def clip_planes(mesh, Zs, TZs, K, width=0):
     """TZs[i] <- T_1 .. T_{K-1} of the recurrence on the parts Zs, all hops in ONE launch (qt_cheb_clip_fwd).  The planes are
-    written SLICE-major: TZs[i] (allocated (K - 1, N, C_i)) then holds (K - 1, C_i / 4, N, 4)."""
+    written SLICE-major: TZs[i] (allocated (K - 1, N, C_i)) then holds (K - 1, C_i / 4, N, 4).  width: channels per workgroup
+    (0 = the library's choice; 2 / 4 pin it: diagnostics and parity tests)."""
     two = len(Zs) > 1
     _lib.call('qt_cheb_clip_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off),
               ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_rec), mesh.B, Zs[0].shape[0], K, Zs[0].shape[1], ptr(Zs[0]), _ld(Zs[0]), ptr(TZs[0]),
-              Zs[1].shape[1] if two else 0, ptr(Zs[1]) if two else None, _ld(Zs[1]) if two else 0, ptr(TZs[1]) if two else None)
+              Zs[1].shape[1] if two else 0, ptr(Zs[1]) if two else None, _ld(Zs[1]) if two else 0, ptr(TZs[1]) if two else None, int(width))
 
 
-def clip_clenshaw(mesh, Gs, K, sm=0):
+def clip_clenshaw(mesh, Gs, K, sm=0, width=0):
     """Gs[i] (K, N, C_i) gradient planes: plane 0 <- A_0 + L^ b_1 - b_2 (Clenshaw), all hops in ONE launch (qt_cheb_clip_bwd).
     sm: planes 1 .. K-1 are stored slice-major (written so by the data-gradient kernels on request)."""
     two = len(Gs) > 1
     _lib.call('qt_cheb_clip_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off),
               ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_rec), mesh.B, Gs[0].shape[1], K, Gs[0].shape[2], ptr(Gs[0]),
-              Gs[1].shape[2] if two else 0, ptr(Gs[1]) if two else None, int(sm))
+              Gs[1].shape[2] if two else 0, ptr(Gs[1]) if two else None, int(sm), int(width))
 
 
 def _cheb_planes(Zs, mesh, K):
@@ -1288,8 +1289,11 @@ def head_input(O, ln_o, concat, hp, mesh, acc=None):
 # ------------------------------------------------------------------------------ mesh <-> image
 def _pool_raw(mesh, C, out, out_stride, out_coff, mean, img=None, S=1, src_val=None, src_mesh=None, src_inv=False,
               img_clip_stride=0):
-    if _CLIP_REMESH and img is not None and S * C <= 64:
-        # a few scalar channels: one workgroup per (clip, 64 x 64 tile, frame, channel), LDS pyramid
+    if _CLIP_REMESH and img is not None and C <= 8 and S * C <= 64:
+        # a few scalar channels per pixel (the shapes it was measured on: the encoder's input frames S = 10, C = 4 and the
+        # decoder's concat layer S = C = 1): one workgroup per (clip, 64 x 64 tile, frame, channel), LDS pyramid.  Wide rows
+        # (C up to 64 in a gather's backward) would read scalars strided by C floats from every workgroup: they stay on
+        # qt_pool's float4 path (round-3 advisor finding)
         _lib.call('qt_pool_clip', ptr(img), S, img_clip_stride, C, ptr(mesh.labels), ptr(mesh.level), ptr(mesh.npix), int(mean),
                   mesh.B, mesh.n, mesh.m, mesh.N, ptr(out), out_stride, out_coff)
         return

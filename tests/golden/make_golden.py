@@ -324,6 +324,23 @@ def rollouts():
             t_in=2, t_out=3, transform=dist_from_05, seed=62, scale=0.1)
 
 
+def rollouts_large():
+    """Re-meshing rollouts on frames of SEVERAL 64x64 base cells (model/seq2seq.py:339-398,434-491 with the base-cell stack of
+    model/graph_functions.py:199-205): (a) 96x128 with a land mask -- base cells 2x2, the lower row cropped --, hidden 8,
+    2 layers, stacks of 2 ChebConvs; (b) the shape BASELINE configs[3] runs: 128x128, 5 channels, transform_func=dist_from_05,
+    thresh 0.15, hidden 32, 1 layer, stacks of 3 ChebConvs (ice_exp.py:145-162).  Model seeds chosen so that every image a
+    COMPARED mesh is built from keeps its pixels >= 8e-5 away from the threshold (the re-mesh after the last step is never
+    used; its image may come closer)."""
+    f, m = synthetic.make_ice_like(41, shape=(96, 128), channels=3, n_frames=5)
+    concat = f[2:5, ..., :1].copy() * 0.5
+    rollout('ice96x128_masked_h8', f[:2], f[2:5, ..., :1].copy(), concat, m, hidden=8, n_layers=2, n_conv=2, thresh=0.15,
+            t_in=2, t_out=3, transform=dist_from_05, seed=79, scale=0.07)
+    f, m = synthetic.make_ice_like(42, shape=(128, 128), channels=5, n_frames=5)
+    concat = f[2:5, ..., :1].copy() * 0.5
+    rollout('ice128_h32', f[:2], f[2:5, ..., :1].copy(), concat, m, hidden=32, n_layers=1, n_conv=3, thresh=0.15,
+            t_in=2, t_out=3, transform=dist_from_05, seed=78, scale=0.05, bscale=0.02)
+
+
 def rollout_gcn():
     """convolution_type='GCNConv' (model/model.py:41,50: GCNConv(add_self_loops=False)) through the reference's whole
     Seq2Seq rollout with re-meshing: two layers, stacks of two convolutions, noisy frames (meshes of 1-3 k nodes)."""
@@ -676,6 +693,8 @@ if __name__ == '__main__':
         transformer_cases()
     if only in ('', 'rollouts'):
         rollouts()
+    if only in ('', 'large'):
+        rollouts_large()
     if only in ('', 'gcn'):
         rollout_gcn()
     if only in ('', 'checkpoint'):

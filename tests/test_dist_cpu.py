@@ -16,9 +16,10 @@ def _free_port():
 
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
-    from qtmpnn.dist import allreduce_gradients, broadcast_parameters, init_from_env, shard_range
+    from qtmpnn.dist import HostBarrier, allreduce_gradients, broadcast_parameters, init_from_env, shard_range
     r, w, _ = init_from_env('gloo')
     assert (r, w) == (rank, world)
+    side = HostBarrier(timeout_s=60)                   # gloo side group (public API): what bench.py's ranks wait in on the host
     torch.manual_seed(100 + rank)                      # different initial weights per rank
     model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
     broadcast_parameters(model)
@@ -38,6 +39,14 @@ def _worker(rank, world, port, out):
         assert torch.allclose(p.grad, torch.full_like(p, want)), (i, p.grad.flatten()[0].item(), want)
     lo, hi = shard_range(64, rank, world)
     assert (lo, hi) == (32 * rank, 32 * rank + 32)
+    # rank 1 waits on the host while rank 0 'works' for a while: both leave the barrier only after rank 0 arrives
+    import time
+    t0 = time.perf_counter()
+    if rank == 0:
+        time.sleep(0.5)
+    side.wait()
+    assert time.perf_counter() - t0 >= 0.45
+    side.wait()
     dist.barrier()
     dist.destroy_process_group()
     out.put(rank)

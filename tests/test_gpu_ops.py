@@ -728,23 +728,14 @@ def test_spmm_two_row_strided_parts_equal_one_matrix():
     assert torch.equal(torch.cat([oa, ob], dim=1), ref)
 
 
-@pytest.fixture
-def clip_width(request):
-    """Pin the slice width of the clip-resident launches (0 = the library's own choice) for one test."""
-    from qtmpnn import _lib
-    prev = _lib.value('qt_cheb_clip_width', request.param)
-    yield request.param
-    _lib.value('qt_cheb_clip_width', prev)
-
-
-@pytest.mark.parametrize('clip_width', [4, 2, 0], indirect=True)
+@pytest.mark.parametrize('clip_width', [4, 2, 0])
 @pytest.mark.parametrize('K,widths,B', [(5, (4, 16), 3), (3, (16, 4), 2), (5, (16,), 1), (2, (8,), 2), (3, (32,), 2)])
 def test_clip_resident_recurrence_equals_per_hop_launches(K, widths, B, clip_width):
     """csrc/chebclip.hip (all hops of a ChebConv recurrence in one launch, a clip's rows in LDS) against one qt_spmm2 launch per
     hop: forward planes T_1 .. T_{K-1} and the Clenshaw backward, bit for bit; row-strided column views as Z; a mesh with big
     cells beside small ones (rows with more than four edges take the CSR tail); static capacities (node counts on the device,
     capacity rows poisoned with NaN) give the same valid rows.  Both slice widths of the kernel (4 and 2 channels per
-    workgroup) and the automatic choice."""
+    workgroup; the `width` argument of the entry points) and the automatic choice."""
     from qtmpnn import _lib, ops
     from qtmpnn._lib import ptr
     from qtmpnn.mesh import spmm2
@@ -759,7 +750,7 @@ def test_clip_resident_recurrence_equals_per_hop_launches(K, widths, B, clip_wid
         Zs.append(wide[:, o:o + w])
         o += w
     fused = [torch.empty(K - 1, N, w, device=dev()) for w in widths]
-    ops.clip_planes(mesh, Zs, fused, K)
+    ops.clip_planes(mesh, Zs, fused, K, width=clip_width)
     prev, ops._CLIP_CHEB = ops._CLIP_CHEB, False          # one qt_spmm2 launch per hop
     try:
         ref, sm = ops._cheb_planes(Zs, mesh, K)
@@ -771,7 +762,7 @@ def test_clip_resident_recurrence_equals_per_hop_launches(K, widths, B, clip_wid
     # backward: Clenshaw on random gradient planes
     G = [torch.randn(K, N, w, device=dev()) for w in widths]
     Gf = [g.clone() for g in G]
-    ops.clip_clenshaw(mesh, Gf, K)
+    ops.clip_clenshaw(mesh, Gf, K, width=clip_width)
     Gr = [g.clone() for g in G]
     for k in range(K - 2, 0, -1):
         spmm2(mesh, [g[k + 1] for g in Gr], 2.0, [g[k] for g in Gr], 1.0, [g[k + 2] for g in Gr] if k + 2 < K else None, -1.0,
@@ -786,9 +777,25 @@ def test_clip_resident_recurrence_equals_per_hop_launches(K, widths, B, clip_wid
         t = g0.clone()
         t[1:] = g0[1:].view(K - 1, N, w // 4, 4).permute(0, 2, 1, 3).reshape(K - 1, N, w)
         Gs.append(t)
-    ops.clip_clenshaw(mesh, Gs, K, sm=1)
+    ops.clip_clenshaw(mesh, Gs, K, sm=1, width=clip_width)
     for a, r in zip(Gs, Gr):
         assert torch.equal(a[0], r[0])
+
+
+def test_clip_resident_pool_overflow_walks_the_csr():
+    """csrc/chebclip.hip's pool-full path (a clip with more tail edges than QT_TAIL_CAP: the rows whose run did not fit carry
+    info base 0xffff and walk the CSR arrays in every hop) cannot be reached with the shipped capacity on ordinary meshes, so the
+    Makefile also builds the library with QT_TAIL_CAP = 48 (libqtmpnn_hip_smallcaps.so).  A child process loads THAT build and
+    checks forward planes and Clenshaw backward against the per-hop launches bit for bit (tests/_clip_overflow_child.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(os.path.dirname(here), 'quadtree-mpnnlstm_amd', 'qtmpnn', 'libqtmpnn_hip_smallcaps.so')
+    assert os.path.exists(lib), 'run __graft_entry__.build() (make -C quadtree-mpnnlstm_amd/csrc)'
+    env = dict(os.environ, QT_LIB_PATH=lib)
+    r = subprocess.run([sys.executable, os.path.join(here, '_clip_overflow_child.py')], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'overflow ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_clip_resident_recurrence_static_capacities():
@@ -810,7 +817,7 @@ def test_clip_resident_recurrence_static_capacities():
     from qtmpnn import _lib
     from qtmpnn._lib import ptr
     _lib.call('qt_cheb_clip_fwd', ptr(sm.rowptr), ptr(sm.col), ptr(sm.nrm), ptr(sm.ell), ptr(sm.node_off), ptr(sm.tail_cnt),
-              ptr(sm.tail_pool), ptr(sm.tail_rec), sm.B, sm.N, 4, 16, ptr(Zs), 16, ptr(got), 0, None, 0, None)
+              ptr(sm.tail_pool), ptr(sm.tail_rec), sm.B, sm.N, 4, 16, ptr(Zs), 16, ptr(got), 0, None, 0, None, 0)
     got = ops.planes_rowmajor(got, 1)
     assert torch.equal(got[:, :nv], ref)
     assert bool((got[:, nv:] == 7.0).all())

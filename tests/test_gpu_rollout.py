@@ -78,6 +78,78 @@ def test_rollout_golden(name):
     _check_grads(model, g)
 
 
+LARGE = ['ice96x128_masked_h8', 'ice128_h32']
+
+
+@pytest.mark.parametrize('name', LARGE)
+def test_rollout_large_frames_golden(name):
+    """Re-meshing rollouts on frames of SEVERAL 64x64 base cells against the reference's traces (model/seq2seq.py:339-398,
+    434-491; base-cell stack model/graph_functions.py:199-205): 96x128 with a land mask (2x2 base cells, lower row cropped;
+    hidden 8, 2 layers, stacks of 2 ChebConvs) and the BASELINE configs[3] shape (128x128, 5 channels, transform_func,
+    thresh 0.15, hidden 32, 1 layer, stacks of 3; ice_exp.py:145-162).  These frames take the per-hop / halo recurrences,
+    the multi-tile state transfer (Mesh.cell_off), stage 3's cross-cell scan and the hidden-32 cell, none of which a 64x64
+    trace reaches.  Per-step labels bit-exact, outputs, loss, all gradients -- single clip and as a 2-clip batch."""
+    g = golden(f'rollout_{name}.npz')
+    model, outs, meshes, loss = _run(g)
+    _check_trace(g, outs, meshes)
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss'])), (float(loss), float(g['loss']))
+    loss.backward()
+    _check_grads(model, g)
+    _assert_grads_do_not_alias(model)
+    model, outs, meshes, loss = _run(g, batch=2)
+    for c in range(2):
+        _check_trace(g, outs, meshes, clip=c)
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    loss.backward()
+    _check_grads(model, g)
+
+
+@pytest.mark.parametrize('name', LARGE)
+def test_rollout_large_frames_static_capacity_graph_step(name):
+    """The same two traces through what the benchmarks time: static capacities (node counts read on the device) with
+    forward + loss + backward captured into ONE hipGraph and replayed on a 2-clip batch; labels bit-exact at every step,
+    outputs, loss and all gradients against the reference."""
+    from model.mpnnlstm import masked_mse
+    g = golden(f'rollout_{name}.npz')
+    x, y, concat = (torch.from_numpy(g[k]).to(dev()).unsqueeze(0).repeat(2, *[1] * g[k].ndim) for k in ('x', 'y', 'concat'))
+    model = _model_from_golden(g, g['x'])
+    model.static_shapes = True
+    # (ONE mask / region object for every call: the device copy is cached per object, an upload inside a capture is an error)
+    mask, hir = g['mask'], (g['hir'] if 'hir' in g.files else None)
+    params = list(model.parameters())
+    n, m = g['x'].shape[1:3]
+
+    def fwd_bwd(a, b, c):
+        for p in params:
+            p.grad = None
+        outs, meshes = model(a, b, c, teacher_forcing_ratio=0, mask=mask, high_interest_region=hir)
+        loss = masked_mse(outs, meshes, b, mask)
+        loss.backward()
+        return outs, meshes, loss.detach()
+    sx, sy, sc = (torch.zeros_like(t) for t in (x, y, concat))          # captured on other data than it is replayed on
+    sx.copy_(x.flip(0).roll(1, 1)); sy.copy_(y); sc.copy_(concat)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd_bwd(sx, sy, sc)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        outs, meshes, loss = fwd_bwd(sx, sy, sc)
+    sx.copy_(x)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert all(ms.n_dev is not None and ms.N == 2 * n * m for ms in meshes)
+    for i, ms in enumerate(meshes):
+        off = ms.node_off.cpu().numpy()
+        for c in range(2):
+            lab = ms.labels[c].cpu().numpy()
+            assert np.array_equal(np.where(lab >= 0, lab - off[c], -1), g[f'labels_{i}']), f'mesh {i} clip {c}'
+            close(outs[i][off[c]:off[c + 1]], g[f'out_{i}'], msg=f'output step {i} clip {c}')
+    assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss'])), (float(loss), float(g['loss']))
+    _check_grads(model, g)
+
+
 def test_rollout_gcnconv_golden():
     """convolution_type='GCNConv' (model/model.py:41,50) through the whole rollout with re-meshing against the reference's
     trace (two layers, stacks of two GCNConvs composed in weight space as the Chebyshev series [0, -W^T]): per-step labels

@@ -72,8 +72,8 @@ def test_bad_arguments_fail_loudly_without_gpu():
         'qt_proj_group': (None, 0, 0, 1, 4, None, None, None, 0, 1, 1, 4, None, 0, 0, 0, 4, None, None),
         'qt_wgrad_groups': (1, None, None, None, None, None, None, 4, 4, 4, 4, 0, 1, 0, 0, 0, None, None),
         'qt_dense_sb': (None, 0, 16, None, None, 1, 4, 0, 4, None, None, None, None),
-        'qt_cheb_clip_fwd': (None,) * 8 + (1, 4, 3, 4, None, 0, None, 0, None, 0, None, None),
-        'qt_cheb_clip_bwd': (None,) * 8 + (1, 4, 3, 4, None, 0, None, 0, None),
+        'qt_cheb_clip_fwd': (None,) * 8 + (1, 4, 3, 4, None, 0, None, 0, None, 0, None, 0, None),
+        'qt_cheb_clip_bwd': (None,) * 8 + (1, 4, 3, 4, None, 0, None, 0, 0, None),
         'qt_dense2': (None, 0, None, None, 0, None, 1, 4, 0, None, None, None, 0, None, 1, 4, 0, 4, None, 0, None, 0, None, None, None, 0, None, None, None),
     }
     for name, args in null_calls.items():
@@ -280,3 +280,34 @@ def test_library_issues_only_kernels_on_the_callers_stream():
     for banned in ('hipMemset', 'hipMemcpy', 'hipMalloc', 'hipFree', 'hipStreamCreate', 'hipEventCreate', 'hipDeviceSynchronize',
                    'hipStreamSynchronize'):
         assert banned not in src, f'{banned} found in csrc/: device work must be kernels on the caller stream'
+
+
+def test_library_keeps_no_mutable_global_state():
+    """SURVEY 8(b) / INTEGRATION.md section 2: "no global state, thread-safe per stream" -- the only file-scope variable of
+    the library is the thread-local error string; tuning knobs are arguments (round 3 had a process-wide slice-width switch,
+    `qt_cheb_clip_width`; it is the `width` argument of qt_cheb_clip_fwd / _bwd now).  Diagnostics builds (`#ifdef
+    QT_*_TIMING` blocks: in-kernel time stamps, never part of the shipped library) are exempt."""
+    import glob
+    decl = re.compile(r'^(?:static\s+)?(?:thread_local\s+)?(?:unsigned\s+|long\s+)*[A-Za-z_][\w:<>]*[\s\*&]+\**\s*(g_\w+|\w+)\s*(?:\[[^\]]*\])?\s*(?:=[^;(]*)?;\s*$')
+    found = []
+    for f in sorted(glob.glob(os.path.join(ROOT, 'quadtree-mpnnlstm_amd', 'csrc', '*.h*'))):
+        text = re.sub(r'/\*.*?\*/', '', open(f).read(), flags=re.S)
+        depth, timing, stack = 0, 0, []
+        for line in text.split('\n'):
+            code = re.sub(r'//.*', '', line).rstrip()
+            st = code.strip()
+            if st.startswith('#if'):
+                stack.append(bool(re.search(r'QT_\w*TIMING', st)))
+                timing += stack[-1]
+            elif st.startswith('#endif') and stack:
+                timing -= stack.pop()
+            if st.startswith('#'):
+                continue
+            if depth == 0 and not timing and st and not st.startswith(('constexpr', 'static constexpr', 'const ', 'static const ',
+                                                                       'using ', 'typedef', 'extern', 'template', 'namespace',
+                                                                       'struct', '}', 'return')):
+                m = decl.match(st)
+                if m and '(' not in st.split('=')[0]:
+                    found.append((os.path.basename(f), st))
+            depth += code.count('{') - code.count('}')
+    assert [s for _, s in found] == ['static thread_local char g_qt_err[512] = "";'], found

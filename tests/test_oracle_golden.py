@@ -131,7 +131,8 @@ def oracle_rollout(g):
     return model, outs, maps, trace, loss
 
 
-@pytest.mark.parametrize('name', ['mnist64_h16', 'mnist64_noise_h8', 'ice64_masked_h8', 'mnist64_l4_h8', 'cfg2_mnist64'])
+@pytest.mark.parametrize('name', ['mnist64_h16', 'mnist64_noise_h8', 'ice64_masked_h8', 'mnist64_l4_h8', 'cfg2_mnist64',
+                                  'ice96x128_masked_h8', 'ice128_h32'])
 def test_rollout(golden_dir, name):
     g = load(golden_dir, f'rollout_{name}.npz')
     model, outs, maps, trace, loss = oracle_rollout(g)

@@ -56,5 +56,20 @@ for i in range(steps):
     l = step(*pool[i % 2])
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+rec = {}
+if os.environ.get('QT_CFG_ROOFLINE', '1') == '1':
+    # the message-aggregate roofline object of bench.py for THIS configuration (per-launch algorithmic bytes / measured launch
+    # time, HIP events around graph replays of every distinct launch of one forward + backward on the model as initialised)
+    sys.path.insert(0, ROOT)
+    import bench
+    del step
+    nfp._graph = None
+    torch.manual_seed(1)
+    fresh = NextFramePredictorS2S(thresh=thresh, input_features=feat, input_timesteps=t_in, output_timesteps=t_out, device=dev,
+                                  transform_func=tf, model_kwargs=kw)
+    fresh.initiate_training(lr=0.01, lr_decay=0.95, capturable=False)
+    fresh.model.train()
+    if kw.get('convolution_type', 'ChebConv') == 'ChebConv':
+        rec['roofline'] = bench.spmm_roofline(fresh, pool[0], mask, traffic_files=())
 print(json.dumps({'config': cfg, 'frames_per_s': round(B * (t_in + t_out) * steps / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 2),
-                  'clips': B, 'shape': shape, 't_in': t_in, 't_out': t_out, 'loss': round(float(l), 5), 'launch': 'hipGraph replay'}))
+                  'clips': B, 'shape': shape, 't_in': t_in, 't_out': t_out, 'loss': round(float(l), 5), 'launch': 'hipGraph replay', **rec}))

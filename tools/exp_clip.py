@@ -58,9 +58,7 @@ for K, widths in [(5, (4, 16)), (5, (16,)), (3, (4, 16)), (3, (16,)), (3, (16, 4
     from qtmpnn import _lib
     per_w = {}
     for wd in (4, 2):
-        _lib.value('qt_cheb_clip_width', wd)
-        per_w[wd] = (timeit(lambda: ops.clip_planes(mesh, Zs, TZ, K)), timeit(lambda: ops.clip_clenshaw(mesh, G, K)))
-    _lib.value('qt_cheb_clip_width', 0)
+        per_w[wd] = (timeit(lambda: ops.clip_planes(mesh, Zs, TZ, K, width=wd)), timeit(lambda: ops.clip_clenshaw(mesh, G, K, width=wd)))
     print(f'   slice width 4: {per_w[4][0]:6.2f} / {per_w[4][1]:6.2f} us   width 2: {per_w[2][0]:6.2f} / {per_w[2][1]:6.2f} us   (automatic below)')
     t_cf, t_cb = timeit(lambda: ops.clip_planes(mesh, Zs, TZ, K)), timeit(lambda: ops.clip_clenshaw(mesh, G, K))
     nv, C = mesh.n_valid, sum(widths)
