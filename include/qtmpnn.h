@@ -48,6 +48,20 @@ extern "C" {
 #define QT_TAIL_CNT_STRIDE 32 /* ints between the per-clip tail counters (one 128-byte line each): [0] tail edges, [1] rows with a tail */
 #define QT_TAIL_REC_CAP 4096 /* records (rows with more than four edges) per clip = the most rows a clip-resident clip can have */
 
+/* Frames of several 64 x 64 base cells ("tiles"): the tile-resident recurrence kernel (qt_cheb_tile_fwd / _bwd) keeps ONE TILE's
+ * rows in LDS and exchanges the rows on tile borders between the workgroups of a clip after every hop.  qt_edges_norm_tiles
+ * leaves per tile (slot = clip * T + tile in label order, as qt_quadtree_stage3's cell_off):
+ *   counters  tile_cnt[QT_TILE_CNT_STRIDE * slot + ..]: [0] interior pool entries, [1] interior records (rows with more than four
+ *             edges, all of them inside the tile), [2] halo entries (directed edges that leave the tile), [3] boundary records
+ *             (rows with at least one such edge), [4] boundary pool entries, [5] != 0: a capacity below was exceeded (never for
+ *             quadtree meshes: a tile has at most 256 pixel adjacencies across its border) */
+#define QT_TILE_CNT_STRIDE 32
+#define QT_TILE_REC_CAP 4096  /* interior records per tile */
+#define QT_TILE_POOL_CAP 1372 /* interior pool entries per tile held in LDS (more: those rows walk the CSR arrays) */
+#define QT_TILE_HALO_CAP 256  /* halo entries = boundary records at most, per tile */
+#define QT_TILE_BPOOL_CAP 1024 /* boundary pool entries per tile (sum over border cells of 4 side - 4 < 1024) */
+#define QT_TILE_SLICES 12     /* 4-channel slices per launch the exchange buffer and the sync words are laid out for (Ca + Cb <= 48) */
+
 #define QT_ACT_NONE 0
 #define QT_ACT_RELU 1
 #define QT_ACT_TANH_RES 2 /* y = tanh(drop * acc) + res */
@@ -119,7 +133,9 @@ int qt_node_features(const int32_t* cell, int N, const int32_t* n_dev, int n, in
 int qt_edges_blocks(int N);
 int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, const int32_t* n_dev, int n, int m,
                    int32_t* cnt4, int32_t* sums /* nblk+1 */, int32_t* tail_cnt /* optional (B * QT_TAIL_CNT_STRIDE): clip c's counter
-                   [QT_TAIL_CNT_STRIDE * c] is zeroed here for qt_edges_norm */, int B, void* stream);
+                   [QT_TAIL_CNT_STRIDE * c] is zeroed here for qt_edges_norm */, int B,
+                   int32_t* zero_buf /* optional: zero_len ints set to 0 by the same launch (the tile counters and sync words
+                   of qt_edges_norm_tiles / qt_cheb_tile_*) */, int zero_len, void* stream);
 int qt_edges_fill(const int32_t* labels, const int32_t* cell, const int32_t* cnt4, const int32_t* sums /* as counted */,
                   int N, const int32_t* n_dev, int n, int m, float resolution,
                   int32_t* rowptr /* N+1 */, int32_t* col, float* w, float* dis /* N */, void* stream);
@@ -139,6 +155,22 @@ int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const float* w, con
  *   (column << 4) | (next column << 20); w = their weights' bits; info = the row's tail_info word.
  * qt_cheb_clip_fwd / _bwd read tail_cnt, tail_pool and tail_rec: thread j of a clip's workgroup takes record j. */
 int qt_tail_cap(void);
+/* qt_edges_norm for frames of several base cells (n x m > 4096, max_size 64): nrm and ell as qt_edges_norm, and per TILE
+ * (tile_off = qt_quadtree_stage3's cell_off, (B * T + 1); T = tiles per clip, nbj = tiles per tile row; counters zeroed by
+ * qt_edges_count's zero_buf) what qt_cheb_tile_fwd / _bwd run from:
+ *   tile_rec   (B T, QT_TILE_REC_CAP, 8)  interior records, the format of tail_rec with columns relative to the TILE's first node
+ *   tile_pool  (B T, QT_TILE_POOL_CAP, 2) {column - tile first node, weight bits} runs of those rows
+ *   tile_brec  (B T, QT_TILE_HALO_CAP, 8) boundary records {lc01, lc23, w0, w1}, {w2, w3, info, row - tile first node}: a 16-bit
+ *              column field is (local row << 4), or (halo slot << 4) | 1 for a neighbour in another tile; info = run base in
+ *              tile_bpool | edge count << 16
+ *   tile_bpool (B T, QT_TILE_BPOOL_CAP, 2) {local row, or 0x80000000 | halo slot; weight bits}: edges 5.. of the boundary rows
+ *   tile_halo  (B T, QT_TILE_HALO_CAP)    global row of every halo slot
+ *   brec_addr  (N)                        for a boundary row: tile slot * QT_TILE_HALO_CAP + its boundary record's index (where the
+ *              other tiles look for the row's published values); other rows: not written */
+int qt_edges_norm_tiles(const int32_t* rowptr, const int32_t* col, const float* w, const float* dis, int N,
+                        const int32_t* n_dev, float* nrm, int32_t* ell, const int32_t* cell, const int32_t* tile_off,
+                        int T, int nbj, int32_t* tile_cnt, int32_t* tile_pool, int32_t* tile_rec, int32_t* tile_brec,
+                        int32_t* tile_bpool, int32_t* tile_halo, int32_t* brec_addr, void* stream);
 
 /* ---------------------------------------------------------------- mesh <-> image transfers
  * flatten / unflatten, model/graph_functions.py:391-419, 451-458, by labels instead of the dense
@@ -262,6 +294,32 @@ int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm
                      int B, int N, int K, int Ca, float* Ga, int Cb, float* Gb,
                      int planes_sm /* != 0: planes 1 .. K-1 of Ga / Gb are slice-major (written so by qt_lstm_bwd_dgrad / qt_dense2) */,
                      int width, void* stream);
+
+/* The same recurrences on frames of SEVERAL 64 x 64 base cells (128 x 128, 256 x 256, 96 x 128 ..; BASELINE configs[2]-[4]):
+ * one workgroup per (clip, TILE, 4-channel slice) keeps the tile's <= 4096 rows in LDS; rows on a tile border have neighbours
+ * in other tiles of the clip, so after every hop the tiles of a (clip, slice) exchange their border rows through global memory
+ * as 8-byte {value, tag} granules (write-through stores by the row's owner, sc1 polls by the tiles that need it; the tag counts
+ * launches and hops, so nothing is ever reset: csrc/chebclip.hip, TILE = true) instead of ending the launch.  Replaces K - 1
+ * qt_spmm2 calls per ChebConv pass (model/model.py:53,96); the planes are bit-identical.
+ *   tile_off = qt_quadtree_stage3's cell_off; tile_cnt .. tile_halo, brec_addr: from qt_edges_norm_tiles; xbuf: per (tile, slice,
+ *   hop parity) QT_TILE_HALO_CAP slots of four granules;
+ *   xbuf: qt_cheb_tile_xbuf_words(B, T) ints and sync: qt_cheb_tile_sync_words(B) ints, both zeroed ONCE per mesh (qt_edges_count's
+ *   zero_buf).  The LAST sync word is an error word: bit 0 = a wait for a neighbour tile timed out (the launch then finishes with
+ *   garbage instead of hanging), bit 1 = a tile capacity of the mesh build was exceeded.  T tiles per clip in rows of nbj;
+ *   N = plane stride in rows; Ca + Cb <= 4 QT_TILE_SLICES, K <= 16.  The launches are cut so that every workgroup of one is
+ *   resident (<= one per CU).  Planes as qt_cheb_clip_fwd / _bwd. */
+int qt_cheb_tile_xbuf_words(int B, int T);
+int qt_cheb_tile_sync_words(int B);
+int qt_cheb_tile_fwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* tile_off,
+                     const int32_t* tile_cnt, const int32_t* tile_pool, const int32_t* tile_rec, const int32_t* tile_brec,
+                     const int32_t* tile_bpool, const int32_t* tile_halo, const int32_t* brec_addr, int32_t* xbuf, int32_t* sync,
+                     int B, int T, int nbj, int N, int K,
+                     int Ca, const float* za, int lda, float* Ta, int Cb, const float* zb, int ldb, float* Tb, void* stream);
+int qt_cheb_tile_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* tile_off,
+                     const int32_t* tile_cnt, const int32_t* tile_pool, const int32_t* tile_rec, const int32_t* tile_brec,
+                     const int32_t* tile_bpool, const int32_t* tile_halo, const int32_t* brec_addr, int32_t* xbuf, int32_t* sync,
+                     int B, int T, int nbj, int N, int K,
+                     int Ca, float* Ga, int Cb, float* Gb, int planes_sm, void* stream);
 
 /* qt_dense: out planes = act( [A planes | S] @ [W ; Ws] ), the gate GEMM.
  *   A: Ka planes, plane k at a0 (k == 0) or a_rest + (k-1)*N*Ca, each (N, Ca)   (T_0 = Z stays in the caller's tensor)

@@ -59,6 +59,18 @@ struct ClipArgs {
     int Ncap;                      // plane stride in rows (the capacity in static mode)
     int bwd_sm;                    // backward: the gradient planes 1 .. K-1 are slice-major (plane 0 is always row-major)
     ClipPart a, b;
+    // TILE = true (frames of several 64 x 64 base cells; qt_cheb_tile_fwd / _bwd): a workgroup owns (clip, tile, slice)
+    const int32_t* tile_off;       // (B T + 1) first node of every tile in label order
+    const int32_t* tile_cnt;       // (B T * QT_TILE_CNT_STRIDE) counters of qt_edges_norm_tiles
+    const int2* tile_pool;         // (B T, QT_TILE_POOL_CAP)
+    const int4* tile_rec;          // (B T, QT_TILE_REC_CAP, 2 x int4) interior records
+    const int4* tile_brec;         // (B T, QT_TILE_HALO_CAP, 2 x int4) boundary records
+    const int2* tile_bpool;        // (B T, QT_TILE_BPOOL_CAP)
+    const int32_t* tile_halo;      // (B T, QT_TILE_HALO_CAP) global row of every halo slot
+    const int32_t* brec_addr;      // (N) boundary rows: tile slot * QT_TILE_HALO_CAP + boundary record index
+    unsigned long long* xbuf;      // (B T, QT_TILE_SLICES, QT_TILE_HALO_CAP, 4) {value, tag} granules: the published boundary rows
+    unsigned* sync;                // (2 B QT_TILE_SLICES + 1): launch generation and arrivals per (clip, slice); error word
+    int T, nbj, s0, ns;            // tiles per clip, tiles per tile row; first slice and slice count of THIS launch
 #ifdef QT_CLIP_TIMING
     long long* dbg;                // diagnostics build (tools/exp_clip_timing.py): 16 stamps per workgroup
 #endif
@@ -148,22 +160,100 @@ __device__ __forceinline__ void gather_tail_csr(fvec<W>& a, const char* __restri
 // W: channels per workgroup.  The hops are bound by the CU's own work (vector issue, LDS), not by memory: with W = 4 the
 // benchmark's 32 clips x 4 .. 5 slices occupy 128 .. 160 of the 256 CUs; W = 2 (8-byte slice rows, twice the workgroups) is
 // taken when B * C / 2 workgroups still fit the CUs in one round (clip_launch).  Same arithmetic per channel either way.
-template <bool BWD, int W>
+//
+// TILE = true: frames of several 64 x 64 base cells.  A workgroup owns (clip, TILE, slice): a tile's nodes are one contiguous
+// label range (qt_quadtree_stage3's cell_off) of at most 4096 rows, so its planes fit LDS exactly like a 64 x 64 clip's; what is
+// new is that rows on the tile border have neighbours in other tiles of the clip.  Per tile the mesh build (qt_edges_norm_tiles)
+// leaves: boundary records (rows with an edge that leaves the tile: first four edges as local rows or HALO slots, the rest in a
+// boundary pool) and the halo list (the global row behind every slot; <= 256 per tile).  Interior rows run exactly as in the
+// one-tile kernel.  After every hop the T workgroups of a (clip, slice) exchange their boundary rows THROUGH GLOBAL MEMORY:
+//   hop c:  waves 0-3 finish the boundary rows first (their neighbours: LDS plane or the halo buffer HB = T_{c-1} of the halo
+//           rows) and PUBLISH each as four 8-byte granules {value, tag} in the tile's exchange slots (xbuf; write-through), tag =
+//           launch generation of the (clip, slice) * 16 + c;  after their interior rows they poll the granules of THEIR halo
+//           row (sc1 loads from the owner tile's slots: brec_addr of the row) until all four tags match and write HB before
+//           the hop's one workgroup barrier.  (Requesting the granules half way through the interior rows gained nothing: a
+//           publication takes ~1.5 us to become visible and a poll ~1.5 us to return, so the early poll usually missed.)
+//   The data is its own flag (MI355X_MICROARCH.md, hand-off form R2: 8-byte granules written by one sc1 store each; "granules
+//   for latency"): no drain, no separate flag, no dependent load behind a poll.  A first version with write-through rows + a
+//   drained per-tile hop flag + sc1 halo loads behind the poll took 6 - 7 us per hop -- no faster than a k_spmm launch per hop
+//   (8 us at 128 x 128 x 8 clips); with granules a hop costs ~4.3 us (tools/exp_tile.py: K = 5 at 128 x 128 x 8 clips 30 -> 21 us
+//   forward, 32 -> 27 us backward; 32 channels 38 -> 25 / 46 -> 32), which is the chain boundary rows (0.6 us) -> store visible
+//   (~1.5 us) -> poll round trip (~1.5 us): what a cross-CU hand-off costs on this chip, tile size notwithstanding.  So the path
+//   pays for K >= 4 when all workgroups fit the CUs in one round, and is NOT taken otherwise (ops._tile_resident): two hops are
+//   no faster than two k_spmm launches, and 640 workgroups (hidden 32: 16 clips x 4 tiles x 10 slices) take three rounds.  Tags only ever grow (the generation word is bumped by the last workgroup of the (clip, slice)
+//   to leave), so nothing is reset between launches or hipGraph replays; the exchange buffer is zeroed once per mesh build.
+// No dependence on dispatch order beyond forward progress: spins are bounded (a timeout sets the error word and the launch
+// finishes with garbage instead of hanging) and the launches are cut so that all workgroups of one are co-resident.
+constexpr unsigned TILE_SPIN_LIMIT = 200000u;              // polls of ~1 us: ~0.2 s before a poll gives up
+
+template <bool BWD, int W, bool TILE = false>
 __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
     using V = fvec<W>;
+    static_assert(!TILE || W == 4, "the tile exchange moves 16-byte rows");
+    constexpr int NPOOL = TILE ? QT_TILE_POOL_CAP : CL_TAIL;
     __shared__ __attribute__((aligned(16))) char Pl[2 * CL_ROWS * 4 * W];
-    __shared__ int2 TE[CL_TAIL];
+    __shared__ int2 TE[NPOOL];
+    __shared__ __attribute__((aligned(16))) char HB[TILE ? QT_TILE_HALO_CAP * 4 * W : 16];     // T_{c-1} of the halo rows
+    __shared__ int4 BR[TILE ? 2 * QT_TILE_HALO_CAP : 1];                                        // boundary records
+    __shared__ int2 BP[TILE ? QT_TILE_BPOOL_CAP : 1];                                           // boundary pool
+    __shared__ int HC[TILE ? QT_TILE_HALO_CAP : 1];                                             // global row of every halo slot
+    __shared__ unsigned arrive;                                                                 // boundary waves that drained their stores
     const int t = threadIdx.x;
-    const int c = (int)blockIdx.x % g.B, s = (int)blockIdx.x / g.B;
+    int c, s, ts = 0, tl = 0;
+    if constexpr (TILE) {
+        // groups (clip, slice) of this launch; the T workgroups of a group get ids 8 apart (one XCD under round-robin
+        // placement: a speed matter only) inside a window of 8 T consecutive ids
+        const int gi = ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x / (8 * g.T));
+        tl = ((int)blockIdx.x >> 3) % g.T;
+        if (gi >= g.B * g.ns) return;
+        c = gi % g.B;
+        s = g.s0 + gi / g.B;
+        ts = c * g.T + tl;
+    } else {
+        c = (int)blockIdx.x % g.B;
+        s = (int)blockIdx.x / g.B;
+    }
     const bool second = s >= g.nsa;
     const ClipPart& pt = second ? g.b : g.a;
     const int C = pt.C;
     const int ch = W * (second ? s - g.nsa : s);
-    const int r0 = g.node_off[c];
-    const int nr = min(g.node_off[c + 1] - r0, CL_ROWS);
-    if (nr <= 0) return;                                   // (workgroup-uniform)
-    const int ntail = min(g.tail_cnt[QT_TAIL_CNT_STRIDE * c], CL_TAIL);
-    const int ntr = min(g.tail_cnt[QT_TAIL_CNT_STRIDE * c + 1], CL_ROWS);
+    const int r0 = TILE ? g.tile_off[ts] : g.node_off[c];
+    const int nr = min((TILE ? g.tile_off[ts + 1] : g.node_off[c + 1]) - r0, CL_ROWS);
+    // TILE: the sync words of this (clip, slice): launch generation (read by every workgroup at its start, bumped by the last
+    // one to leave) and the count of workgroups that have left
+    unsigned* const ggen = TILE ? g.sync + ((int64_t)c * QT_TILE_SLICES + s) : nullptr;
+    unsigned* const gdone = TILE ? g.sync + ((int64_t)(g.B + c) * QT_TILE_SLICES + s) : nullptr;
+    unsigned* const gerr = TILE ? g.sync + (int64_t)2 * g.B * QT_TILE_SLICES : nullptr;
+    unsigned tag0 = 0;                       // generation * 16: a hop's tag is tag0 + hop number
+    if constexpr (TILE) tag0 = __hip_atomic_load(ggen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 4;
+    auto leave = [&]() {
+        if constexpr (TILE) {
+            if (t == 0) {
+                const unsigned old = __hip_atomic_fetch_add(gdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == (unsigned)g.T - 1u) {          // every workgroup of the group has read the generation and left
+                    __hip_atomic_store(gdone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(ggen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    };
+    if (nr <= 0) {                                         // (workgroup-uniform)
+        leave();
+        return;
+    }
+    const int32_t* cnts = TILE ? g.tile_cnt + (int64_t)QT_TILE_CNT_STRIDE * ts : g.tail_cnt + QT_TAIL_CNT_STRIDE * c;
+    const int ntail = min(cnts[0], NPOOL);
+    const int ntr = min(cnts[1], CL_ROWS);
+    const int nh = TILE ? min(cnts[2], QT_TILE_HALO_CAP) : 0;
+    const int nb = TILE ? min(cnts[3], QT_TILE_HALO_CAP) : 0;
+    const int nbp = TILE ? min(cnts[4], QT_TILE_BPOOL_CAP) : 0;
+    if constexpr (TILE) {
+        if (t == 0) {
+            arrive = 0u;
+            if (cnts[5]) __hip_atomic_fetch_or(gerr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a tile capacity was exceeded)
+        }
+    }
+    bool dead = false;                       // TILE: a poll timed out: no further waiting, the error word is set
     CL_STAMP(0);
     const int K = g.K;
     const unsigned pstride = (unsigned)g.Ncap * (unsigned)C;      // (K * Ncap * C < 2^31: checked by the host entry -- 32-bit offsets)
@@ -197,7 +287,9 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
         const int i = t + CL_T * u;
         rowc[u] = (unsigned)(r0 + min(i, nr - 1));
         const bool isrec = i >= nr && i - nr < nslot;
-        const int4* src = isrec ? g.tail_rec + 2 * ((int64_t)c * CL_ROWS + (i - nr)) : g.ell + 2 * (int64_t)rowc[u];
+        const int4* src = isrec ? (TILE ? g.tile_rec + 2 * ((int64_t)ts * QT_TILE_REC_CAP + (i - nr))
+                                        : g.tail_rec + 2 * ((int64_t)c * CL_ROWS + (i - nr)))
+                                : g.ell + 2 * (int64_t)rowc[u];
         c4[u] = src[0];
         wb[u] = src[1];
         if constexpr (!BWD) {
@@ -207,14 +299,37 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
         }
     }
     {
-        const int2* src = g.tail_pool + (int64_t)c * CL_TAIL;
-        int2 te[(CL_TAIL + CL_T - 1) / CL_T];
+        const int2* src = TILE ? g.tile_pool + (int64_t)ts * QT_TILE_POOL_CAP : g.tail_pool + (int64_t)c * CL_TAIL;
+        int2 te[(NPOOL + CL_T - 1) / CL_T];
 #pragma unroll
-        for (int i = 0; i < (CL_TAIL + CL_T - 1) / CL_T; ++i)
+        for (int i = 0; i < (NPOOL + CL_T - 1) / CL_T; ++i)
             if (t + CL_T * i < ntail) te[i] = src[t + CL_T * i];
 #pragma unroll
-        for (int i = 0; i < (CL_TAIL + CL_T - 1) / CL_T; ++i)
+        for (int i = 0; i < (NPOOL + CL_T - 1) / CL_T; ++i)
             if (t + CL_T * i < ntail) TE[t + CL_T * i] = te[i];
+    }
+    // TILE: the boundary records, their pool and the halo list of this tile -> LDS; the halo rows' first operand -> HB (an
+    // input of the launch: plain loads, nothing to wait for)
+    V bnx = vzero<W>();                      // backward: A_k of this thread's boundary record row, requested one hop ahead
+    if constexpr (TILE) {
+        if (t < nb) {
+            const int4* bs = g.tile_brec + 2 * ((int64_t)ts * QT_TILE_HALO_CAP + t);
+            const int4 b0 = bs[0], b1 = bs[1];
+            BR[2 * t] = b0;
+            BR[2 * t + 1] = b1;
+            if constexpr (BWD) bnx = ldg<W>(pt.planes + grad_off(K - 2, (unsigned)r0 + ((unsigned)b1.w & (CL_ROWS - 1))));
+        }
+        if (t < nbp) BP[t] = g.tile_bpool[(int64_t)ts * QT_TILE_BPOOL_CAP + t];
+        if (t < nh) {
+            const int hc = g.tile_halo[(int64_t)ts * QT_TILE_HALO_CAP + t];
+            // granule index of the halo row's published values: (owner tile * slices + this slice) * 256 + its record, * 4
+            const int ba = g.brec_addr[hc];
+            HC[t] = (((ba >> 8) * QT_TILE_SLICES + s) * 2 * QT_TILE_HALO_CAP + (ba & (QT_TILE_HALO_CAP - 1))) * 4;
+            V hv;
+            if constexpr (!BWD) hv = ldg<W>(pt.z + ((unsigned)hc * (unsigned)pt.ld + ch));
+            else hv = ldg<W>(pt.planes + grad_off(K - 1, (unsigned)hc));
+            vstore<W>(HB + t * (4 * W), hv);
+        }
     }
     CL_STAMP(1);
     unsigned lc[CL_RPT][2];
@@ -241,7 +356,11 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
         } else {
             const bool tail = c4[u].w < 0;  // (the ELL array flags a row with more edges by complementing its last column)
             if (tail) c4[u].w = ~c4[u].w;
-            if (ok && !tail) mine |= 1u << u;
+            bool remote = false;            // TILE: a neighbour in another tile -> the row runs from its boundary record
+            if constexpr (TILE)
+                remote = (unsigned)(c4[u].x - r0) >= (unsigned)nr || (unsigned)(c4[u].y - r0) >= (unsigned)nr ||
+                         (unsigned)(c4[u].z - r0) >= (unsigned)nr || (unsigned)(c4[u].w - r0) >= (unsigned)nr;
+            if (ok && !tail && !remote) mine |= 1u << u;
             lc[u][0] = ((unsigned)((c4[u].x - r0) & (CL_ROWS - 1)) << 4) | ((unsigned)((c4[u].y - r0) & (CL_ROWS - 1)) << 20);
             lc[u][1] = ((unsigned)((c4[u].z - r0) & (CL_ROWS - 1)) << 4) | ((unsigned)((c4[u].w - r0) & (CL_ROWS - 1)) << 20);
             w[u][0] = __int_as_float(wb[u].x);
@@ -266,12 +385,17 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
     // in it) -- then the tail of a record's row,  r = alpha * acc;  addend(r) (backward: + A_k of the row);  r += beta * own;
     // fin(row, r) stores the row.
     constexpr unsigned PLANE = (unsigned)CL_ROWS * 4u * W;
-    auto hop = [&](auto co_tag, auto own_tag, float alpha, float beta, auto&& addend, auto&& fin) {
+    // TILE: hopc = 1, 2, .. counts the hops of the launch (the tag of its granules); more = a further hop follows (the last hop
+    // publishes and fetches nothing)
+    struct Xch { unsigned hopc; bool more; };
+    [[maybe_unused]] const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(TILE ? g.xbuf : nullptr, 0, -1, 0x00020000);
+    using U4 = unsigned __attribute__((ext_vector_type(4)));
+    auto hop = [&](auto co_tag, auto own_tag, float alpha, float beta, auto&& addend, auto&& fin, const Xch& x) {
         constexpr unsigned CO = decltype(co_tag)::value;
         constexpr bool OWN = decltype(own_tag)::value;
         const char* Pc = Pl + CO;
         char* Pn = Pl + (CO ^ PLANE);
-        auto finish = [&](const V& acc, const V& own, V& nx, char* slot, unsigned grow, bool live) {
+        auto finish = [&](const V& acc, const V& own, V& nx, char* slot, unsigned grow, bool live, auto&& fn) {
             V r;
 #pragma unroll
             for (int i = 0; i < W; ++i) r[i] = alpha * acc[i];
@@ -280,12 +404,62 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
 #pragma unroll
                 for (int i = 0; i < W; ++i) r[i] = __builtin_fmaf(beta, own[i], r[i]);
             }
-            if (live) fin(grow, r, slot);
+            if (live) fn(grow, r, slot);
         };
+        [[maybe_unused]] const unsigned tag = tag0 + x.hopc;
+        if constexpr (TILE) {
+            // ---- boundary rows first (waves 0-3, one record per thread): neighbours from the LDS plane or the halo buffer, the
+            // same chain of fused multiply-adds in CSR order; the row is stored like any other and, when a further hop follows,
+            // PUBLISHED as four {value, tag} granules in this tile's exchange slots (two 16-byte write-through stores)
+            if (t < nb) {
+                const int4 b0 = BR[2 * t], b1 = BR[2 * t + 1];
+                const unsigned lrow = (unsigned)b1.w & (CL_ROWS - 1), info = (unsigned)b1.z;
+                auto gat = [&](unsigned f16) -> V {
+                    return (f16 & 1u) ? vload<W>(HB + (f16 >> 4) * (4u * W)) : lds_row<W>(Pc, f16 & 0xfff0u);
+                };
+                V f[4], own = vzero<W>();
+                f[0] = gat((unsigned)b0.x & 0xffffu);
+                f[1] = gat((unsigned)b0.x >> 16);
+                f[2] = gat((unsigned)b0.y & 0xffffu);
+                f[3] = gat((unsigned)b0.y >> 16);
+                char* slot = Pn + lrow * (4u * W);
+                if constexpr (OWN) own = vload<W>(slot);
+                const float bw[4] = {__int_as_float(b0.z), __int_as_float(b0.w), __int_as_float(b1.x), __int_as_float(b1.y)};
+                V acc = vzero<W>();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vfma<W>(acc, bw[e], f[e]);
+                const unsigned pb = info & 0xffffu, pc = info >> 16;
+                for (unsigned j0 = 0; j0 < pc; j0 += 4) {
+                    int2 e[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) e[v] = BP[pb + min(j0 + v, pc - 1)];
+                    V ff[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        ff[v] = e[v].x < 0 ? vload<W>(HB + ((unsigned)e[v].x & 0xffu) * (4u * W)) : lds_row<W>(Pc, (unsigned)e[v].x << 4);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (j0 + v < pc) vfma<W>(acc, __int_as_float(e[v].y), ff[v]);
+                }
+                finish(acc, own, bnx, slot, (unsigned)r0 + lrow, true, [&](unsigned grow, const V& r, char* own_slot) {
+                    fin(grow, r, own_slot);
+                    if (x.more) {
+                        const int off = (((ts * QT_TILE_SLICES + s) * 2 + (int)(x.hopc & 1u)) * QT_TILE_HALO_CAP + t) * 32;
+                        const U4 g0 = {__float_as_uint(r[0]), tag, __float_as_uint(r[1]), tag};
+                        const U4 g1 = {__float_as_uint(r[2]), tag, __float_as_uint(r[3]), tag};
+                        __builtin_amdgcn_raw_buffer_store_b128(g0, xrsrc, off, 0, 16);           // sc1
+                        __builtin_amdgcn_raw_buffer_store_b128(g1, xrsrc, off + 16, 0, 16);
+                    }
+                });
+            }
+            // (the halo buffer may be overwritten once all four boundary waves are through with it: they count themselves here)
+            if (x.more && t < 256 && (t & 63) == 0) atomicAdd(&arrive, 1u);
+        }
         // (the packed column offsets and the row numbers are made opaque once per hop: otherwise the loop-invariant unpacked LDS
         // addresses -- one per gather -- and 64-bit row addresses are kept in registers across the hops, and the kernel spills)
 #pragma unroll
         for (int u = 0; u < CL_RPT; ++u) asm volatile("" : "+v"(lc[u][0]), "+v"(lc[u][1]), "+v"(rowc[u]));
+        [[maybe_unused]] const int xoff = TILE ? (HC[t < nh ? t : 0] + (int)(x.hopc & 1u) * QT_TILE_HALO_CAP * 4) * 8 : 0;
 #pragma unroll
         for (int u = 0; u < CL_RPT; ++u) {
             V f[4], own = vzero<W>();
@@ -304,8 +478,39 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
                 else
                     gather_tail_csr<W>(acc, Pc, rowc[u], r0, g.rowptr, g.col, g.nrm);
             }
-            finish(acc, own, nxt[u], slot, rowc[u], (mine >> u) & 1u);      // (loads unconditional, the stores predicated)
+            finish(acc, own, nxt[u], slot, rowc[u], (mine >> u) & 1u, fin);      // (loads unconditional, the stores predicated)
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (TILE) {
+            if (x.more && t < 256) {
+                // this thread's halo row as its owner tile published it in THIS hop: poll the four granules until every tag says so
+                // (each wave for itself; the owners published before their interior rows, so the first poll usually matches)
+                V hv = vzero<W>();
+                if (!dead) {
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool ok = true;
+                        if (t < nh) {
+                            const U4 q0 = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff, 0, 16);          // sc1
+                            const U4 q1 = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff + 16, 0, 16);
+                            ok = q0.y == tag && q0.w == tag && q1.y == tag && q1.w == tag;
+                            hv[0] = __uint_as_float(q0.x);
+                            hv[1] = __uint_as_float(q0.z);
+                            hv[2] = __uint_as_float(q1.x);
+                            hv[3] = __uint_as_float(q1.z);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                        if (++spins > TILE_SPIN_LIMIT) {
+                            dead = true;
+                            if ((t & 63) == 0) __hip_atomic_fetch_or(gerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                while (*(volatile unsigned*)&arrive < 4u * x.hopc) __builtin_amdgcn_s_sleep(1);
+                if (t < nh) vstore<W>(HB + t * (4 * W), hv);
+            }
         }
         lds_barrier();
         CL_STAMP(stamp++);
@@ -330,10 +535,11 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
 #endif
             };
         };
-        hop(Co0{}, No{}, 1.0f, 0.0f, none, store(1));
+        auto xch = [&](int k) { return Xch{(unsigned)k, k + 1 < K}; };
+        hop(Co0{}, No{}, 1.0f, 0.0f, none, store(1), xch(1));
         for (int k = 2; k < K; k += 2) {
-            hop(Co1{}, Yes{}, 2.0f, -1.0f, none, store(k));
-            if (k + 1 < K) hop(Co0{}, Yes{}, 2.0f, -1.0f, none, store(k + 1));
+            hop(Co1{}, Yes{}, 2.0f, -1.0f, none, store(k), xch(k));
+            if (k + 1 < K) hop(Co0{}, Yes{}, 2.0f, -1.0f, none, store(k + 1), xch(k + 1));
         }
     } else {
         // Clenshaw on the gradient planes A_0 .. A_{K-1}: b_{K-1} = A_{K-1}; b_k = A_k + 2 L^ b_{k+1} - b_{k+2};
@@ -359,13 +565,15 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
                     vstore<W>(own, r);
             };
         };
+        auto xch = [&](int k) { return Xch{(unsigned)(K - 1 - k), k > 0}; };
         int k = K - 2;
-        hop(Co0{}, No{}, k == 0 ? 1.0f : 2.0f, 0.0f, add_ak(k), put(k));          // b_{K-2} = A_{K-2} + 2 L^ b_{K-1}
+        hop(Co0{}, No{}, k == 0 ? 1.0f : 2.0f, 0.0f, add_ak(k), put(k), xch(k));          // b_{K-2} = A_{K-2} + 2 L^ b_{K-1}
         for (--k; k >= 0; k -= 2) {
-            hop(Co1{}, Yes{}, k == 0 ? 1.0f : 2.0f, -1.0f, add_ak(k), put(k));
-            if (k - 1 >= 0) hop(Co0{}, Yes{}, k - 1 == 0 ? 1.0f : 2.0f, -1.0f, add_ak(k - 1), put(k - 1));
+            hop(Co1{}, Yes{}, k == 0 ? 1.0f : 2.0f, -1.0f, add_ak(k), put(k), xch(k));
+            if (k - 1 >= 0) hop(Co0{}, Yes{}, k - 1 == 0 ? 1.0f : 2.0f, -1.0f, add_ak(k - 1), put(k - 1), xch(k - 1));
         }
     }
+    leave();
 }
 
 }  // namespace
@@ -459,6 +667,115 @@ extern "C" int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const
     if (N <= 0) return QT_OK;
     const ClipMesh m = {rowptr, col, nrm, ell, node_off, tail_cnt, tail_pool, tail_rec, B};
     clip_launch(true, m, N, K, Ca, nullptr, 0, Ga, Cb, nullptr, 0, Gb, stream, width, planes_sm);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+// ---- frames of several 64 x 64 base cells: the same recurrences with one workgroup per (clip, TILE, slice) and a halo exchange
+// between the tiles of a clip after every hop (k_cheb_clip<.., TILE = true>)
+struct TileMesh {
+    const int32_t *rowptr, *col;
+    const float* nrm;
+    const int32_t *ell, *tile_off, *tile_cnt, *tile_pool, *tile_rec, *tile_brec, *tile_bpool, *tile_halo, *brec_addr;
+    int32_t *xbuf, *sync;
+    int B, T, nbj;
+};
+
+static int tile_launch(bool bwd, const TileMesh& m, int Ncap, int K, int Ca, const float* za, int lda, float* Pa, int Cb,
+                       const float* zb, int ldb, float* Pb, void* stream, int bwd_sm) {
+    ClipArgs g;
+    g.bwd_sm = bwd_sm != 0;
+    g.rowptr = m.rowptr;
+    g.col = m.col;
+    g.nrm = m.nrm;
+    g.ell = reinterpret_cast<const int4*>(m.ell);
+    g.node_off = nullptr;
+    g.tail_cnt = nullptr;
+    g.tail_pool = nullptr;
+    g.tail_rec = nullptr;
+    g.B = m.B;
+    g.K = K;
+    g.nsa = Ca / 4;
+    g.Ncap = Ncap;
+#ifdef QT_CLIP_TIMING
+    g.dbg = nullptr;
+#endif
+    g.a = ClipPart{za, Pa, Ca, lda ? lda : Ca};
+    g.b = ClipPart{zb, Pb, Cb, ldb ? ldb : Cb};
+    g.tile_off = m.tile_off;
+    g.tile_cnt = m.tile_cnt;
+    g.tile_pool = reinterpret_cast<const int2*>(m.tile_pool);
+    g.tile_rec = reinterpret_cast<const int4*>(m.tile_rec);
+    g.tile_brec = reinterpret_cast<const int4*>(m.tile_brec);
+    g.tile_bpool = reinterpret_cast<const int2*>(m.tile_bpool);
+    g.tile_halo = m.tile_halo;
+    g.brec_addr = m.brec_addr;
+    g.xbuf = reinterpret_cast<unsigned long long*>(m.xbuf);
+    g.sync = reinterpret_cast<unsigned*>(m.sync);
+    g.T = m.T;
+    g.nbj = m.nbj;
+    // One launch holds whole (clip, slice) groups and at most one workgroup per CU (160 KB of LDS each): all of its workgroups
+    // are resident together, so a workgroup that waits for a neighbour tile never waits for one that has not been dispatched.
+    const int S = (Ca + Cb) / 4;
+    int per = qt_num_cus() / (m.B * m.T);          // slices per launch
+    if (per < 1) per = 1;                          // (more tiles than CUs: relies on in-order dispatch; the spins are bounded)
+    for (int s0 = 0; s0 < S; s0 += per) {
+        g.s0 = s0;
+        g.ns = S - s0 < per ? S - s0 : per;
+        const int groups = m.B * g.ns;
+        const int grid = ((groups + 7) / 8) * 8 * m.T;
+        if (bwd)
+            hipLaunchKernelGGL((k_cheb_clip<true, 4, true>), dim3(grid), dim3(CL_T), 0, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL((k_cheb_clip<false, 4, true>), dim3(grid), dim3(CL_T), 0, (hipStream_t)stream, g);
+    }
+    return 0;
+}
+
+#define TILE_MESH_ARGS_OK                                                                                                         \
+    QT_ARG(rowptr && col && nrm && ell && tile_off && tile_cnt && tile_pool && tile_rec && tile_brec && tile_bpool && tile_halo && brec_addr && \
+               xbuf && sync && B > 0 && K >= 2 && K <= 16 && T >= 2 && nbj >= 1 && T % nbj == 0 && ((uintptr_t)xbuf & 15) == 0,         \
+           "bad arguments (the tile arrays of qt_edges_norm_tiles, the exchange buffer and the sync words zeroed by qt_edges_count are required)")
+
+extern "C" int qt_cheb_tile_sync_words(int B) { return 2 * B * QT_TILE_SLICES + 1; }
+extern "C" int qt_cheb_tile_xbuf_words(int B, int T) { return B * T * QT_TILE_SLICES * 2 * QT_TILE_HALO_CAP * 8; }   // (hop parity) x 4 granules of 2 ints per slot
+
+extern "C" int qt_cheb_tile_fwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell,
+                                const int32_t* tile_off, const int32_t* tile_cnt, const int32_t* tile_pool, const int32_t* tile_rec,
+                                const int32_t* tile_brec, const int32_t* tile_bpool, const int32_t* tile_halo, const int32_t* brec_addr,
+                                int32_t* xbuf, int32_t* sync,
+                                int B, int T, int nbj, int N, int K, int Ca, const float* za, int lda, float* Ta, int Cb,
+                                const float* zb, int ldb, float* Tb, void* stream) {
+    TILE_MESH_ARGS_OK;
+    QT_ARG(za && Ta && Ca > 0 && Ca % 4 == 0 && Cb >= 0 && Cb % 4 == 0 && (Cb == 0 || (zb && Tb)), "bad operands");
+    QT_ARG((Ca + Cb) / 4 <= QT_TILE_SLICES, "at most QT_TILE_SLICES 4-channel slices per launch");
+    QT_ARG((lda | ldb) % 4 == 0, "row strides must be multiples of 4");
+    QT_ARG((((uintptr_t)za | (uintptr_t)Ta | (uintptr_t)zb | (uintptr_t)Tb | (uintptr_t)ell | (uintptr_t)tile_pool | (uintptr_t)tile_rec |
+             (uintptr_t)tile_brec | (uintptr_t)tile_bpool) & 15) == 0, "operands must be 16-byte aligned");
+    QT_ARG((int64_t)K * N * max(Ca, Cb) < ((int64_t)1 << 31) && (int64_t)N * max(max(lda, ldb), 4) < ((int64_t)1 << 31),
+           "planes too large for 32-bit offsets");
+    if (N <= 0) return QT_OK;
+    const TileMesh m = {rowptr, col, nrm, ell, tile_off, tile_cnt, tile_pool, tile_rec, tile_brec, tile_bpool, tile_halo, brec_addr, xbuf, sync, B, T, nbj};
+    tile_launch(false, m, N, K, Ca, za, lda, Ta, Cb, zb, ldb, Tb, stream, 0);
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_cheb_tile_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell,
+                                const int32_t* tile_off, const int32_t* tile_cnt, const int32_t* tile_pool, const int32_t* tile_rec,
+                                const int32_t* tile_brec, const int32_t* tile_bpool, const int32_t* tile_halo, const int32_t* brec_addr,
+                                int32_t* xbuf, int32_t* sync,
+                                int B, int T, int nbj, int N, int K, int Ca, float* Ga, int Cb, float* Gb, int planes_sm,
+                                void* stream) {
+    TILE_MESH_ARGS_OK;
+    QT_ARG(Ga && Ca > 0 && Ca % 4 == 0 && Cb >= 0 && Cb % 4 == 0 && (Cb == 0 || Gb), "bad operands");
+    QT_ARG((Ca + Cb) / 4 <= QT_TILE_SLICES, "at most QT_TILE_SLICES 4-channel slices per launch");
+    QT_ARG((((uintptr_t)Ga | (uintptr_t)Gb | (uintptr_t)ell | (uintptr_t)tile_pool | (uintptr_t)tile_rec | (uintptr_t)tile_brec |
+             (uintptr_t)tile_bpool) & 15) == 0, "operands must be 16-byte aligned");
+    QT_ARG((int64_t)K * N * max(Ca, Cb) < ((int64_t)1 << 31), "planes too large for 32-bit offsets");
+    if (N <= 0) return QT_OK;
+    const TileMesh m = {rowptr, col, nrm, ell, tile_off, tile_cnt, tile_pool, tile_rec, tile_brec, tile_bpool, tile_halo, brec_addr, xbuf, sync, B, T, nbj};
+    tile_launch(true, m, N, K, Ca, nullptr, 0, Ga, Cb, nullptr, 0, Gb, stream, planes_sm);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -48,9 +48,11 @@ constexpr int ET = 1024;
 __global__ __launch_bounds__(ET) void k_edges_count(const int32_t* __restrict__ labels, const int32_t* __restrict__ cell,
                                                     int Ncap, const int32_t* __restrict__ n_dev, int n, int m,
                                                     int32_t* __restrict__ cnt4, int32_t* __restrict__ sums,
-                                                    int32_t* __restrict__ tail_cnt, int B) {
+                                                    int32_t* __restrict__ tail_cnt, int B, int32_t* __restrict__ zero_buf,
+                                                    int zero_len) {
     __shared__ int red[16];
     const int idx = blockIdx.x * ET + threadIdx.x;
+    for (int z = idx; z < zero_len; z += (int)gridDim.x * ET) zero_buf[z] = 0;      // (tile counters + sync words of multi-tile frames)
     if (tail_cnt) {                      // the per-clip counters k_edges_nrm adds to (two launches later): tail edges, rows with a tail
         for (int c = idx; c < B; c += (int)gridDim.x * ET) {      // (grid-stride: any number of clips)
             tail_cnt[QT_TAIL_CNT_STRIDE * c] = 0;
@@ -195,17 +197,113 @@ __global__ void k_edges_nrm(const int32_t* __restrict__ rowptr, const int32_t* _
     }
 }
 
+// qt_edges_norm for frames of several 64 x 64 base cells ("tiles"): nrm / ell as k_edges_nrm, and per TILE the structures the
+// tile-resident recurrence kernel (chebclip.hip, TILE = true) runs from.  A tile's nodes are one contiguous label range
+// [t0, t0 + nr) (qt_quadtree_stage3's cell_off).  A row is
+//   * a BOUNDARY row when at least one of its edges leaves the tile: it gets a boundary record (first four edges, local rows or
+//     halo slots) + a run in the boundary pool; every edge that leaves the tile takes one HALO slot of the tile (the global row
+//     of the neighbour goes to tile_halo) -- at most 256 of each per tile: a boundary row owns at least one of the tile's
+//     <= 256 pixel adjacencies across its border, and so does every (row, outside neighbour) pair;
+//   * else, with more than four edges, an INTERIOR record + a run in the interior pool (k_edges_nrm's scheme per tile).
+// Slot / run order: as the atomics arrive; contents do not depend on it.
+__global__ void k_edges_nrm_tile(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
+                                 const float* __restrict__ dis, int Ncap, const int32_t* __restrict__ n_dev,
+                                 float* __restrict__ nrm, int4* __restrict__ ell, const int32_t* __restrict__ cell,
+                                 const int32_t* __restrict__ tile_off, int T, int nbj, int32_t* __restrict__ tile_cnt,
+                                 int2* __restrict__ tile_pool, int4* __restrict__ tile_rec, int4* __restrict__ tile_brec,
+                                 int2* __restrict__ tile_bpool, int32_t* __restrict__ tile_halo,
+                                 int32_t* __restrict__ brec_addr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= qt_rows(n_dev, Ncap)) return;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    const int4 cl = reinterpret_cast<const int4*>(cell)[i];
+    const int base = (cl.x >> 6) * nbj + (cl.y >> 6);
+    const int ts = cl.w * T + (T - 1 - base);                  // tile slot in label order (cell_off's slots)
+    const int t0 = tile_off[ts], nr = tile_off[ts + 1] - t0;
+    int32_t* cnts = tile_cnt + (int64_t)QT_TILE_CNT_STRIDE * ts;
+    int nrem = 0;
+    for (int e = e0; e < e1; ++e) {
+        const unsigned lj = (unsigned)(col[e] - t0);
+        nrem += lj >= (unsigned)nr;
+    }
+    const int cnt = min(max(e1 - e0 - 4, 0), 0xffff);
+    uint32_t info = 0;
+    int2* run = nullptr;
+    int4* rec = nullptr;
+    int hbase = 0;
+    if (nrem > 0) {                                            // boundary row
+        hbase = atomicAdd(&cnts[2], nrem);
+        const int slot = atomicAdd(&cnts[3], 1);
+        int pbase = 0;
+        if (cnt > 0) pbase = atomicAdd(&cnts[4], cnt);
+        if (hbase + nrem <= QT_TILE_HALO_CAP && slot < QT_TILE_HALO_CAP && pbase + cnt <= QT_TILE_BPOOL_CAP) {
+            rec = tile_brec + 2 * ((int64_t)ts * QT_TILE_HALO_CAP + slot);
+            run = tile_bpool + (int64_t)ts * QT_TILE_BPOOL_CAP + pbase;
+            info = (uint32_t)pbase | ((uint32_t)cnt << 16);
+            brec_addr[i] = ts * QT_TILE_HALO_CAP + slot;        // where the other tiles find this row's published values
+        } else {
+            cnts[5] = 1;                                       // (cannot happen on a quadtree mesh; the kernel reports it)
+            nrem = 0;
+        }
+    } else if (cnt > 0) {                                      // interior row with a tail
+        const int pbase = atomicAdd(&cnts[0], cnt);
+        if (pbase + cnt <= QT_TILE_POOL_CAP) {
+            run = tile_pool + (int64_t)ts * QT_TILE_POOL_CAP + pbase;
+            info = (uint32_t)pbase | ((uint32_t)cnt << 16);
+        } else {
+            info = 0xffffu | ((uint32_t)cnt << 16);            // pool full: the row walks the CSR arrays
+        }
+        const int slot = atomicAdd(&cnts[1], 1);
+        if (slot < QT_TILE_REC_CAP) rec = tile_rec + 2 * ((int64_t)ts * QT_TILE_REC_CAP + slot);
+    }
+    const float di = dis[i];
+    int c4[4] = {i, i, i, i};              // (an unused slot re-reads the row itself with weight 0)
+    float w4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    unsigned l4[4];                        // the first four columns as the kernel's 16-bit fields
+    l4[0] = l4[1] = l4[2] = l4[3] = ((unsigned)(i - t0) & (QT_TILE_REC_CAP - 1)) << 4;
+    int hk = 0;
+    for (int e = e0; e < e1; ++e) {
+        const int cj = col[e];
+        const float v = -(di * w[e] * dis[cj]);
+        nrm[e] = v;
+        const unsigned lj = (unsigned)(cj - t0);
+        const bool remote = lj >= (unsigned)nr;
+        int hs = 0;
+        if (remote && nrem > 0) {
+            hs = hbase + hk++;
+            tile_halo[(int64_t)ts * QT_TILE_HALO_CAP + hs] = cj;
+        }
+        if (e - e0 < 4) {
+            c4[e - e0] = cj;
+            w4[e - e0] = v;
+            l4[e - e0] = remote ? (((unsigned)hs << 4) | 1u) : ((lj & (QT_TILE_REC_CAP - 1)) << 4);
+        } else if (run && e - e0 - 4 < 0xffff) {
+            run[e - e0 - 4] = make_int2(remote ? (int)(0x80000000u | (unsigned)hs) : (int)lj, __float_as_int(v));
+        }
+    }
+    if (ell) {
+        if (e1 - e0 > 4) c4[3] = ~c4[3];
+        ell[2 * (int64_t)i] = make_int4(c4[0], c4[1], c4[2], c4[3]);
+        ell[2 * (int64_t)i + 1] = make_int4(__float_as_int(w4[0]), __float_as_int(w4[1]), __float_as_int(w4[2]), __float_as_int(w4[3]));
+    }
+    if (rec) {
+        rec[0] = make_int4((int)(l4[0] | (l4[1] << 16)), (int)(l4[2] | (l4[3] << 16)), __float_as_int(w4[0]), __float_as_int(w4[1]));
+        rec[1] = make_int4(__float_as_int(w4[2]), __float_as_int(w4[3]), (int)info, i - t0);
+    }
+}
+
 }  // namespace
 
 extern "C" int qt_edges_blocks(int N) { return N > 0 ? qt_cdiv(4 * (int64_t)N + 1, ET) : 0; }
 
 extern "C" int qt_edges_count(const int32_t* labels, const int32_t* cell, int N, const int32_t* n_dev, int n, int m,
-                              int32_t* cnt4, int32_t* sums, int32_t* tail_cnt, int B, void* stream) {
+                              int32_t* cnt4, int32_t* sums, int32_t* tail_cnt, int B, int32_t* zero_buf, int zero_len, void* stream) {
     QT_ARG(labels && cell && cnt4 && sums, "null pointer");
     QT_ARG(!tail_cnt || B > 0, "tail_cnt needs the number of clips");
+    QT_ARG(zero_len >= 0 && (zero_len == 0 || zero_buf), "zero_buf");
     if (N <= 0) return QT_OK;
     hipLaunchKernelGGL(k_edges_count, dim3(qt_edges_blocks(N)), dim3(ET), 0, (hipStream_t)stream, labels, cell, N, n_dev, n, m,
-                       cnt4, sums, tail_cnt, B);
+                       cnt4, sums, tail_cnt, B, zero_buf, zero_len);
     QT_LAUNCHED();
     return QT_OK;
 }
@@ -235,6 +333,24 @@ extern "C" int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const fl
     hipLaunchKernelGGL(k_edges_nrm, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, w, dis, N, n_dev, nrm,
                        reinterpret_cast<int4*>(ell), cell, node_off, tail_cnt, reinterpret_cast<int2*>(tail_pool),
                        reinterpret_cast<uint32_t*>(tail_info), reinterpret_cast<int4*>(tail_rec));
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_edges_norm_tiles(const int32_t* rowptr, const int32_t* col, const float* w, const float* dis, int N,
+                                   const int32_t* n_dev, float* nrm, int32_t* ell, const int32_t* cell, const int32_t* tile_off,
+                                   int T, int nbj, int32_t* tile_cnt, int32_t* tile_pool, int32_t* tile_rec, int32_t* tile_brec,
+                                   int32_t* tile_bpool, int32_t* tile_halo, int32_t* brec_addr, void* stream) {
+    QT_ARG(rowptr && col && w && dis && nrm && cell && tile_off && tile_cnt && tile_pool && tile_rec && tile_brec && tile_bpool && tile_halo &&
+               brec_addr, "null pointer");
+    QT_ARG(T >= 1 && nbj >= 1 && T % nbj == 0, "T tiles per clip in rows of nbj");
+    QT_ARG((((uintptr_t)ell | (uintptr_t)tile_pool | (uintptr_t)tile_rec | (uintptr_t)tile_brec | (uintptr_t)tile_bpool) & 15) == 0,
+           "ell and the tile arrays must be 16-byte aligned");
+    if (N <= 0) return QT_OK;
+    hipLaunchKernelGGL(k_edges_nrm_tile, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, w, dis, N, n_dev, nrm,
+                       reinterpret_cast<int4*>(ell), cell, tile_off, T, nbj, tile_cnt, reinterpret_cast<int2*>(tile_pool),
+                       reinterpret_cast<int4*>(tile_rec), reinterpret_cast<int4*>(tile_brec), reinterpret_cast<int2*>(tile_bpool),
+                       tile_halo, brec_addr);
     QT_LAUNCHED();
     return QT_OK;
 }

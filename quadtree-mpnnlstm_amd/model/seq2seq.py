@@ -305,18 +305,24 @@ class Seq2Seq(nn.Module):
                 df({k[2:]: v for k, v in outs.items() if k.startswith('d.')}))
 
     # -- mesh helpers -----------------------------------------------------------------
-    def _mesh_from_image(self, img0, mask, hir):
+    def _mesh_from_image(self, img0, mask, hir, tiles=None):
         B, n, m = img0.shape
+        if tiles is None:
+            # the per-tile structures of the tile-resident recurrences (frames of several base cells) pay on the INPUT mesh
+            # when the encoder's composed stacks have at least three hops (K = 2 n_conv + 1 >= 4); the decoder's cells are
+            # single ChebConvs (K = 3, model/seq2seq.py:106): its re-meshes skip them
+            conv = getattr(self.encoder.rnns[0], 'convolution_type', 'ChebConv')
+            tiles = conv == 'ChebConv' and 2 * getattr(self.encoder.rnns[0], 'n_conv_layers', 1) + 1 >= ops._TILE_MIN_K
         return build_mesh(src=_criterion(img0, n, m, self.max_grid_size, self.transform_func), n=n, m=m,
                           thresh=self.thresh, condition=self.condition, mask=mask, high_interest_region=hir,
-                          max_size=self.max_grid_size, static=self.static_shapes)
+                          max_size=self.max_grid_size, static=self.static_shapes, tiles=tiles)
 
     def _mesh_from_nodes(self, out, mesh, mask, hir):
         if self.transform_func is not None:
             img0 = ops.gather_pixels(out.detach(), mesh).view(mesh.B, mesh.n, mesh.m)
-            return self._mesh_from_image(img0, mask, hir)
+            return self._mesh_from_image(img0, mask, hir, tiles=False)
         return build_mesh(prev=(out.detach()[:, 0], mesh), thresh=self.thresh, condition=self.condition, mask=mask,
-                          high_interest_region=hir, max_size=self.max_grid_size, static=self.static_shapes)
+                          high_interest_region=hir, max_size=self.max_grid_size, static=self.static_shapes, tiles=False)
 
     # -- encoder ------------------------------------------------------------------------
     def process_inputs(self, x, mask=None, high_interest_region=None, graph_structure=None):

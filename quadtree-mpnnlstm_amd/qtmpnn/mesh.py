@@ -18,6 +18,7 @@ CONDITIONS = ('max_larger_than', 'max_smaller_than', 'min_larger_than', 'min_sma
 
 
 _MASKS = {}
+_TILE_CHEB = os.environ.get('QT_NO_TILE_CHEB') != '1'      # (A/B switch: 1 = frames of several base cells stay on one k_spmm launch per hop)
 _ONES1 = {}
 
 
@@ -51,6 +52,7 @@ class Mesh:
         self.n_dev = None        # device int32[1] with the valid node count when N is a capacity (static mode)
         self.ell = None          # (N, 8) int32: [col x4 | nrm bits x4] of the first four edges of every row
         self.tail_cnt = self.tail_pool = self.tail_info = self.tail_rec = None     # the edges beyond the fourth, per clip (qt_edges_norm)
+        self.tiles = None        # frames of several base cells: the per-TILE arrays of qt_edges_norm_tiles (dict) for qt_cheb_tile_*
         self.cell_off = None     # (B * tiles + 1) first node of every 64 x 64 tile in label order (None: no such contiguity)
         self.pixelwise = False   # every unmasked pixel is a node (thresh = -inf); unflatten then NaN-fills the mask
         self.recipe = None       # arguments that rebuild a data-independent mesh for another batch size
@@ -193,7 +195,7 @@ def spmm2(mesh, xs, alpha, ps, beta, qs, gamma, outs):
 
 
 def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition='max_larger_than', mask=None,
-               high_interest_region=None, max_size=64, resolution=0.25, size_norm=None, device=None, static=False):
+               high_interest_region=None, max_size=64, resolution=0.25, size_norm=None, device=None, static=False, tiles=True):
     """Quadtree-decompose B criterion images and emit the block-diagonal mesh.
 
     src  : (B, rows, cols) fp32 criterion image (edge-padded on the fly), or
@@ -201,6 +203,9 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
            un-flattened previous output, never materialised.
     static: size every buffer for the worst case N = B*n*m and keep the node count on the device
             (mesh.n_dev): no host sync, fixed shapes -> the whole step can be captured in a hipGraph.
+    tiles : frames of several 64 x 64 base cells: also build the per-tile structures of the tile-resident recurrences
+            (qt_edges_norm_tiles; ~10 us more per build).  Seq2Seq asks for them only on the meshes whose recurrences can
+            take that path (K >= 4: the encoder's stacks of two or more ChebConvs).
     """
     assert condition in CONDITIONS, f'unknown condition {condition}'
     assert max_size & (max_size - 1) == 0
@@ -282,11 +287,11 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
     if static:
         ms.n_dev = ms.node_off[B:]                # view of the last entry = N
         nd = ptr(ms.n_dev)
-    _finish_mesh(ms, device, None, resolution, nd)
+    _finish_mesh(ms, device, None, resolution, nd, tiles)
     return ms
 
 
-def _finish_mesh(ms, device, size_norm, resolution, nd):
+def _finish_mesh(ms, device, size_norm, resolution, nd, want_tiles=True):
     """CSR adjacency (and, when size_norm is given, the node features) of a mesh whose labels / level / cell / node_off
     are in place: count -> fill (+ degree) -> normalise, three launches."""
     N, n, m, B = ms.N, ms.n, ms.m, ms.B
@@ -314,7 +319,27 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
         ms.tail_pool = torch.empty(B, tcap, 2, **i32)
         ms.tail_info = torch.empty(N, **i32)
         ms.tail_rec = torch.empty(B, 4096, 8, **i32)         # (B, QT_TAIL_REC_CAP, 8): one record per row with more than four edges
-    _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4), ptr(sums), ptr(ms.tail_cnt), B)
+    # frames of several 64 x 64 base cells whose tiles are label ranges (quadtree meshes with max_size 64): per-TILE records,
+    # pools, boundary records and halo lists for the tile-resident recurrences (csrc/chebclip.hip, TILE = true), plus their sync
+    # words; counters and sync words are zeroed by qt_edges_count's launch
+    tiles = None
+    if (want_tiles and _TILE_CHEB and n * m > _lib.value('qt_cheb_clip_rows') and ms.cell_off is not None and ms.cell_off is not ms.node_off
+            and getattr(ms, 'max_size', 0) == 64):
+        nbj = -(m // -64)
+        T = (-(n // -64)) * nbj
+        if T <= 64:
+            BT = B * T
+            nsync, nx = _lib.value('qt_cheb_tile_sync_words', B), _lib.value('qt_cheb_tile_xbuf_words', B, T)
+            # [tile counters | sync words (padded to 16 bytes) | exchange buffer]: one buffer, zeroed by qt_edges_count's launch
+            ns4 = (nsync + 3) // 4 * 4
+            zbuf = torch.empty(BT * 32 + ns4 + nx, **i32)
+            tiles = dict(T=T, nbj=nbj, cnt=zbuf[:BT * 32], sync=zbuf[BT * 32:BT * 32 + nsync], xbuf=zbuf[BT * 32 + ns4:],
+                         pool=torch.empty(BT, 1372, 2, **i32), rec=torch.empty(BT, 4096, 8, **i32), brec=torch.empty(BT, 256, 8, **i32),
+                         bpool=torch.empty(BT, 1024, 2, **i32), halo=torch.empty(BT, 256, **i32), baddr=torch.empty(max(N, 1), **i32),
+                         zbuf=zbuf)
+    ms.tiles = tiles
+    _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4), ptr(sums), ptr(ms.tail_cnt), B,
+              ptr(tiles['zbuf']) if tiles else None, tiles['zbuf'].numel() if tiles else 0)
     emax = 4 * B * n * m                          # every directed edge owns >= 1 of the 4*P pixel adjacencies
     ms.col = torch.empty(emax, **i32)
     ms.w = torch.empty(emax, device=device)
@@ -322,8 +347,13 @@ def _finish_mesh(ms, device, size_norm, resolution, nd):
     _lib.call('qt_edges_fill', ptr(ms.labels), ptr(ms.cell), ptr(cnt4), ptr(sums), N, nd, n, m, float(resolution),
               ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis))
     ms.ell = torch.empty(N, 8, **i32)             # first four edges per row as two 16-byte vectors (k_spmm's fast path)
-    _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm), ptr(ms.ell), ptr(ms.cell),
-              ptr(ms.node_off), ptr(ms.tail_cnt), ptr(ms.tail_pool), ptr(ms.tail_info), ptr(ms.tail_rec))
+    if tiles:
+        _lib.call('qt_edges_norm_tiles', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm), ptr(ms.ell),
+                  ptr(ms.cell), ptr(ms.cell_off), tiles['T'], tiles['nbj'], ptr(tiles['cnt']), ptr(tiles['pool']), ptr(tiles['rec']),
+                  ptr(tiles['brec']), ptr(tiles['bpool']), ptr(tiles['halo']), ptr(tiles['baddr']))
+    else:
+        _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm), ptr(ms.ell), ptr(ms.cell),
+                  ptr(ms.node_off), ptr(ms.tail_cnt), ptr(ms.tail_pool), ptr(ms.tail_info), ptr(ms.tail_rec))
 
 
 def build_homogeneous_mesh(n, m, max_size, mask, B=1, device=None, resolution=0.25):

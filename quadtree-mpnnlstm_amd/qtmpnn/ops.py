@@ -268,13 +268,48 @@ _CLIP_MIN_K = int(os.environ.get('QT_CLIP_MIN_K', '3'))
 _CLIP_ROWS = []
 
 
-def _clip_resident(mesh, widths, K):
-    """True when the K - 1 hops of a recurrence run as ONE clip-resident launch (csrc/chebclip.hip): every clip of the block-
-    diagonal mesh fits the kernel's LDS planes (n x m <= 4096 nodes), rows are float4 slices, the ELL side array exists."""
+def _CLIP_ROWS_OF():
     if not _CLIP_ROWS:
         _CLIP_ROWS.append(_lib.value('qt_cheb_clip_rows'))
+    return _CLIP_ROWS[0]
+
+
+def _clip_resident(mesh, widths, K):
+    """True when the K - 1 hops of a recurrence run as ONE clip-resident launch (csrc/chebclip.hip): every clip of the block-
+    diagonal mesh fits the kernel's LDS planes (n x m <= 4096 nodes), rows are float4 slices, the ELL side array exists -- or
+    as tile-resident launches on a frame of several base cells (_tile_resident).  Either way the planes leave slice-major."""
+    _CLIP_ROWS_OF()
+    if _tile_resident(mesh, widths, K):
+        return True
     return (_CLIP_CHEB and K >= max(_CLIP_MIN_K, 2) and mesh.N > 0 and mesh.ell is not None and mesh.tail_rec is not None and mesh.n * mesh.m <= _CLIP_ROWS[0]
             and len(widths) <= 2 and all(w % 4 == 0 for w in widths) and getattr(mesh, 'node_off', None) is not None)
+
+
+_TILE_MIN_K = int(os.environ.get('QT_TILE_MIN_K', '4'))
+_NUM_CUS = []
+
+
+def _tile_resident(mesh, widths, K):
+    """True when the K - 1 hops of a recurrence on a frame of SEVERAL 64 x 64 base cells run as ONE tile-resident launch
+    (csrc/chebclip.hip, TILE = true): one workgroup per (clip, tile, 4-channel slice), the rows on tile borders exchanged between
+    the tiles of a clip after every hop.  Taken where it was measured faster than one k_spmm launch per hop (tools/exp_tile.py):
+    at least three hops (a hop costs ~4.3 us here -- a cross-CU hand-off -- against 7 - 8 us per k_spmm launch, after a ~5 us
+    prologue) and all workgroups resident in one round (8 clips x 4 tiles x 5 .. 8 slices; 640 workgroups -- hidden 32 on 16
+    clips -- would take three rounds and lose)."""
+    tl = getattr(mesh, 'tiles', None)
+    if not (_CLIP_CHEB and tl is not None and K >= max(_TILE_MIN_K, 2) and K <= 16 and mesh.N > 0 and mesh.ell is not None
+            and len(widths) <= 2 and all(w % 4 == 0 for w in widths) and sum(widths) <= 48):
+        return False
+    if not _NUM_CUS:
+        _NUM_CUS.append(_lib.value('qt_num_cus'))
+    return mesh.B * tl['T'] * (sum(widths) // 4) <= _NUM_CUS[0]
+
+
+def _tile_args(mesh):
+    tl = mesh.tiles
+    return (ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.cell_off), ptr(tl['cnt']), ptr(tl['pool']),
+            ptr(tl['rec']), ptr(tl['brec']), ptr(tl['bpool']), ptr(tl['halo']), ptr(tl['baddr']), ptr(tl['xbuf']), ptr(tl['sync']),
+            mesh.B, tl['T'], tl['nbj'])
 
 
 def clip_planes(mesh, Zs, TZs, K, width=0):
@@ -282,6 +317,10 @@ def clip_planes(mesh, Zs, TZs, K, width=0):
     written SLICE-major: TZs[i] (allocated (K - 1, N, C_i)) then holds (K - 1, C_i / 4, N, 4).  width: channels per workgroup
     (0 = the library's choice; 2 / 4 pin it: diagnostics and parity tests)."""
     two = len(Zs) > 1
+    if getattr(mesh, 'tiles', None) is not None and mesh.n * mesh.m > _CLIP_ROWS_OF():
+        _lib.call('qt_cheb_tile_fwd', *_tile_args(mesh), Zs[0].shape[0], K, Zs[0].shape[1], ptr(Zs[0]), _ld(Zs[0]), ptr(TZs[0]),
+                  Zs[1].shape[1] if two else 0, ptr(Zs[1]) if two else None, _ld(Zs[1]) if two else 0, ptr(TZs[1]) if two else None)
+        return
     _lib.call('qt_cheb_clip_fwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off),
               ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_rec), mesh.B, Zs[0].shape[0], K, Zs[0].shape[1], ptr(Zs[0]), _ld(Zs[0]), ptr(TZs[0]),
               Zs[1].shape[1] if two else 0, ptr(Zs[1]) if two else None, _ld(Zs[1]) if two else 0, ptr(TZs[1]) if two else None, int(width))
@@ -291,6 +330,10 @@ def clip_clenshaw(mesh, Gs, K, sm=0, width=0):
     """Gs[i] (K, N, C_i) gradient planes: plane 0 <- A_0 + L^ b_1 - b_2 (Clenshaw), all hops in ONE launch (qt_cheb_clip_bwd).
     sm: planes 1 .. K-1 are stored slice-major (written so by the data-gradient kernels on request)."""
     two = len(Gs) > 1
+    if getattr(mesh, 'tiles', None) is not None and mesh.n * mesh.m > _CLIP_ROWS_OF():
+        _lib.call('qt_cheb_tile_bwd', *_tile_args(mesh), Gs[0].shape[1], K, Gs[0].shape[2], ptr(Gs[0]),
+                  Gs[1].shape[2] if two else 0, ptr(Gs[1]) if two else None, int(sm))
+        return
     _lib.call('qt_cheb_clip_bwd', ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.node_off),
               ptr(mesh.tail_cnt), ptr(mesh.tail_pool), ptr(mesh.tail_rec), mesh.B, Gs[0].shape[1], K, Gs[0].shape[2], ptr(Gs[0]),
               Gs[1].shape[2] if two else 0, ptr(Gs[1]) if two else None, int(sm), int(width))

@@ -798,6 +798,201 @@ def test_clip_resident_pool_overflow_walks_the_csr():
     assert r.returncode == 0 and 'overflow ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def _tile_mesh(kind, B, static=False):
+    """Meshes of several 64 x 64 base cells: (mesh, criterion image)."""
+    from qtmpnn import synthetic
+    from qtmpnn.mesh import build_mesh
+    from helpers import dist_from_05
+    mask = tf = None
+    thresh = 0.1
+    if kind == 'mnist128_sparse':                      # big cells across tile borders
+        img = np.stack([synthetic.make_clip(30 + i, canvas=(128, 128), n_digits=2, n_frames=1, pixel_noise=0.0)[0, ..., 0] for i in range(B)])
+    elif kind == 'mnist128_noisy':                     # nearly one node per pixel: tiles of ~4096 rows, 250 halo rows each
+        img = np.stack([synthetic.make_clip(40 + i, canvas=(128, 128), n_digits=2, n_frames=1, pixel_noise=0.05)[0, ..., 0] for i in range(B)])
+    elif kind == 'wide64x128':
+        img = np.stack([synthetic.make_clip(50 + i, canvas=(128, 64), n_digits=1, n_frames=1, pixel_noise=0.02)[0, ..., 0] for i in range(B)])
+    else:
+        shape = (96, 128) if kind == 'ice96x128' else (256, 256)
+        clips = [synthetic.make_ice_like(60 + i, shape=shape, channels=1, n_frames=1) for i in range(B)]
+        img = np.stack([abs(abs(c[0][0, ..., 0] - 0.5) - 0.5) for c in clips])
+        mask, thresh = clips[0][1], 0.15
+    mesh = build_mesh(src=torch.from_numpy(np.ascontiguousarray(img)).to(dev()), thresh=thresh, mask=mask, static=static)
+    return mesh, img
+
+
+@pytest.mark.parametrize('kind,B', [('mnist128_sparse', 2), ('mnist128_noisy', 1), ('wide64x128', 3), ('ice96x128', 2), ('ice256', 1)])
+def test_tile_records_of_multi_tile_meshes(kind, B):
+    """qt_edges_norm_tiles: per tile (a contiguous label range, Mesh.cell_off) every row with an edge that leaves the tile has
+    exactly one boundary record -- first four CSR edges as local rows or halo slots, the rest in the boundary pool, weights =
+    nrm --, every such edge owns one halo slot that names the neighbour's global row, every other row with more than four edges
+    one interior record; counts stay inside the capacities the kernel's LDS is laid out for."""
+    mesh, _ = _tile_mesh(kind, B)
+    tl = mesh.tiles
+    assert tl is not None and mesh.tail_rec is None
+    T, BT = tl['T'], mesh.B * tl['T']
+    off = mesh.cell_off.cpu().numpy()
+    rp, col, nrm = mesh.rowptr.cpu().numpy(), mesh.col.cpu().numpy(), mesh.nrm.cpu().numpy()
+    cnt = tl['cnt'].cpu().numpy().reshape(BT, 32)
+    brec = tl['brec'].cpu().numpy().view(np.uint32)
+    bpool = tl['bpool'].cpu().numpy().view(np.uint32)
+    rec = tl['rec'].cpu().numpy().view(np.uint32)
+    pool = tl['pool'].cpu().numpy().view(np.uint32)
+    halo = tl['halo'].cpu().numpy()
+    assert not cnt[:, 5].any() and off[-1] == mesh.N
+    seen_b = seen_i = 0
+    for ts in range(BT):
+        t0, nr = int(off[ts]), int(off[ts + 1] - off[ts])
+        deg = rp[t0 + 1:t0 + nr + 1] - rp[t0:t0 + nr]
+        remote = [[not (t0 <= col[e] < t0 + nr) for e in range(rp[t0 + r], rp[t0 + r + 1])] for r in range(nr)]
+        brows = {r for r in range(nr) if any(remote[r])}
+        irows = {r for r in range(nr) if deg[r] > 4 and r not in brows}
+        assert cnt[ts, 3] == len(brows) <= 256 and cnt[ts, 2] == sum(sum(x) for x in remote) <= 256
+        assert cnt[ts, 1] == len(irows) and nr + len(irows) <= 4096 and cnt[ts, 4] <= 1024
+        got = set()
+        for j in range(int(cnt[ts, 3])):
+            ent = brec[ts, j]
+            r = int(ent[7])
+            assert r in brows and r not in got
+            got.add(r)
+            e0 = int(rp[t0 + r])
+            fields = [int(ent[0]) & 0xffff, int(ent[0]) >> 16, int(ent[1]) & 0xffff, int(ent[1]) >> 16]
+            wts = ent[2:6].view(np.float32)
+            info = int(ent[6])
+            d = int(deg[r])
+            assert (info >> 16) == max(d - 4, 0)
+            for k in range(d):
+                if k < 4:
+                    f, wv = fields[k], wts[k]
+                    idx, is_halo = f >> 4, bool(f & 1)
+                else:
+                    pe = bpool[ts, (info & 0xffff) + k - 4]
+                    idx, is_halo, wv = int(pe[0]) & 0x7fffffff, bool(int(pe[0]) >> 31), pe[1:2].view(np.float32)[0]
+                cj = int(col[e0 + k])
+                assert is_halo == remote[r][k]
+                assert (int(halo[ts, idx]) if is_halo else t0 + idx) == cj
+                assert wv == nrm[e0 + k]
+        assert got == brows
+        goti = set()
+        for j in range(int(cnt[ts, 1])):
+            ent = rec[ts, j]
+            r = int(ent[7])
+            assert r in irows and r not in goti
+            goti.add(r)
+            e0 = int(rp[t0 + r])
+            assert [(int(ent[0]) >> 4) & 4095, int(ent[0]) >> 20, (int(ent[1]) >> 4) & 4095, int(ent[1]) >> 20] == [int(col[e0 + k]) - t0 for k in range(4)]
+            info = int(ent[6])
+            if (info & 0xffff) != 0xffff:
+                for k in range(4, int(deg[r])):
+                    pe = pool[ts, (info & 0xffff) + k - 4]
+                    assert int(pe[0]) == int(col[e0 + k]) - t0 and pe[1:2].view(np.float32)[0] == nrm[e0 + k]
+        assert goti == irows
+        seen_b += len(brows)
+        seen_i += len(irows)
+    assert seen_b > 0
+
+
+@pytest.mark.parametrize('kind,B', [('mnist128_sparse', 2), ('mnist128_noisy', 2), ('wide64x128', 3), ('ice96x128', 2), ('ice256', 1),
+                                    ('ice256', 2)])      # (2 x 16 tiles x 10 slices = 320 workgroups: two launches of whole groups)
+@pytest.mark.parametrize('K,widths', [(3, (4, 16)), (5, (16, 16)), (7, (8, 32)), (4, (16,))])
+def test_tile_resident_recurrence_equals_per_hop_launches(kind, B, K, widths):
+    """csrc/chebclip.hip with TILE = true -- frames of several 64 x 64 base cells: one workgroup per (clip, tile, slice), rows on
+    tile borders exchanged between the workgroups of a clip after every hop through global memory -- against one qt_spmm2 launch
+    per hop: forward planes T_1 .. T_{K-1} and the Clenshaw backward (row-major and slice-major gradient planes), bit for bit;
+    the error word stays 0, the launch generations count the launches and no arrival is left pending."""
+    from qtmpnn import ops
+    from qtmpnn.mesh import spmm2
+    mesh, _ = _tile_mesh(kind, B)
+    assert mesh.tiles is not None          # (ops._tile_resident gates the path by shape; the launches are called directly here)
+    torch.manual_seed(K)
+    N = mesh.N
+    wide = torch.randn(N, sum(widths) + 8, device=dev())
+    Zs, o = [], 4
+    for w in widths:
+        Zs.append(wide[:, o:o + w])
+        o += w
+    fused = [torch.empty(K - 1, N, w, device=dev()) for w in widths]
+    ops.clip_planes(mesh, Zs, fused, K)
+    assert int(mesh.tiles['sync'][-1]) == 0, 'error word set by the forward launch'
+    prev, ops._CLIP_CHEB = ops._CLIP_CHEB, False          # one qt_spmm2 launch per hop
+    try:
+        ref, sm = ops._cheb_planes(Zs, mesh, K)
+        assert sm == 0
+    finally:
+        ops._CLIP_CHEB = prev
+    for a, r in zip(fused, ref):
+        assert torch.equal(ops.planes_rowmajor(a, 1), r)
+    G = [torch.randn(K, N, w, device=dev()) for w in widths]
+    Gr = [g.clone() for g in G]
+    for k in range(K - 2, 0, -1):
+        spmm2(mesh, [g[k + 1] for g in Gr], 2.0, [g[k] for g in Gr], 1.0, [g[k + 2] for g in Gr] if k + 2 < K else None, -1.0,
+              [g[k] for g in Gr])
+    spmm2(mesh, [g[1] for g in Gr], 1.0, [g[0] for g in Gr], 1.0, [g[2] for g in Gr] if K > 2 else None, -1.0, [g[0] for g in Gr])
+    Gf = [g.clone() for g in G]
+    ops.clip_clenshaw(mesh, Gf, K)
+    Gs = []
+    for g0, w in zip(G, widths):
+        t = g0.clone()
+        t[1:] = g0[1:].view(K - 1, N, w // 4, 4).permute(0, 2, 1, 3).reshape(K - 1, N, w)
+        Gs.append(t)
+    ops.clip_clenshaw(mesh, Gs, K, sm=1)
+    for a, b, r, g0 in zip(Gf, Gs, Gr, G):
+        assert torch.equal(a[0], r[0]) and torch.equal(b[0], r[0])
+        assert torch.equal(a[1:], g0[1:])                          # planes 1 .. K-1 stay as given
+    sync = mesh.tiles['sync'].cpu().numpy()
+    ns = (len(sync) - 1) // 2
+    assert sync[-1] == 0 and not sync[ns:2 * ns].any() and sync[:ns].max() == 3      # three launches per used slice, none pending
+
+
+def test_tile_resident_recurrence_static_capacities_and_graph_replay():
+    """The tile-resident launches on a static-capacity mesh (node counts and tile ranges read on the device), captured into a
+    hipGraph together with the mesh build and replayed on another image: valid rows equal the exact-size mesh's planes."""
+    from qtmpnn import ops
+    from qtmpnn.mesh import build_mesh
+    mesh_a, img_a = _tile_mesh('mnist128_sparse', 2)
+    mesh_b, img_b = _tile_mesh('ice96x128', 2)
+    K, w = 5, 16
+    img = torch.zeros(2, 128, 128, device=dev())
+    Z = torch.randn(2 * 128 * 128, w, device=dev())
+    out = torch.zeros(K - 1, 2 * 128 * 128, w, device=dev())
+    Gp = torch.randn(K, 2 * 128 * 128, w, device=dev())
+    Gw = torch.zeros_like(Gp)
+
+    def run():
+        sm = build_mesh(src=img, thresh=0.1, static=True)
+        ops.clip_planes(sm, [Z], [out], K)
+        Gw.copy_(Gp)
+        ops.clip_clenshaw(sm, [Gw], K)
+        return sm
+    img.copy_(torch.from_numpy(img_a).to(dev()))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        sm = run()
+    for im in (img_a, np.roll(img_a, 7, axis=2), img_a):
+        img.copy_(torch.from_numpy(np.ascontiguousarray(im)).to(dev()))
+        graph.replay()
+        torch.cuda.synchronize()
+        exact = build_mesh(src=img.clone(), thresh=0.1)
+        nv = exact.N
+        assert sm.n_valid == nv and int(sm.tiles['sync'][-1]) == 0
+        prev, ops._CLIP_CHEB = ops._CLIP_CHEB, False
+        try:
+            ref, _ = ops._cheb_planes([Z[:nv].contiguous()], exact, K)
+        finally:
+            ops._CLIP_CHEB = prev
+        assert torch.equal(ops.planes_rowmajor(out, 1)[:, :nv], ref[0])
+        Gr = Gp[:, :nv].clone()
+        from qtmpnn.mesh import spmm2
+        for k in range(K - 2, 0, -1):
+            spmm2(exact, [Gr[k + 1]], 2.0, [Gr[k]], 1.0, [Gr[k + 2]] if k + 2 < K else None, -1.0, [Gr[k]])
+        spmm2(exact, [Gr[1]], 1.0, [Gr[0]], 1.0, [Gr[2]], -1.0, [Gr[0]])
+        assert torch.equal(Gw[0, :nv], Gr[0])
+
+
 def test_clip_resident_recurrence_static_capacities():
     """The same launch on a static-capacity mesh (N = B n m rows, valid counts per clip in node_off on the device): valid rows
     equal the exact-size mesh's, capacity rows are never read (NaN poison) or written."""
