@@ -207,7 +207,7 @@ def spmm_roofline(nfp, batch, mask, reps=10, traffic_files=('r04_pmc_traffic.jso
            'bytes_formula': "per launch: k_spmm (one hop) 4(N+1) + 8E' + 8NC (SURVEY 8(d)); fused K-1 hops: forward "
                             "4(N+1) + 8E' + 4NC K, backward 4(N+1) + 8E' + 4NC (K+1)"}
     if fused:
-        rec['limiter'] = ('not HBM: one CU\'s vector issue + LDS per workgroup (SQ counters: profiles/r03_pmc_clip_sq.json); '
+        rec['limiter'] = ('not HBM: one CU\'s vector issue + LDS per workgroup (SQ counters: profiles/r04_pmc_clip_sq.json); '
                           '`bound` names the roof the contract prices against')
     if traffic:
         rec['traffic_gbs'] = round(traffic / (tot['us'] / n * 1e-6) / 1e9, 1)
@@ -269,7 +269,7 @@ def gemm_mfma(nfp, batch, mask, reps=20):
            'launch_us': round(us, 2), 'achieved_tflops': round(tflops, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
            'frac': round(tflops / MFMA_F32_PEAK_TFLOPS, 3),
            'hbm_gbs': round(4.0 * nv * (Kt + 7 * h) / us / 1e3, 1)}
-    for name in ('r03_pmc_gemm.json', 'r02_pmc_gemm.json'):
+    for name in ('r04_pmc_gemm.json', 'r03_pmc_gemm.json', 'r02_pmc_gemm.json'):
         pmc = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pmc):
             rec['counters'] = {k: v for k, v in json.load(open(pmc)).items() if k in ('mfma_busy_frac', 'wave_stall_frac', 'source')}

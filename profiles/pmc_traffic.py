@@ -29,6 +29,8 @@ def avg(d, counter):
 
 
 fetch, write = avg(sys.argv[1], 'FETCH_SIZE'), avg(sys.argv[2], 'WRITE_SIZE')
+cmd = sys.argv[3] if len(sys.argv) > 3 else ('python3 bench.py --steps 2 --warmup 3 --frozen-steps 0 --repeats 0 --no-split-variant '
+                                            '--no-cpu-baseline --no-roofline')
 kernels = {}
 for k in sorted(fetch, key=lambda k: -sum(fetch[k]) - sum(write.get(k, [0]))):
     f, w = fetch[k], write.get(k, [0.0])
@@ -39,8 +41,7 @@ clip = [k for k in kernels if k.startswith('k_cheb_clip')]
 n = sum(kernels[k]['dispatches'] for k in clip)
 top = int(round(sum(kernels[k]['traffic_bytes_per_launch'] * kernels[k]['dispatches'] for k in clip) / n)) if n else None
 print(json.dumps({
-    'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) -- python3 bench.py '
-              '--steps 2 --warmup 3 --frozen-steps 0 --repeats 0 --no-split-variant --no-cpu-baseline --no-roofline',
+    'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) -- ' + cmd,
     'correction': 'FETCH_SIZE doubled (gfx950 counts the 128-B requests of 16-B-per-lane loads at 64 B, MI355X_MICROARCH.md HBM '
                   'section); WRITE_SIZE exact',
     'kernel': 'k_cheb_clip (forward and backward instantiations, launch-weighted)', 'traffic_bytes_per_launch': top,
