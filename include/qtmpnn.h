@@ -321,6 +321,14 @@ int qt_cheb_tile_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm
                      int B, int T, int nbj, int N, int K,
                      int Ca, float* Ga, int Cb, float* Gb, int planes_sm, void* stream);
 
+/* The decoder head's backward products in ONE launch (model/seq2seq.py:115-121,164-171 backwards): G = relu'(Y) (.) (gU @ Wb2)
+ * (N, 16) -- stored: the weight gradient of fc_out1 reads it -- and the data gradient of fc_out1, planes = G @ Wb1^T, as K planes
+ * in two column parts (N, Cb) | (N, Cbb), planes 1.. slice-major on request.  gU (N, 4): gradient at the coefficient columns of
+ * fc_out2; Wb2 (4, 16); Y (N, 16): fc_out1's ReLU output; Wb1 (K (Cb + Cbb), 16): the rows of fc_out1's weight.  Bit-identical to
+ * the two qt_dense2 launches it replaces. */
+int qt_head_dgrad(const float* gU, const float* Wb2, const float* Y, const float* Wb1, int K, int Cb, int Cbb, int N,
+                  const int32_t* n_dev, float* G, float* out, float* outb, int out_sm, void* stream);
+
 /* qt_dense: out planes = act( [A planes | S] @ [W ; Ws] ), the gate GEMM.
  *   A: Ka planes, plane k at a0 (k == 0) or a_rest + (k-1)*N*Ca, each (N, Ca)   (T_0 = Z stays in the caller's tensor)
  *   W: (Ka*Ca, Kb*Cb) row-major;  S: (N, Ks) or NULL with Ws (Ks, Kb*Cb)

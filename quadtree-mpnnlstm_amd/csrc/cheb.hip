@@ -876,6 +876,153 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g) {
         *reinterpret_cast<float4*>(plane_piece(g.outb, pl, row, ch - g.Cb, g.Cbb, g.M, g.out_sm, g.Cbb)) = v;
 }
 
+// ---- one lane = one node row, ALL 16 output columns: the decoder head's products (fc_out1: 20 -> 16 channels over K = 3 planes,
+// model/seq2seq.py:115-121,164-171).  k_gemm_skinny<64> gives a wave 4 of the 16 columns, so the four waves of a workgroup load
+// the same 64 operand rows four times over (16 quads each) in four dependent trips; here a lane keeps its row's 16 accumulators,
+// every operand quad is loaded ONCE and all of them are in flight together.  W rows come through scalar loads (uniform
+// addresses).  The same chain of fused multiply-adds per output element (k ascending): bit-identical to k_gemm_skinny.
+// Epilogue as k_gemm_skinny<64>: ReLU / ReLU-backward mask, the second product post_out = [act(out) | 1 0 0 0] @ post_W.
+__global__ __launch_bounds__(64) void k_gemm_row16(GemmArgs g) {
+    __shared__ const float* qptr[MAXQ];
+    __shared__ int qstr[MAXQ];
+    const int t = threadIdx.x;
+    const int64_t rows = qt_rows(g.n_dev, g.M);
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    if (row0 >= rows) return;
+    const int nquad = g.K >> 2;
+    build_quad_table(g.A, qptr, qstr, nquad);          // (nquad <= 64 = the threads of this workgroup: one entry each)
+    __syncthreads();
+    const int64_t row = row0 + t;
+    const bool ok = row < rows;
+    float4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto step = [&](float a, int k) {
+        const float* __restrict__ wr = g.B + (int64_t)k * 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 w = *reinterpret_cast<const float4*>(wr + 4 * c);
+            acc[c].x = fmaf(a, w.x, acc[c].x); acc[c].y = fmaf(a, w.y, acc[c].y);
+            acc[c].z = fmaf(a, w.z, acc[c].z); acc[c].w = fmaf(a, w.w, acc[c].w);
+        }
+    };
+    constexpr int INF = 8;                               // operand quads in flight per trip
+    for (int Q = 0; Q < nquad; Q += INF) {
+        float4 aq[INF];
+#pragma unroll
+        for (int u = 0; u < INF; ++u) {
+            aq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && Q + u < nquad) aq[u] = gload4(qptr[Q + u] + row * qstr[Q + u]);
+        }
+#pragma unroll
+        for (int u = 0; u < INF; ++u)
+            if (Q + u < nquad) {
+                step(aq[u].x, 4 * (Q + u)); step(aq[u].y, 4 * (Q + u) + 1); step(aq[u].z, 4 * (Q + u) + 2); step(aq[u].w, 4 * (Q + u) + 3);
+            }
+    }
+    if (!ok) return;
+    if (g.act == QT_ACT_RELU) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc[c].x = fmaxf(acc[c].x, 0.0f); acc[c].y = fmaxf(acc[c].y, 0.0f); acc[c].z = fmaxf(acc[c].z, 0.0f); acc[c].w = fmaxf(acc[c].w, 0.0f);
+        }
+    }
+    if (g.act == QT_ACT_RELU_BWD) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 y = *reinterpret_cast<const float4*>(g.res + row * g.res_stride + 4 * c);
+            acc[c].x = y.x > 0.0f ? acc[c].x : 0.0f; acc[c].y = y.y > 0.0f ? acc[c].y : 0.0f;
+            acc[c].z = y.z > 0.0f ? acc[c].z : 0.0f; acc[c].w = y.w > 0.0f ? acc[c].w : 0.0f;
+        }
+    }
+    if (g.post_W) {
+        float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int Q = 0; Q <= 4; ++Q) {
+            const float4 a = Q < 4 ? acc[Q] : make_float4(1.f, 0.f, 0.f, 0.f);
+            const float4 w0 = *reinterpret_cast<const float4*>(g.post_W + (4 * Q + 0) * 4);
+            const float4 w1 = *reinterpret_cast<const float4*>(g.post_W + (4 * Q + 1) * 4);
+            const float4 w2 = *reinterpret_cast<const float4*>(g.post_W + (4 * Q + 2) * 4);
+            const float4 w3 = *reinterpret_cast<const float4*>(g.post_W + (4 * Q + 3) * 4);
+            u.x = fmaf(a.x, w0.x, u.x); u.y = fmaf(a.x, w0.y, u.y); u.z = fmaf(a.x, w0.z, u.z); u.w = fmaf(a.x, w0.w, u.w);
+            u.x = fmaf(a.y, w1.x, u.x); u.y = fmaf(a.y, w1.y, u.y); u.z = fmaf(a.y, w1.z, u.z); u.w = fmaf(a.y, w1.w, u.w);
+            u.x = fmaf(a.z, w2.x, u.x); u.y = fmaf(a.z, w2.y, u.y); u.z = fmaf(a.z, w2.z, u.z); u.w = fmaf(a.z, w2.w, u.w);
+            u.x = fmaf(a.w, w3.x, u.x); u.y = fmaf(a.w, w3.y, u.y); u.z = fmaf(a.w, w3.z, u.z); u.w = fmaf(a.w, w3.w, u.w);
+        }
+        *reinterpret_cast<float4*>(g.post_out + row * 4) = u;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(g.out + row * 16 + 4 * c) = acc[c];
+}
+
+// ---- the decoder head's backward products in ONE launch, one lane per node row:
+//   G = relu'(Y) (.) (gU @ Wb2)          (N, 16): the gradient at fc_out1's output (Wb2 (4, 16) = the coefficient columns of
+//                                         fc_out2 transposed); stored -- the deferred weight gradient of fc_out1 reads it
+//   planes = G @ Wb1^T                   (K, N, Ca | Cbb): the data gradient of fc_out1, Wb1 (K (Ca + Cbb), 16) = its rows
+// Replaces a k_gemm_skinny launch (gU -> G) and a k_gemm_fwd<2, 128> launch (G -> planes: 16 x 60 on the MFMA) whose operand G made
+// a round trip through memory in between: 25 -> ~11 us per decoder step.  The chains are the k-ordered fused multiply-adds of the
+// two launches (v_mfma_f32_32x32x2_f32 accumulates in k order): bit-identical planes.
+struct HeadDgradArgs {
+    const float *gU, *Wb2, *Y, *Wb1;
+    float *G, *out, *outb;
+    int N, K, Cb, Cbb, out_sm;
+    const int32_t* n_dev;
+};
+__global__ __launch_bounds__(64) void k_head_dgrad(HeadDgradArgs g) {
+    const int64_t rows = qt_rows(g.n_dev, g.N);
+    const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if ((int64_t)blockIdx.x * 64 >= rows) return;
+    const bool ok = row < rows;
+    const int64_t r = ok ? row : rows - 1;              // (clamped loads, predicated stores)
+    const float4 gu = gload4(g.gU + r * 4);
+    float4 y[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) y[c] = gload4(g.Y + r * 16 + 4 * c);
+    float G[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float guv[4] = {gu.x, gu.y, gu.z, gu.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 w = *reinterpret_cast<const float4*>(g.Wb2 + k * 16 + 4 * c);
+            a.x = fmaf(guv[k], w.x, a.x); a.y = fmaf(guv[k], w.y, a.y); a.z = fmaf(guv[k], w.z, a.z); a.w = fmaf(guv[k], w.w, a.w);
+        }
+        a.x = y[c].x > 0.0f ? a.x : 0.0f; a.y = y[c].y > 0.0f ? a.y : 0.0f; a.z = y[c].z > 0.0f ? a.z : 0.0f; a.w = y[c].w > 0.0f ? a.w : 0.0f;
+        G[4 * c] = a.x; G[4 * c + 1] = a.y; G[4 * c + 2] = a.z; G[4 * c + 3] = a.w;
+        if (ok) *reinterpret_cast<float4*>(g.G + row * 16 + 4 * c) = a;
+    }
+    const int ct = g.Cb + g.Cbb;
+    for (int pl = 0; pl < g.K; ++pl) {
+        for (int ch = 0; ch < ct; ch += 4) {
+            const float* __restrict__ wr = g.Wb1 + (int64_t)(pl * ct + ch) * 16;      // rows of the four output columns (uniform)
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // the reduction order of k_gemm_fwd's MFMA stream (v_mfma_f32_32x32x2_f32: lanes 0-31 carry k = 8 j + i, lanes 32-63
+                // k = 8 j + 4 + i of instruction i): 0 4 1 5 2 6 3 7 | 8 12 9 13 10 14 11 15 -- bit-identical planes
+                float a = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 wl = *reinterpret_cast<const float4*>(wr + q * 16 + 8 * j);
+                    const float4 wh = *reinterpret_cast<const float4*>(wr + q * 16 + 8 * j + 4);
+                    a = fmaf(G[8 * j + 0], wl.x, a); a = fmaf(G[8 * j + 4], wh.x, a);
+                    a = fmaf(G[8 * j + 1], wl.y, a); a = fmaf(G[8 * j + 5], wh.y, a);
+                    a = fmaf(G[8 * j + 2], wl.z, a); a = fmaf(G[8 * j + 6], wh.z, a);
+                    a = fmaf(G[8 * j + 3], wl.w, a); a = fmaf(G[8 * j + 7], wh.w, a);
+                }
+                o[q] = a;
+            }
+            if (!ok) continue;
+            const float4 v = make_float4(o[0], o[1], o[2], o[3]);
+            if (ch < g.Cb)
+                *reinterpret_cast<float4*>(plane_piece(g.out, pl, row, ch, g.Cb, g.N, g.out_sm, g.Cb)) = v;
+            else
+                *reinterpret_cast<float4*>(plane_piece(g.outb, pl, row, ch - g.Cb, g.Cbb, g.N, g.out_sm, g.Cbb)) = v;
+        }
+    }
+}
+
 // ---- bf16x3 variant of the forward / data-gradient GEMM -------------------------------------------------------------
 // fp32 MFMA runs at the VALU FLOP rate on gfx950 and bounds k_gemm_fwd.  Here every fp32 operand
 // is split into three bf16 terms (x = hi + mid + lo, each rounded to nearest) and a product group is six bf16 MFMAs
@@ -1993,8 +2140,11 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
     static const bool exact_fp32 = getenv("QT_GEMM_BF16X3") == nullptr;
     static const bool no_skinny = getenv("QT_GEMM_NO_SKINNY") != nullptr;
     if ((!no_skinny || post_W || act == QT_ACT_RELU_BWD) && g.NB <= 16 && W) {       // (wide outputs of short reductions measured slower here: 24.5 vs 14.5 us)
+        static const bool no_row16 = getenv("QT_GEMM_NO_ROW16") != nullptr;       // (A/B switch)
         if (g.NB <= 4)
             hipLaunchKernelGGL((k_gemm_skinny<256>), dim3(qt_cdiv(N, 256), 1, 1), dim3(256), 0, (hipStream_t)stream, g);
+        else if (!no_row16 && g.NB == 16 && Kb == 1 && Cbb == 0 && act != QT_ACT_TANH_RES && g.K <= 256)
+            hipLaunchKernelGGL(k_gemm_row16, dim3(qt_cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, g);
         else
             hipLaunchKernelGGL((k_gemm_skinny<64>), dim3(qt_cdiv(N, 64), qt_cdiv(g.NB, 16), 1), dim3(256), 0, (hipStream_t)stream, g);
     } else if (exact_fp32) {
@@ -2005,6 +2155,18 @@ extern "C" int qt_dense2(const float* a0, int lda0, const float* a_rest, const f
         else
             hipLaunchKernelGGL((k_gemm_fwd3<2, 128>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 64), 1), dim3(256), 0, (hipStream_t)stream, g);
     }
+    QT_LAUNCHED();
+    return QT_OK;
+}
+
+extern "C" int qt_head_dgrad(const float* gU, const float* Wb2, const float* Y, const float* Wb1, int K, int Cb, int Cbb, int N,
+                             const int32_t* n_dev, float* G, float* out, float* outb, int out_sm, void* stream) {
+    QT_ARG(gU && Wb2 && Y && Wb1 && G && out && K >= 1 && Cb > 0 && Cb % 4 == 0 && Cbb >= 0 && Cbb % 4 == 0 && (Cbb == 0 || outb), "bad arguments");
+    QT_ARG((((uintptr_t)gU | (uintptr_t)Wb2 | (uintptr_t)Y | (uintptr_t)Wb1 | (uintptr_t)G | (uintptr_t)out | (uintptr_t)outb) & 15) == 0,
+           "operands must be 16-byte aligned");
+    if (N <= 0) return QT_OK;
+    HeadDgradArgs g = {gU, Wb2, Y, Wb1, G, out, outb, N, K, Cb, Cbb, out_sm != 0, n_dev};
+    hipLaunchKernelGGL(k_head_dgrad, dim3(qt_cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, g);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -27,6 +27,7 @@ _SIGNATURES = {
     'qt_edges_fill': [_P, _P, _P, _P, _I, _P, _I, _I, _F, _P, _P, _P, _P, _P],
     'qt_edges_norm': [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'qt_tail_cap': [],
+    'qt_head_dgrad': [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     'qt_edges_norm_tiles': [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     'qt_cheb_tile_sync_words': [_I],
     'qt_cheb_tile_xbuf_words': [_I, _I],

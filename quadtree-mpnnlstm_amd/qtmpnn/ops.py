@@ -12,6 +12,7 @@ from ._lib import ptr
 from .mesh import spmm, spmm2
 
 ACT_NONE, ACT_RELU, ACT_TANH_RES, ACT_RELU_BWD = 0, 1, 2, 3
+_HEAD_DGRAD = os.environ.get('QT_NO_HEAD_DGRAD') != '1'    # (A/B switch: 1 = the head's two backward products as two launches)
 _HEAD_FUSE = os.environ.get('QT_NO_HEAD_FUSE') != '1'      # (A/B switch: 1 = the decoder head's two products as two launches each way)
 
 # Arithmetic of the backward pass's gate-GEMM data gradient (gG W^T).  False (default): exact fp32 products on the fp32 MFMA,
@@ -545,6 +546,20 @@ class _ChebPoly(Function):
             Wb2, _ = _dgrad_weight(W2, 1, [Co], [0], ctx.acc2)               # (4, Co): W2[:Co]^T
             G = Y.new_empty(N, Co)
             fuse = act == ACT_RELU and gY is None
+            need = list(ctx.needs_input_grad[:nz])
+            if _HEAD_DGRAD and fuse and N > 0 and all(need) and Co == 16:
+                # both backward products of the head in ONE launch, one lane per node row (qt_head_dgrad): G = relu'(Y) (gU Wb2)
+                # stays in registers between them (and is stored for the deferred weight gradient)
+                Cs = [Z.shape[1] for Z in Zs]
+                Wb1, sk1 = _dgrad_weight(W, K, Cs, list(range(nz)), ctx.acc)
+                assert not sk1 and Wb1.is_contiguous()
+                gsm = int(_clip_resident(mesh, Cs, K))
+                gTs = [Y.new_empty(K, N, c) for c in Cs]
+                _lib.call('qt_head_dgrad', ptr(gU), ptr(Wb2), ptr(Y), ptr(Wb1), K, Cs[0], Cs[1] if nz > 1 else 0, N, ptr(mesh.n_dev),
+                          ptr(G), ptr(gTs[0]), ptr(gTs[1]) if nz > 1 else None, gsm)
+                gZs, gW = _cheb_backward(Zs, TZs, W, G, mesh, K, Ks, ctx.acc, ctx.use_idx, need, ctx.needs_input_grad[2],
+                                         gTs_pre=(gTs, gsm), sm=ctx.sm)
+                return gZs[0], (gZs[1] if nz > 1 else None), gW, None, None, None, None, None, None, None, gW2, None
             if N > 0:
                 _lib.call('qt_dense2', ptr(gU), 0, None, None, 0, None, 1, 4, 0, ptr(Wb2), None, None, 0, None, 1, Co, 0, N,
                           ptr(mesh.n_dev), ACT_RELU_BWD if fuse else ACT_NONE, ptr(Y) if fuse else None, Co if fuse else 0, None,

@@ -1231,15 +1231,57 @@ def test_head_products_in_one_launch_each_way():
     W20 = 0.3 * torch.randn(16 + 1, 4, device=dev())
     gU = torch.randn(N, 4, device=dev())
     res = []
-    for fuse in (True, False):
-        prev, ops._HEAD_FUSE = ops._HEAD_FUSE, fuse
+    # (forward fused, backward products in one launch): the shipped path; the round-3 path (gU -> G by the VALU kernel, G -> planes
+    # on the MFMA); two separate cheb_poly calls
+    for fuse, dgrad in ((True, True), (True, False), (False, False)):
+        prev, ops._HEAD_FUSE, ops._HEAD_DGRAD = (ops._HEAD_FUSE, ops._HEAD_DGRAD), fuse, dgrad
         try:
             Za, Zb, W1, W2 = (t.clone().requires_grad_(True) for t in (Za0, Zb0, W10, W20))
             acc1, acc2 = ops.GradAcc(), ops.GradAcc()
             Y, U = ops.cheb_poly((Za, Zb), W1, mesh, 3, 1, ops.ACT_RELU, acc=acc1, post=(W2, acc2))
             grads = torch.autograd.grad(U, [Za, Zb, W1, W2], gU)
         finally:
-            ops._HEAD_FUSE = prev
+            ops._HEAD_FUSE, ops._HEAD_DGRAD = prev
         res.append((Y.detach(), U.detach(), *grads))
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+
+
+def test_row_per_lane_head_gemm_equals_the_column_split_kernel(tmp_path):
+    """k_gemm_row16 (one lane = one node row, all 16 output columns: every operand quad loaded once) against k_gemm_skinny<64>
+    (a wave per 4 columns), which it replaced for 16-column products: same outputs bit for bit, forward (ReLU + the second
+    product in the epilogue) and as the ReLU-backward product.  The old kernel is selected by QT_GEMM_NO_ROW16=1, which the
+    library reads once: a child process computes the reference."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.join(sys.argv[1], 'quadtree-mpnnlstm_amd'))
+sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+from qtmpnn import ops, synthetic
+from qtmpnn.mesh import build_mesh
+dev = torch.device('cuda', 0)
+img = np.stack([synthetic.make_clip(9 + i, n_frames=1, pixel_noise=0.02)[0, ..., 0] for i in range(2)])
+mesh = build_mesh(src=torch.from_numpy(img).to(dev), thresh=0.1)
+torch.manual_seed(2)
+N = mesh.N
+Za, Zb = torch.randn(N, 16, device=dev), torch.randn(N, 4, device=dev)
+W1, W2 = 0.2 * torch.randn(3 * 20 + 1, 16, device=dev), 0.3 * torch.randn(16 + 1, 4, device=dev)
+gU = torch.randn(N, 4, device=dev)
+prev, ops._HEAD_DGRAD = ops._HEAD_DGRAD, False
+Za.requires_grad_(True); Zb.requires_grad_(True)
+Y, U = ops.cheb_poly((Za, Zb), W1, mesh, 3, 1, ops.ACT_RELU, acc=ops.GradAcc(), post=(W2, ops.GradAcc()))
+gza, gzb = torch.autograd.grad(U, [Za, Zb], gU)
+np.savez(sys.argv[2], Y=Y.detach().cpu().numpy(), U=U.detach().cpu().numpy(), gza=gza.cpu().numpy(), gzb=gzb.cpu().numpy())
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, extra in (('new', {}), ('old', {'QT_GEMM_NO_ROW16': '1'})):
+        f = str(tmp_path / f'{tag}.npz')
+        r = subprocess.run([sys.executable, '-c', code, root, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(np.load(f))
+    for k in ('Y', 'U', 'gza', 'gzb'):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
