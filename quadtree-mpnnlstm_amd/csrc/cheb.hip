@@ -403,7 +403,13 @@ template <int NT, int KWT, int CELL = 0>     // CELL: 0 = plain epilogue, else t
 #ifndef QT_GEMM_OCC
 #define QT_GEMM_OCC 4
 #endif
-__global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? 2 : (NT == 3 ? 3 : QT_GEMM_OCC)) void k_gemm_fwd(GemmArgs g) {   // 4 workgroups per CU: all N/128 blocks of the
+#ifndef QT_GEMM_OCC3
+#define QT_GEMM_OCC3 3
+#endif
+#ifndef QT_GEMM_OCC4C
+#define QT_GEMM_OCC4C 2
+#endif
+__global__ __launch_bounds__(256, (NT == 4 && CELL != 0) ? QT_GEMM_OCC4C : (NT == 3 ? QT_GEMM_OCC3 : QT_GEMM_OCC)) void k_gemm_fwd(GemmArgs g) {   // 4 workgroups per CU: all N/128 blocks of the
                                                                       // bench shape are resident at once (<= 128 registers)
     constexpr int BNT = 32 * NT;
     constexpr int PITCH = KWT + 4;      // == 4 (mod 64) floats: the 16 lanes of a ds_read_b128 group hit distinct banks
@@ -2100,11 +2106,17 @@ static inline int gemm_nt(int NB) {
     }
     return NB <= 64 ? 2 : best;
 }
+#ifndef QT_GEMM_KWT3
+#define QT_GEMM_KWT3 128
+#endif
+#ifndef QT_GEMM_KWT4
+#define QT_GEMM_KWT4 64      // k rows of W staged per pass by the 128-column tiles (NT = 4)
+#endif
 static void launch_gemm_fwd(const GemmArgs& g, int N, int G, hipStream_t stream) {
     switch (gemm_nt(g.NB)) {
         case 2: hipLaunchKernelGGL((k_gemm_fwd<2, 128>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 64), G), dim3(256), 0, stream, g); break;
-        case 3: hipLaunchKernelGGL((k_gemm_fwd<3, 128>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 96), G), dim3(256), 0, stream, g); break;
-        default: hipLaunchKernelGGL((k_gemm_fwd<4, 64>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128), G), dim3(256), 0, stream, g); break;
+        case 3: hipLaunchKernelGGL((k_gemm_fwd<3, QT_GEMM_KWT3>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 96), G), dim3(256), 0, stream, g); break;
+        default: hipLaunchKernelGGL((k_gemm_fwd<4, QT_GEMM_KWT4>), dim3(qt_cdiv(N, BM), qt_cdiv(g.NB, 128), G), dim3(256), 0, stream, g); break;
     }
 }
 
@@ -2372,7 +2384,7 @@ extern "C" int qt_dense_lstm(const float* a0, int lda0, const float* a_rest, con
     }
     const dim3 grid(qt_cdiv(N, BM), 1, 1);
     if (h == 32)
-        hipLaunchKernelGGL((k_gemm_fwd<4, 64, 8>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL((k_gemm_fwd<4, QT_GEMM_KWT4, 8>), grid, dim3(256), 0, (hipStream_t)stream, g);
     else if (h == 16)
         hipLaunchKernelGGL((k_gemm_fwd<2, 128, 4>), grid, dim3(256), 0, (hipStream_t)stream, g);
     else
