@@ -524,6 +524,8 @@ def main():
                 line['cpu_baseline'] = cpu_baseline(args.cpu_clips)
             except Exception as e:                                            # pragma: no cover
                 line['cpu_baseline'] = {'error': repr(e)[:200]}
+        from qtmpnn.mesh import tile_error_word
+        assert tile_error_word() == 0, 'a tile-resident launch reported an error (sync word)'
         print(json.dumps(line), flush=True)
     if world > 1:
         host_barrier()

@@ -888,6 +888,9 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g) {
 // every operand quad is loaded ONCE and all of them are in flight together.  W rows come through scalar loads (uniform
 // addresses).  The same chain of fused multiply-adds per output element (k ascending): bit-identical to k_gemm_skinny.
 // Epilogue as k_gemm_skinny<64>: ReLU / ReLU-backward mask, the second product post_out = [act(out) | 1 0 0 0] @ post_W.
+#ifndef QT_ROW16_INF
+#define QT_ROW16_INF 8
+#endif
 __global__ __launch_bounds__(64) void k_gemm_row16(GemmArgs g) {
     __shared__ const float* qptr[MAXQ];
     __shared__ int qstr[MAXQ];
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(64) void k_gemm_row16(GemmArgs g) {
             acc[c].z = fmaf(a, w.z, acc[c].z); acc[c].w = fmaf(a, w.w, acc[c].w);
         }
     };
-    constexpr int INF = 8;                               // operand quads in flight per trip
+    constexpr int INF = QT_ROW16_INF;                    // operand quads in flight per trip
     for (int Q = 0; Q < nquad; Q += INF) {
         float4 aq[INF];
 #pragma unroll

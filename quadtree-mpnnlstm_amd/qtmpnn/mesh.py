@@ -18,6 +18,7 @@ CONDITIONS = ('max_larger_than', 'max_smaller_than', 'min_larger_than', 'min_sma
 
 
 _MASKS = {}
+_TILE_SYNC = []          # weak references to the sync words of the meshes that carry tile structures (tile_error_word)
 _TILE_CHEB = os.environ.get('QT_NO_TILE_CHEB') != '1'      # (A/B switch: 1 = frames of several base cells stay on one k_spmm launch per hop)
 _ONES1 = {}
 
@@ -338,6 +339,9 @@ def _finish_mesh(ms, device, size_norm, resolution, nd, want_tiles=True):
                          bpool=torch.empty(BT, 1024, 2, **i32), halo=torch.empty(BT, 256, **i32), baddr=torch.empty(max(N, 1), **i32),
                          zbuf=zbuf)
     ms.tiles = tiles
+    if tiles is not None:
+        import weakref
+        _TILE_SYNC[:] = [r for r in _TILE_SYNC if r() is not None][-63:] + [weakref.ref(tiles['sync'])]
     _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4), ptr(sums), ptr(ms.tail_cnt), B,
               ptr(tiles['zbuf']) if tiles else None, tiles['zbuf'].numel() if tiles else 0)
     emax = 4 * B * n * m                          # every directed edge owns >= 1 of the 4*P pixel adjacencies
@@ -354,6 +358,17 @@ def _finish_mesh(ms, device, size_norm, resolution, nd, want_tiles=True):
     else:
         _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm), ptr(ms.ell), ptr(ms.cell),
                   ptr(ms.node_off), ptr(ms.tail_cnt), ptr(ms.tail_pool), ptr(ms.tail_info), ptr(ms.tail_rec))
+
+
+def tile_error_word():
+    """OR of the error words of every live mesh with tile structures (one device read each: diagnostics, end of a run): bit 0 = a
+    tile-resident launch gave up waiting for a neighbour tile, bit 1 = a tile capacity of the mesh build was exceeded."""
+    err = 0
+    for r in _TILE_SYNC:
+        t = r()
+        if t is not None:
+            err |= int(t[-1].item())
+    return err
 
 
 def build_homogeneous_mesh(n, m, max_size, mask, B=1, device=None, resolution=0.25):

@@ -96,6 +96,8 @@ def test_rollout_large_frames_golden(name):
     loss.backward()
     _check_grads(model, g)
     _assert_grads_do_not_alias(model)
+    from qtmpnn.mesh import tile_error_word
+    assert tile_error_word() == 0          # (no tile-resident launch gave up waiting for a neighbour tile)
     model, outs, meshes, loss = _run(g, batch=2)
     for c in range(2):
         _check_trace(g, outs, meshes, clip=c)
