@@ -309,6 +309,7 @@ int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm
  *   N = plane stride in rows; Ca + Cb <= 4 QT_TILE_SLICES, K <= 16.  The launches are cut so that every workgroup of one is
  *   resident (<= one per CU).  Planes as qt_cheb_clip_fwd / _bwd. */
 int qt_cheb_tile_xbuf_words(int B, int T);
+int qt_tile_cap(int which); /* the QT_TILE_* capacities: 0 pool, 1 records, 2 halo slots / boundary records, 3 boundary pool, 4 slices */
 int qt_cheb_tile_sync_words(int B);
 int qt_cheb_tile_fwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* tile_off,
                      const int32_t* tile_cnt, const int32_t* tile_pool, const int32_t* tile_rec, const int32_t* tile_brec,

@@ -737,6 +737,18 @@ static int tile_launch(bool bwd, const TileMesh& m, int Ncap, int K, int Ca, con
                xbuf && sync && B > 0 && K >= 2 && K <= 16 && T >= 2 && nbj >= 1 && T % nbj == 0 && ((uintptr_t)xbuf & 15) == 0,         \
            "bad arguments (the tile arrays of qt_edges_norm_tiles, the exchange buffer and the sync words zeroed by qt_edges_count are required)")
 
+// the capacities the tile structures are laid out for (the caller allocates them): 0 interior pool entries, 1 interior records,
+// 2 halo slots = boundary records, 3 boundary pool entries (all per tile), 4 slices per launch
+extern "C" int qt_tile_cap(int which) {
+    switch (which) {
+        case 0: return QT_TILE_POOL_CAP;
+        case 1: return QT_TILE_REC_CAP;
+        case 2: return QT_TILE_HALO_CAP;
+        case 3: return QT_TILE_BPOOL_CAP;
+        case 4: return QT_TILE_SLICES;
+        default: return 0;
+    }
+}
 extern "C" int qt_cheb_tile_sync_words(int B) { return 2 * B * QT_TILE_SLICES + 1; }
 extern "C" int qt_cheb_tile_xbuf_words(int B, int T) { return B * T * QT_TILE_SLICES * 2 * QT_TILE_HALO_CAP * 8; }   // (hop parity) x 4 granules of 2 ints per slot
 

@@ -31,6 +31,7 @@ _SIGNATURES = {
     'qt_edges_norm_tiles': [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     'qt_cheb_tile_sync_words': [_I],
     'qt_cheb_tile_xbuf_words': [_I, _I],
+    'qt_tile_cap': [_I],
     'qt_cheb_tile_fwd': [_P] * 14 + [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P],
     'qt_cheb_tile_bwd': [_P] * 14 + [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     'qt_gather': [_P, _I, _P, _P, _L, _P, _P],
@@ -86,7 +87,7 @@ _SIGNATURES = {
     'qt_head_fwd': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P],
     'qt_head_bwd': [_P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
 }
-_PLAIN = {'qt_abi_version', 'qt_cheb_clip_rows', 'qt_cheb_tile_sync_words', 'qt_cheb_tile_xbuf_words', 'qt_remesh_clip_rows', 'qt_tail_cap', 'qt_num_cus', 'qt_lstm_fused_blocks', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_lstm_dgrad_blocks', 'qt_attn_blocks'}  # return a value, not an error code
+_PLAIN = {'qt_abi_version', 'qt_cheb_clip_rows', 'qt_cheb_tile_sync_words', 'qt_cheb_tile_xbuf_words', 'qt_tile_cap', 'qt_remesh_clip_rows', 'qt_tail_cap', 'qt_num_cus', 'qt_lstm_fused_blocks', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_lstm_dgrad_blocks', 'qt_attn_blocks'}  # return a value, not an error code
 
 _lib = None
 

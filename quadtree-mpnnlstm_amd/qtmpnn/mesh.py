@@ -331,12 +331,13 @@ def _finish_mesh(ms, device, size_norm, resolution, nd, want_tiles=True):
         if T <= 64:
             BT = B * T
             nsync, nx = _lib.value('qt_cheb_tile_sync_words', B), _lib.value('qt_cheb_tile_xbuf_words', B, T)
+            cap = lambda w: _lib.value('qt_tile_cap', w)
             # [tile counters | sync words (padded to 16 bytes) | exchange buffer]: one buffer, zeroed by qt_edges_count's launch
             ns4 = (nsync + 3) // 4 * 4
             zbuf = torch.empty(BT * 32 + ns4 + nx, **i32)
             tiles = dict(T=T, nbj=nbj, cnt=zbuf[:BT * 32], sync=zbuf[BT * 32:BT * 32 + nsync], xbuf=zbuf[BT * 32 + ns4:],
-                         pool=torch.empty(BT, 1372, 2, **i32), rec=torch.empty(BT, 4096, 8, **i32), brec=torch.empty(BT, 256, 8, **i32),
-                         bpool=torch.empty(BT, 1024, 2, **i32), halo=torch.empty(BT, 256, **i32), baddr=torch.empty(max(N, 1), **i32),
+                         pool=torch.empty(BT, cap(0), 2, **i32), rec=torch.empty(BT, cap(1), 8, **i32), brec=torch.empty(BT, cap(2), 8, **i32),
+                         bpool=torch.empty(BT, cap(3), 2, **i32), halo=torch.empty(BT, cap(2), **i32), baddr=torch.empty(max(N, 1), **i32),
                          zbuf=zbuf)
     ms.tiles = tiles
     if tiles is not None:

@@ -299,7 +299,7 @@ def _tile_resident(mesh, widths, K):
     clips -- would take three rounds and lose)."""
     tl = getattr(mesh, 'tiles', None)
     if not (_CLIP_CHEB and tl is not None and K >= max(_TILE_MIN_K, 2) and K <= 16 and mesh.N > 0 and mesh.ell is not None
-            and len(widths) <= 2 and all(w % 4 == 0 for w in widths) and sum(widths) <= 48):
+            and len(widths) <= 2 and all(w % 4 == 0 for w in widths) and sum(widths) <= 4 * _lib.value('qt_tile_cap', 4)):
         return False
     if not _NUM_CUS:
         _NUM_CUS.append(_lib.value('qt_num_cus'))
