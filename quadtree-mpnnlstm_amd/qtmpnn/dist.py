@@ -20,6 +20,10 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
+        if os.environ['MASTER_ADDR'] in ('127.0.0.1', 'localhost'):
+            # one node: gloo (the CPU tests' backend and the host-side barrier's side group) binds to the loopback interface instead
+            # of looking the host name up (container host names may not resolve)
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
