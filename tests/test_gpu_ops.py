@@ -666,15 +666,16 @@ def test_bf16x3_gemm_matches_fp32_gemm():
     assert errs['0'] < 2e-6 and errs['1'] < 2e-6, errs
 
 
-@pytest.mark.parametrize('with_c,h', [(True, 16), (False, 16), (True, 8), (True, 32)])
-def test_fused_gate_cell_equals_gemm_then_cell(with_c, h):
+@pytest.mark.parametrize('with_c,h,K', [(True, 16, 3), (False, 16, 3), (True, 8, 3), (True, 32, 3), (True, 32, 7), (False, 32, 5)])
+def test_fused_gate_cell_equals_gemm_then_cell(with_c, h, K):
     """qt_dense_lstm (the cell as the gate GEMM's epilogue, h = 8 / 16 / 32) on Z given as two row-strided column views [X | H]
     == qt_dense on the whole Z followed by qt_lstm_fwd, bit for bit, forward and every gradient; a node count that is
     not a multiple of the 128-row tile."""
     from qtmpnn import ops
     mesh, _ = _mesh_64(5, noise=0.03, B=2)
     torch.manual_seed(3)
-    C, K, Ks = 4 + h, 3, 1
+    C, Ks = (8 if K > 3 else 4) + h, 1          # (hidden 32, K = 7, 8 + 32 channels: the 280 output columns of BASELINE configs[3] / [4])
+    cx = C - h
     mk = lambda *s: torch.randn(*s, device=dev()).requires_grad_(True)
     Z, W = mk(mesh.N, C), mk(K * C + 4, 4 * h)
     Cp = mk(mesh.N, h) if with_c else None
@@ -684,7 +685,7 @@ def test_fused_gate_cell_equals_gemm_then_cell(with_c, h):
 
     def run(fused):
         if fused:
-            outs = ops.gate_cell(Z[:, :4], Z[:, 4:], W, Cp, wc, b, ln, mesh, K, Ks)
+            outs = ops.gate_cell(Z[:, :cx], Z[:, cx:], W, Cp, wc, b, ln, mesh, K, Ks)
         else:
             outs = ops.lstm_cell(ops.cheb_poly(Z, W, mesh, K, Ks), Cp, wc, b, ln, mesh)
         grads = torch.autograd.grad(outs, ins, gs)
@@ -698,7 +699,7 @@ def test_fused_gate_cell_equals_gemm_then_cell(with_c, h):
             assert torch.equal(a, r), n
     finally:
         del os.environ['QT_NO_DGRAD_FUSION']
-    # default backward: the cell backward and the data gradient in one launch (qt_lstm_bwd_dgrad, h = 8 / 16).  The forward and
+    # default backward: the cell backward and the data gradient in one launch (qt_lstm_bwd_dgrad, h = 8 / 16 / 32).  The forward and
     # the state / weight gradients stay bit-identical; the parameter partials are summed per 128-node workgroup instead of
     # per grid-stride sweep (fp32 rounding); the data gradient is the exact fp32 product (the split-bf16 form is opt-in:
     # ops.DGRAD_SPLIT_BF16, tests/test_gpu_headline.py).
