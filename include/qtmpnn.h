@@ -307,7 +307,10 @@ int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm
  *   zero_buf).  The LAST sync word is an error word: bit 0 = a wait for a neighbour tile timed out (the launch then finishes with
  *   garbage instead of hanging), bit 1 = a tile capacity of the mesh build was exceeded.  T tiles per clip in rows of nbj;
  *   N = plane stride in rows; Ca + Cb <= 4 QT_TILE_SLICES, K <= 16.  The launches are cut so that every workgroup of one is
- *   resident (<= one per CU).  Planes as qt_cheb_clip_fwd / _bwd. */
+ *   resident (<= one per CU).  Planes as qt_cheb_clip_fwd / _bwd.
+ *   Co-residency is what makes the waits safe: a GPU SHARED with another process that issues the same launches can leave two
+ *   half-resident grids waiting for each other until the bounded spins give up (error word bit 0, garbage planes) -- one
+ *   process per GPU, as everywhere in this library's multi-GPU use. */
 int qt_cheb_tile_xbuf_words(int B, int T);
 int qt_tile_cap(int which); /* the QT_TILE_* capacities: 0 pool, 1 records, 2 halo slots / boundary records, 3 boundary pool, 4 slices */
 int qt_cheb_tile_sync_words(int B);
