@@ -168,20 +168,23 @@ __device__ __forceinline__ void gather_tail_csr(fvec<W>& a, const char* __restri
 // boundary pool) and the halo list (the global row behind every slot; <= 256 per tile).  Interior rows run exactly as in the
 // one-tile kernel.  After every hop the T workgroups of a (clip, slice) exchange their boundary rows THROUGH GLOBAL MEMORY:
 //   hop c:  waves 0-3 finish the boundary rows first (their neighbours: LDS plane or the halo buffer HB = T_{c-1} of the halo
-//           rows) and PUBLISH each as four 8-byte granules {value, tag} in the tile's exchange slots (xbuf; write-through), tag =
+//           rows) and PUBLISH each as four 8-byte granules {value, tag} in the tile's exchange slots (xbuf; two 16-byte write-
+//           through stores of two granules each), tag =
 //           launch generation of the (clip, slice) * 16 + c;  after their interior rows they poll the granules of THEIR halo
 //           row (sc1 loads from the owner tile's slots: brec_addr of the row) until all four tags match and write HB before
 //           the hop's one workgroup barrier.  (Requesting the granules half way through the interior rows gained nothing: a
 //           publication takes ~1.5 us to become visible and a poll ~1.5 us to return, so the early poll usually missed.)
-//   The data is its own flag (MI355X_MICROARCH.md, hand-off form R2: 8-byte granules written by one sc1 store each; "granules
-//   for latency"): no drain, no separate flag, no dependent load behind a poll.  A first version with write-through rows + a
+//   The data is its own flag (MI355X_MICROARCH.md, hand-off form R2: naturally aligned {value, tag} granules, observed untorn
+//   also as the two halves of a 16-byte sc1 access; "granules for latency"): no drain, no separate flag, no dependent load
+//   behind a poll; a reader that catches a row between its two stores sees a stale tag in one half and polls again.  A first version with write-through rows + a
 //   drained per-tile hop flag + sc1 halo loads behind the poll took 6 - 7 us per hop -- no faster than a k_spmm launch per hop
 //   (8 us at 128 x 128 x 8 clips); with granules a hop costs ~4.3 us (tools/exp_tile.py: K = 5 at 128 x 128 x 8 clips 30 -> 21 us
 //   forward, 32 -> 27 us backward; 32 channels 38 -> 25 / 46 -> 32), which is the chain boundary rows (0.6 us) -> store visible
 //   (~1.5 us) -> poll round trip (~1.5 us): what a cross-CU hand-off costs on this chip, tile size notwithstanding.  So the path
 //   pays for K >= 4 when all workgroups fit the CUs in one round, and is NOT taken otherwise (ops._tile_resident): two hops are
-//   no faster than two k_spmm launches, and 640 workgroups (hidden 32: 16 clips x 4 tiles x 10 slices) take three rounds.  Tags only ever grow (the generation word is bumped by the last workgroup of the (clip, slice)
-//   to leave), so nothing is reset between launches or hipGraph replays; the exchange buffer is zeroed once per mesh build.
+//   no faster than two k_spmm launches, and 640 workgroups (hidden 32: 16 clips x 4 tiles x 10 slices) take three rounds.
+//   Tags only ever grow (the generation word is bumped by the last workgroup of the (clip, slice) to leave), so nothing is reset
+//   between launches or hipGraph replays; the exchange buffer is zeroed once per mesh build.
 // No dependence on dispatch order beyond forward progress: spins are bounded (a timeout sets the error word and the launch
 // finishes with garbage instead of hanging) and the launches are cut so that all workgroups of one are co-resident.
 constexpr unsigned TILE_SPIN_LIMIT = 200000u;              // polls of ~1 us: ~0.2 s before a poll gives up
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
     __shared__ __attribute__((aligned(16))) char HB[TILE ? QT_TILE_HALO_CAP * 4 * W : 16];     // T_{c-1} of the halo rows
     __shared__ int4 BR[TILE ? 2 * QT_TILE_HALO_CAP : 1];                                        // boundary records
     __shared__ int2 BP[TILE ? QT_TILE_BPOOL_CAP : 1];                                           // boundary pool
-    __shared__ int HC[TILE ? QT_TILE_HALO_CAP : 1];                                             // global row of every halo slot
-    __shared__ unsigned arrive;                                                                 // boundary waves that drained their stores
+    __shared__ int HC[TILE ? QT_TILE_HALO_CAP : 1];                                             // granule index of every halo slot's row in xbuf
+    __shared__ unsigned arrive;                                                                 // boundary waves through with the halo buffer, 4 per hop
     const int t = threadIdx.x;
     int c, s, ts = 0, tl = 0;
     if constexpr (TILE) {
