@@ -812,6 +812,17 @@ def _tile_mesh(kind, B, static=False):
         img = np.stack([synthetic.make_clip(40 + i, canvas=(128, 128), n_digits=2, n_frames=1, pixel_noise=0.05)[0, ..., 0] for i in range(B)])
     elif kind == 'wide64x128':
         img = np.stack([synthetic.make_clip(50 + i, canvas=(128, 64), n_digits=1, n_frames=1, pixel_noise=0.02)[0, ..., 0] for i in range(B)])
+    elif kind in ('one_busy_tile', 'masked_tile'):
+        # one tile at full resolution beside tiles that are ONE 64 x 64 cell each (a row with ~64 neighbours in another tile per side),
+        # and the same with one whole tile under the mask (an empty tile: its workgroups only count themselves out)
+        rng = np.random.default_rng(70)
+        img = np.zeros((B, 128, 128), np.float32)
+        img[:, :64, :64] = rng.random((B, 64, 64)).astype(np.float32)
+        img[:, 64:, 64:80] = 0.5 * rng.random((B, 64, 16)).astype(np.float32)
+        if kind == 'masked_tile':
+            mask = np.zeros((128, 128), dtype=bool)
+            mask[:64, 64:] = True
+        thresh = 0.3
     else:
         shape = (96, 128) if kind == 'ice96x128' else (256, 256)
         clips = [synthetic.make_ice_like(60 + i, shape=shape, channels=1, n_frames=1) for i in range(B)]
@@ -821,7 +832,8 @@ def _tile_mesh(kind, B, static=False):
     return mesh, img
 
 
-@pytest.mark.parametrize('kind,B', [('mnist128_sparse', 2), ('mnist128_noisy', 1), ('wide64x128', 3), ('ice96x128', 2), ('ice256', 1)])
+@pytest.mark.parametrize('kind,B', [('mnist128_sparse', 2), ('mnist128_noisy', 1), ('wide64x128', 3), ('ice96x128', 2), ('ice256', 1),
+                                    ('one_busy_tile', 2), ('masked_tile', 2)])
 def test_tile_records_of_multi_tile_meshes(kind, B):
     """qt_edges_norm_tiles: per tile (a contiguous label range, Mesh.cell_off) every row with an edge that leaves the tile has
     exactly one boundary record -- first four CSR edges as local rows or halo slots, the rest in the boundary pool, weights =
@@ -893,7 +905,7 @@ def test_tile_records_of_multi_tile_meshes(kind, B):
 
 
 @pytest.mark.parametrize('kind,B', [('mnist128_sparse', 2), ('mnist128_noisy', 2), ('wide64x128', 3), ('ice96x128', 2), ('ice256', 1),
-                                    ('ice256', 2)])      # (2 x 16 tiles x 10 slices = 320 workgroups: two launches of whole groups)
+                                    ('ice256', 2), ('one_busy_tile', 2), ('masked_tile', 2)])      # (2 x 16 tiles x 10 slices = 320 workgroups: two launches of whole groups)
 @pytest.mark.parametrize('K,widths', [(3, (4, 16)), (5, (16, 16)), (7, (8, 32)), (4, (16,))])
 def test_tile_resident_recurrence_equals_per_hop_launches(kind, B, K, widths):
     """csrc/chebclip.hip with TILE = true -- frames of several 64 x 64 base cells: one workgroup per (clip, tile, slice), rows on
