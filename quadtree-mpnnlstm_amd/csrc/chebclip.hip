@@ -296,7 +296,11 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
         c4[u] = src[0];
         wb[u] = src[1];
         if constexpr (!BWD) {
+#ifdef QT_EXP_CLIP_SMZ            // (timing experiment: the first operand read as if it were stored slice-major -- wrong values, same buffer)
+            first[u] = ldg<W>(pt.z + (((unsigned)(ch >> 2) * (unsigned)g.Ncap + rowc[u]) * 4u + (unsigned)(ch & 3)));
+#else
             first[u] = ldg<W>(pt.z + (rowc[u] * (unsigned)pt.ld + ch));
+#endif
         } else {
             first[u] = ldg<W>(pt.planes + grad_off(K - 1, rowc[u]));
         }
