@@ -1006,6 +1006,20 @@ def test_tile_resident_recurrence_static_capacities_and_graph_replay():
         assert torch.equal(Gw[0, :nv], Gr[0])
 
 
+def test_tile_path_is_taken_where_it_was_measured_faster():
+    """ops._tile_resident: frames of several base cells take the tile-resident launch for K >= 4 when all workgroups of the launch
+    fit the CUs in one round (BASELINE configs[2]: 8 clips x 4 tiles x 5 .. 8 slices), and stay on one k_spmm launch per hop
+    otherwise (two hops; 16 clips x 4 tiles x 10 slices = 640 workgroups); 64 x 64 frames never take it."""
+    from qtmpnn import ops
+    m8, _ = _tile_mesh('mnist128_noisy', 8)
+    assert ops._tile_resident(m8, [4, 16], 5) and ops._tile_resident(m8, [16, 16], 5) and ops._clip_resident(m8, [16], 5)
+    assert not ops._tile_resident(m8, [4, 16], 3) and not ops._clip_resident(m8, [4, 16], 3)
+    m16, _ = _tile_mesh('ice96x128', 16)
+    assert not ops._tile_resident(m16, [8, 32], 7) and ops._tile_resident(m16, [8], 7)
+    small, _ = _mesh_64(3, noise=0.02, B=2)
+    assert small.tiles is None and not ops._tile_resident(small, [4, 16], 5) and ops._clip_resident(small, [4, 16], 5)
+
+
 def test_clip_resident_recurrence_static_capacities():
     """The same launch on a static-capacity mesh (N = B n m rows, valid counts per clip in node_off on the device): valid rows
     equal the exact-size mesh's, capacity rows are never read (NaN poison) or written."""
