@@ -209,6 +209,48 @@ def image_to_graph(img, thresh=0.05, max_grid_size=64, mask=None, high_interest_
                 edge_index=ei, edge_attrs=attrs)
 
 
+def pixel_graph(img, mask=None, use_edge_attrs=True, resolution=0.25):
+    """image_to_graph_pixelwise + get_adj_pixelwise (model/graph_functions.py:471-539): every unmasked pixel is a node in raster
+    order, node size = resolution^2, 4-neighbour edges without self pairs; edge_attrs = [angle, dist] or None (-> the convolution
+    runs unweighted).  Edge list in canonical (src, dst) order."""
+    ns, w, h, c = img.shape
+    keep = np.ones((w, h), dtype=bool) if mask is None else ~np.asarray(mask, dtype=bool)
+    labels = np.where(keep, np.cumsum(keep.reshape(-1)).reshape(w, h) - 1, -1).astype(np.int64)
+    n_nodes = int(keep.sum())
+    data = img[:, torch.as_tensor(keep), :]
+    xx, yy = data[0, :, -2] * h * resolution, data[0, :, -1] * w * resolution
+    data = torch.cat([data, torch.full((ns, n_nodes, 1), resolution ** 2, dtype=img.dtype)], dim=-1)
+    ei = torch.as_tensor(adjacency_sorted(labels))
+    ei = ei[:, ei[0] != ei[1]]
+    attrs = torch.stack([edge_angle(ei[0], ei[1], xx, yy), edge_dist(ei[0], ei[1], xx, yy)]).T if use_edge_attrs else None
+    return dict(labels=labels, n_pixels_per_node=torch.ones(n_nodes), data=data, edge_index=ei, edge_attrs=attrs, pixelwise=True)
+
+
+def static_graph(image_shape, max_grid_size, mask, high_interest_region=None, use_edge_attrs=True, resolution=0.25,
+                 homogeneous=False):
+    """create_static_heterogeneous_graph (model/graph_functions.py:683-699): the quadtree of an all-zero image at thresh = +inf,
+    i.e. cells split only where they touch the mask / the high-interest region.  homogeneous=True:
+    create_static_homogeneous_graph (:707-737) -- the same without a mask (uniform cells), then every cell that lies entirely
+    under the mask is deleted together with its edges and the rest renumbered in order; a partly masked cell keeps ALL its pixels."""
+    w, h = image_shape
+    img = add_positional_encoding(torch.zeros(1, w, h, 1))
+    g = image_to_graph(img, thresh=np.inf, max_grid_size=max_grid_size, mask=None if homogeneous else mask,
+                       high_interest_region=None if homogeneous else high_interest_region, use_edge_attrs=use_edge_attrs,
+                       resolution=resolution)
+    del g['data']
+    if not homogeneous:
+        return g
+    labels, npix = g['labels'], g['n_pixels_per_node'].numpy()
+    unmasked = np.bincount(labels.reshape(-1), weights=(~np.asarray(mask, dtype=bool)).reshape(-1).astype(np.float64),
+                           minlength=len(npix))
+    kept = unmasked > 0                                                        # get_nan_nodes (:701-702), inverted
+    new_id = np.cumsum(kept) - 1
+    ei = g['edge_index'].numpy()
+    ok = kept[ei[0]] & kept[ei[1]]
+    return dict(labels=np.where(kept[labels], new_id[labels], -1), n_pixels_per_node=torch.as_tensor(npix[kept]),
+                edge_index=torch.as_tensor(new_id[ei[:, ok]]), edge_attrs=g['edge_attrs'][torch.as_tensor(ok)])
+
+
 # --------------------------------------------------------------------------- R10 / R11
 def cheb_norm(edge_index, edge_weight, n_nodes):
     """torch_geometric 2.2.0 ChebConv.__norm__ (normalization='sym', lambda_max=2.0), restated:
@@ -278,6 +320,8 @@ def gcn_conv(x, edge_index, edge_weight, weight, bias):
     index, out = A^ (x W^T) + b.  PARITY UNPINNED (module header)."""
     row, col = edge_index
     n = x.shape[0]
+    if edge_weight is None:                       # PyG gcn_norm: unweighted graph -> unit weights (pixelwise meshes)
+        edge_weight = torch.ones(row.numel(), dtype=x.dtype)
     deg = torch.zeros(n, dtype=edge_weight.dtype).index_add_(0, col, edge_weight)
     dis = deg.pow(-0.5)
     dis[torch.isinf(dis)] = 0
@@ -483,9 +527,17 @@ class Seq2Seq(nn.Module):
                               use_edge_attrs=self.use_edge_attrs)
 
     def forward(self, x, concat_layers, mask=None, high_interest_region=None, remesh_every=1,
-                skip_last_remesh=True):
+                skip_last_remesh=True, graph_structure=None):
         w, h = x.shape[1:3]
-        g = self._graph(add_positional_encoding(x), mask, high_interest_region)
+        if graph_structure is not None:
+            # preset mesh (seq2seq.py:288-294): flatten onto it, node size = n_pixels_per_node / 4 ("Don't assume 4 !!")
+            npx = graph_structure['n_pixels_per_node']
+            data = flatten(add_positional_encoding(x), graph_structure['labels'], npx.numpy())
+            g = dict(graph_structure, data=torch.cat([data, (npx / 4.0).view(1, -1, 1).expand(data.shape[0], -1, 1)], dim=-1))
+        elif self.thresh == -np.inf:                                            # graph_functions.py:629-630
+            g = pixel_graph(add_positional_encoding(x), mask, self.use_edge_attrs)
+        else:
+            g = self._graph(add_positional_encoding(x), mask, high_interest_region)
         trace = dict(labels=[g['labels']], images=[], edge_index=[g['edge_index']])
         feats, hidden, cell = g['data'], None, None
         for t in range(self.input_timesteps):                                   # seq2seq.py:308-330
@@ -500,7 +552,7 @@ class Seq2Seq(nn.Module):
             outputs.append(out)
             maps.append(g['labels'])
             last = t == self.output_timesteps - 1
-            if (t + 1) % remesh_every == 0 and not (last and skip_last_remesh):  # seq2seq.py:434-491
+            if self.thresh != -np.inf and (t + 1) % remesh_every == 0 and not (last and skip_last_remesh):  # seq2seq.py:393, 434-491
                 img = unflatten(out, g['labels'], (w, h))
                 h_img = unflatten(hidden, g['labels'], (w, h))
                 c_img = unflatten(cell, g['labels'], (w, h))
@@ -525,12 +577,12 @@ def clip_loss(outputs, maps, y, image_shape, mask):
     return F.mse_loss(y_hat[:, keep], y[:, keep])
 
 
-def train_step(model, optimizer, x, y, concat_layers, mask, max_norm=10.0):
+def train_step(model, optimizer, x, y, concat_layers, mask, max_norm=10.0, **forward_kw):
     """model/mpnnlstm.py:229-257 for one clip; returns the loss value."""
     optimizer.zero_grad()
-    outputs, maps, _ = model(x, concat_layers, mask=mask)
+    outputs, maps, _ = model(x, concat_layers, mask=mask, **forward_kw)
     loss = clip_loss(outputs, maps, y, x.shape[1:3], mask)
     loss.backward()
     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
     optimizer.step()
-    return float(loss)
+    return float(loss.detach())

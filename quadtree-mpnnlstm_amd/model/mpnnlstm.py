@@ -7,6 +7,7 @@ Same constructor / train / predict / save / load surface; the train step (mpnnls
 import datetime
 import os
 import time
+from abc import ABC, abstractmethod
 
 import numpy as np
 import pandas as pd
@@ -53,20 +54,43 @@ def masked_mse(outputs, meshes, y, mask=None, binary=False):
     return part.sum() / float(mesh0.B * len(outputs) * n_valid)        # one reduction for all steps
 
 
-class NextFramePredictorS2S:
+class NextFramePredictor(ABC):
+    """The abstract trainer facade of the reference (model/mpnnlstm.py:34-79; moving_mnist_example.ipynb cell 2 imports it):
+    it holds the decomposition settings and names the three methods a predictor offers.  `thresh` is kept as given here;
+    the concrete class turns `decompose=False` into thresh = -inf (:113)."""
+
+    def __init__(self, thresh, experiment_name='experiment', decompose=True, input_features=1, transform_func=None,
+                 condition='max_larger_than', device=None):
+        self.experiment_name, self.device, self.model = experiment_name, device, None
+        self.thresh, self.decompose = thresh, decompose
+        self.transform_func, self.condition, self.input_features = transform_func, condition, input_features
+
+    @abstractmethod
+    def train(self, loader_train, loader_test, n_epochs=200, lr=0.01, lr_decay=0.95, mask=None):
+        ...
+
+    @abstractmethod
+    def predict(self, x, mask=None, rollout=None):
+        ...
+
+    @abstractmethod
+    def score(self, x, y, rollout=None):
+        ...
+
+
+class NextFramePredictorS2S(NextFramePredictor):
     def __init__(self, thresh, experiment_name='experiment', decompose=True, input_features=1, input_timesteps=3,
                  output_timesteps=3, device=None, transform_func=None, condition='max_larger_than', remesh_input=False,
                  binary=False, debug=False, model_kwargs={}):
-        self.input_timesteps, self.output_timesteps, self.input_features = input_timesteps, output_timesteps, input_features
-        self.binary, self.debug, self.device = binary, debug, device
+        super().__init__(thresh=thresh, experiment_name=experiment_name, decompose=decompose, input_features=input_features,
+                         transform_func=transform_func, condition=condition, device=device)
+        self.input_timesteps, self.output_timesteps = input_timesteps, output_timesteps
+        self.binary, self.debug = binary, debug
         self.thresh = thresh if decompose else -np.inf
-        self.decompose, self.transform_func, self.condition = decompose, transform_func, condition
-        self.experiment_name = experiment_name
-        model_kwargs = dict(model_kwargs)
-        model_kwargs.setdefault('transform_func', transform_func)
-        model_kwargs.setdefault('condition', condition)
+        # As in the reference (:123-133) the Seq2Seq gets the RAW `thresh` (decompose=False changes self.thresh only) and
+        # its transform_func / condition from model_kwargs alone (ice_exp.py:153-176 passes transform_func twice for that).
         self.model = Seq2Seq(input_features=input_features + 3,      # + positional encoding (x, y) + node size
-                             input_timesteps=input_timesteps, output_timesteps=output_timesteps, thresh=self.thresh,
+                             input_timesteps=input_timesteps, output_timesteps=output_timesteps, thresh=thresh,
                              device=device, remesh_input=remesh_input, binary=binary, debug=debug,
                              **model_kwargs).to(device)
         self.training_initiated = False
@@ -183,13 +207,18 @@ class NextFramePredictorS2S:
                            truncated_backprop=45):
         """The reference's truncated-BPTT loop (mpnnlstm.py:281-315), quirks included: every chunk re-runs the encoder
         and unrolls ITS steps from the encoder state, `zero_grad` runs per chunk (so only the last chunk's gradient
-        survives to optimizer.step()), and the chunk bound is min(start + tb, T_out + 1).  Returns the chunk losses."""
+        survives to optimizer.step()), and the chunk bound is min(start + tb, T_out + 1).  Returns the chunk losses.
+
+        Beyond the reference: a chunk is clamped to the steps that exist, range(max(step - tb, 0), min(step, T_out)).  HEAD
+        unrolls range(step - tb, step) as it stands, which leaves [0, T_out) whenever tb does not divide T_out -- the default
+        tb = 45 with the notebook's T_out = 10 gives range(-34, 11) and ends in an IndexError at y[unroll_steps] (:308).
+        Where HEAD runs (tb divides T_out: ice_exp.py exp 5 / 6) the clamp changes nothing."""
         losses, step = [], 0
         if y.dim() == 4:
             y = y.unsqueeze(0)
         while step < self.output_timesteps:
             step = min(step + truncated_backprop, self.output_timesteps + 1)
-            steps = range(step - truncated_backprop, step)
+            steps = range(max(step - truncated_backprop, 0), min(step, self.output_timesteps))
             self.zero_grad()
             self.model.process_inputs(x, mask=mask, high_interest_region=high_interest_region, graph_structure=graph_structure)
             y_hat, meshes = self.model.unroll_output(steps, y, concat_layers=concat_layers, teacher_forcing_ratio=0, mask=mask,
@@ -303,7 +332,7 @@ class NextFramePredictorS2S:
         batch_step = 0
         for epoch in range(n_epochs):
             running, steps = 0.0, 0
-            self.model.train()
+            # (the mode is the caller's, as in the reference: train() never calls model.train() / .eval(); ice_exp.py:181, 218 do)
             for x, y, launch_date in loader_train:
                 x, y = self._clip(x), self._clip(y)
                 concat = self.get_climatology_array(climatology, launch_date) if climatology is not None else None
@@ -322,6 +351,10 @@ class NextFramePredictorS2S:
                         loss = graphed[key](x, y, concat)
                 else:
                     loss = self.train_step(x, y, concat, mask, high_interest_region, graph_structure)
+                    if self.debug:      # gradient norms of the two halves of the model (:259-276; clipped like the reference's)
+                        for part in ('encoder', 'decoder'):
+                            gs = [p.grad.detach().norm() for p in getattr(self.model, part).parameters() if p.grad is not None]
+                            self.writer.add_scalar(f'Grad/{part}/grad_norms', torch.stack(gs).norm().item(), batch_step)
                 self.writer.add_scalar('Loss/train', loss.item(), batch_step)
                 running += loss.item()
                 steps += 1

@@ -117,7 +117,7 @@ def randomize(module, seed, scale=0.3, bscale=0.2):
 
 
 def state_arrays(module, prefix):
-    return {prefix + k: v.detach().numpy() for k, v in module.state_dict().items()}
+    return {prefix + k: v.detach().numpy().copy() for k, v in module.state_dict().items()}      # (a copy: a later optimizer step must not reach it)
 
 
 # ------------------------------------------------------------------ known-answer tests
@@ -636,6 +636,102 @@ def ice_exp_case():
     print('ice_exp case: losses', out['loss_0'], out['loss_1'], 'N', len(outs[0]), 'params', int(out['n_params']), 'pred', pred.shape)
 
 
+def _mesh_arrays(gs, shape, prefix):
+    """labels / npix / sorted edges / [angle, dist] of a preset mesh dict (the dense mapping never leaves this script)."""
+    mp = gs['mapping'].cpu().numpy()
+    ei, at = sort_edges(gs['edge_index'].cpu(), gs['edge_attrs'].cpu())
+    return {prefix + 'labels': np.where(mp.sum(0) > 0, mp.argmax(0), -1).reshape(shape).astype(np.int32),
+            prefix + 'npix': gs['n_pixels_per_node'].cpu().numpy(), prefix + 'edges': ei, prefix + 'attrs': at}
+
+
+def ice_exp_preset_cases():
+    """ice_exp.py exp 9 / 10 (:82-87, 109-112, 127-130, 184-206): preset heterogeneous / homogeneous mesh with max_grid_size=4,
+    use_edge_attrs=True, resolution=1/6 (half) and 1/12 (full), TransformerConv x hidden 32 x 3 conv layers x land mask, ONE
+    model trained by the reference's own NextFramePredictorS2S.train() at half resolution and then at full resolution
+    (truncated_backprop=0), followed by predict().  Two deviations from the script, both forced by HEAD: the half-resolution
+    phase gets a climatology too (without one HEAD fails at fc_out1, SURVEY 3.5 -- the script's own commented-out lines
+    :106-107, 188), and the model stays in eval mode (train() never switches modes itself; attention / decoder dropout
+    cannot be RNG matched).  Also a forward + backward trace at the initial weights on the full-resolution mesh.
+    exp 1 (:64-65, 145): GCNConv on the pixelwise mesh (edge_attrs=None -> unit weights), same recordings."""
+    from model import mpnnlstm as RP
+    import datetime as _dt
+    half, full = (24, 32), (48, 64)
+    m_half = synthetic.make_ice_like(31, shape=half, channels=1, n_frames=1)[1]
+    m_full = synthetic.make_ice_like(32, shape=full, channels=1, n_frames=1)[1]
+    hir = np.zeros_like(m_full); hir[10:20, 30:44] = True
+    t_in, t_out = 2, 3
+
+    def clips(seed0, n, shape):
+        fs = [synthetic.make_ice_like(seed0 + i, shape=shape, channels=5, n_frames=t_in + t_out)[0] for i in range(n)]
+        return np.stack([f[:t_in] for f in fs]), np.stack([f[t_in:, ..., :1] for f in fs])
+    launch = np.array([int(_dt.datetime(2010, 6, 1 + i, 12, tzinfo=_dt.timezone.utc).timestamp()) * 10 ** 9 for i in range(3)],
+                      dtype=np.int64)
+
+    def loader(x, y, shape):
+        ld = _Loader([(torch.from_numpy(x[c])[None], torch.from_numpy(y[c])[None], torch.tensor([launch[c]])) for c in range(len(x))])
+        ld.dataset = _DS(shape)
+        return ld
+    xh, yh = clips(300, 3, half)
+    xf, yf = clips(310, 3, full)
+    base_h = synthetic.make_ice_like(34, shape=half, channels=1, n_frames=1)[0][0, ..., 0]
+    base_f = synthetic.make_ice_like(33, shape=full, channels=1, n_frames=1)[0][0, ..., 0]
+    clim_h, clim_f = torch.from_numpy(climatology_from_base(base_h)), torch.from_numpy(climatology_from_base(base_f))
+    lr = 1e-3
+
+    for name, conv, preset in (('ice_exp9', 'TransformerConv', 'heterogeneous'), ('ice_exp10', 'TransformerConv', 'homogeneous'),
+                               ('ice_exp1', 'GCNConv', False)):
+        kw = dict(hidden_size=32, dropout=0.1, n_layers=1, transform_func=dist_from_05, dummy=False, n_conv_layers=3,
+                  rnn_type='LSTM', convolution_type=conv)
+        nfp = RP.NextFramePredictorS2S(thresh=-np.inf, experiment_name=name, input_features=5, input_timesteps=t_in,
+                                       output_timesteps=t_out, device=torch.device('cpu'), transform_func=dist_from_05,
+                                       binary=False, debug=False, model_kwargs=kw)
+        randomize(nfp.model, 120 + len(name), scale=0.08, bscale=0.04)
+        nfp.model.eval()
+        out = dict(x_half=xh, y_half=yh, x=xf, y=yf, mask_half=m_half, mask=m_full, hir=hir, clim_base_half=base_h,
+                   clim_base=base_f, launch=launch, lr=np.float64(lr), n_params=np.int64(nfp.get_n_params()),
+                   preset=np.array(str(preset)), conv=np.array(conv))
+        gs_h = gs_f = None
+        if preset == 'heterogeneous':
+            gs_h = RG.create_static_heterogeneous_graph(half, 4, m_half, use_edge_attrs=True, resolution=1/6, device=torch.device('cpu'))
+            gs_f = RG.create_static_heterogeneous_graph(full, 4, m_full, use_edge_attrs=True, resolution=1/12, device=torch.device('cpu'))
+        elif preset == 'homogeneous':
+            gs_h = RG.create_static_homogeneous_graph(half, 4, m_half, use_edge_attrs=True, resolution=1/6, device=torch.device('cpu'))
+            gs_f = RG.create_static_homogeneous_graph(full, 4, m_full, use_edge_attrs=True, resolution=1/12, device=torch.device('cpu'))
+        if preset:
+            out.update(_mesh_arrays(gs_h, half, 'half_'))
+            out.update(_mesh_arrays(gs_f, full, 'full_'))
+        out.update(state_arrays(nfp.model, 'w/'))
+        # forward + backward at the initial weights, full resolution, clip 0 (mpnnlstm.py:233-249)
+        mk = torch.from_numpy(m_full)
+        concat = nfp.get_climatology_array(clim_f, torch.tensor([launch[0]]))
+        nfp.model.zero_grad()
+        outs, maps = nfp.model(torch.from_numpy(xf[0]), torch.from_numpy(yf[0]), concat, teacher_forcing_ratio=0, mask=m_full,
+                               high_interest_region=hir, graph_structure=gs_f)
+        y_hat = torch.stack([RG.unflatten(outs[i], maps[i], full, m_full) for i in range(t_out)])
+        loss = torch.nn.MSELoss()(y_hat[:, ~mk], torch.from_numpy(yf[0])[:, ~mk])
+        loss.backward()
+        out['loss0'] = np.float64(loss.item())
+        for i, o in enumerate(outs):
+            out[f'out_{i}'] = o.detach().numpy()
+        for k, p in nfp.model.named_parameters():
+            out['g/' + k] = p.grad.numpy().copy() if p.grad is not None else np.zeros(p.shape, np.float32)
+        nfp.model.zero_grad()
+        # the script's training sequence: two clips train / one clip test per phase, one epoch each
+        if preset:
+            nfp.train(loader(xh[:2], yh[:2], half), loader(xh[2:], yh[2:], half), clim_h, lr=lr, n_epochs=1, mask=m_half,
+                      truncated_backprop=0, graph_structure=gs_h)
+            out.update(state_arrays(nfp.model, 'w1/'))
+        nfp.train(loader(xf[:2], yf[:2], full), loader(xf[2:], yf[2:], full), clim_f, lr=lr, n_epochs=1, mask=m_full,
+                  high_interest_region=hir, truncated_backprop=0, graph_structure=gs_f)
+        out['train_loss'] = nfp.loss['train_loss'].values.astype(np.float64)
+        out['test_loss'] = nfp.loss['test_loss'].values.astype(np.float64)
+        out.update(state_arrays(nfp.model, 'w2/'))
+        out['pred'] = nfp.predict(loader(xf[2:], yf[2:], full), clim_f, mask=m_full, graph_structure=gs_f)
+        np.savez_compressed(os.path.join(HERE, f'variant_{name}.npz'), **out)
+        print(name, 'N', len(outs[0]), 'loss0', out['loss0'], 'train', out['train_loss'], 'test', out['test_loss'],
+              'params', int(out['n_params']), 'pred', out['pred'].shape)
+
+
 def teacher_fixed_cases():
     """Teacher forcing where no re-mesh happens (model/seq2seq.py:420-425): the decoder's next input is rebuilt as
     [flatten(teacher + positional encoding) | RAW n_pixels_per_node] -- on a pixelwise mesh (thresh = -inf), on a preset
@@ -705,4 +801,6 @@ if __name__ == '__main__':
         ice_exp_case()
     if only in ('', 'teacher_fixed'):
         teacher_fixed_cases()
+    if only in ('', 'ice_presets'):
+        ice_exp_preset_cases()
     print('golden vectors written to', HERE)

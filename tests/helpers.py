@@ -68,3 +68,48 @@ class TinyLoader(list):
     def __init__(self, items, image_shape):
         super().__init__(items)
         self.dataset = type('DS', (), {'image_shape': tuple(image_shape)})()
+
+
+class TinyMovingMNISTDataset(torch.utils.data.Dataset):
+    """Stand-in for the reference's ModMovingMNISTDataset (data/mod_moving_mnist.py:8-38; it downloads MNIST): the same
+    constructor arguments, `.x (n, T_in, W, H, 1)`, `.y (n, T_out, W, H, 1)`, `.frame_id`, `.image_shape` and item layout
+    `(x, y, frame_id)`, filled by the procedural generator."""
+
+    def __init__(self, n_samples, input_timesteps, output_timesteps, n_digits=1, gap=0, canvas_size=(32, 32),
+                 digit_size=(12, 12), pixel_noise=0.05, velocity_noise=0.25, seed=0):
+        from qtmpnn import synthetic
+        clips = [synthetic.make_clip(7000 + 100 * seed + i, canvas=canvas_size, digit=digit_size, n_digits=n_digits,
+                                     n_frames=input_timesteps + gap + output_timesteps, pixel_noise=pixel_noise,
+                                     velocity_noise=velocity_noise) for i in range(n_samples)]
+        self.x = np.stack([c[:input_timesteps] for c in clips]).astype(np.float32)
+        self.y = np.stack([c[-output_timesteps:] for c in clips]).astype(np.float32)
+        self.frame_id = np.arange(len(self.y)).astype(np.float32)
+        self.image_shape = self.x.shape[2:4]
+
+    def __len__(self):
+        return len(self.y)
+
+    def __getitem__(self, idx):
+        return self.x[idx], self.y[idx], self.frame_id[idx]
+
+
+class TinyIceDataset(torch.utils.data.Dataset):
+    """Stand-in for the reference's IceDataset (ice_dataset.py:7-17; it needs xarray + the ERA5 / GLORYS files): `.x (n, T_in,
+    lat, lon, C)`, `.y (n, T_out, lat, lon, 1)`, `.launch_dates` (int64 ns), `.image_shape`, items `(x, y, launch_date)`."""
+
+    def __init__(self, n_samples, input_timesteps, output_timesteps, shape, channels=5, seed=0, first_day=(2010, 3, 1)):
+        import datetime
+        from qtmpnn import synthetic
+        clips = [synthetic.make_ice_like(8000 + 100 * seed + i, shape=shape, channels=channels,
+                                         n_frames=input_timesteps + output_timesteps)[0] for i in range(n_samples)]
+        self.x = np.stack([c[:input_timesteps] for c in clips]).astype(np.float32)
+        self.y = np.stack([c[input_timesteps:, ..., :1] for c in clips]).astype(np.float32)
+        t0 = int(datetime.datetime(*first_day, 12, tzinfo=datetime.timezone.utc).timestamp()) * 10 ** 9
+        self.launch_dates = np.array([t0 + 86400 * 10 ** 9 * i for i in range(n_samples)], dtype=np.int64)
+        self.image_shape = self.x[0].shape[1:-1]
+
+    def __len__(self):
+        return len(self.y)
+
+    def __getitem__(self, idx):
+        return self.x[idx], self.y[idx], self.launch_dates[idx]

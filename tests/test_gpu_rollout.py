@@ -453,6 +453,7 @@ def test_baseline_config_shapes_train(cfg):
         y = np.stack([c[0][t_in:, ..., :1] for c in clips])
         mask, thresh, feat = clips[0][1], 0.15, 5
         tf = lambda a: abs(abs(a - 0.5) - 0.5)
+        kw['transform_func'] = tf          # (the model takes it from model_kwargs, ice_exp.py:157)
     attention = cfg.endswith('transformer')          # (its attention dropout, p = 0.1, is part of the convolution's kwargs)
     xt, yt = torch.from_numpy(x).to(dev()), torch.from_numpy(y).to(dev())
     concat = torch.zeros(B, t_out, *shape, 1, device=dev())

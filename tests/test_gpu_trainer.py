@@ -198,3 +198,85 @@ def test_test_threshold_smoke():
     assert img.shape == (64, 64) and abs(float(img.mean()) - float(clip[0, ..., 0].mean())) < 1e-5
     import matplotlib.pyplot as plt
     plt.close(fig)
+
+
+@pytest.mark.parametrize('name', ['ice_exp9', 'ice_exp10', 'ice_exp1'])
+def test_ice_exp_preset_experiments_golden(name):
+    """ice_exp.py exp 9 / 10 / 1 against traces of the reference's own trainer (tests/golden/make_golden.py::ice_exp_preset_cases):
+    preset heterogeneous / homogeneous mesh x max_grid_size 4 x use_edge_attrs=True x resolution 1/6 and 1/12 x TransformerConv
+    x hidden 32 x 3 conv layers x land mask, and GCNConv on the pixelwise mesh.  Meshes: labels / npix / edge lists bit-exact,
+    [angle, dist] at 2e-5; forward + backward at the initial weights: outputs, loss, all gradients at 1e-4; then the script's
+    sequence -- train() at half resolution, train() again at full resolution with the same model and optimizer, predict() --
+    per-epoch losses, the weights after each phase and the prediction."""
+    from model.graph_functions import create_static_heterogeneous_graph, create_static_homogeneous_graph
+    from model.mpnnlstm import NextFramePredictorS2S, masked_mse
+    g = golden(f'variant_{name}.npz')
+    preset, conv = str(g['preset']), str(g['conv'])
+    t_in, t_out = g['x'].shape[1], g['y'].shape[1]
+    half, full = g['mask_half'].shape, g['mask'].shape
+    kw = dict(hidden_size=32, dropout=0.1, n_layers=1, transform_func=dist_from_05, dummy=False, n_conv_layers=3,
+              rnn_type='LSTM', convolution_type=conv)
+    nfp = NextFramePredictorS2S(thresh=-np.inf, experiment_name=name, input_features=5, input_timesteps=t_in,
+                                output_timesteps=t_out, device=dev(), transform_func=dist_from_05, binary=False, debug=False,
+                                model_kwargs=kw)
+    assert nfp.get_n_params() == int(g['n_params'])
+    load_state(nfp.model, g, 'w/')
+    nfp.model.eval()                                   # like the golden run (dropout cannot be RNG matched)
+    gs_h = gs_f = None
+    if preset != 'False':
+        make = create_static_heterogeneous_graph if preset == 'heterogeneous' else create_static_homogeneous_graph
+        gs_h = make(half, 4, g['mask_half'], use_edge_attrs=True, resolution=1 / 6, device=dev())
+        gs_f = make(full, 4, g['mask'], use_edge_attrs=True, resolution=1 / 12, device=dev())
+        for gs, pre, shape in ((gs_h, 'half_', half), (gs_f, 'full_', full)):
+            mesh = gs['mapping']
+            assert np.array_equal(mesh.labels[0].cpu().numpy(), g[pre + 'labels']), pre + 'labels'
+            assert np.array_equal(gs['n_pixels_per_node'].cpu().numpy(), g[pre + 'npix']), pre + 'npix'
+            assert np.array_equal(gs['edge_index'].cpu().numpy(), g[pre + 'edges']), pre + 'edges'
+            close(gs['edge_attrs'], g[pre + 'attrs'], rtol=2e-5, atol=2e-5, msg=pre + 'attrs')
+    clim_h = torch.from_numpy(climatology_from_base(g['clim_base_half'])).to(dev())
+    clim_f = torch.from_numpy(climatology_from_base(g['clim_base'])).to(dev())
+    launch, mask, hir = g['launch'], g['mask'], g['hir']
+
+    # forward + backward at the initial weights (full resolution, clip 0)
+    x, y = torch.from_numpy(g['x'][0]).to(dev()), torch.from_numpy(g['y'][0]).to(dev())
+    concat = nfp.get_climatology_array(clim_f, torch.tensor([launch[0]]))
+    outs, meshes = nfp.model(x, y, concat, teacher_forcing_ratio=0, mask=mask, high_interest_region=hir, graph_structure=gs_f)
+    for i, o in enumerate(outs):
+        assert o.shape[0] == g[f'out_{i}'].shape[0], f'mesh size of step {i}'
+        close(o, g[f'out_{i}'], msg=f'step {i}')
+    loss = masked_mse(outs, meshes, y, mask)
+    assert abs(float(loss) - float(g['loss0'])) <= 1e-4 * float(g['loss0'])
+    loss.backward()
+    for k, p in nfp.model.named_parameters():
+        ref = g['g/' + k]
+        if p.grad is None:
+            assert not ref.any(), k
+            continue
+        grad_close(p.grad, ref, msg=k, floor=0.05 if k.endswith('lin_key.bias') else 1e-3)
+    nfp.model.zero_grad(set_to_none=True)
+
+    # the script's sequence through train() / predict(); loaders in fixed order like the golden run
+    def loader(xs, ys, shape, lo, hi):
+        return TinyLoader([(torch.from_numpy(xs[c])[None], torch.from_numpy(ys[c])[None], torch.tensor([launch[c - lo]]))
+                           for c in range(lo, hi)], shape)
+    lr, steps = float(g['lr']), 0
+
+    def weights_close(prefix, steps):
+        # Adam moves a weight by at most lr per step: hold the weights to 1e-4 relative plus 1 % of that reach (a gradient
+        # entry that is rounding noise of an exact zero moves its weight by lr * g / (|g| + eps) either way)
+        for k, v in nfp.model.state_dict().items():
+            close(v, g[prefix + k], rtol=1e-4, atol=0.01 * steps * lr, msg=prefix + k)
+    if preset != 'False':
+        nfp.train(loader(g['x_half'], g['y_half'], half, 0, 2), loader(g['x_half'], g['y_half'], half, 2, 3), clim_h, lr=lr,
+                  n_epochs=1, mask=g['mask_half'], truncated_backprop=0, graph_structure=gs_h)
+        steps += 2
+        weights_close('w1/', steps)
+    nfp.train(loader(g['x'], g['y'], full, 0, 2), loader(g['x'], g['y'], full, 2, 3), clim_f, lr=lr, n_epochs=1, mask=mask,
+              high_interest_region=hir, truncated_backprop=0, graph_structure=gs_f)
+    steps += 2
+    weights_close('w2/', steps)
+    np.testing.assert_allclose(nfp.loss['train_loss'].values, g['train_loss'], rtol=2e-4)
+    np.testing.assert_allclose(nfp.loss['test_loss'].values, g['test_loss'], rtol=2e-4)
+    pred = nfp.predict(loader(g['x'], g['y'], full, 2, 3), clim_f, mask=mask, graph_structure=gs_f)
+    assert pred.shape == g['pred'].shape and np.array_equal(np.isnan(pred), np.isnan(g['pred']))
+    np.testing.assert_allclose(np.nan_to_num(pred), np.nan_to_num(g['pred']), rtol=2e-4, atol=2e-5)

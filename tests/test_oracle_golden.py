@@ -176,3 +176,74 @@ def test_rollout_transformerconv(golden_dir):
         np.testing.assert_allclose(o.detach().numpy(), g[f'out_{i}'], rtol=RTOL, atol=ATOL)
     loss = O.clip_loss(outs, maps, y, (64, 64), g['mask'])
     assert abs(float(loss.detach()) - float(g['loss'])) <= RTOL * abs(float(g['loss']))
+
+
+def _climatology(base):
+    d = np.arange(365, dtype=np.float32)[:, None, None]
+    return (base[None] * (0.5 + 0.5 * np.cos(2 * np.pi * d / 365.0)) + 0.001 * d)[None].astype(np.float32)
+
+
+def _doys(launch, t_out):
+    import datetime
+    return [datetime.datetime.fromtimestamp((int(launch) + 8.640e13 * t) / 1e9).timetuple().tm_yday - 1 for t in range(t_out)]
+
+
+@pytest.mark.parametrize('name', ['ice_exp9', 'ice_exp10', 'ice_exp1'])
+def test_ice_exp_preset_experiments(golden_dir, name):
+    """ice_exp.py exp 9 / 10 / 1 (preset heterogeneous / homogeneous mesh x edge attributes x resolution x TransformerConv; GCNConv on
+    the pixelwise mesh): the oracle's preset-mesh and pixelwise paths against the reference's trainer trace -- meshes bit-exact,
+    forward + backward at the initial weights, and the two train() phases (clip_grad_norm_(10) + Adam, per-epoch losses with the
+    reference's /(steps + 1), weights after each phase)."""
+    g = load(golden_dir, f'variant_{name}.npz')
+    preset, conv = str(g['preset']), str(g['conv'])
+    t_in, t_out = g['x'].shape[1], g['y'].shape[1]
+    half, full = g['mask_half'].shape, g['mask'].shape
+    gs_h = gs_f = None
+    if preset != 'False':
+        hom = preset == 'homogeneous'
+        gs_h = O.static_graph(half, 4, g['mask_half'], use_edge_attrs=True, resolution=1 / 6, homogeneous=hom)
+        gs_f = O.static_graph(full, 4, g['mask'], use_edge_attrs=True, resolution=1 / 12, homogeneous=hom)
+        for gs, pre in ((gs_h, 'half_'), (gs_f, 'full_')):
+            assert np.array_equal(gs['labels'], g[pre + 'labels'])
+            assert np.array_equal(gs['n_pixels_per_node'].numpy(), g[pre + 'npix'])
+            assert np.array_equal(gs['edge_index'].numpy(), g[pre + 'edges'])
+            np.testing.assert_allclose(gs['edge_attrs'].numpy(), g[pre + 'attrs'], rtol=2e-5, atol=2e-5)
+    model = O.Seq2Seq(32, 0.1, -np.inf, input_timesteps=t_in, input_features=8, output_timesteps=t_out, n_layers=1,
+                      n_conv_layers=3, transform_func=dist_from_05, convolution_type=conv)
+    _load_state(model, g, 'w/')
+    model.eval()
+    clim = {half: torch.from_numpy(_climatology(g['clim_base_half'])), full: torch.from_numpy(_climatology(g['clim_base']))}
+
+    def concat_of(shape, launch):
+        return torch.moveaxis(clim[shape][:, _doys(launch, t_out)], 0, -1)
+    x, y = torch.from_numpy(g['x'][0]), torch.from_numpy(g['y'][0])
+    outs, maps, _ = model(x, concat_of(full, g['launch'][0]), mask=g['mask'], graph_structure=gs_f)
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().numpy(), g[f'out_{i}'], rtol=RTOL, atol=ATOL)
+    loss = O.clip_loss(outs, maps, y, full, g['mask'])
+    assert abs(float(loss.detach()) - float(g['loss0'])) <= RTOL * float(g['loss0'])
+    loss.backward()
+    for k, p in model.named_parameters():
+        ref = g['g/' + k]
+        got = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-4 * max(1e-3, np.abs(ref).max()), err_msg=k)
+    model.zero_grad()
+
+    opt = torch.optim.Adam(model.parameters(), lr=float(g['lr']))               # mpnnlstm.py:174, kept across train() calls
+    train_loss, test_loss = [], []
+
+    def phase(xs, ys, shape, mask, gs, prefix):
+        run = sum(O.train_step(model, opt, torch.from_numpy(xs[c]), torch.from_numpy(ys[c]), concat_of(shape, g['launch'][c]), mask,
+                               graph_structure=gs) for c in range(2))
+        with torch.no_grad():
+            o, m, _ = model(torch.from_numpy(xs[2]), concat_of(shape, g['launch'][0]), mask=mask, graph_structure=gs)
+            tl = float(O.clip_loss(o, m, torch.from_numpy(ys[2]), shape, mask))
+        train_loss.append(run / 3)                                              # running / (step + 1), mpnnlstm.py:360-361
+        test_loss.append(tl / 2)
+        for k, v in model.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), g[prefix + k], rtol=1e-4, atol=2e-5, err_msg=prefix + k)
+    if preset != 'False':
+        phase(g['x_half'], g['y_half'], half, g['mask_half'], gs_h, 'w1/')
+    phase(g['x'], g['y'], full, g['mask'], gs_f, 'w2/')
+    np.testing.assert_allclose(train_loss, g['train_loss'], rtol=1e-4)
+    np.testing.assert_allclose(test_loss, g['test_loss'], rtol=1e-4)

@@ -35,6 +35,7 @@ else:
     if cfg == 'cfg4tp':
         thresh = -np.inf
     tf = lambda a: abs(abs(a - 0.5) - 0.5)
+    kw['transform_func'] = tf
     mask = synthetic.make_ice_like(40, shape=shape, channels=5, n_frames=2)[1]
     def batch(i):
         clips = [synthetic.make_ice_like(1000 * i + k, shape=shape, channels=5, n_frames=t_in + t_out)[0] for k in range(B)]

@@ -11,7 +11,8 @@ B, t_in, t_out, shape = int(os.environ.get('QT_B', 4)), 12, 6, (128, 128)
 torch.manual_seed(1)
 nfp = NextFramePredictorS2S(thresh=0.15, input_features=5, input_timesteps=t_in, output_timesteps=t_out, device=dev,
                             transform_func=lambda a: abs(abs(a - 0.5) - 0.5),
-                            model_kwargs=dict(hidden_size=32, dropout=0.1, n_layers=1, n_conv_layers=3, convolution_type=os.environ.get('QT_CONV', 'TransformerConv')))
+                            model_kwargs=dict(hidden_size=32, dropout=0.1, n_layers=1, n_conv_layers=3, convolution_type=os.environ.get('QT_CONV', 'TransformerConv'),
+                                              transform_func=lambda a: abs(abs(a - 0.5) - 0.5)))
 nfp.initiate_training(lr=0.01, lr_decay=0.95, capturable=True)
 nfp.model.train(); nfp.model.static_shapes = True
 mask = synthetic.make_ice_like(40, shape=shape, channels=5, n_frames=2)[1]

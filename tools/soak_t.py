@@ -11,7 +11,8 @@ B, t_in, t_out, shape = 16, 12, 6, (128, 128)
 torch.manual_seed(1)
 nfp = NextFramePredictorS2S(thresh=0.15, input_features=5, input_timesteps=t_in, output_timesteps=t_out, device=dev,
                             transform_func=lambda a: abs(abs(a - 0.5) - 0.5),
-                            model_kwargs=dict(hidden_size=32, dropout=0.1, n_layers=1, n_conv_layers=3, convolution_type='TransformerConv'))
+                            model_kwargs=dict(hidden_size=32, dropout=0.1, n_layers=1, n_conv_layers=3, convolution_type='TransformerConv',
+                                              transform_func=lambda a: abs(abs(a - 0.5) - 0.5)))
 nfp.initiate_training(lr=0.003, lr_decay=0.95, capturable=True)
 nfp.model.train()
 mask = synthetic.make_ice_like(40, shape=shape, channels=5, n_frames=2)[1]
