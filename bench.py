@@ -525,7 +525,7 @@ def main():
             except Exception as e:                                            # pragma: no cover
                 line['cpu_baseline'] = {'error': repr(e)[:200]}
         from qtmpnn.mesh import tile_error_word
-        assert tile_error_word() == 0, 'a tile-resident launch reported an error (sync word)'
+        assert tile_error_word() == 0, 'a tile-resident launch reported an error (persistent error word)'
         print(json.dumps(line), flush=True)
     if world > 1:
         host_barrier()

@@ -58,7 +58,9 @@ extern "C" {
 #define QT_TILE_CNT_STRIDE 32
 #define QT_TILE_REC_CAP 4096  /* interior records per tile */
 #define QT_TILE_POOL_CAP 1372 /* interior pool entries per tile held in LDS (more: those rows walk the CSR arrays) */
-#define QT_TILE_HALO_CAP 256  /* halo entries = boundary records at most, per tile */
+#ifndef QT_TILE_HALO_CAP /* (the small-caps test build shrinks it to force the capacity-overflow report) */
+#define QT_TILE_HALO_CAP 256  /* halo entries = boundary records at most, per tile: a power of two <= 256 */
+#endif
 #define QT_TILE_BPOOL_CAP 1024 /* boundary pool entries per tile (sum over border cells of 4 side - 4 < 1024) */
 #define QT_TILE_SLICES 12     /* 4-channel slices per launch the exchange buffer and the sync words are laid out for (Ca + Cb <= 48) */
 
@@ -166,11 +168,13 @@ int qt_tail_cap(void);
  *   tile_bpool (B T, QT_TILE_BPOOL_CAP, 2) {local row, or 0x80000000 | halo slot; weight bits}: edges 5.. of the boundary rows
  *   tile_halo  (B T, QT_TILE_HALO_CAP)    global row of every halo slot
  *   brec_addr  (N)                        for a boundary row: tile slot * QT_TILE_HALO_CAP + its boundary record's index (where the
- *              other tiles look for the row's published values); other rows: not written */
+ *              other tiles look for the row's published values); -1 when its record did not fit; other rows: not written
+ *   err        optional: the caller's PERSISTENT error word (see qt_cheb_tile_fwd); bit 1 is OR-ed in when a boundary row's
+ *              record, halo slots or pool run exceed the tile capacities (no quadtree mesh does; any other CSR may) */
 int qt_edges_norm_tiles(const int32_t* rowptr, const int32_t* col, const float* w, const float* dis, int N,
                         const int32_t* n_dev, float* nrm, int32_t* ell, const int32_t* cell, const int32_t* tile_off,
                         int T, int nbj, int32_t* tile_cnt, int32_t* tile_pool, int32_t* tile_rec, int32_t* tile_brec,
-                        int32_t* tile_bpool, int32_t* tile_halo, int32_t* brec_addr, void* stream);
+                        int32_t* tile_bpool, int32_t* tile_halo, int32_t* brec_addr, int32_t* err, void* stream);
 
 /* ---------------------------------------------------------------- mesh <-> image transfers
  * flatten / unflatten, model/graph_functions.py:391-419, 451-458, by labels instead of the dense
@@ -304,10 +308,15 @@ int qt_cheb_clip_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm
  *   tile_off = qt_quadtree_stage3's cell_off; tile_cnt .. tile_halo, brec_addr: from qt_edges_norm_tiles; xbuf: per (tile, slice,
  *   hop parity) QT_TILE_HALO_CAP slots of four granules;
  *   xbuf: qt_cheb_tile_xbuf_words(B, T) ints and sync: qt_cheb_tile_sync_words(B) ints, both zeroed ONCE per mesh (qt_edges_count's
- *   zero_buf).  The LAST sync word is an error word: bit 0 = a wait for a neighbour tile timed out (the launch then finishes with
- *   garbage instead of hanging), bit 1 = a tile capacity of the mesh build was exceeded.  T tiles per clip in rows of nbj;
- *   N = plane stride in rows; Ca + Cb <= 4 QT_TILE_SLICES, K <= 16.  The launches are cut so that every workgroup of one is
- *   resident (<= one per CU).  Planes as qt_cheb_clip_fwd / _bwd.
+ *   zero_buf).  err: ONE int32 the caller owns for as long as it wants to know (allocated once, zeroed once, never touched by a
+ *   mesh build: it outlives the meshes and hipGraph replays); the launches OR into it: bit 0 = a wait for a neighbour tile
+ *   timed out (the launch then finishes with garbage instead of hanging), bit 1 = a tile capacity of the mesh build was
+ *   exceeded (the rows concerned are not computed).  A non-zero word means the planes of some launch since the word was last
+ *   zero are WRONG: the caller must read it before trusting results (the Python host does so once per training epoch, every
+ *   64 graph replays, after predict() and after every eager training step that issued such a launch).
+ *   T tiles per clip in rows of nbj; N = plane stride in rows; Ca + Cb <= 4 QT_TILE_SLICES, K <= 16.  The launches are cut so
+ *   that every workgroup of one is resident (<= one per CU); B * T > qt_num_cus() is refused (QT_E_ARG).  Planes as
+ *   qt_cheb_clip_fwd / _bwd.
  *   Co-residency is what makes the waits safe: a GPU SHARED with another process that issues the same launches can leave two
  *   half-resident grids waiting for each other until the bounded spins give up (error word bit 0, garbage planes) -- one
  *   process per GPU, as everywhere in this library's multi-GPU use. */
@@ -317,12 +326,12 @@ int qt_cheb_tile_sync_words(int B);
 int qt_cheb_tile_fwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* tile_off,
                      const int32_t* tile_cnt, const int32_t* tile_pool, const int32_t* tile_rec, const int32_t* tile_brec,
                      const int32_t* tile_bpool, const int32_t* tile_halo, const int32_t* brec_addr, int32_t* xbuf, int32_t* sync,
-                     int B, int T, int nbj, int N, int K,
+                     int32_t* err, int B, int T, int nbj, int N, int K,
                      int Ca, const float* za, int lda, float* Ta, int Cb, const float* zb, int ldb, float* Tb, void* stream);
 int qt_cheb_tile_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell, const int32_t* tile_off,
                      const int32_t* tile_cnt, const int32_t* tile_pool, const int32_t* tile_rec, const int32_t* tile_brec,
                      const int32_t* tile_bpool, const int32_t* tile_halo, const int32_t* brec_addr, int32_t* xbuf, int32_t* sync,
-                     int B, int T, int nbj, int N, int K,
+                     int32_t* err, int B, int T, int nbj, int N, int K,
                      int Ca, float* Ga, int Cb, float* Gb, int planes_sm, void* stream);
 
 /* The decoder head's backward products in ONE launch (model/seq2seq.py:115-121,164-171 backwards): G = relu'(Y) (.) (gU @ Wb2)

@@ -69,7 +69,9 @@ struct ClipArgs {
     const int32_t* tile_halo;      // (B T, QT_TILE_HALO_CAP) global row of every halo slot
     const int32_t* brec_addr;      // (N) boundary rows: tile slot * QT_TILE_HALO_CAP + boundary record index
     unsigned long long* xbuf;      // (B T, QT_TILE_SLICES, QT_TILE_HALO_CAP, 4) {value, tag} granules: the published boundary rows
-    unsigned* sync;                // (2 B QT_TILE_SLICES + 1): launch generation and arrivals per (clip, slice); error word
+    unsigned* sync;                // (2 B QT_TILE_SLICES): launch generation and arrivals per (clip, slice)
+    unsigned* err;                 // the caller's persistent error word (never reset by the library): bit 0 a wait for a neighbour
+                                   // tile gave up, bit 1 a tile capacity of the mesh build was exceeded
     int T, nbj, s0, ns;            // tiles per clip, tiles per tile row; first slice and slice count of THIS launch
 #ifdef QT_CLIP_TIMING
     long long* dbg;                // diagnostics build (tools/exp_clip_timing.py): 16 stamps per workgroup
@@ -187,7 +189,12 @@ __device__ __forceinline__ void gather_tail_csr(fvec<W>& a, const char* __restri
 //   between launches or hipGraph replays; the exchange buffer is zeroed once per mesh build.
 // No dependence on dispatch order beyond forward progress: spins are bounded (a timeout sets the error word and the launch
 // finishes with garbage instead of hanging) and the launches are cut so that all workgroups of one are co-resident.
-constexpr unsigned TILE_SPIN_LIMIT = 200000u;              // polls of ~1 us: ~0.2 s before a poll gives up
+#ifndef QT_TILE_SPIN_LIMIT
+#define QT_TILE_SPIN_LIMIT 200000u                         // polls of ~1 us: ~0.2 s before a poll gives up (a test build shrinks it)
+#endif
+constexpr unsigned TILE_SPIN_LIMIT = QT_TILE_SPIN_LIMIT;
+static_assert((QT_TILE_HALO_CAP & (QT_TILE_HALO_CAP - 1)) == 0 && QT_TILE_HALO_CAP <= 256,
+              "halo slots: a power of two (slot masks) of at most 256 (the boundary pool keeps a slot in 8 bits; waves 0-3 own them)");
 
 template <bool BWD, int W, bool TILE = false>
 __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
     // one to leave) and the count of workgroups that have left
     unsigned* const ggen = TILE ? g.sync + ((int64_t)c * QT_TILE_SLICES + s) : nullptr;
     unsigned* const gdone = TILE ? g.sync + ((int64_t)(g.B + c) * QT_TILE_SLICES + s) : nullptr;
-    unsigned* const gerr = TILE ? g.sync + (int64_t)2 * g.B * QT_TILE_SLICES : nullptr;
+    unsigned* const gerr = TILE ? g.err : nullptr;
     unsigned tag0 = 0;                       // generation * 16: a hop's tag is tag0 + hop number
     if constexpr (TILE) tag0 = __hip_atomic_load(ggen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 4;
     auto leave = [&]() {
@@ -330,8 +337,14 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
         if (t < nh) {
             const int hc = g.tile_halo[(int64_t)ts * QT_TILE_HALO_CAP + t];
             // granule index of the halo row's published values: (owner tile * slices + this slice) * 256 + its record, * 4
+            // (negative: the owner tile's boundary record did not fit -- qt_edges_norm_tiles reported it; nobody publishes that
+            // row, so this lane never waits for it)
             const int ba = g.brec_addr[hc];
-            HC[t] = (((ba >> 8) * QT_TILE_SLICES + s) * 2 * QT_TILE_HALO_CAP + (ba & (QT_TILE_HALO_CAP - 1))) * 4;
+            if (ba < 0) {
+                dead = true;
+                __hip_atomic_fetch_or(gerr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            HC[t] = ba < 0 ? 0 : (((ba / QT_TILE_HALO_CAP) * QT_TILE_SLICES + s) * 2 * QT_TILE_HALO_CAP + (ba & (QT_TILE_HALO_CAP - 1))) * 4;
             V hv;
             if constexpr (!BWD) hv = ldg<W>(pt.z + ((unsigned)hc * (unsigned)pt.ld + ch));
             else hv = ldg<W>(pt.planes + grad_off(K - 1, (unsigned)hc));
@@ -395,7 +408,9 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
     // TILE: hopc = 1, 2, .. counts the hops of the launch (the tag of its granules); more = a further hop follows (the last hop
     // publishes and fetches nothing)
     struct Xch { unsigned hopc; bool more; };
-    [[maybe_unused]] const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(TILE ? g.xbuf : nullptr, 0, -1, 0x00020000);
+    // (num_records = the exchange buffer's real size: an out-of-range poll reads 0, never matches a tag and times out)
+    [[maybe_unused]] const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        TILE ? g.xbuf : nullptr, 0, TILE ? g.B * g.T * (QT_TILE_SLICES * 2 * QT_TILE_HALO_CAP * 32) : 0, 0x00020000);
     using U4 = unsigned __attribute__((ext_vector_type(4)));
     auto hop = [&](auto co_tag, auto own_tag, float alpha, float beta, auto&& addend, auto&& fin, const Xch& x) {
         constexpr unsigned CO = decltype(co_tag)::value;
@@ -435,7 +450,8 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
                 V acc = vzero<W>();
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vfma<W>(acc, bw[e], f[e]);
-                const unsigned pb = info & 0xffffu, pc = info >> 16;
+                const bool real = info != 0xffffffffu;          // (a NULL record: a row whose record did not fit, qt_edges_norm_tiles)
+                const unsigned pb = info & 0xffffu, pc = real ? info >> 16 : 0u;
                 for (unsigned j0 = 0; j0 < pc; j0 += 4) {
                     int2 e[4];
 #pragma unroll
@@ -448,7 +464,7 @@ __global__ __launch_bounds__(CL_T) void k_cheb_clip(ClipArgs g) {
                     for (int v = 0; v < 4; ++v)
                         if (j0 + v < pc) vfma<W>(acc, __int_as_float(e[v].y), ff[v]);
                 }
-                finish(acc, own, bnx, slot, (unsigned)r0 + lrow, true, [&](unsigned grow, const V& r, char* own_slot) {
+                finish(acc, own, bnx, slot, (unsigned)r0 + lrow, real, [&](unsigned grow, const V& r, char* own_slot) {
                     fin(grow, r, own_slot);
                     if (x.more) {
                         const int off = (((ts * QT_TILE_SLICES + s) * 2 + (int)(x.hopc & 1u)) * QT_TILE_HALO_CAP + t) * 32;
@@ -684,7 +700,7 @@ struct TileMesh {
     const int32_t *rowptr, *col;
     const float* nrm;
     const int32_t *ell, *tile_off, *tile_cnt, *tile_pool, *tile_rec, *tile_brec, *tile_bpool, *tile_halo, *brec_addr;
-    int32_t *xbuf, *sync;
+    int32_t *xbuf, *sync, *err;
     int B, T, nbj;
 };
 
@@ -719,13 +735,13 @@ static int tile_launch(bool bwd, const TileMesh& m, int Ncap, int K, int Ca, con
     g.brec_addr = m.brec_addr;
     g.xbuf = reinterpret_cast<unsigned long long*>(m.xbuf);
     g.sync = reinterpret_cast<unsigned*>(m.sync);
+    g.err = reinterpret_cast<unsigned*>(m.err);
     g.T = m.T;
     g.nbj = m.nbj;
     // One launch holds whole (clip, slice) groups and at most one workgroup per CU (160 KB of LDS each): all of its workgroups
     // are resident together, so a workgroup that waits for a neighbour tile never waits for one that has not been dispatched.
     const int S = (Ca + Cb) / 4;
-    int per = qt_num_cus() / (m.B * m.T);          // slices per launch
-    if (per < 1) per = 1;                          // (more tiles than CUs: relies on in-order dispatch; the spins are bounded)
+    const int per = qt_num_cus() / (m.B * m.T);    // slices per launch (>= 1: the entry points refuse B T > CUs)
     for (int s0 = 0; s0 < S; s0 += per) {
         g.s0 = s0;
         g.ns = S - s0 < per ? S - s0 : per;
@@ -741,8 +757,12 @@ static int tile_launch(bool bwd, const TileMesh& m, int Ncap, int K, int Ca, con
 
 #define TILE_MESH_ARGS_OK                                                                                                         \
     QT_ARG(rowptr && col && nrm && ell && tile_off && tile_cnt && tile_pool && tile_rec && tile_brec && tile_bpool && tile_halo && brec_addr && \
-               xbuf && sync && B > 0 && K >= 2 && K <= 16 && T >= 2 && nbj >= 1 && T % nbj == 0 && ((uintptr_t)xbuf & 15) == 0,         \
-           "bad arguments (the tile arrays of qt_edges_norm_tiles, the exchange buffer and the sync words zeroed by qt_edges_count are required)")
+               xbuf && sync && err && B > 0 && K >= 2 && K <= 16 && T >= 2 && nbj >= 1 && T % nbj == 0 && ((uintptr_t)xbuf & 15) == 0,  \
+           "bad arguments (the tile arrays of qt_edges_norm_tiles, the exchange buffer and the sync words zeroed by qt_edges_count, "     \
+           "and the caller's persistent error word are required)");                                                                    \
+    /* the tiles of a (clip, slice) wait for each other: all of them must be resident at once, one workgroup (160 KB of LDS) per CU */ \
+    QT_ARG(B * T <= qt_num_cus(), "more tiles (B x T) than compute units: the tile-resident launch needs them co-resident -- "          \
+                                  "use one qt_spmm launch per hop for this mesh")
 
 // the capacities the tile structures are laid out for (the caller allocates them): 0 interior pool entries, 1 interior records,
 // 2 halo slots = boundary records, 3 boundary pool entries (all per tile), 4 slices per launch
@@ -756,13 +776,13 @@ extern "C" int qt_tile_cap(int which) {
         default: return 0;
     }
 }
-extern "C" int qt_cheb_tile_sync_words(int B) { return 2 * B * QT_TILE_SLICES + 1; }
+extern "C" int qt_cheb_tile_sync_words(int B) { return 2 * B * QT_TILE_SLICES; }
 extern "C" int qt_cheb_tile_xbuf_words(int B, int T) { return B * T * QT_TILE_SLICES * 2 * QT_TILE_HALO_CAP * 8; }   // (hop parity) x 4 granules of 2 ints per slot
 
 extern "C" int qt_cheb_tile_fwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell,
                                 const int32_t* tile_off, const int32_t* tile_cnt, const int32_t* tile_pool, const int32_t* tile_rec,
                                 const int32_t* tile_brec, const int32_t* tile_bpool, const int32_t* tile_halo, const int32_t* brec_addr,
-                                int32_t* xbuf, int32_t* sync,
+                                int32_t* xbuf, int32_t* sync, int32_t* err,
                                 int B, int T, int nbj, int N, int K, int Ca, const float* za, int lda, float* Ta, int Cb,
                                 const float* zb, int ldb, float* Tb, void* stream) {
     TILE_MESH_ARGS_OK;
@@ -774,7 +794,7 @@ extern "C" int qt_cheb_tile_fwd(const int32_t* rowptr, const int32_t* col, const
     QT_ARG((int64_t)K * N * max(Ca, Cb) < ((int64_t)1 << 31) && (int64_t)N * max(max(lda, ldb), 4) < ((int64_t)1 << 31),
            "planes too large for 32-bit offsets");
     if (N <= 0) return QT_OK;
-    const TileMesh m = {rowptr, col, nrm, ell, tile_off, tile_cnt, tile_pool, tile_rec, tile_brec, tile_bpool, tile_halo, brec_addr, xbuf, sync, B, T, nbj};
+    const TileMesh m = {rowptr, col, nrm, ell, tile_off, tile_cnt, tile_pool, tile_rec, tile_brec, tile_bpool, tile_halo, brec_addr, xbuf, sync, err, B, T, nbj};
     tile_launch(false, m, N, K, Ca, za, lda, Ta, Cb, zb, ldb, Tb, stream, 0);
     QT_LAUNCHED();
     return QT_OK;
@@ -783,7 +803,7 @@ extern "C" int qt_cheb_tile_fwd(const int32_t* rowptr, const int32_t* col, const
 extern "C" int qt_cheb_tile_bwd(const int32_t* rowptr, const int32_t* col, const float* nrm, const int32_t* ell,
                                 const int32_t* tile_off, const int32_t* tile_cnt, const int32_t* tile_pool, const int32_t* tile_rec,
                                 const int32_t* tile_brec, const int32_t* tile_bpool, const int32_t* tile_halo, const int32_t* brec_addr,
-                                int32_t* xbuf, int32_t* sync,
+                                int32_t* xbuf, int32_t* sync, int32_t* err,
                                 int B, int T, int nbj, int N, int K, int Ca, float* Ga, int Cb, float* Gb, int planes_sm,
                                 void* stream) {
     TILE_MESH_ARGS_OK;
@@ -793,7 +813,7 @@ extern "C" int qt_cheb_tile_bwd(const int32_t* rowptr, const int32_t* col, const
              (uintptr_t)tile_bpool) & 15) == 0, "operands must be 16-byte aligned");
     QT_ARG((int64_t)K * N * max(Ca, Cb) < ((int64_t)1 << 31), "planes too large for 32-bit offsets");
     if (N <= 0) return QT_OK;
-    const TileMesh m = {rowptr, col, nrm, ell, tile_off, tile_cnt, tile_pool, tile_rec, tile_brec, tile_bpool, tile_halo, brec_addr, xbuf, sync, B, T, nbj};
+    const TileMesh m = {rowptr, col, nrm, ell, tile_off, tile_cnt, tile_pool, tile_rec, tile_brec, tile_bpool, tile_halo, brec_addr, xbuf, sync, err, B, T, nbj};
     tile_launch(true, m, N, K, Ca, nullptr, 0, Ga, Cb, nullptr, 0, Gb, stream, planes_sm);
     QT_LAUNCHED();
     return QT_OK;

@@ -212,7 +212,7 @@ __global__ void k_edges_nrm_tile(const int32_t* __restrict__ rowptr, const int32
                                  const int32_t* __restrict__ tile_off, int T, int nbj, int32_t* __restrict__ tile_cnt,
                                  int2* __restrict__ tile_pool, int4* __restrict__ tile_rec, int4* __restrict__ tile_brec,
                                  int2* __restrict__ tile_bpool, int32_t* __restrict__ tile_halo,
-                                 int32_t* __restrict__ brec_addr) {
+                                 int32_t* __restrict__ brec_addr, int32_t* __restrict__ err) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= qt_rows(n_dev, Ncap)) return;
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
@@ -242,7 +242,19 @@ __global__ void k_edges_nrm_tile(const int32_t* __restrict__ rowptr, const int32
             info = (uint32_t)pbase | ((uint32_t)cnt << 16);
             brec_addr[i] = ts * QT_TILE_HALO_CAP + slot;        // where the other tiles find this row's published values
         } else {
-            cnts[5] = 1;                                       // (cannot happen on a quadtree mesh; the kernel reports it)
+            // (cannot happen on a quadtree mesh -- but this entry accepts any CSR: the row gets no record, the other tiles find a
+            // sentinel instead of an address and do not wait for it, and the caller's error word says so)
+            cnts[5] = 1;
+            brec_addr[i] = -1;
+            if (err) atomicOr(err, 2);
+            // what this row took from the counters stays addressable: a NULL record (info = ~0: the kernel computes and stores
+            // nothing for it) in its slot, and its own row number in its halo slots (a valid row whose address is the sentinel)
+            if (slot < QT_TILE_HALO_CAP) {
+                int4* nul = tile_brec + 2 * ((int64_t)ts * QT_TILE_HALO_CAP + slot);
+                nul[0] = make_int4(0, 0, 0, 0);
+                nul[1] = make_int4(0, 0, -1, 0);
+            }
+            for (int h = hbase; h < min(hbase + nrem, QT_TILE_HALO_CAP); ++h) tile_halo[(int64_t)ts * QT_TILE_HALO_CAP + h] = i;
             nrem = 0;
         }
     } else if (cnt > 0) {                                      // interior row with a tail
@@ -255,6 +267,7 @@ __global__ void k_edges_nrm_tile(const int32_t* __restrict__ rowptr, const int32
         }
         const int slot = atomicAdd(&cnts[1], 1);
         if (slot < QT_TILE_REC_CAP) rec = tile_rec + 2 * ((int64_t)ts * QT_TILE_REC_CAP + slot);
+        else if (err) atomicOr(err, 2);                        // (more rows with a tail than rows: not a tile of <= 4096 nodes)
     }
     const float di = dis[i];
     int c4[4] = {i, i, i, i};              // (an unused slot re-reads the row itself with weight 0)
@@ -340,7 +353,7 @@ extern "C" int qt_edges_norm(const int32_t* rowptr, const int32_t* col, const fl
 extern "C" int qt_edges_norm_tiles(const int32_t* rowptr, const int32_t* col, const float* w, const float* dis, int N,
                                    const int32_t* n_dev, float* nrm, int32_t* ell, const int32_t* cell, const int32_t* tile_off,
                                    int T, int nbj, int32_t* tile_cnt, int32_t* tile_pool, int32_t* tile_rec, int32_t* tile_brec,
-                                   int32_t* tile_bpool, int32_t* tile_halo, int32_t* brec_addr, void* stream) {
+                                   int32_t* tile_bpool, int32_t* tile_halo, int32_t* brec_addr, int32_t* err, void* stream) {
     QT_ARG(rowptr && col && w && dis && nrm && cell && tile_off && tile_cnt && tile_pool && tile_rec && tile_brec && tile_bpool && tile_halo &&
                brec_addr, "null pointer");
     QT_ARG(T >= 1 && nbj >= 1 && T % nbj == 0, "T tiles per clip in rows of nbj");
@@ -350,7 +363,7 @@ extern "C" int qt_edges_norm_tiles(const int32_t* rowptr, const int32_t* col, co
     hipLaunchKernelGGL(k_edges_nrm_tile, dim3(qt_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, w, dis, N, n_dev, nrm,
                        reinterpret_cast<int4*>(ell), cell, tile_off, T, nbj, tile_cnt, reinterpret_cast<int2*>(tile_pool),
                        reinterpret_cast<int4*>(tile_rec), reinterpret_cast<int4*>(tile_brec), reinterpret_cast<int2*>(tile_bpool),
-                       tile_halo, brec_addr);
+                       tile_halo, brec_addr, err);
     QT_LAUNCHED();
     return QT_OK;
 }

@@ -20,6 +20,7 @@ from model.utils import add_positional_encoding, get_n_params, int_to_datetime
 from qtmpnn import ops
 from qtmpnn.dist import allreduce_gradients
 from qtmpnn.flat import flat_params
+from qtmpnn.mesh import check_tile_errors
 
 try:                                        # pragma: no cover - optional dependency
     from torch.utils.tensorboard import SummaryWriter
@@ -201,6 +202,7 @@ class NextFramePredictorS2S(NextFramePredictor):
         loss = self.forward_loss(x, y, concat_layers, mask, high_interest_region, graph_structure)
         loss.backward()
         self._clip_and_step(self._grads_ready(self._world(), self.process_group), max_norm)
+        check_tile_errors()          # (reads the device only when this step issued tile-resident launches; raises on a failed one)
         return loss.detach()
 
     def truncated_backward(self, x, y, concat_layers, mask, high_interest_region=None, graph_structure=None,
@@ -300,6 +302,14 @@ class NextFramePredictorS2S(NextFramePredictor):
                 flat.mul_(1.0 / world)
                 update(clip_params)
 
+        # the captured launches report failures (a tile-resident launch that gave up waiting) only through the device's persistent
+        # error word: it is read here after the capture and then every 64 replays -- one 4-byte copy, only for graphs that
+        # contain such launches at all
+        from qtmpnn import mesh as _mesh
+        uses_tiles = bool(_mesh._TILE_USED)
+        check_tile_errors(always=uses_tiles)
+        replays = [0]
+
         def step(x, y, concat_layers=None):
             sx.copy_(x)
             sy.copy_(y)
@@ -309,7 +319,11 @@ class NextFramePredictorS2S(NextFramePredictor):
             if multi:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
                 graph2.replay()
+            replays[0] += 1
+            if uses_tiles and replays[0] % 64 == 0:
+                check_tile_errors(always=True)
             return static_loss
+        step.check = lambda: check_tile_errors(always=uses_tiles)
         return step
 
     def train(self, loader_train, loader_test, climatology=None, n_epochs=200, lr=0.01, lr_decay=0.95, mask=None,
@@ -366,6 +380,7 @@ class NextFramePredictorS2S(NextFramePredictor):
                 with torch.no_grad():
                     running_test += self.forward_loss(x, y, concat, mask, high_interest_region, graph_structure).item()
                 steps_test += 1
+            check_tile_errors(always=True)      # once per epoch: the graph-replayed steps and the test loop report only here
             running, running_test = running / (steps + 1), running_test / (steps_test + 1)   # (+1 as the reference, :360-361)
             if np.isnan(running_test):
                 raise ValueError('NaN loss :(')
@@ -407,6 +422,7 @@ class NextFramePredictorS2S(NextFramePredictor):
                 frames = [unflatten(o, ms, image_shape, mask).cpu().numpy() for o, ms in zip(y_hat, meshes)]
             frames = np.stack(frames, axis=0 if x.dim() == 4 else 1)
             preds.extend([frames] if x.dim() == 4 else list(frames))
+        check_tile_errors(always=True)
         return np.stack(preds, 0)
 
     def score(self, x, y, rollout=None):

@@ -28,12 +28,12 @@ _SIGNATURES = {
     'qt_edges_norm': [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'qt_tail_cap': [],
     'qt_head_dgrad': [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
-    'qt_edges_norm_tiles': [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    'qt_edges_norm_tiles': [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'qt_cheb_tile_sync_words': [_I],
     'qt_cheb_tile_xbuf_words': [_I, _I],
     'qt_tile_cap': [_I],
-    'qt_cheb_tile_fwd': [_P] * 14 + [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P],
-    'qt_cheb_tile_bwd': [_P] * 14 + [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
+    'qt_cheb_tile_fwd': [_P] * 15 + [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P],
+    'qt_cheb_tile_bwd': [_P] * 15 + [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     'qt_gather': [_P, _I, _P, _P, _L, _P, _P],
     'qt_pool': [_P, _I, _L, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],
     'qt_sse_rollout': [_I, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64, _I, _I, _I, _P, _P],

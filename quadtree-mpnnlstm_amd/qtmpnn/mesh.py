@@ -18,29 +18,61 @@ CONDITIONS = ('max_larger_than', 'max_smaller_than', 'min_larger_than', 'min_sma
 
 
 _MASKS = {}
-_TILE_SYNC = []          # weak references to the sync words of the meshes that carry tile structures (tile_error_word)
+_TILE_ERR = {}           # device -> the persistent error word of the tile-resident launches (tile_error_word / check_tile_errors)
+_TILE_USED = set()       # devices that issued a tile-resident launch since their word was last checked
 _TILE_CHEB = os.environ.get('QT_NO_TILE_CHEB') != '1'      # (A/B switch: 1 = frames of several base cells stay on one k_spmm launch per hop)
 _ONES1 = {}
 
 
+def _mask_key(a):
+    """Cache key of a mask by CONTENT (host arrays / tensors: shape + hash of the bytes, so an array changed in place is a new
+    mask and an equal array built anew is the same one) or by identity (CUDA tensors: never read back)."""
+    if a is None:
+        return None
+    if torch.is_tensor(a):
+        if a.is_cuda:
+            return ('cuda', a.data_ptr(), tuple(a.shape), a._version)
+        a = a.numpy()
+    arr = np.ascontiguousarray(np.asarray(a) != 0)
+    return (arr.shape, hash(arr.tobytes()))
+
+
 def _as_u8(a, device, shape):
-    """Device uint8 copy of a host mask, cached per (object, device): the upload happens once, outside any
-    hipGraph capture (a warm-up step always precedes capture)."""
+    """Device uint8 copy of a host mask, cached per (content, device): the upload happens once, outside any hipGraph capture
+    (a warm-up step always precedes capture).  A mask whose content has not been seen before cannot be uploaded while a
+    capture is running -- that is reported as what it is instead of hipErrorStreamCaptureUnsupported."""
     if a is None:
         return None
     if torch.is_tensor(a) and a.is_cuda and a.dtype == torch.uint8:
         return a.contiguous()
-    key = (id(a), str(device))
+    key = (_mask_key(a), str(device))
     hit = _MASKS.get(key)
-    if hit is not None and hit[0] is a:
-        return hit[1]
+    if hit is not None:
+        return hit
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('a mask / high_interest_region with new content was passed inside a hipGraph capture: its upload is a '
+                           'host-to-device copy, which a capture cannot hold.  Run one eager (warm-up) step with this mask first '
+                           '(make_graphed_step does), or pass it as a CUDA uint8 tensor')
     t = torch.as_tensor(np.asarray(a)) if not torch.is_tensor(a) else a
     assert tuple(t.shape) == tuple(shape), f'mask shape {tuple(t.shape)} != image shape {tuple(shape)}'
-    d = t.to(device=device, dtype=torch.uint8).contiguous()
+    d = (t != 0).to(device=device, dtype=torch.uint8).contiguous()
     if len(_MASKS) > 64:
         _MASKS.clear()
-    _MASKS[key] = (a, d)
+    _MASKS[key] = d
     return d
+
+
+def tile_err_word(device):
+    """The device's persistent error word of the tile-resident launches (include/qtmpnn.h, qt_cheb_tile_fwd): one int32,
+    allocated once OUTSIDE any hipGraph memory pool and never zeroed by a mesh build, so it outlives meshes and graph replays."""
+    key = str(device)
+    w = _TILE_ERR.get(key)
+    if w is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('the first mesh with tile structures was built inside a hipGraph capture: run one eager (warm-up) '
+                               'step first (make_graphed_step does)')
+        w = _TILE_ERR[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
 
 
 class Mesh:
@@ -341,8 +373,7 @@ def _finish_mesh(ms, device, size_norm, resolution, nd, want_tiles=True):
                          zbuf=zbuf)
     ms.tiles = tiles
     if tiles is not None:
-        import weakref
-        _TILE_SYNC[:] = [r for r in _TILE_SYNC if r() is not None][-63:] + [weakref.ref(tiles['sync'])]
+        tiles['err'] = tile_err_word(device)
     _lib.call('qt_edges_count', ptr(ms.labels), ptr(ms.cell), N, nd, n, m, ptr(cnt4), ptr(sums), ptr(ms.tail_cnt), B,
               ptr(tiles['zbuf']) if tiles else None, tiles['zbuf'].numel() if tiles else 0)
     emax = 4 * B * n * m                          # every directed edge owns >= 1 of the 4*P pixel adjacencies
@@ -355,21 +386,40 @@ def _finish_mesh(ms, device, size_norm, resolution, nd, want_tiles=True):
     if tiles:
         _lib.call('qt_edges_norm_tiles', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm), ptr(ms.ell),
                   ptr(ms.cell), ptr(ms.cell_off), tiles['T'], tiles['nbj'], ptr(tiles['cnt']), ptr(tiles['pool']), ptr(tiles['rec']),
-                  ptr(tiles['brec']), ptr(tiles['bpool']), ptr(tiles['halo']), ptr(tiles['baddr']))
+                  ptr(tiles['brec']), ptr(tiles['bpool']), ptr(tiles['halo']), ptr(tiles['baddr']), ptr(tiles['err']))
     else:
         _lib.call('qt_edges_norm', ptr(ms.rowptr), ptr(ms.col), ptr(ms.w), ptr(ms.dis), N, nd, ptr(ms.nrm), ptr(ms.ell), ptr(ms.cell),
                   ptr(ms.node_off), ptr(ms.tail_cnt), ptr(ms.tail_pool), ptr(ms.tail_info), ptr(ms.tail_rec))
 
 
-def tile_error_word():
-    """OR of the error words of every live mesh with tile structures (one device read each: diagnostics, end of a run): bit 0 = a
-    tile-resident launch gave up waiting for a neighbour tile, bit 1 = a tile capacity of the mesh build was exceeded."""
+def tile_error_word(reset=False):
+    """OR of the persistent error words of all devices (one 4-byte device read each): bit 0 = a tile-resident launch gave up
+    waiting for a neighbour tile, bit 1 = a tile capacity of the mesh build was exceeded.  The words are never reset by the
+    library: they report every launch since the process started (or since reset=True was last passed)."""
     err = 0
-    for r in _TILE_SYNC:
-        t = r()
-        if t is not None:
-            err |= int(t[-1].item())
+    for w in _TILE_ERR.values():
+        err |= int(w.item())
+        if reset:
+            w.zero_()
+    _TILE_USED.clear()
     return err
+
+
+def check_tile_errors(always=False):
+    """Raise if a tile-resident launch since the last check produced wrong planes (host side of the error word: the trainer
+    calls this after every eager training step that issued such a launch, once per epoch, every 64 graph replays and after
+    predict()).  Without `always` the device is read only when such a launch was issued since the last check."""
+    if not (_TILE_USED or (always and _TILE_ERR)):
+        return
+    err = tile_error_word(reset=True)
+    if err:
+        why = []
+        if err & 1:
+            why.append('a tile waited in vain for a neighbour tile of its clip (the tiles of a launch were not all resident: is '
+                       'another process using this GPU?  one process per GPU, or QT_NO_TILE_CHEB=1)')
+        if err & 2:
+            why.append('a tile capacity of the mesh build was exceeded (QT_TILE_HALO_CAP / QT_TILE_BPOOL_CAP: not a quadtree mesh?)')
+        raise RuntimeError('tile-resident Chebyshev launch failed, results since the last check are invalid: ' + '; '.join(why))
 
 
 def build_homogeneous_mesh(n, m, max_size, mask, B=1, device=None, resolution=0.25):
@@ -410,10 +460,10 @@ def build_pixel_mesh(B, n, m, mask=None, device=None, resolution=0.25):
     model/graph_functions.py:471-539).  Data independent: built once per (mask, B, shape) and cached.
     The reference passes edge_weight=None (unit weights) here; the CSR carries the uniform pixel distance instead,
     which gives the same L^ because the symmetric normalisation is scale invariant."""
-    key = (id(mask), B, n, m, str(device))
+    key = (_mask_key(mask), B, n, m, str(device), float(resolution))
     hit = _PIXEL_MESHES.get(key)
-    if hit is not None and hit[0] is mask:
-        return hit[1]
+    if hit is not None:
+        return hit
     mk = _as_u8(mask, device, (n, m))
     valid = torch.ones(n, m, dtype=torch.bool, device=device) if mk is None else mk == 0
     flat = valid.reshape(-1)
@@ -435,5 +485,5 @@ def build_pixel_mesh(B, n, m, mask=None, device=None, resolution=0.25):
     _finish_mesh(ms, device, 1.0 / (resolution ** 2), resolution, None)          # size feature = resolution^2 (:521)
     if len(_PIXEL_MESHES) > 16:
         _PIXEL_MESHES.clear()
-    _PIXEL_MESHES[key] = (mask, ms)
+    _PIXEL_MESHES[key] = ms
     return ms

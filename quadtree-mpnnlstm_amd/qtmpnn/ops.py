@@ -8,6 +8,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
+from . import mesh as _mesh
 from ._lib import ptr
 from .mesh import spmm, spmm2
 
@@ -303,14 +304,30 @@ def _tile_resident(mesh, widths, K):
         return False
     if not _NUM_CUS:
         _NUM_CUS.append(_lib.value('qt_num_cus'))
+    if _shared_device():
+        return False
     return mesh.B * tl['T'] * (sum(widths) // 4) <= _NUM_CUS[0]
+
+
+def _shared_device():
+    """True when several ranks of this job run on ONE GPU (more local ranks than devices -- bench.py's QT_DIST_BACKEND=gloo
+    rehearsal mode, the two-rank test on a one-GPU box -- or QT_SHARED_GPU=1): the tile-resident launches need all tiles of a
+    launch co-resident, which two processes issuing them side by side cannot promise, so those runs stay on one k_spmm launch
+    per hop.  (QT_SHARED_GPU=0 overrides the rank count.)"""
+    flag = os.environ.get('QT_SHARED_GPU')
+    if flag is not None:
+        return flag == '1'
+    try:
+        return int(os.environ.get('LOCAL_WORLD_SIZE', '1')) > max(torch.cuda.device_count(), 1)
+    except ValueError:
+        return False
 
 
 def _tile_args(mesh):
     tl = mesh.tiles
     return (ptr(mesh.rowptr), ptr(mesh.col), ptr(mesh.nrm), ptr(mesh.ell), ptr(mesh.cell_off), ptr(tl['cnt']), ptr(tl['pool']),
             ptr(tl['rec']), ptr(tl['brec']), ptr(tl['bpool']), ptr(tl['halo']), ptr(tl['baddr']), ptr(tl['xbuf']), ptr(tl['sync']),
-            mesh.B, tl['T'], tl['nbj'])
+            ptr(tl['err']), mesh.B, tl['T'], tl['nbj'])
 
 
 def clip_planes(mesh, Zs, TZs, K, width=0):
@@ -319,6 +336,7 @@ def clip_planes(mesh, Zs, TZs, K, width=0):
     (0 = the library's choice; 2 / 4 pin it: diagnostics and parity tests)."""
     two = len(Zs) > 1
     if getattr(mesh, 'tiles', None) is not None and mesh.n * mesh.m > _CLIP_ROWS_OF():
+        _mesh._TILE_USED.add(str(Zs[0].device))
         _lib.call('qt_cheb_tile_fwd', *_tile_args(mesh), Zs[0].shape[0], K, Zs[0].shape[1], ptr(Zs[0]), _ld(Zs[0]), ptr(TZs[0]),
                   Zs[1].shape[1] if two else 0, ptr(Zs[1]) if two else None, _ld(Zs[1]) if two else 0, ptr(TZs[1]) if two else None)
         return
@@ -332,6 +350,7 @@ def clip_clenshaw(mesh, Gs, K, sm=0, width=0):
     sm: planes 1 .. K-1 are stored slice-major (written so by the data-gradient kernels on request)."""
     two = len(Gs) > 1
     if getattr(mesh, 'tiles', None) is not None and mesh.n * mesh.m > _CLIP_ROWS_OF():
+        _mesh._TILE_USED.add(str(Gs[0].device))
         _lib.call('qt_cheb_tile_bwd', *_tile_args(mesh), Gs[0].shape[1], K, Gs[0].shape[2], ptr(Gs[0]),
                   Gs[1].shape[2] if two else 0, ptr(Gs[1]) if two else None, int(sm))
         return

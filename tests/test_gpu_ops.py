@@ -925,7 +925,7 @@ def test_tile_resident_recurrence_equals_per_hop_launches(kind, B, K, widths):
         o += w
     fused = [torch.empty(K - 1, N, w, device=dev()) for w in widths]
     ops.clip_planes(mesh, Zs, fused, K)
-    assert int(mesh.tiles['sync'][-1]) == 0, 'error word set by the forward launch'
+    assert int(mesh.tiles['err']) == 0, 'error word set by the forward launch'
     prev, ops._CLIP_CHEB = ops._CLIP_CHEB, False          # one qt_spmm2 launch per hop
     try:
         ref, sm = ops._cheb_planes(Zs, mesh, K)
@@ -952,8 +952,8 @@ def test_tile_resident_recurrence_equals_per_hop_launches(kind, B, K, widths):
         assert torch.equal(a[0], r[0]) and torch.equal(b[0], r[0])
         assert torch.equal(a[1:], g0[1:])                          # planes 1 .. K-1 stay as given
     sync = mesh.tiles['sync'].cpu().numpy()
-    ns = (len(sync) - 1) // 2
-    assert sync[-1] == 0 and not sync[ns:2 * ns].any() and sync[:ns].max() == 3      # three launches per used slice, none pending
+    ns = len(sync) // 2
+    assert int(mesh.tiles['err']) == 0 and not sync[ns:2 * ns].any() and sync[:ns].max() == 3      # three launches per used slice, none pending
 
 
 def test_tile_resident_recurrence_static_capacities_and_graph_replay():
@@ -991,7 +991,7 @@ def test_tile_resident_recurrence_static_capacities_and_graph_replay():
         torch.cuda.synchronize()
         exact = build_mesh(src=img.clone(), thresh=0.1)
         nv = exact.N
-        assert sm.n_valid == nv and int(sm.tiles['sync'][-1]) == 0
+        assert sm.n_valid == nv and int(sm.tiles['err']) == 0
         prev, ops._CLIP_CHEB = ops._CLIP_CHEB, False
         try:
             ref, _ = ops._cheb_planes([Z[:nv].contiguous()], exact, K)
@@ -1004,6 +1004,182 @@ def test_tile_resident_recurrence_static_capacities_and_graph_replay():
             spmm2(exact, [Gr[k + 1]], 2.0, [Gr[k]], 1.0, [Gr[k + 2]] if k + 2 < K else None, -1.0, [Gr[k]])
         spmm2(exact, [Gr[1]], 1.0, [Gr[0]], 1.0, [Gr[2]], -1.0, [Gr[0]])
         assert torch.equal(Gw[0, :nv], Gr[0])
+
+
+
+def _unpublish_one_boundary_row(mesh):
+    """Point the published-values address of one boundary row at a halo slot of its tile that no record owns (the last one): the
+    neighbour tiles that need the row then poll for a tag nobody writes.  Returns (global row, bad address)."""
+    tl = mesh.tiles
+    cap = tl['brec'].shape[1]
+    cnt = tl['cnt'].cpu().numpy().reshape(-1, 32)
+    off = mesh.cell_off.cpu().numpy()
+    ts = next(t for t in range(cnt.shape[0]) if 0 < cnt[t, 3] < cap - 1)
+    row = int(off[ts]) + int(tl['brec'][ts, 0, 7])
+    bad = ts * cap + cap - 1
+    assert int(tl['baddr'][row]) == ts * cap
+    tl['baddr'][row:row + 1].fill_(bad)
+    return row, bad
+
+
+def test_missed_tile_handoff_sets_the_persistent_error_word_and_raises():
+    """A tile that waits for a neighbour tile's boundary row that is never published gives up after a BOUNDED spin, the launch
+    ends (garbage planes) and bit 0 goes into the device's persistent error word: the word outlives the mesh (it is not part of the
+    buffers a mesh build zeroes), survives mesh builds and hipGraph replays, and check_tile_errors() turns it into a RuntimeError
+    and clears it.  A negative test of a bounded path, run once."""
+    import time
+    from qtmpnn import mesh as M, ops
+    assert M.tile_error_word(reset=True) == 0
+    mesh, img = _tile_mesh('mnist128_sparse', 2)
+    _unpublish_one_boundary_row(mesh)
+    K, N = 5, mesh.N
+    Z = torch.randn(N, 16, device=dev())
+    out = torch.empty(K - 1, N, 16, device=dev())
+    t0 = time.time()
+    ops.clip_planes(mesh, [Z], [out], K)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 30, 'the spin is not bounded'
+    assert int(mesh.tiles['err']) == 1
+    del mesh, out
+    other, _ = _tile_mesh('ice96x128', 2)                    # another mesh build does not clear the word
+    assert M.tile_error_word() == 1 and int(other.tiles['err']) == 1
+    with pytest.raises(RuntimeError, match='waited in vain'):
+        M.check_tile_errors(always=True)
+    assert M.tile_error_word() == 0                           # (the check reports once and clears)
+    M.check_tile_errors(always=True)
+
+    # the same inside a captured sequence: mesh build + corrupted address + launch, replayed twice
+    src = torch.from_numpy(np.ascontiguousarray(img)).to(dev())
+    probe = M.build_mesh(src=src, thresh=0.1, static=True)
+    row, bad = _unpublish_one_boundary_row(probe)
+    Zc = torch.randn(2 * 128 * 128, 16, device=dev())
+    outc = torch.zeros(K - 1, 2 * 128 * 128, 16, device=dev())
+
+    def run():
+        sm = M.build_mesh(src=src, thresh=0.1, static=True)
+        sm.tiles['baddr'][row:row + 1].fill_(bad)
+        ops.clip_planes(sm, [Zc], [outc], K)
+        return sm
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    assert M.tile_error_word(reset=True) == 1
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        keep = run()
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert M.tile_error_word() == 1
+    del keep, graph
+    with pytest.raises(RuntimeError, match='tile-resident'):
+        M.check_tile_errors(always=True)
+
+
+def test_training_step_and_predict_raise_on_a_missed_tile_handoff(monkeypatch):
+    """The product path reads the error word: an eager train_step() that issued tile-resident launches checks it before returning,
+    predict() at its end, train() once per epoch -- a missed hand-off is a RuntimeError, not a silently wrong gradient."""
+    from model.mpnnlstm import NextFramePredictorS2S
+    from qtmpnn import mesh as M, synthetic
+    assert M.tile_error_word(reset=True) == 0
+    orig = M._finish_mesh
+
+    def finish_and_unpublish(ms, *a, **k):
+        orig(ms, *a, **k)
+        if ms.tiles is not None:
+            _unpublish_one_boundary_row(ms)
+    x, y = synthetic.make_batch(3, 0, 1, 2, 1, n_digits=2, pixel_noise=0.0, canvas=(128, 128))
+    xt, yt = torch.from_numpy(x[0]).to(dev()), torch.from_numpy(y[0]).to(dev())
+    mask = np.zeros((128, 128), dtype=bool)
+    torch.manual_seed(0)
+    nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=2, output_timesteps=1, device=dev(),
+                                model_kwargs=dict(hidden_size=8, dropout=0.0, n_layers=1, n_conv_layers=2))
+    nfp.initiate_training(1e-3, 0.95)
+    good = float(nfp.train_step(xt, yt, None, mask))           # the healthy path does not raise
+    assert np.isfinite(good)
+    monkeypatch.setattr(M, '_finish_mesh', finish_and_unpublish)
+    with pytest.raises(RuntimeError, match='waited in vain'):
+        nfp.train_step(xt, yt, None, mask)
+    assert M.tile_error_word() == 0
+    loader = TinyLoaderLocal([(xt[None].cpu(), yt[None].cpu(), torch.tensor([0]))], (128, 128))
+    with pytest.raises(RuntimeError, match='waited in vain'):
+        nfp.predict(loader, mask=mask)
+    with pytest.raises(RuntimeError, match='waited in vain'):
+        nfp.train(loader, loader, n_epochs=1, lr=1e-3, mask=mask, truncated_backprop=0)
+    monkeypatch.setattr(M, '_finish_mesh', orig)
+    M.tile_error_word(reset=True)
+    assert np.isfinite(float(nfp.train_step(xt, yt, None, mask)))
+
+
+class TinyLoaderLocal(list):
+    def __init__(self, items, image_shape):
+        super().__init__(items)
+        self.dataset = type('DS', (), {'image_shape': tuple(image_shape)})()
+
+
+def test_tile_capacity_overflow_is_reported_not_waited_for():
+    """The capacity-overflow path of qt_edges_norm_tiles / qt_cheb_tile_* cannot be reached with the shipped capacities on a quadtree
+    mesh, so the small-caps build of the library (QT_TILE_HALO_CAP = 16) runs it in a child process: rows whose boundary record
+    does not fit get the sentinel address -1, nobody waits for them (the launch returns at once), the error word is exactly
+    bit 1 and check_tile_errors() names the cause (tests/_tile_overflow_child.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(os.path.dirname(here), 'quadtree-mpnnlstm_amd', 'qtmpnn', 'libqtmpnn_hip_smallcaps.so')
+    assert os.path.exists(lib), 'run __graft_entry__.build() (make -C quadtree-mpnnlstm_amd/csrc)'
+    env = dict(os.environ, QT_LIB_PATH=lib)
+    r = subprocess.run([sys.executable, os.path.join(here, '_tile_overflow_child.py')], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'tile overflow ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_more_tiles_than_compute_units_is_an_argument_error():
+    """qt_cheb_tile_fwd / _bwd need every tile of a launch resident at once: B x T > CUs is refused by the entry point itself (the
+    Python gate ops._tile_resident never gets there)."""
+    from qtmpnn import _lib, ops
+    ncu = _lib.value('qt_num_cus')
+    B = ncu // 4 + 1
+    img = np.zeros((B, 128, 128), np.float32)
+    img[:, 40:90, 30:100] = 1.0
+    from qtmpnn.mesh import build_mesh
+    mesh = build_mesh(src=torch.from_numpy(img).to(dev()), thresh=0.1)
+    assert mesh.tiles is not None and mesh.B * mesh.tiles['T'] > ncu
+    assert not ops._tile_resident(mesh, [16], 5)
+    Z = torch.randn(mesh.N, 16, device=dev())
+    with pytest.raises(RuntimeError, match='more tiles'):
+        ops.clip_planes(mesh, [Z], [torch.empty(4, mesh.N, 16, device=dev())], 5)
+    with pytest.raises(RuntimeError, match='more tiles'):
+        ops.clip_clenshaw(mesh, [torch.randn(5, mesh.N, 16, device=dev())], 5)
+
+
+def test_masks_are_cached_by_content():
+    """A host mask is uploaded once per CONTENT: an array changed in place is a new mask (round 4 cached by object identity and
+    went stale), an equal array built anew is the same one; new content inside a hipGraph capture is a clear error."""
+    from qtmpnn.mesh import build_mesh, build_pixel_mesh
+    img = torch.rand(1, 64, 64, device=dev())
+    mask = np.zeros((64, 64), dtype=bool)
+    mask[:8, :8] = True
+    a = build_mesh(src=img, thresh=0.5, mask=mask)
+    assert (a.labels[0, :8, :8] == -1).all() and int(a.labels[0, 20, 20]) >= 0
+    mask[16:24, 16:24] = True                                  # in place
+    b = build_mesh(src=img, thresh=0.5, mask=mask)
+    assert (b.labels[0, 16:24, 16:24] == -1).all() and b.N == a.N - 64
+    c = build_mesh(src=img, thresh=0.5, mask=mask.copy())
+    assert c.mask.data_ptr() == b.mask.data_ptr()              # same content: the cached upload
+    p1 = build_pixel_mesh(1, 64, 64, mask, dev())
+    mask[40, 40] = True
+    p2 = build_pixel_mesh(1, 64, 64, mask, dev())
+    assert p2.N == p1.N - 1 and int(p2.labels[0, 40, 40]) == -1
+    fresh = np.zeros((64, 64), dtype=bool)
+    fresh[5, 50] = True
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match='warm-up'):
+        with torch.cuda.graph(graph, stream=side):
+            build_mesh(src=img, thresh=0.5, mask=fresh, static=True)
 
 
 def test_tile_path_is_taken_where_it_was_measured_faster():

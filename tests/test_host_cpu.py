@@ -74,9 +74,9 @@ def test_bad_arguments_fail_loudly_without_gpu():
         'qt_dense_sb': (None, 0, 16, None, None, 1, 4, 0, 4, None, None, None, None),
         'qt_cheb_clip_fwd': (None,) * 8 + (1, 4, 3, 4, None, 0, None, 0, None, 0, None, 0, None),
         'qt_cheb_clip_bwd': (None,) * 8 + (1, 4, 3, 4, None, 0, None, 0, 0, None),
-        'qt_cheb_tile_fwd': (None,) * 14 + (1, 4, 2, 4, 3, 4, None, 0, None, 0, None, 0, None, None),
-        'qt_cheb_tile_bwd': (None,) * 14 + (1, 4, 2, 4, 3, 4, None, 0, None, 0, None),
-        'qt_edges_norm_tiles': (None,) * 4 + (4, None, None, None, None, None, 4, 2, None, None, None, None, None, None, None, None),
+        'qt_cheb_tile_fwd': (None,) * 15 + (1, 4, 2, 4, 3, 4, None, 0, None, 0, None, 0, None, None),
+        'qt_cheb_tile_bwd': (None,) * 15 + (1, 4, 2, 4, 3, 4, None, 0, None, 0, None),
+        'qt_edges_norm_tiles': (None,) * 4 + (4, None, None, None, None, None, 4, 2, None, None, None, None, None, None, None, None, None),
         'qt_dense2': (None, 0, None, None, 0, None, 1, 4, 0, None, None, None, 0, None, 1, 4, 0, 4, None, 0, None, 0, None, None, None, 0, None, None, None),
     }
     for name, args in null_calls.items():

@@ -73,6 +73,6 @@ if os.environ.get('QT_CFG_ROOFLINE', '1') == '1':
     if kw.get('convolution_type', 'ChebConv') == 'ChebConv':
         rec['roofline'] = bench.spmm_roofline(fresh, pool[0], mask, traffic_files=())
 from qtmpnn.mesh import tile_error_word
-assert tile_error_word() == 0, 'a tile-resident launch reported an error (sync word)'
+assert tile_error_word() == 0, 'a tile-resident launch reported an error (persistent error word)'
 print(json.dumps({'config': cfg, 'frames_per_s': round(B * (t_in + t_out) * steps / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 2),
                   'clips': B, 'shape': shape, 't_in': t_in, 't_out': t_out, 'loss': round(float(l), 5), 'launch': 'hipGraph replay', **rec}))
