@@ -53,6 +53,9 @@ def parse():
     ap.add_argument('--eager', action='store_true', help='Python-driven launches instead of hipGraph replay')
     ap.add_argument('--host-inputs', action='store_true',
                     help='keep the batches in pinned host memory and copy them in every step (PCIe-inclusive rate; informational)')
+    ap.add_argument('--force-multi', action='store_true',
+                    help='--gpus 1 only: a process group of ONE rank over RCCL and the multi-rank step structure (graph 1, flat '
+                         'all-reduce, graph 2) -- what a rank of an N-GPU run does per step, measured on one GPU (informational)')
     return ap.parse_args()
 
 
@@ -329,6 +332,13 @@ def main():
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    # stdout carries ONE JSON line and nothing else: RCCL prints its version banner to file descriptor 1 when the first
+    # communicator is created (seen with --force-multi), so fd 1 is pointed at stderr for the run and the line is written to
+    # the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -341,6 +351,11 @@ def main():
     side = HostBarrier()                 # (collective: every rank, right after init)
     device = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(device)
+    if args.force_multi:
+        assert world == 1 and not args.eager, '--force-multi is the one-GPU rehearsal of the multi-rank step (hipGraph replay)'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29513')
+        dist.init_process_group(backend='nccl', rank=0, world_size=1)
     assert not ops.DGRAD_SPLIT_BF16, 'the headline is the exact-fp32 step: unset QT_DGRAD_SPLIT_BF16'
     nfp = make_predictor(device, capturable=not args.eager)
     if world > 1:
@@ -428,7 +443,7 @@ def main():
         # learning rate at 0 when the frozen phase follows: see frozen_ms)
         if args.frozen_steps > 0:
             set_lr(nfp.optimizer, 0.0)
-        step = nfp.make_graphed_step(*pool[0], mask=mask, warmup=2)
+        step = nfp.make_graphed_step(*pool[0], mask=mask, warmup=2, force_multi=args.force_multi)
         log('training step captured into a hipGraph')
     frozen = None
     if args.frozen_steps > 0 and args.eager:
@@ -507,7 +522,8 @@ def main():
                                    f'{args.batch} clips per GPU, pixel noise {args.noise}, thresh {THRESH}, hidden {HIDDEN}, '
                                    f'{N_LAYERS} layers, ChebConv K=3, dropout {DROPOUT}, Adam',
                        'global_batch': global_batch, 'frames_per_clip': T_IN + T_OUT, 'parallelism': f'dp{world}',
-                       'launch': 'eager' if args.eager else 'hipGraph replay',
+                       'launch': 'eager' if args.eager else 'graph 1 (forward + loss + backward), RCCL all-reduce of the flat '
+                                 'gradient in a group of one rank, graph 2 (clip + Adam)' if args.force_multi else 'hipGraph replay',
                        'inputs': 'pinned host memory, copied every step' if args.host_inputs else 'resident in HBM',
                        'arithmetic': 'fp32 throughout: every GEMM (forward, data gradient, weight gradient) on '
                                      'v_mfma_f32_32x32x2_f32; no reduced-precision operand anywhere in the timed step',
@@ -526,10 +542,12 @@ def main():
                 line['cpu_baseline'] = {'error': repr(e)[:200]}
         from qtmpnn.mesh import tile_error_word
         assert tile_error_word() == 0, 'a tile-resident launch reported an error (persistent error word)'
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + '\n').encode())
     if world > 1:
         host_barrier()
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

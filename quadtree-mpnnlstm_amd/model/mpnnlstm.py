@@ -160,20 +160,20 @@ class NextFramePredictorS2S(NextFramePredictor):
         else:
             self.optimizer.zero_grad(set_to_none=True)
 
-    def _grads_ready(self, world=1, group=None):
+    def _grads_ready(self, world=1, group=None, force=False):
         """After backward: average the gradients over the ranks (ONE all-reduce of one flat tensor) and hand them to the
-        optimizer.  Returns the tensors clip_grad_norm_ has to see."""
+        optimizer.  Returns the tensors clip_grad_norm_ has to see.  force: issue the collective even in a group of one."""
         if self.flat is None:
             params = list(self.model.parameters())
-            if world > 1:
-                allreduce_gradients(params, group)
+            if world > 1 or force:
+                allreduce_gradients(params, group, force=force)
             return params
         if not self.flat.intact(self.model):
             raise RuntimeError('the model parameters were moved or replaced after initiate_training(): call it again')
         g = self.flat.grad_vector()
         if g is None:                          # gradients that did not come from the model-wide packing gather: by copy
             g = self.flat.gather_grads()
-        if world > 1:
+        if world > 1 or force:
             torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=group)
             g.mul_(1.0 / world)
         self.flat.param.grad = g
@@ -231,7 +231,7 @@ class NextFramePredictorS2S(NextFramePredictor):
         return losses
 
     def make_graphed_step(self, x, y, concat_layers=None, mask=None, high_interest_region=None, max_norm=10.0,
-                          warmup=2, graph_structure=None):
+                          warmup=2, graph_structure=None, force_multi=False):
         """Capture one whole training step in hipGraphs and return `step(x, y, concat) -> loss`.
 
         The rollout is data dependent (every decoder step re-meshes on its own output), so the capture runs in
@@ -241,10 +241,15 @@ class NextFramePredictorS2S(NextFramePredictor):
         first graph ends with the gradients packed into one flat buffer; the step is then
         `graph1.replay(); all_reduce(flat); graph2.replay()` with graph2 = average + clip + fused Adam on views of
         that buffer: one collective and three host calls per step.  The `warmup` eager steps are real training steps.
+        force_multi: take the multi-rank structure (graph1, all-reduce, graph2) also in a process group of ONE rank -- the
+        collective then averages over one rank, i.e. changes nothing, but RCCL, its stream ordering against the two graph
+        replays and the capture beside its watchdog thread all run for real (tests/test_gpu_dist.py; bench.py --force-multi).
         """
         import torch.distributed as dist
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        world = dist.get_world_size() if multi else 1
+        if force_multi and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError('force_multi=True needs an initialised torch.distributed process group')
+        multi = force_multi or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        world = dist.get_world_size(self.process_group) if multi else 1
         self.model.static_shapes = True
         if not self.optimizer.defaults.get('capturable', False):
             lr = self.optimizer.param_groups[0]['lr']
@@ -267,7 +272,7 @@ class NextFramePredictorS2S(NextFramePredictor):
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self.last_warmup_loss = fwd_bwd()        # (a real training step on this batch)
-                update(self._grads_ready(world, self.process_group))
+                update(self._grads_ready(world, self.process_group, force=multi))
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         self.zero_grad()

@@ -56,13 +56,14 @@ def shard_range(n_items, rank, world):
     return rank * per, (rank + 1) * per
 
 
-def allreduce_gradients(params, group=None):
-    """Average gradients over the group with a single flat all-reduce (missing grads count as zero)."""
+def allreduce_gradients(params, group=None, force=False):
+    """Average gradients over the group with a single flat all-reduce (missing grads count as zero).  force: issue the
+    collective in a group of one rank too (it changes nothing there; used to exercise the transport)."""
     params = [p for p in params if p.requires_grad]
     if not params:
         return
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

@@ -84,6 +84,60 @@ def test_two_ranks_equal_one_process():
         np.testing.assert_allclose(res[0][2][k], ref[k].numpy(), rtol=2e-3, atol=2e-4, err_msg=k)
 
 
+
+def _rccl_world_of_one(port, out):
+    """Child: backend "nccl" (= RCCL) with ONE rank on cuda:0; the multi-rank step structure forced (graph1, all-reduce, graph2)
+    against the single-graph step from the same seed."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    assert dist.get_backend() == 'nccl'
+    t = torch.arange(8, dtype=torch.float32, device='cuda:0')
+    dist.all_reduce(t)                                   # the communicator (and RCCL's kernels) exist before any capture
+    torch.cuda.synchronize()
+    assert t.tolist() == list(range(8))
+    mask = np.zeros((64, 64), dtype=bool)
+    res = {}
+    for name, force in (('forced', True), ('single', False)):
+        nfp, dev = _setup()
+        x, y, c = _data(dev, 0, B)
+        step = nfp.make_graphed_step(x, y, c, mask, warmup=1, force_multi=force)
+        losses = [float(step(x, y, c)) for _ in range(3)]
+        torch.cuda.synchronize()
+        res[name] = (losses, {k: v.detach().cpu().numpy() for k, v in nfp.model.state_dict().items()})
+    rccl = [m.split()[-1] for m in open('/proc/self/maps') if 'librccl' in m]
+    out.put((res, sorted(set(rccl))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_runs_the_multi_rank_step_structure_in_a_world_of_one():
+    """No second GPU is ever visible to these tests, so RCCL itself is exercised with world_size = 1: under backend "nccl" the
+    forced multi-rank step -- graph1.replay() (forward + loss + backward), dist.all_reduce(flat) on the replay stream,
+    graph2.replay() (average + clip + fused Adam) -- must give bit-identical losses and weights to the single-graph step over
+    three steps.  It proves that librccl loads, that the collective is ordered correctly between two hipGraph replays on the
+    side stream, and that capture_error_mode='thread_local' survives the process group's watchdog thread."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.environ['PYTHONPATH'] = os.pathsep.join([os.path.join(root, 'quadtree-mpnnlstm_amd'), root, os.path.join(root, 'tests'),
+                                                os.environ.get('PYTHONPATH', '')])
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_world_of_one, args=(port, out))
+    p.start()
+    res, rccl = out.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    assert rccl, 'librccl is not mapped into the process: the collective did not go through RCCL'
+    (la, wa), (lb, wb) = res['forced'], res['single']
+    assert la == lb, (la, lb)
+    for k in wa:
+        assert np.array_equal(wa[k], wb[k]), k
+
+
 def test_bench_two_ranks_prints_one_line_with_probes():
     """bench.py --gpus 2 (spawned through torchrun as the driver does): rank 0 runs the roofline probes alone after the
     timed region, so they must be collective-free -- the run has to end with ONE JSON line carrying `roofline`."""
