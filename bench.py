@@ -71,7 +71,7 @@ def make_predictor(device, capturable=False):
     return nfp
 
 
-def spmm_roofline(nfp, batch, mask, reps=10, traffic_files=('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_spmm.json')):
+def spmm_roofline(nfp, batch, mask, reps=10, traffic_files=('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_spmm.json')):
     """Roofline of the message-aggregate kernels, measured live with HIP events on the launch stream.
 
     One extra (untimed) eager forward + backward records every message-aggregate launch of the real workload: the clip-resident
@@ -210,11 +210,105 @@ def spmm_roofline(nfp, batch, mask, reps=10, traffic_files=('r04_pmc_traffic.jso
            'bytes_formula': "per launch: k_spmm (one hop) 4(N+1) + 8E' + 8NC (SURVEY 8(d)); fused K-1 hops: forward "
                             "4(N+1) + 8E' + 4NC K, backward 4(N+1) + 8E' + 4NC (K+1)"}
     if fused:
-        rec['limiter'] = ('not HBM: one CU\'s vector issue + LDS per workgroup (SQ counters: profiles/r04_pmc_clip_sq.json); '
+        rec['limiter'] = ('not HBM: one CU\'s vector issue + LDS per workgroup (SQ counters: profiles/r05_pmc_clip_sq.json); '
                           '`bound` names the roof the contract prices against')
     if traffic:
         rec['traffic_gbs'] = round(traffic / (tot['us'] / n * 1e-6) / 1e9, 1)
     return rec
+
+
+def rollout_sizes(nfp, batch, mask):
+    """N_t and E'_t (valid nodes, directed non-self edges) of the input mesh and of the mesh every decoder step runs
+    on, for one forward pass of `batch` on the model as it is -- so that the bytes of a step can be recomputed from the per-step
+    sizes and the formulas of DESIGN.md section 5 instead of from launch averages."""
+    import torch
+    with torch.no_grad():
+        _, meshes = nfp.model(batch[0], batch[1], batch[2], teacher_forcing_ratio=0, mask=mask)
+    out = []
+    for t, ms in enumerate(meshes):
+        out.append({'step': t, 'N': int(ms.n_valid), 'E': int(ms.E), 'mesh': 'input' if t == 0 else f're-mesh after step {t - 1}'})
+    return {'clips': int(meshes[0].B), 'pixels_per_clip': int(meshes[0].P), 'meshes': out,
+            'note': "mesh of decoder step t (step 0 runs on the input mesh, which also serves the T_in encoder steps); N = nodes of the "
+                    "block-diagonal batch graph, E = directed edges without self pairs (E' of SURVEY 8(d))"}
+
+
+def attn_roofline(nfp, batch, mask):
+    """Roofline object of the attention launches (TransformerConv configurations; tools/bench_configs.py): every qt_attn_fwd /
+    qt_attn_bwd call of one eager forward + backward is bracketed by HIP events on the launch stream (a qt_attn_bwd call is the
+    target pass + the source pass, two kernels).  Algorithmic bytes = the operands once (G heads, N nodes, C channels, E' edges;
+    DESIGN.md section 5): forward 20 G N C (q, k, v, skip read; out written) + 8 G N (softmax stats) + index arrays; backward
+    44 G N C (target pass: g, q, k, v, out read, dq and dskip written = 28; source pass: g, q read, dk, dv written = 16)
+    + 16 G (E' + N) (the per-message coefficients written and read once) + index arrays twice."""
+    import torch
+    from qtmpnn import _lib
+    events, orig = [], _lib.call
+
+    def spy(name, *args):
+        if name in ('qt_attn_fwd', 'qt_attn_bwd'):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            orig(name, *args)
+            b.record()
+            if name == 'qt_attn_fwd':      # (rowptr, col, xy, eattr, self, proj, ld, We, C, c_real, N, n_dev, ..., G at 17)
+                C, N, G = args[8], args[10], args[17]
+            else:                          # (..., C at 8, N at 10, ..., E at 25, G at 26)
+                C, N, G = args[8], args[10], args[26]
+            events.append((name, a, b, G, N, C))
+        else:
+            orig(name, *args)
+    from qtmpnn import ops
+    _lib.call = spy
+    try:
+        nfp.zero_grad()
+        loss = nfp.forward_loss(*batch, mask)
+        mesh0 = nfp.model.graph.mapping
+        loss.backward()
+        nfp.zero_grad()
+        torch.cuda.synchronize()
+    finally:
+        _lib.call = orig
+    nv, E = mesh0.n_valid, mesh0.E
+    idx = 4.0 * (nv + 1) + 12.0 * E + 12.0 * nv            # rowptr, col, [angle, dist] per edge, centroids, self-pair flags
+    tot = {}
+    for name, a, b, G, N, C in events:
+        us = a.elapsed_time(b) * 1e3
+        if name == 'qt_attn_fwd':
+            by = 20.0 * G * nv * C + 8.0 * G * nv + idx
+        else:
+            by = 44.0 * G * nv * C + 16.0 * G * (E + nv) + 8.0 * G * nv + 2 * idx + 4.0 * E
+        d = tot.setdefault(name, {'launches': 0, 'us': 0.0, 'bytes': 0.0})
+        d['launches'] += 1
+        d['us'] += us
+        d['bytes'] += by
+    us = sum(d['us'] for d in tot.values())
+    by = sum(d['bytes'] for d in tot.values())
+    n = sum(d['launches'] for d in tot.values())
+    ach = by / (us * 1e-6) / 1e9
+    return {'bound': 'hbm', 'kernel': 'k_attn_fwd / k_attn_bwd_target / k_attn_bwd_source (edge-softmax attention, 8 heads per launch)',
+            'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+            'launches_per_step': n, 'us_per_step': round(us, 1), 'avg_launch_us': round(us / n, 2), 'avg_bytes_per_launch': round(by / n),
+            'kernels': {k: {'launches_per_step': d['launches'], 'avg_launch_us': round(d['us'] / d['launches'], 2),
+                            'avg_bytes_per_launch': round(d['bytes'] / d['launches']),
+                            'achieved_gbs': round(d['bytes'] / (d['us'] * 1e-6) / 1e9, 1)} for k, d in tot.items()},
+            'timing': 'HIP events on the launch stream around every call of one eager forward + backward (qt_attn_bwd = target + source pass)',
+            'bytes_formula': "forward 20 G N C + 8 G N + idx; backward 44 G N C + 16 G (E' + N) + 8 G N + 2 idx + 4 E'; "
+                             "idx = 4 (N + 1) + 12 E' + 12 N"}
+
+
+def step_record(ms_per_step):
+    """The whole-step record (profiles/r05_step_summary.json: launches, launch-floor tail and HBM-side bytes of one replayed step
+    from a rocprofv3 kernel trace + the PMC traffic passes of the same build) with the rate THIS run's step time implies."""
+    for name in ('r05_step_summary.json',):
+        f = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(f):
+            rec = json.load(open(f))
+            rec = {k: rec[k] for k in ('launches', 'launches_lt_10us', 'launches_lt_10us_ms', 'hbm_bytes', 'hbm_gb',
+                                       'floor_ms_at_copy_rate', 'copy_rate_tbs') if k in rec}
+            rec['implied_tbs'] = round(rec['hbm_bytes'] / (ms_per_step * 1e-3) / 1e12, 2)
+            rec['frac_of_hbm_peak'] = round(rec['implied_tbs'] * 1e3 / HBM_PEAK_GBS, 3)
+            rec['source'] = 'profiles/' + name + ' (bytes, launch counts: rocprofv3 passes of the same build); rate: this run'
+            return rec
+    return None
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= the fp32 vector rate)
@@ -272,7 +366,7 @@ def gemm_mfma(nfp, batch, mask, reps=20):
            'launch_us': round(us, 2), 'achieved_tflops': round(tflops, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
            'frac': round(tflops / MFMA_F32_PEAK_TFLOPS, 3),
            'hbm_gbs': round(4.0 * nv * (Kt + 7 * h) / us / 1e3, 1)}
-    for name in ('r04_pmc_gemm.json', 'r03_pmc_gemm.json', 'r02_pmc_gemm.json'):
+    for name in ('r05_pmc_gemm.json', 'r04_pmc_gemm.json', 'r03_pmc_gemm.json', 'r02_pmc_gemm.json'):
         pmc = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pmc):
             rec['counters'] = {k: v for k, v in json.load(open(pmc)).items() if k in ('mfma_busy_frac', 'wave_stall_frac', 'source')}
@@ -482,6 +576,7 @@ def main():
                 m = gemm_mfma(fresh, pool[0], mask)
                 if m is not None:
                     probes['mfma'] = m
+                probes['rollout_sizes'] = rollout_sizes(fresh, pool[0], mask)
             except Exception as e:                                            # pragma: no cover
                 probes.setdefault('roofline', {'error': repr(e)[:200]})
             log('roofline probes done')
@@ -535,6 +630,9 @@ def main():
             'rank_ms_per_step': {'min': round(min(per_rank) / args.steps * 1e3, 3), 'max': round(max(per_rank) / args.steps * 1e3, 3)},
         }
         line.update(probes)
+        st = step_record(dt / args.steps * 1e3)
+        if st is not None:
+            line['step'] = st
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(args.cpu_clips)

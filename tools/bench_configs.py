@@ -70,8 +70,23 @@ if os.environ.get('QT_CFG_ROOFLINE', '1') == '1':
                                   transform_func=tf, model_kwargs=kw)
     fresh.initiate_training(lr=0.01, lr_decay=0.95, capturable=False)
     fresh.model.train()
+    # HBM-side bytes per launch from the committed PMC passes of THIS configuration, when there are any
+    tf_name = f'r05_pmc_traffic_{cfg}.json'
     if kw.get('convolution_type', 'ChebConv') == 'ChebConv':
-        rec['roofline'] = bench.spmm_roofline(fresh, pool[0], mask, traffic_files=())
+        rec['roofline'] = bench.spmm_roofline(fresh, pool[0], mask, traffic_files=(tf_name,))
+        pmc = os.path.join(ROOT, 'profiles', tf_name)
+        if os.path.exists(pmc):       # per-kernel records: the per-hop kernel's own figure beside the launch-weighted one
+            ks = json.load(open(pmc))['kernels']
+            rec['roofline']['traffic_by_kernel'] = {k: v['traffic_bytes_per_launch'] for k, v in ks.items()
+                                                    if k.startswith(('k_spmm<', 'k_cheb_clip'))}
+    else:
+        rec['roofline'] = bench.attn_roofline(fresh, pool[0], mask)
+        pmc = os.path.join(ROOT, 'profiles', tf_name)
+        if os.path.exists(pmc):
+            ks = json.load(open(pmc))['kernels']
+            rec['roofline']['traffic_by_kernel'] = {k: v['traffic_bytes_per_launch'] for k, v in ks.items() if k.startswith('k_attn')}
+            rec['roofline']['traffic_source'] = 'profiles/' + tf_name
+    rec['rollout_sizes'] = bench.rollout_sizes(fresh, pool[0], mask)
 from qtmpnn.mesh import tile_error_word
 assert tile_error_word() == 0, 'a tile-resident launch reported an error (persistent error word)'
 print(json.dumps({'config': cfg, 'frames_per_s': round(B * (t_in + t_out) * steps / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 2),

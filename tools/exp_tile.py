@@ -68,5 +68,10 @@ for K, widths in shapes:
         spmm2(mesh, [g[1] for g in G], 1.0, [g[0] for g in G], 1.0, [g[2] for g in G] if K > 2 else None, -1.0, [g[0] for g in G])
     t_hf, t_hb = timeit(hops_fwd), timeit(hops_bwd)
     t_cf, t_cb = timeit(lambda: ops.clip_planes(mesh, Zs, TZ, K)), timeit(lambda: ops.clip_clenshaw(mesh, G, K))
+    S, ncu = sum(widths) // 4, _lib.value('qt_num_cus')
+    per = max(ncu // (mesh.B * tl['T']), 1)
+    nl = -(S // -per)
+    split = ' + '.join(str(mesh.B * tl['T'] * min(per, S - i * per)) for i in range(nl))
     print(f'K={K} widths={widths}: forward per-hop {t_hf:7.2f} us  tile {t_cf:7.2f} us | backward per-hop {t_hb:7.2f} us  tile {t_cb:7.2f} us'
-          f'   (error word {int(tl["sync"][-1])})')
+          f'   ({mesh.B} clips x {tl["T"]} tiles x {S} slices = {mesh.B * tl["T"] * S} workgroups as {nl} launch(es) of {split} co-resident '
+          f'workgroups; error word {int(tl["err"])})')

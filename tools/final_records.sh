@@ -1,6 +1,6 @@
 # the round's record runs: bench.py (default + noise 0) and every other BASELINE configuration
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${1:-r4}
+R=${1:-r5}
 python bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.log
 python bench.py --noise 0 --no-cpu-baseline > gpurun_out/${R}_bench_noise0.json 2> gpurun_out/${R}_bench_noise0.log
 : > gpurun_out/${R}_configs.jsonl
