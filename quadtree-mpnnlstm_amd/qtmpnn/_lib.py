@@ -77,6 +77,8 @@ _SIGNATURES = {
     'qt_wgrad_groups': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _I, _P, _P],
     'qt_dense_sb': [_P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     'qt_num_cus': [],
+    'qt_proj_bwd_blocks': [_I],
+    'qt_proj_bwd': [_P, _L, _L, _P, _L, _P, _L, _P, _L, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'qt_lstm_fused_blocks': [],
     'qt_lstm_bwd_fused': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P,
                           _P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
@@ -87,7 +89,7 @@ _SIGNATURES = {
     'qt_head_fwd': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P],
     'qt_head_bwd': [_P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
 }
-_PLAIN = {'qt_abi_version', 'qt_cheb_clip_rows', 'qt_cheb_tile_sync_words', 'qt_cheb_tile_xbuf_words', 'qt_tile_cap', 'qt_remesh_clip_rows', 'qt_tail_cap', 'qt_num_cus', 'qt_lstm_fused_blocks', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_lstm_dgrad_blocks', 'qt_attn_blocks'}  # return a value, not an error code
+_PLAIN = {'qt_proj_bwd_blocks', 'qt_abi_version', 'qt_cheb_clip_rows', 'qt_cheb_tile_sync_words', 'qt_cheb_tile_xbuf_words', 'qt_tile_cap', 'qt_remesh_clip_rows', 'qt_tail_cap', 'qt_num_cus', 'qt_lstm_fused_blocks', 'qt_wgrad_blocks', 'qt_lstm_bwd_blocks', 'qt_lstm_dgrad_blocks', 'qt_attn_blocks'}  # return a value, not an error code
 
 _lib = None
 

@@ -80,10 +80,11 @@ class GradAcc:
     forward use -- the last one to run in the backward pass, because the recurrent state chains the uses --
     reduces the slabs and hands the gradient to autograd.
     """
-    __slots__ = ('uses', 'done', 'part', 'wt', 'pending', 'wslab')
+    __slots__ = ('uses', 'done', 'part', 'wt', 'pending', 'wslab', 'pslab')
 
     def __init__(self):
         self.uses, self.done, self.part, self.wt, self.pending, self.wslab = 0, 0, None, {}, [], None
+        self.pslab = {}        # segment -> (blocks, G, cin + 4, co) slabs of the one-pass projection backward (qt_proj_bwd)
 
     def enter(self):
         self.uses += 1
@@ -947,6 +948,7 @@ def attention(proj, We, mesh, c_real, dropout_p=0.0, training=False, acc=None, h
     return _Attention.apply(proj, We, mesh, c_real, keep, seed, acc, heads, gmod)
 
 
+_PROJ_BWD_FUSED = os.environ.get('QT_NO_PROJ_BWD_FUSED') != '1'      # (A/B switch)
 _STATS = {'skip_alias': 0}      # (how often a layer's gradient array was completed in place: tests look at it)
 
 
@@ -1043,9 +1045,23 @@ class _MultiConv(Function):
         else:
             gP.zero_()
         gAs = []
+        pslab = acc.pslab if acc is not None else {}
+        fused = set()
         for s, ((hoff, gin, cin, co, lda, gsa), A, W) in enumerate(zip(ctx.segs, As, Ws)):
             if not ctx.needs_input_grad[7 + s]:
                 gAs.append(None)
+                continue
+            if (_PROJ_BWD_FUSED and gin > 1 and N > 0 and cin == 32 and C == 32 and co == 4 * C and ctx.needs_input_grad[7 + nseg + s]
+                    and A.is_contiguous() and W.is_contiguous()):
+                # data gradient AND this use's weight gradient in one pass over the gradient planes (csrc/projbwd.hip): the planes are
+                # read once and need not be kept for the deferred grouped weight gradient
+                nxt = A.new_empty(gin, 4, N, cin)
+                if s not in pslab:
+                    pslab[s] = W.new_zeros(_lib.value('qt_proj_bwd_blocks', gin), gin, cin + 4, co)
+                _lib.call('qt_proj_bwd', gP.data_ptr() + 4 * hoff * 4 * N * C, 4 * N * C, N * C, ptr(A), N * cin, ptr(W), (cin + 4) * co,
+                          nxt.data_ptr() + 4 * 3 * N * cin, 4 * N * cin, cin, ptr(pslab[s]), N, ptr(mesh.n_dev), gin, cin, C, 1, 1)
+                fused.add(s)
+                gAs.append(nxt[:, 3])
                 continue
             if gin > 1 and N > 0:
                 # the input is the previous layer's output (gin, N, cin): its gradient goes into block 3 of a fresh (gin, 4, N, cin)
@@ -1065,14 +1081,18 @@ class _MultiConv(Function):
         last = acc is None or acc.leave(ctx.use_idx)
         need_w = any(ctx.needs_input_grad[7 + nseg:7 + 2 * nseg])
         pending = acc.pending if acc is not None else []
-        if need_w and N > 0:
+        if need_w and N > 0 and len(fused) < nseg:
             pending.append((As, gP, N, mesh.n_dev, mesh.cheb_ones(1)))
         if not last:
             return (None,) * 7 + tuple(gAs) + (None,) * (nseg + 1)
         gWs = [None] * nseg
         if need_w:
             for s, (seg, W) in enumerate(zip(ctx.segs, Ws)):
-                gWs[s] = _wgrad_groups(pending, s, seg, C, W)
+                if s in pslab:           # every use of the pass added its partial sums into the same slabs
+                    gWs[s] = torch.empty_like(W)
+                    _lib.call('qt_colsum', ptr(pslab[s]), pslab[s].shape[0], W.numel(), ptr(gWs[s]))
+                else:
+                    gWs[s] = _wgrad_groups(pending, s, seg, C, W)
         if acc is not None:
             acc.pending = []
         psum = P.new_empty(G * 2 * C)

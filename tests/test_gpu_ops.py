@@ -493,7 +493,9 @@ def test_transformer_cell_layerwise_launches_equal_per_convolution_path(keep_h):
         close(a, b, rtol=1e-5, atol=1e-6, msg=name)
     names = [n for n, t in (('gX', X), ('gH', H), ('gC', C)) if t is not None] + [k for k, _ in cell.named_parameters()]
     for a, b, name in zip(g1, g0, names):
-        grad_close(a, b, rtol=1e-5, rel_atol=2e-6, msg=name)
+        # (the key bias has an exactly-zero gradient -- a shift of every key moves all scores of a target equally --: what is computed
+        # is rounding noise of the column sums, and the one-pass projection backward sums the rows in another order)
+        grad_close(a, b, rtol=1e-5, rel_atol=2e-6, msg=name, floor=10.0 if name.endswith('lin_key.bias') else 1e-3)
 
 
 def test_multi_head_attention_equals_separate_calls():
@@ -604,6 +606,89 @@ def test_proj_group_and_grouped_weight_gradient_equal_dense_calls():
         Ah = torch.cat([A[h], ones], dim=1).double()
         ref = Ah.t() @ gP[h].permute(1, 0, 2).reshape(N, co).double()
         close(gW[h], ref.float(), rtol=1e-5, atol=1e-4, msg=f'wgrad {h}')
+
+
+
+@pytest.mark.parametrize('N,valid', [(1000, None), (4133, None), (5000, 3777), (100, None)])
+def test_projection_backward_in_one_pass(N, valid):
+    """qt_proj_bwd (csrc/projbwd.hip: data gradient + partial weight gradient of the grouped projection in ONE pass over the gradient
+    planes, hidden size 32) against the fp64 products, and its data gradient against qt_proj_group on the same planes BIT FOR BIT
+    (same reduction order on the same MFMA); two uses add into the same slabs; ragged row counts, a device-side row count
+    (capacity rows beyond it are ignored and their outputs left alone)."""
+    from qtmpnn import _lib
+    from qtmpnn._lib import ptr
+    torch.manual_seed(N)
+    G, cin, C = 8, 32, 32
+    co = 4 * C
+    nv = valid or N
+    n_dev = torch.tensor([nv], dtype=torch.int32, device=dev()) if valid else None
+    nb = _lib.value('qt_proj_bwd_blocks', G)
+    assert nb * G <= 2 * _lib.value('qt_num_cus')          # every workgroup resident: two per CU
+    part = torch.zeros(nb, G, cin + 4, co, device=dev())
+    W = torch.randn(G, cin + 4, co, device=dev()) * 0.3
+    ref_w = torch.zeros(G, cin + 4, co, dtype=torch.float64, device=dev())
+    for use in range(2):
+        A = torch.randn(G, N, cin, device=dev())
+        gP = torch.randn(G, 4, N, C, device=dev())
+        nxt = torch.full((G, 4, N, cin), 7.0, device=dev())         # the data gradient lands in block 3 of the next layer's array
+        _lib.call('qt_proj_bwd', ptr(gP), 4 * N * C, N * C, ptr(A), N * cin, ptr(W), (cin + 4) * co, nxt.data_ptr() + 4 * 3 * N * cin,
+                  4 * N * cin, cin, ptr(part), N, ptr(n_dev), G, cin, C, 1, use)
+        old = torch.full((G, N, cin), 7.0, device=dev())
+        _lib.call('qt_proj_group', ptr(gP), C, 4 * N * C, 4, C, None, None, ptr(W), (cin + 4) * co, G, 1, cin, ptr(old), cin, N * cin, 1, N,
+                  ptr(n_dev))
+        assert torch.equal(nxt[:, 3], old), 'data gradient differs from qt_proj_group'
+        assert (nxt[:, :3] == 7.0).all() and (nxt[:, 3, nv:] == 7.0).all()
+        ones = torch.zeros(nv, 4, dtype=torch.float64, device=dev())
+        ones[:, 0] = 1
+        for h in range(G):
+            g2 = gP[h, :, :nv].permute(1, 0, 2).reshape(nv, co).double()
+            close(nxt[h, 3, :nv], (g2 @ W[h, :cin].double().t()).float(), rtol=1e-5, atol=1e-5, msg=f'dgrad {h}')
+            ref_w[h] += torch.cat([A[h, :nv].double(), ones], dim=1).t() @ g2
+    gW = torch.empty(G, cin + 4, co, device=dev())
+    _lib.call('qt_colsum', ptr(part), nb, gW.numel(), ptr(gW))
+    close(gW, ref_w.float(), rtol=1e-5, atol=2e-4, msg='weight gradient of two uses')
+    assert not gW[:, cin + 1:].any()
+    # accumulate == 0 overwrites the slabs
+    _lib.call('qt_proj_bwd', ptr(gP), 4 * N * C, N * C, ptr(A), N * cin, ptr(W), (cin + 4) * co, nxt.data_ptr() + 4 * 3 * N * cin,
+              4 * N * cin, cin, ptr(part), N, ptr(n_dev), G, cin, C, 0, 0)
+    _lib.call('qt_colsum', ptr(part), nb, gW.numel(), ptr(gW))
+    g2 = gP[:, :, :nv].permute(0, 2, 1, 3).reshape(G, nv, co).double()
+    last = torch.cat([A[:, :nv].double(), ones.unsqueeze(0).expand(G, -1, -1)], dim=2).transpose(1, 2) @ g2
+    close(gW, last.float(), rtol=1e-5, atol=2e-4, msg='weight gradient, overwrite mode')
+
+
+def test_transformer_cell_hidden32_one_pass_projection_backward_equals_two_launch_path():
+    """A hidden-32 TransformerConv cell, three layers deep (what ice_exp.py:153-162 runs): the backward with the one-pass projection
+    backward (default) against the data-gradient launch + deferred grouped weight gradient (QT_NO_PROJ_BWD_FUSED): input gradients
+    bit-identical (same reduction order), weight gradients at 1e-5 of their scale (another summation order over the rows)."""
+    from model.model import GConvLSTM
+    from qtmpnn import ops
+    mesh, _ = _tile_mesh('mnist128_sparse', 1)
+    N = mesh.N
+    torch.manual_seed(4)
+    cell = GConvLSTM(8, 32, n_conv_layers=3, convolution_type='TransformerConv').to(dev()).eval()
+    X, H, Cc = (torch.randn(N, w, device=dev(), requires_grad=True) for w in (8, 32, 32))
+    gO, gH, gC = (torch.randn(N, 32, device=dev()) for _ in range(3))
+    res = {}
+    for flag in (True, False):
+        prev, ops._PROJ_BWD_FUSED = ops._PROJ_BWD_FUSED, flag
+        try:
+            Oo, Hn, Cn = cell(X, mesh, None, H, Cc)
+            grads = torch.autograd.grad([Oo, Hn, Cn], [X, H, Cc] + list(cell.parameters()), [gO, gH, gC], allow_unused=True)
+        finally:
+            ops._PROJ_BWD_FUSED = prev
+        res[flag] = grads
+    names = ['X', 'H', 'C'] + [k for k, _ in cell.named_parameters()]
+    for i, (a, b, name) in enumerate(zip(res[True], res[False], names)):
+        if a is None or b is None:
+            assert a is None and b is None
+            continue
+        if i < 3:
+            assert torch.equal(a, b), f'input gradient {name}'
+        elif name.endswith('lin_key.bias'):       # an exact zero: both are rounding noise of column sums over N rows of O(1) terms
+            assert float(a.abs().max()) < 2e-5 and float(b.abs().max()) < 2e-5, name
+        else:
+            close(a, b, rtol=1e-5, atol=1e-5 * max(float(b.abs().max()), 1e-3), msg=name)
 
 
 @pytest.mark.parametrize('K,Cb,Cbb,Kb', [(128, 8, 32, 7), (64, 16, 0, 3), (128, 32, 0, 1)])
