@@ -69,6 +69,12 @@ def main(d, pat):
                           'L1 / L2) -> one output row; waves wait on those global loads for most of the launch (waiting_on_memory_or_barrier) '
                           'and issue vector instructions for the rest -- the launch is bound by the memory system\'s latency x requests in '
                           'flight, cf. the PMC traffic record of the same run')
+    elif pat.startswith('k_remesh'):
+        out['reading'] = ('no MFMA work, 2 x 1024 threads per CU: stage a 4-channel source slice in LDS (global loads), gather it per pixel '
+                          '(LDS), lane-group sums, scattered 16-byte row stores.  Waves are issue-stalled -- instructions ready but the LDS / '
+                          'vector-memory queues of the CU full -- for about half of the launch and wait on memory or one of the three '
+                          'barriers for most of the rest; they issue for < 10 %.  The launch is one workgroup\'s chain of dependent phases, '
+                          'not a bandwidth stream: PMC traffic = its operands once')
     elif pat.startswith('k_attn'):
         out['reading'] = ('no MFMA work: one node per lane group, online softmax over gathered k / v rows; waves wait on the gathers of the '
                           'neighbour rows (global memory) for most of the launch')
