@@ -63,7 +63,7 @@ def main(d, pat):
     if busy > 0:
         out['reading'] = (f'the fp32 MFMA pipe is busy for {busy:.2f} of the launch and no wave class is saturated: the launch is the sum of '
                           'its phases (operand latency, MFMA chain, cell arithmetic on the same vector pipe, store drain) rather than their '
-                          'maximum -- see DESIGN.md section 6')
+                          'maximum -- see HISTORY.md section C')
     elif pat.startswith('k_spmm'):
         out['reading'] = ('no MFMA work and no LDS: a thread walks the dependent chain row pointer / ELL entry -> neighbour rows (gathers through '
                           'L1 / L2) -> one output row; waves wait on those global loads for most of the launch (waiting_on_memory_or_barrier) '
@@ -80,7 +80,7 @@ def main(d, pat):
                           'neighbour rows (global memory) for most of the launch')
     else:
         out['reading'] = ('no MFMA work: waves wait on LDS / barriers / the prologue\'s loads for more than half of the launch and issue '
-                          'vector instructions for the rest (a wave64 instruction occupies a SIMD for 4 cycles) -- see DESIGN.md section 6')
+                          'vector instructions for the rest (a wave64 instruction occupies a SIMD for 4 cycles) -- see HISTORY.md section C')
     print(json.dumps(out, indent=1))
 
 

@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(64) void k_head_dgrad(HeadDgradArgs g) {
 }
 
 // ---- bf16x3 variant of the forward / data-gradient GEMM -------------------------------------------------------------
-// fp32 MFMA runs at the VALU FLOP rate on gfx950 and bounds k_gemm_fwd.  Here every fp32 operand
+// fp32 MFMA runs at the VALU FLOP rate on gfx950 and bounds k_gemm_fwd (HISTORY.md section C).  Here every fp32 operand
 // is split into three bf16 terms (x = hi + mid + lo, each rounded to nearest) and a product group is six bf16 MFMAs
 // (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) accumulated in fp32: the dropped terms are O(2^-24) of the product,
 // i.e. fp32-level error, at 16 k per 32-cycle instruction instead of 2 k per 64-cycle instruction.

@@ -1290,7 +1290,7 @@ class _GateCell(Function):
             # ... and, on request, the weight gradient too (qt_lstm_bwd_fused: gG never leaves the launch).  OFF by default: at
             # the bench shape the persistent launch takes 71 us against 47 + 21 us for this launch plus its share of the
             # deferred weight gradient -- fp32 MFMA issues on the vector pipe, so its 18 us of MFMA time, the cell arithmetic
-            # and the memory phases add up instead of overlapping; 9.17 vs 8.98 ms per step.
+            # and the memory phases add up instead of overlapping (HISTORY.md section C); 9.17 vs 8.98 ms per step.
             if (os.environ.get('QT_WGRAD_FUSION') == '1' and not ctx.sm and ctx.needs_input_grad[2] and ctx.acc_w is not None
                     and W.shape[0] <= 128 and NB <= (128 if h == 16 else 64)):
                 ksp = (ctx.Ks + 3) // 4 * 4

@@ -1,4 +1,4 @@
-"""ONE controlled look at a hipMemsetAsync node inside a captured hipGraph (VERDICT r1 item 10 / DESIGN.md section 9: in
+"""ONE controlled look at a hipMemsetAsync node inside a captured hipGraph (VERDICT r1 item 10 / HISTORY.md section E: in
 round 1 a 4-byte hipMemsetAsync on a counter, issued by a C-ABI entry during the capture of the training step, aborted at
 replay and was replaced by a fill kernel; no log was kept).  Each variant runs in its own subprocess, once, under a timeout:
 
