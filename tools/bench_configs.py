@@ -79,6 +79,12 @@ if os.environ.get('QT_CFG_ROOFLINE', '1') == '1':
             ks = json.load(open(pmc))['kernels']
             rec['roofline']['traffic_by_kernel'] = {k: v['traffic_bytes_per_launch'] for k, v in ks.items()
                                                     if k.startswith(('k_spmm<', 'k_cheb_clip'))}
+            # `traffic`: launch-weighted over ALL message-aggregate launches of the step (per-hop k_spmm on rows of >= 4 channels and
+            # the fused launches), not over the fused ones alone -- on the big frames the per-hop kernel dominates
+            agg = [v for k, v in ks.items() if k.startswith('k_cheb_clip') or (k.startswith('k_spmm<') and not k.startswith('k_spmm<1,'))]
+            if agg:
+                rec['roofline']['traffic'] = int(sum(v['traffic_bytes_per_launch'] * v['dispatches'] for v in agg) / sum(v['dispatches'] for v in agg))
+                rec['roofline']['traffic_source'] = 'profiles/' + tf_name
     else:
         rec['roofline'] = bench.attn_roofline(fresh, pool[0], mask)
         pmc = os.path.join(ROOT, 'profiles', tf_name)
