@@ -268,12 +268,24 @@ class NextFramePredictorS2S(NextFramePredictor):
             self._clip_and_step(clip_params, max_norm)
 
         side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        if multi:
+            # The warm-up steps all-reduce, and torch issues a synchronous collective -- and records its completion event -- on the
+            # CURRENT stream.  The process group's watchdog thread polls that event (hipEventQuery) until the work is reaped, and
+            # HIP refuses the query while the event's stream is capturing (hipErrorCapturedEvent: the watchdog dies and takes the
+            # process with it; seen in round 5 as soon as RCCL was executed at all).  So under torch.distributed the warm-up runs
+            # on the caller's stream and only the capture on the side stream: no collective ever touches a stream that captures.
             for _ in range(warmup):
                 self.last_warmup_loss = fwd_bwd()        # (a real training step on this batch)
                 update(self._grads_ready(world, self.process_group, force=multi))
-        torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            side.wait_stream(torch.cuda.current_stream())
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self.last_warmup_loss = fwd_bwd()        # (a real training step on this batch)
+                    update(self._grads_ready(world, self.process_group, force=multi))
+            torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         self.zero_grad()
         # thread_local: other threads (the RCCL watchdog under torch.distributed) may issue HIP calls meanwhile

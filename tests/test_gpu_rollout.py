@@ -454,7 +454,22 @@ def test_baseline_config_shapes_train(cfg):
         mask, thresh, feat = clips[0][1], 0.15, 5
         tf = lambda a: abs(abs(a - 0.5) - 0.5)
         kw['transform_func'] = tf          # (the model takes it from model_kwargs, ice_exp.py:157)
-    attention = cfg.endswith('transformer')          # (its attention dropout, p = 0.1, is part of the convolution's kwargs)
+    attention = cfg.endswith('transformer')
+    # (attention dropout, p = 0.1, is part of the convolution's kwargs and its masks are seeded by a per-process launch counter: with it
+    # on, eager and captured steps draw different masks and their losses agree only statistically -- round 4 held them to 20 %, which
+    # depended on how many attention launches earlier tests had issued.  It is switched off for this comparison; replays drawing new
+    # masks is test_graphed_transformerconv_step_matches_eager_steps' subject)
+    from model.model import CONVOLUTION_KWARGS
+    conv_kw = dict(CONVOLUTION_KWARGS['TransformerConv'])
+    CONVOLUTION_KWARGS['TransformerConv']['dropout'] = 0.0
+    try:
+        _baseline_config_body(cfg, attention, B, t_in, t_out, shape, kw, x, y, mask, thresh, tf, feat, gc)
+    finally:
+        CONVOLUTION_KWARGS['TransformerConv'].update(conv_kw)
+
+
+def _baseline_config_body(cfg, attention, B, t_in, t_out, shape, kw, x, y, mask, thresh, tf, feat, gc):
+    from model.mpnnlstm import NextFramePredictorS2S
     xt, yt = torch.from_numpy(x).to(dev()), torch.from_numpy(y).to(dev())
     concat = torch.zeros(B, t_out, *shape, 1, device=dev())
     P_valid = int((~mask).sum())
@@ -491,8 +506,7 @@ def test_baseline_config_shapes_train(cfg):
     lg = [float(step(xt, yt, concat)) for _ in range(2)]
     assert np.isfinite(lg).all(), lg
     for a, b in zip(le[2:], lg):
-        # (attention dropout draws other masks in the captured step: its seeds mix in a per-launch host counter)
-        assert abs(a - b) <= (0.2 if attention else 1e-4) * abs(a), (le, lg)
+        assert abs(a - b) <= 1e-4 * abs(a), (le, lg)
     del graphed, step
     gc.collect()
     torch.cuda.empty_cache()
