@@ -408,17 +408,20 @@ int qt_wgrad_groups(int nseg, const float* const* a0, const int* lda0, const flo
 int qt_proj_group(const float* A, int lda, int64_t gsA, int Ka, int Ca, const float* S, const float* W, const float* WT, int64_t gsW,
                   int G, int Kb, int Cb, float* out, int ldo, int64_t gsO, int reverse /* groups from the last to the first */, int N,
                   const int32_t* n_dev, void* stream);
-/* Backward of qt_proj_group for the deeper layers of the attention stacks (every group has its own input: G groups of (N, 32) rows,
- * W_g (32 + 4, 128), gradient planes gP_g = 4 planes (N, 32) -- hidden size 32, what ice_exp.py:153-162 runs) in ONE pass over the
- * gradient planes: gA_g = gP_g W_g[:32]^T is written (rows ldo apart, group stride gsO) and the partial weight gradient
- * [A_g | 1 0 0 0]^T gP_g of workgroup b is written to (accumulate == 0) or added into (!= 0) slab (b, g) of part
- * ((qt_proj_bwd_blocks(G), G, 36, 128)); qt_colsum over the slabs gives the (G, 36, 128) weight gradient of all uses that added.
- * Replaces a qt_proj_group call on the gradient planes plus the use's share of the deferred qt_wgrad_groups launch, which read the
- * planes twice.  reverse != 0: groups are dealt to the workgroups last to first. */
+/* Backward of qt_proj_group for attention stacks of hidden size 32 (what ice_exp.py:153-162 runs) in ONE pass over the gradient
+ * planes.  Group g: input rows A_g (N, 32), lda floats apart, from A + g gsA, weights W_g = 32 + 4 rows of 128 columns from W + g gsW with row pitch ldw,
+ * gradient planes gP_g = 4 planes (N, 32).  gA_g = gP_g W_g[:32]^T is written (rows ldo apart, group stride gsO) and the partial
+ * weight gradient [A_g | 1 0 0 0]^T gP_g of workgroup b is written to (accumulate == 0) or added into (!= 0) slab b of part
+ * (qt_proj_bwd_blocks(G) slabs of G 36 128 floats, each laid out like W); qt_colsum over the slabs gives the weight gradient of
+ * all uses that added.  Two layouts: deeper layers -- every stack has its own input and its own (36, 128) matrix: ldw = 128,
+ * gsW = 36 128; a cell's first layer -- G heads share ONE input (gsA = 0) and sit side by side in one (36, G 128) matrix:
+ * ldw = G 128, gsW = 128, and the caller adds the G partial data gradients.  Replaces a qt_proj_group call on the gradient planes
+ * plus the use's share of the deferred qt_wgrad_groups launch, which read the planes twice.  reverse != 0: groups are dealt to the
+ * workgroups last to first. */
 int qt_proj_bwd_blocks(int G);
-int qt_proj_bwd(const float* gP, int64_t gsG, int64_t psG, const float* A, int64_t gsA, const float* W, int64_t gsW, float* gA,
-                int64_t gsO, int ldo, float* part, int N, const int32_t* n_dev, int G, int Cin, int C, int accumulate, int reverse,
-                void* stream);
+int qt_proj_bwd(const float* gP, int64_t gsG, int64_t psG, const float* A, int64_t gsA, int lda, const float* W, int64_t gsW,
+                int ldw, float* gA, int64_t gsO, int ldo, float* part, int N, const int32_t* n_dev, int G, int Cin, int C, int accumulate,
+                int reverse, void* stream);
 /* out[j] = sum_i part[i*len + j], i < nblk */
 int qt_colsum(const float* part, int nblk, int64_t len, float* out, void* stream);
 

@@ -12,6 +12,11 @@
 // partial weight gradient that stays in the waves' accumulators over all the tiles the workgroup walks) -- 64 fp32 MFMAs
 // (v_mfma_f32_32x32x2_f32) per wave and tile; the bias row is the column sum of the tile, accumulated on the vector pipe from the B
 // operands the MFMAs load anyway.
+// A cell's FIRST layer has the same shape turned sideways: the four stacks of a segment share ONE input (gsA = 0, rows lda apart:
+// the state may be a column block of a wider matrix) and their weights sit side by side in one (36, 4 x 128) matrix (ldw = 512,
+// gsW = 128).  Head h is group h: its workgroups write a PARTIAL data gradient (the caller adds the four) and slabs laid out like
+// the weight matrix.  Measured at the cfg4t shape (tools/exp_proj_bwd.py): 108 - 115 us + 17 us for the sum against 101 - 116 (data
+// gradient) + 99 - 112 us (share of the deferred weight gradient).
 // Persistent: `nb` workgroups per group (all G nb of them resident), workgroup b of a group takes the row tiles b, b + nb, ...; the
 // next tile's operands are requested before the current tile's MFMA chain.  Each workgroup
 // owns one slab of the partial weight gradient (fixed summation order: deterministic); the uses of a pass add into the same slabs and
@@ -36,14 +41,16 @@ constexpr int PB_AP = PB_C + 4;     // LDS pitch of the A tile
 struct ProjBwdArgs {
     const float* gP;        // group g: 4 planes (N, 32), plane stride psG, from gP + g gsG
     int64_t gsG, psG;
-    const float* A;         // group g: (N, 32) rows from A + g gsA
+    const float* A;         // group g: (N, 32) rows, lda floats apart, from A + g gsA
     int64_t gsA;
-    const float* W;         // group g: (32 + 4, 128) row-major from W + g gsW
-    int64_t gsW;
+    int lda;
+    const float* W;         // group g: 32 + 4 rows of 128 columns, row pitch ldw, from W + g gsW -- (G, 36, 128) arrays: ldw = 128,
+    int64_t gsW;            // gsW = 36 * 128; G heads side by side in ONE (36, G 128) matrix (a shared input: gsA = 0): ldw = G 128, gsW = 128
+    int ldw;
     float* gA;              // group g: (N, 32) rows, row stride ldo, from gA + g gsO
     int64_t gsO;
     int ldo;
-    float* part;            // (nb, G, 36, 128) slabs
+    float* part;            // nb slabs of G 36 128 floats, each laid out like W (group g at + g gsW, row pitch ldw)
     int N;
     const int32_t* n_dev;
     int G, nb, accumulate, reverse;
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void k_proj_bwd(ProjBwdArgs a) {
     // W_g[:32] -> LDS once: Ws[j][k] = W[j][k] (row j = input channel, k = gradient column)
     for (int e = t; e < PB_C * (PB_CO / 4); e += 256) {
         const int j = e >> 5, q = e & 31;
-        *reinterpret_cast<float4*>(&Ws[j * PB_GP + 4 * q]) = pb_gload4(W + (int64_t)j * PB_CO + 4 * q);
+        *reinterpret_cast<float4*>(&Ws[j * PB_GP + 4 * q]) = pb_gload4(W + (int64_t)j * a.ldw + 4 * q);
     }
 
     // the tile's operands: 8 float4 of the gradient planes and 2 float4 of A per thread.  A plane's 64 rows are one contiguous 8 KB
@@ -104,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void k_proj_bwd(ProjBwdArgs a) {
         const int64_t row0 = (int64_t)tile * PB_ROWS + rs0, row1 = (int64_t)tile * PB_ROWS + rs1;
         live0 = tile < ntiles && row0 < rows;
         live1 = tile < ntiles && row1 < rows;
-        const int64_t o0 = (row0 < last ? row0 : last) * PB_C + c8, o1 = (row1 < last ? row1 : last) * PB_C + c8;
+        const int64_t q0 = row0 < last ? row0 : last, q1 = row1 < last ? row1 : last;
+        const int64_t o0 = q0 * PB_C + c8, o1 = q1 * PB_C + c8;
         pg[0] = pb_gload4(gP + o0);
         pg[1] = pb_gload4(gP + o1);
         pg[2] = pb_gload4(gP + a.psG + o0);
@@ -113,8 +121,8 @@ __global__ __launch_bounds__(256, 2) void k_proj_bwd(ProjBwdArgs a) {
         pg[5] = pb_gload4(gP + 2 * a.psG + o1);
         pg[6] = pb_gload4(gP + 3 * a.psG + o0);
         pg[7] = pb_gload4(gP + 3 * a.psG + o1);
-        pa[0] = pb_gload4(A + o0);
-        pa[1] = pb_gload4(A + o1);
+        pa[0] = pb_gload4(A + q0 * a.lda + c8);
+        pa[1] = pb_gload4(A + q1 * a.lda + c8);
     };
     auto stash = [&]() {
         // (values, not `cond ? pg[i] : z` on the arrays themselves: that is a select of two ADDRESSES, which keeps the arrays in
@@ -239,7 +247,8 @@ __global__ __launch_bounds__(256, 2) void k_proj_bwd(ProjBwdArgs a) {
     if (dwave) return;
     // this workgroup's slab of the weight gradient: rows 0 .. 31 from the accumulators, row 32 = the column sums (even + odd rows),
     // rows 33 .. 35 (the padding of the bias block) zero
-    float* slab = a.part + ((int64_t)b * a.G + g) * (PB_C + 4) * PB_CO;
+    float* slab = a.part + (int64_t)b * a.G * (PB_C + 4) * PB_CO + g * a.gsW;
+    const int ldw = a.ldw;
     // (all 34 slab reads of a lane first, then the stores: written element by element the compiler kept load -> add -> store in
     // order -- the pointers may alias -- and the 34 dependent round trips cost ~50 us per launch)
     float* s0 = slab + ct * 32 + l32;                              // this lane's column of tile ct; tile ct + 1 is 32 floats on
@@ -248,26 +257,26 @@ __global__ __launch_bounds__(256, 2) void k_proj_bwd(ProjBwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-        o0[r] = a.accumulate ? s0[f * PB_CO] : 0.0f;
-        o1[r] = a.accumulate ? s0[f * PB_CO + 32] : 0.0f;
+        o0[r] = a.accumulate ? s0[f * ldw] : 0.0f;
+        o1[r] = a.accumulate ? s0[f * ldw + 32] : 0.0f;
     }
     if (a.accumulate && half == 0) {
-        ob0 = s0[PB_C * PB_CO];
-        ob1 = s0[PB_C * PB_CO + 32];
+        ob0 = s0[PB_C * ldw];
+        ob1 = s0[PB_C * ldw + 32];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-        s0[f * PB_CO] = o0[r] + acc0[r];
-        s0[f * PB_CO + 32] = o1[r] + acc1[r];
+        s0[f * ldw] = o0[r] + acc0[r];
+        s0[f * ldw + 32] = o1[r] + acc1[r];
     }
     const float b0 = bs0 + __shfl_xor(bs0, 32, 64), b1 = bs1 + __shfl_xor(bs1, 32, 64);
     if (half == 0) {
-        s0[PB_C * PB_CO] = ob0 + b0;
-        s0[PB_C * PB_CO + 32] = ob1 + b1;
+        s0[PB_C * ldw] = ob0 + b0;
+        s0[PB_C * ldw + 32] = ob1 + b1;
     } else if (!a.accumulate) {
 #pragma unroll
-        for (int f = 1; f < 4; ++f) s0[(PB_C + f) * PB_CO] = s0[(PB_C + f) * PB_CO + 32] = 0.0f;
+        for (int f = 1; f < 4; ++f) s0[(PB_C + f) * ldw] = s0[(PB_C + f) * ldw + 32] = 0.0f;
     }
 }
 
@@ -286,15 +295,16 @@ extern "C" int qt_proj_bwd_blocks(int G) {
     return nb < 1 ? 1 : nb;
 }
 
-extern "C" int qt_proj_bwd(const float* gP, int64_t gsG, int64_t psG, const float* A, int64_t gsA, const float* W, int64_t gsW,
-                           float* gA, int64_t gsO, int ldo, float* part, int N, const int32_t* n_dev, int G, int Cin, int C,
+extern "C" int qt_proj_bwd(const float* gP, int64_t gsG, int64_t psG, const float* A, int64_t gsA, int lda, const float* W, int64_t gsW,
+                           int ldw, float* gA, int64_t gsO, int ldo, float* part, int N, const int32_t* n_dev, int G, int Cin, int C,
                            int accumulate, int reverse, void* stream) {
     QT_ARG(gP && A && W && gA && part && G >= 1, "null pointer");
     QT_ARG(Cin == PB_C && C == PB_C, "this launch is built for 32 input channels and 32-channel planes (hidden size 32)");
-    QT_ARG(ldo >= Cin && ldo % 4 == 0 && gsO % 4 == 0 && ((uintptr_t)gA & 15) == 0 && gsG % 4 == 0 && psG % 4 == 0 && gsA % 4 == 0 && gsW % 4 == 0, "strides must be multiples of 4 floats");
+    QT_ARG(ldo >= Cin && ldo % 4 == 0 && gsO % 4 == 0 && ((uintptr_t)gA & 15) == 0 && gsG % 4 == 0 && psG % 4 == 0 && gsA % 4 == 0 && lda % 4 == 0 && lda >= Cin && gsW % 4 == 0 && ldw % 4 == 0, "strides must be multiples of 4 floats");
+    QT_ARG(ldw >= PB_CO && (ldw == PB_CO || (int64_t)ldw == (int64_t)G * PB_CO), "ldw: 128 (one matrix per group) or G 128 (the groups side by side in one matrix)");
     QT_ARG((((uintptr_t)gP | (uintptr_t)A | (uintptr_t)W) & 15) == 0, "gP / A / W must be 16-byte aligned");
     if (N <= 0) return QT_OK;
-    ProjBwdArgs a = {gP, gsG, psG, A, gsA, W, gsW, gA, gsO, ldo, part, N, n_dev, G, qt_proj_bwd_blocks(G), accumulate, reverse};
+    ProjBwdArgs a = {gP, gsG, psG, A, gsA, lda, W, gsW, ldw, gA, gsO, ldo, part, N, n_dev, G, qt_proj_bwd_blocks(G), accumulate, reverse};
 #ifdef QT_PB_TIMING
     a.dbg = g_pb_dbg;
 #endif

@@ -78,7 +78,7 @@ _SIGNATURES = {
     'qt_dense_sb': [_P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     'qt_num_cus': [],
     'qt_proj_bwd_blocks': [_I],
-    'qt_proj_bwd': [_P, _L, _L, _P, _L, _P, _L, _P, _L, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    'qt_proj_bwd': [_P, _L, _L, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'qt_lstm_fused_blocks': [],
     'qt_lstm_bwd_fused': [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P,
                           _P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],

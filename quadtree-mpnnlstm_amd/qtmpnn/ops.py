@@ -949,6 +949,7 @@ def attention(proj, We, mesh, c_real, dropout_p=0.0, training=False, acc=None, h
 
 
 _PROJ_BWD_FUSED = os.environ.get('QT_NO_PROJ_BWD_FUSED') != '1'      # (A/B switch)
+_PROJ_BWD_SHARED = os.environ.get('QT_NO_PROJ_BWD_SHARED') != '1'    # (A/B switch: the first-layer segments too)
 _STATS = {'skip_alias': 0}      # (how often a layer's gradient array was completed in place: tests look at it)
 
 
@@ -1051,17 +1052,27 @@ class _MultiConv(Function):
             if not ctx.needs_input_grad[7 + s]:
                 gAs.append(None)
                 continue
-            if (_PROJ_BWD_FUSED and gin > 1 and N > 0 and cin == 32 and C == 32 and co == 4 * C and ctx.needs_input_grad[7 + nseg + s]
-                    and A.is_contiguous() and W.is_contiguous()):
+            heads = co // (4 * C)
+            if (_PROJ_BWD_FUSED and N > 0 and cin == 32 and C == 32 and ctx.needs_input_grad[7 + nseg + s] and W.is_contiguous()
+                    and ((gin > 1 and heads == 1 and A.is_contiguous()) or (_PROJ_BWD_SHARED and gin == 1 and heads > 1 and lda % 4 == 0 and A.data_ptr() % 16 == 0))):
                 # data gradient AND this use's weight gradient in one pass over the gradient planes (csrc/projbwd.hip): the planes are
                 # read once and need not be kept for the deferred grouped weight gradient
-                nxt = A.new_empty(gin, 4, N, cin)
+                G_s = gin * heads
                 if s not in pslab:
-                    pslab[s] = W.new_zeros(_lib.value('qt_proj_bwd_blocks', gin), gin, cin + 4, co)
-                _lib.call('qt_proj_bwd', gP.data_ptr() + 4 * hoff * 4 * N * C, 4 * N * C, N * C, ptr(A), N * cin, ptr(W), (cin + 4) * co,
-                          nxt.data_ptr() + 4 * 3 * N * cin, 4 * N * cin, cin, ptr(pslab[s]), N, ptr(mesh.n_dev), gin, cin, C, 1, 1)
+                    pslab[s] = W.new_zeros(_lib.value('qt_proj_bwd_blocks', G_s), gin, cin + 4, co)
+                if gin > 1:
+                    nxt = A.new_empty(gin, 4, N, cin)
+                    _lib.call('qt_proj_bwd', gP.data_ptr() + 4 * hoff * 4 * N * C, 4 * N * C, N * C, ptr(A), N * cin, cin, ptr(W), (cin + 4) * co, co,
+                              nxt.data_ptr() + 4 * 3 * N * cin, 4 * N * cin, cin, ptr(pslab[s]), N, ptr(mesh.n_dev), gin, cin, C, 1, 1)
+                    gAs.append(nxt[:, 3])
+                else:
+                    # a cell's first layer: the `heads` stacks of the segment share the input (gsA = 0) and sit side by side in one
+                    # weight matrix; every head leaves its own partial data gradient, added here
+                    partial = A.new_empty(heads, N, cin)
+                    _lib.call('qt_proj_bwd', gP.data_ptr() + 4 * hoff * 4 * N * C, 4 * N * C, N * C, ptr(A), 0, lda, ptr(W), 4 * C, co,
+                              ptr(partial), N * cin, cin, ptr(pslab[s]), N, ptr(mesh.n_dev), heads, cin, C, 1, 1)
+                    gAs.append(partial.sum(dim=0))
                 fused.add(s)
-                gAs.append(nxt[:, 3])
                 continue
             if gin > 1 and N > 0:
                 # the input is the previous layer's output (gin, N, cin): its gradient goes into block 3 of a fresh (gin, 4, N, cin)
@@ -1081,18 +1092,21 @@ class _MultiConv(Function):
         last = acc is None or acc.leave(ctx.use_idx)
         need_w = any(ctx.needs_input_grad[7 + nseg:7 + 2 * nseg])
         pending = acc.pending if acc is not None else []
-        if need_w and N > 0 and len(fused) < nseg:
-            pending.append((As, gP, N, mesh.n_dev, mesh.cheb_ones(1)))
+        if need_w and N > 0 and len(fused) < nseg:          # (the segments in `fused` have their share in the slabs already)
+            pending.append((As, gP, N, mesh.n_dev, mesh.cheb_ones(1), fused))
         if not last:
             return (None,) * 7 + tuple(gAs) + (None,) * (nseg + 1)
         gWs = [None] * nseg
         if need_w:
             for s, (seg, W) in enumerate(zip(ctx.segs, Ws)):
-                if s in pslab:           # every use of the pass added its partial sums into the same slabs
+                uses = [u for u in pending if s not in u[5]]
+                if s in pslab:           # every fused use of the pass added its partial sums into the same slabs
                     gWs[s] = torch.empty_like(W)
                     _lib.call('qt_colsum', ptr(pslab[s]), pslab[s].shape[0], W.numel(), ptr(gWs[s]))
+                    if uses:
+                        gWs[s] += _wgrad_groups(uses, s, seg, C, W)
                 else:
-                    gWs[s] = _wgrad_groups(pending, s, seg, C, W)
+                    gWs[s] = _wgrad_groups(uses, s, seg, C, W)
         if acc is not None:
             acc.pending = []
         psum = P.new_empty(G * 2 * C)

@@ -631,8 +631,8 @@ def test_projection_backward_in_one_pass(N, valid):
         A = torch.randn(G, N, cin, device=dev())
         gP = torch.randn(G, 4, N, C, device=dev())
         nxt = torch.full((G, 4, N, cin), 7.0, device=dev())         # the data gradient lands in block 3 of the next layer's array
-        _lib.call('qt_proj_bwd', ptr(gP), 4 * N * C, N * C, ptr(A), N * cin, ptr(W), (cin + 4) * co, nxt.data_ptr() + 4 * 3 * N * cin,
-                  4 * N * cin, cin, ptr(part), N, ptr(n_dev), G, cin, C, 1, use)
+        _lib.call('qt_proj_bwd', ptr(gP), 4 * N * C, N * C, ptr(A), N * cin, cin, ptr(W), (cin + 4) * co, co,
+                  nxt.data_ptr() + 4 * 3 * N * cin, 4 * N * cin, cin, ptr(part), N, ptr(n_dev), G, cin, C, 1, use)
         old = torch.full((G, N, cin), 7.0, device=dev())
         _lib.call('qt_proj_group', ptr(gP), C, 4 * N * C, 4, C, None, None, ptr(W), (cin + 4) * co, G, 1, cin, ptr(old), cin, N * cin, 1, N,
                   ptr(n_dev))
@@ -649,25 +649,63 @@ def test_projection_backward_in_one_pass(N, valid):
     close(gW, ref_w.float(), rtol=1e-5, atol=2e-4, msg='weight gradient of two uses')
     assert not gW[:, cin + 1:].any()
     # accumulate == 0 overwrites the slabs
-    _lib.call('qt_proj_bwd', ptr(gP), 4 * N * C, N * C, ptr(A), N * cin, ptr(W), (cin + 4) * co, nxt.data_ptr() + 4 * 3 * N * cin,
-              4 * N * cin, cin, ptr(part), N, ptr(n_dev), G, cin, C, 0, 0)
+    _lib.call('qt_proj_bwd', ptr(gP), 4 * N * C, N * C, ptr(A), N * cin, cin, ptr(W), (cin + 4) * co, co,
+              nxt.data_ptr() + 4 * 3 * N * cin, 4 * N * cin, cin, ptr(part), N, ptr(n_dev), G, cin, C, 0, 0)
     _lib.call('qt_colsum', ptr(part), nb, gW.numel(), ptr(gW))
     g2 = gP[:, :, :nv].permute(0, 2, 1, 3).reshape(G, nv, co).double()
     last = torch.cat([A[:, :nv].double(), ones.unsqueeze(0).expand(G, -1, -1)], dim=2).transpose(1, 2) @ g2
     close(gW, last.float(), rtol=1e-5, atol=2e-4, msg='weight gradient, overwrite mode')
 
 
-def test_transformer_cell_hidden32_one_pass_projection_backward_equals_two_launch_path():
-    """A hidden-32 TransformerConv cell, three layers deep (what ice_exp.py:153-162 runs): the backward with the one-pass projection
-    backward (default) against the data-gradient launch + deferred grouped weight gradient (QT_NO_PROJ_BWD_FUSED): input gradients
-    bit-identical (same reduction order), weight gradients at 1e-5 of their scale (another summation order over the rows)."""
+@pytest.mark.parametrize('N,valid', [(1000, None), (4133, 3000)])
+def test_projection_backward_in_one_pass_shared_input(N, valid):
+    """qt_proj_bwd on a cell's FIRST layer: the four stacks of a segment share one input (gsA = 0) and sit side by side in one
+    (36, 4 x 128) weight matrix (ldw = 512, gsW = 128), input rows possibly a column block of a wider matrix (lda); every head leaves a partial data gradient (their sum = the data gradient),
+    the slabs are laid out like the weight matrix.  Against the fp64 products; two uses add into the same slabs."""
+    from qtmpnn import _lib
+    from qtmpnn._lib import ptr
+    torch.manual_seed(N + 1)
+    H, cin, C = 4, 32, 32
+    co = H * 4 * C
+    nv = valid or N
+    n_dev = torch.tensor([nv], dtype=torch.int32, device=dev()) if valid else None
+    nb = _lib.value('qt_proj_bwd_blocks', H)
+    part = torch.zeros(nb, 1, cin + 4, co, device=dev())
+    W = torch.randn(1, cin + 4, co, device=dev()) * 0.3
+    ref_w = torch.zeros(cin + 4, co, dtype=torch.float64, device=dev())
+    ones = torch.zeros(nv, 4, dtype=torch.float64, device=dev())
+    ones[:, 0] = 1
+    for use in range(2):
+        lda = cin if use == 0 else 68               # (second use: the rows are a column block of a wider state matrix)
+        A = torch.randn(N, lda, device=dev())[:, lda - cin:]
+        gP = torch.randn(H, 4, N, C, device=dev())
+        partial = torch.full((H, N, cin), 7.0, device=dev())
+        _lib.call('qt_proj_bwd', ptr(gP), 4 * N * C, N * C, ptr(A), 0, lda, ptr(W), 4 * C, co, ptr(partial), N * cin, cin, ptr(part), N,
+                  ptr(n_dev), H, cin, C, 1, use)
+        assert (partial[:, nv:] == 7.0).all()
+        g2 = gP[:, :, :nv].permute(2, 0, 1, 3).reshape(nv, co).double()             # row: head, block, channel = W's columns
+        close(partial[:, :nv].sum(0), (g2 @ W[0, :cin].double().t()).float(), rtol=1e-5, atol=2e-5, msg='data gradient')
+        ref_w += torch.cat([A[:nv].double(), ones], dim=1).t() @ g2
+    gW = torch.empty(1, cin + 4, co, device=dev())
+    _lib.call('qt_colsum', ptr(part), nb, gW.numel(), ptr(gW))
+    close(gW[0], ref_w.float(), rtol=1e-5, atol=2e-4, msg='weight gradient of two uses')
+    assert not gW[0, cin + 1:].any()
+
+
+@pytest.mark.parametrize('cin_x', [8, 32])
+def test_transformer_cell_hidden32_one_pass_projection_backward_equals_two_launch_path(cin_x):
+    """A hidden-32 TransformerConv cell, three layers deep (what ice_exp.py:153-162 runs; cin_x = 32: an upper cell of the stack,
+    whose X segment is fused as well): the backward with the one-pass projection backward (default) against the data-gradient
+    launch + deferred grouped weight gradient (QT_NO_PROJ_BWD_FUSED).  Deeper layers: same reduction order, but a first-layer
+    segment's data gradient is now the sum of four per-head partials -> input gradients at 1e-5 of their scale, like the weight
+    gradients (another summation order over the rows)."""
     from model.model import GConvLSTM
     from qtmpnn import ops
     mesh, _ = _tile_mesh('mnist128_sparse', 1)
     N = mesh.N
     torch.manual_seed(4)
-    cell = GConvLSTM(8, 32, n_conv_layers=3, convolution_type='TransformerConv').to(dev()).eval()
-    X, H, Cc = (torch.randn(N, w, device=dev(), requires_grad=True) for w in (8, 32, 32))
+    cell = GConvLSTM(cin_x, 32, n_conv_layers=3, convolution_type='TransformerConv').to(dev()).eval()
+    X, H, Cc = (torch.randn(N, w, device=dev(), requires_grad=True) for w in (cin_x, 32, 32))
     gO, gH, gC = (torch.randn(N, 32, device=dev()) for _ in range(3))
     res = {}
     for flag in (True, False):
@@ -683,7 +721,7 @@ def test_transformer_cell_hidden32_one_pass_projection_backward_equals_two_launc
         if a is None or b is None:
             assert a is None and b is None
             continue
-        if i < 3:
+        if name == 'C':
             assert torch.equal(a, b), f'input gradient {name}'
         elif name.endswith('lin_key.bias'):       # an exact zero: both are rounding noise of column sums over N rows of O(1) terms
             assert float(a.abs().max()) < 2e-5 and float(b.abs().max()) < 2e-5, name

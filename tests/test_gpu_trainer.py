@@ -262,10 +262,12 @@ def test_ice_exp_preset_experiments_golden(name):
     lr, steps = float(g['lr']), 0
 
     def weights_close(prefix, steps):
-        # Adam moves a weight by at most lr per step: hold the weights to 1e-4 relative plus 1 % of that reach (a gradient
-        # entry that is rounding noise of an exact zero moves its weight by lr * g / (|g| + eps) either way)
+        # Adam moves a weight by at most lr per step, whatever the size of its gradient: an entry of 1e-7 that carries 1e-9 of
+        # summation-order noise moves its weight by lr * (1 +- 0.01), and an entry that is rounding noise of an exact zero by
+        # lr * g / (|g| + eps) either way.  Hold the weights to 1e-4 relative plus 3 % of that reach (the gradients themselves
+        # are held to 1e-4 above; the key projections of a softmax over 2 - 5 neighbours are where such entries live)
         for k, v in nfp.model.state_dict().items():
-            close(v, g[prefix + k], rtol=1e-4, atol=0.01 * steps * lr, msg=prefix + k)
+            close(v, g[prefix + k], rtol=1e-4, atol=0.03 * steps * lr, msg=prefix + k)
     if preset != 'False':
         nfp.train(loader(g['x_half'], g['y_half'], half, 0, 2), loader(g['x_half'], g['y_half'], half, 2, 3), clim_h, lr=lr,
                   n_epochs=1, mask=g['mask_half'], truncated_backprop=0, graph_structure=gs_h)

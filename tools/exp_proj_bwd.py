@@ -27,7 +27,7 @@ big = torch.empty(80 * 1024 * 1024, device=dev)          # 320 MB written betwee
 
 
 def fused():
-    _lib.call('qt_proj_bwd', ptr(gP), 4 * N * C, N * C, ptr(A), N * cin, ptr(W), (cin + 4) * co, nxt.data_ptr() + 4 * 3 * N * cin,
+    _lib.call('qt_proj_bwd', ptr(gP), 4 * N * C, N * C, ptr(A), N * cin, cin, ptr(W), (cin + 4) * co, co, nxt.data_ptr() + 4 * 3 * N * cin,
               4 * N * cin, cin, ptr(part), N, None, G, cin, C, 1, 1)
 
 
@@ -63,6 +63,42 @@ for flush in (True, False):
     tf, td, tw = timeit(fused, flush=flush), timeit(dgrad, flush=flush), timeit(wgrad, flush=flush)
     print(f'N = {N}, operands {"cold" if flush else "warm"}: one pass {tf:7.1f} us ({by / tf / 1e6:.2f} TB/s of its operands once, '
           f'{2 * 2.0 * G * N * 128 * 32 / tf / 1e6:.1f} TFLOP/s)  |  data gradient {td:7.1f} + weight gradient {tw:7.1f} = {td + tw:7.1f} us')
+
+# a cell's first layer: four heads share one input and one (36, 512) weight matrix; the four partial data gradients are added afterwards
+H4 = 4
+A1 = torch.randn(N, cin, device=dev)
+W1 = torch.randn(1, cin + 4, H4 * co, device=dev)
+gP1 = gP[:H4]
+partial = torch.empty(H4, N, cin, device=dev)
+nb1 = _lib.value('qt_proj_bwd_blocks', H4)
+part1 = torch.zeros(nb1, 1, cin + 4, H4 * co, device=dev)
+out1 = torch.empty(N, cin, device=dev)
+partw1 = torch.empty(_lib.value('qt_wgrad_group_blocks', 1, Ns), 1, cin + 4, H4 * co, device=dev)
+
+
+def shared():
+    _lib.call('qt_proj_bwd', ptr(gP1), 4 * N * C, N * C, ptr(A1), 0, cin, ptr(W1), co, H4 * co, ptr(partial), N * cin, cin, ptr(part1), N, None,
+              H4, cin, C, 1, 1)
+
+
+def shared_sum():
+    shared()
+    torch.sum(partial, dim=0, out=out1)
+
+
+def dgrad1():
+    _lib.call('qt_proj_group', ptr(gP1), C, 4 * H4 * N * C, 4 * H4, C, None, None, ptr(W1), (cin + 4) * H4 * co, 1, 1, cin, ptr(out1), cin, 0, 1, N, None)
+
+
+def wgrad1():
+    _lib.call('qt_wgrad_groups', 1, vp(A1.data_ptr()), (ctypes.c_int * 1)(cin), vp(ones.data_ptr()), vp(gP1.data_ptr()), Ns, vp(None), cin, 4, H4 * co,
+              C, C, 1, 0, H4 * co, 1, ptr(partw1))
+
+
+for flush in (True, False):
+    ts, tss, td, tw = (timeit(f, flush=flush) for f in (shared, shared_sum, dgrad1, wgrad1))
+    print(f'first layer (4 heads, one input), operands {"cold" if flush else "warm"}: one pass {ts:7.1f} us, with the sum of the partials {tss:7.1f} us  |  '
+          f'data gradient {td:7.1f} + weight gradient {tw:7.1f} = {td + tw:7.1f} us')
 
 if os.environ.get('QT_LIB', '').startswith('libqt_pbtiming'):
     import ctypes as C_
