@@ -13,6 +13,7 @@ import torch.nn as nn
 from qtmpnn import ops
 from qtmpnn.mesh import Mesh
 
+_ATTN_PLAN = os.environ.get('QT_NO_ATTN_PLAN') != '1'        # (A/B switch: attention models pack per tensor, torch Adam)
 _MULTI_CONV = os.environ.get('QT_NO_MULTI_CONV') != '1'      # (diagnostics: one projection + attention launch pair per convolution)
 
 
@@ -122,21 +123,31 @@ class TransformerConv(nn.Module):
         We = nn.functional.pad(self.lin_edge.weight, (0, 0, 0, cp - cout))
         return PackedConv(W, We, ops.GradAcc(), ops.GradAcc())
 
+    def plan_params(self):
+        """The parameters in module order (= the stand-ins proj_layout receives)."""
+        return [self.lin_key.weight, self.lin_key.bias, self.lin_query.weight, self.lin_query.bias, self.lin_value.weight,
+                self.lin_value.bias, self.lin_edge.weight, self.lin_skip.weight, self.lin_skip.bias]
+
+    @staticmethod
+    def proj_layout(Ts, cin, cout, fill):
+        """(W (n, cin_p + 4, 4 cp), We (n, cp, 2)) of n convolutions of one (in, out) shape from their plan_params() lists (or index
+        stand-ins of them: data movement only, padding = `fill`, see ops.PackPlan): W[i] = [q | k | v | skip] of convolution i
+        with its bias row + 3 padding rows."""
+        n = len(Ts)
+        cin_p, cp = cin + (-cin) % 4, cout + (-cout) % 4
+        w = torch.stack([t for T in Ts for t in (T[2], T[0], T[4], T[7])]).view(n, 4, cout, cin)           # (n, 4, cout, cin)
+        w = nn.functional.pad(w.permute(0, 3, 1, 2), (0, cp - cout, 0, 0, 0, cin_p - cin), value=fill)     # (n, cin_p, 4, cp)
+        b = torch.stack([t for T in Ts for t in (T[3], T[1], T[5], T[8])]).view(n, 1, 4, cout)
+        b = nn.functional.pad(b, (0, cp - cout, 0, 0, 0, 3), value=fill)                                    # bias row + 3 padding rows
+        W = torch.cat([w, b], dim=1).reshape(n, cin_p + 4, 4 * cp)
+        We = nn.functional.pad(torch.stack([T[6] for T in Ts]), (0, 0, 0, cp - cout), value=fill)          # (n, cp, 2)
+        return W, We
+
     @staticmethod
     def stack_proj(convs):
         """(W (n, cin_p + 4, 4 cp), We (n, cp, 2)) of n convolutions of one (in, out) shape: W[i] = [q | k | v | skip] of
         convolution i with its bias row (the matrices pack() builds, in three stack / pad / cat launches)."""
-        c0 = convs[0]
-        cin, cout = c0.in_channels, c0.out_channels
-        cin_p, cp = cin + (-cin) % 4, cout + (-cout) % 4
-        blocks = [[c.lin_query, c.lin_key, c.lin_value, c.lin_skip] for c in convs]
-        w = torch.stack([l.weight for b4 in blocks for l in b4]).view(len(convs), 4, cout, cin)          # (n, 4, cout, cin)
-        w = nn.functional.pad(w.permute(0, 3, 1, 2), (0, cp - cout, 0, 0, 0, cin_p - cin))                 # (n, cin_p, 4, cp)
-        b = torch.stack([l.bias for b4 in blocks for l in b4]).view(len(convs), 1, 4, cout)
-        b = nn.functional.pad(b, (0, cp - cout, 0, 0, 0, 3))                                                # bias row + 3 zero rows
-        W = torch.cat([w, b], dim=1).reshape(len(convs), cin_p + 4, 4 * cp)
-        We = nn.functional.pad(torch.stack([c.lin_edge.weight for c in convs]), (0, 0, 0, cp - cout))     # (n, cp, 2)
-        return W, We
+        return TransformerConv.proj_layout([c.plan_params() for c in convs], convs[0].in_channels, convs[0].out_channels, 0.0)
 
     @staticmethod
     def pack_many(convs):
@@ -328,11 +339,17 @@ class GConvLSTM(nn.Module):
                 layers.append(([W], We, ops.GradAcc()))
         return layers
 
-    # -- packing through one gather (ops.PackPlan): plain ChebConv stacks only ------------------------------------------
+    # -- packing through one gather (ops.PackPlan): plain ChebConv stacks, and TransformerConv stacks on the layer-by-layer path ----
+    @property
+    def _attention_plan(self):
+        return (_ATTN_PLAN and _MULTI_CONV and self.out_channels % 4 == 0 and
+                all(type(c) is TransformerConv for g in self.GATES for br in ('conv_x', 'conv_h')
+                    for c in getattr(self, f'{br}_{g}').convolutions))
+
     @property
     def plannable(self):
-        return all(type(c) is ChebConv and c.bias is not None for g in self.GATES for br in ('conv_x', 'conv_h')
-                   for c in getattr(self, f'{br}_{g}').convolutions)
+        return self._attention_plan or all(type(c) is ChebConv and c.bias is not None for g in self.GATES for br in ('conv_x', 'conv_h')
+                                           for c in getattr(self, f'{br}_{g}').convolutions)
 
     def plan_params(self):
         ps = []
@@ -342,10 +359,32 @@ class GConvLSTM(nn.Module):
                     ps += conv.plan_params()
         return ps + [self.w_c_i, self.w_c_f, self.w_c_o, self.b_i, self.b_f, self.b_c, self.b_o]
 
+    def _plan_layout_attention(self, T, fill, prefix):
+        """The matrices of _pack_multi from stand-ins: M0x / M0h (1, cin_p + 4, 4 x 4C) and E0 (8, C, 2) for layer 0, M<l> (8, C + 4,
+        4C) and E<l> for the deeper layers; wc (3, h), b (4, h)."""
+        L, h, per = self.n_conv_layers, self.out_channels, 9
+        conv = lambda bi, gi, l: T[((bi * 4 + gi) * L + l) * per:((bi * 4 + gi) * L + l + 1) * per]
+        tail = T[2 * 4 * L * per:]
+        out = {prefix + 'wc': torch.cat(tail[0:3], dim=0), prefix + 'b': torch.cat(tail[3:7], dim=0)}
+        for l in range(L):
+            if l == 0:
+                Wes = []
+                for bi, br in enumerate('xh'):
+                    W, We = TransformerConv.proj_layout([conv(bi, gi, 0) for gi in range(4)], self.in_channels if bi == 0 else h, h, fill)
+                    out[f'{prefix}M0{br}'] = W.permute(1, 0, 2).reshape(1, W.shape[1], 4 * W.shape[2])
+                    Wes.append(We)
+                out[prefix + 'E0'] = torch.cat(Wes, dim=0)
+            else:
+                W, We = TransformerConv.proj_layout([conv(bi, gi, l) for bi in range(2) for gi in range(4)], h, h, fill)
+                out[f'{prefix}M{l}'], out[f'{prefix}E{l}'] = W, We
+        return out
+
     def plan_layout(self, T, fill, prefix, in_pad=None, variants=(True,)):
         """Outputs (named with `prefix`): wc (3, h), b (4, h) and, for one conv layer per stack, the gate matrix W of
         every requested variant as (x-bias member, h-bias member) sums; for deeper stacks the per-layer weight / bias
         stacks of both branches, which compose_chebconvs then combines."""
+        if self._attention_plan:
+            return self._plan_layout_attention(T, fill, prefix)
         L, h = self.n_conv_layers, self.out_channels
         K = len(self.conv_x_i.convolutions[0].lins)
         per = K + 1
@@ -382,6 +421,13 @@ class GConvLSTM(nn.Module):
         L, h = self.n_conv_layers, self.out_channels
         wc, b = outs[prefix + 'wc'], outs[prefix + 'b']
         acc_p = ops.GradAcc()
+        if self._attention_plan:
+            multi = [([outs[prefix + 'M0x'], outs[prefix + 'M0h']] if l == 0 else [outs[f'{prefix}M{l}']], outs[f'{prefix}E{l}'], ops.GradAcc())
+                     for l in range(L)]
+            cells = [PackedCell(None, 0, 0, wc, b, ln, None, acc_p) for _ in variants]
+            for c in cells:
+                c.multi = multi
+            return cells
         if L == 1:
             K = len(self.conv_x_i.convolutions[0].lins)
             return [PackedCell(outs[f'{prefix}W{int(v)}'], K, 1, wc, b, ln, ops.GradAcc(), acc_p) for v in variants]

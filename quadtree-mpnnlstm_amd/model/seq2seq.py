@@ -146,8 +146,9 @@ class Decoder(nn.Module):
 
     @property
     def plannable(self):
-        from model.model import ChebConv
-        return all(r.plannable for r in self.rnns) and type(self.fc_out1) is ChebConv and type(self.fc_out2) is ChebConv
+        from model.model import ChebConv, TransformerConv
+        return all(r.plannable for r in self.rnns) and any(type(self.fc_out1) is cls and type(self.fc_out2) is cls
+                                                           for cls in (ChebConv, TransformerConv))
 
     def plan_spec(self, in_pad):
         """(params, layout, finish) of the decoder's weight packing as one parameter gather (see Encoder.plan_spec)."""
@@ -162,6 +163,14 @@ class Decoder(nn.Module):
             for i, (r, n) in enumerate(zip(self.rnns, counts)):
                 out.update(r.plan_layout(T[o:o + n], fill, f'r{i}.', in_pad if i == 0 else None, (True,)))
                 o += n
+            if hasattr(type(self.fc_out1), 'proj_layout'):          # attention head: the two convolutions' [q | k | v | skip] matrices
+                for nm, conv, n in (('h1', self.fc_out1, n1), ('h2', self.fc_out2, n2)):
+                    W, We = type(conv).proj_layout([T[o:o + n]], conv.in_channels, conv.out_channels, fill)
+                    out[nm + 'W'], out[nm + 'E'] = W[0], We[0]
+                    o += n
+                out['ln'] = torch.stack(T[o:o + 4])
+                out['ln_o'] = torch.stack(T[o + 4:o + 6])
+                return out
             out['fc1'] = self.fc_out1.plan_layout(T[o:o + n1], fill, self.head_width, self.hidden_size)
             o += n1
             if _PROJECT_FC2 and self.fc_out2.K == 3:
@@ -175,10 +184,14 @@ class Decoder(nn.Module):
 
         def finish(outs):
             ln = outs['ln']
-            return dict(ln_o=outs['ln_o'], acc_o=ops.GradAcc(),
+            heads = None
+            if 'h1W' in outs:
+                from model.model import PackedConv
+                heads = [PackedConv(outs[nm + 'W'], outs[nm + 'E'], ops.GradAcc(), ops.GradAcc()) for nm in ('h1', 'h2')]
+            return dict(ln_o=outs['ln_o'], acc_o=ops.GradAcc(), heads=heads,
                         rnns=[r.pack_from(outs, f'r{i}.', in_pad if i == 0 else None, ln, (True,))[0]
                               for i, r in enumerate(self.rnns)],
-                        fc1=outs['fc1'], acc1=ops.GradAcc(), fc2=outs.get('fc2'), fc2c=outs.get('fc2c'), acc2=ops.GradAcc())
+                        fc1=outs.get('fc1'), acc1=ops.GradAcc(), fc2=outs.get('fc2'), fc2c=outs.get('fc2c'), acc2=ops.GradAcc())
         return params, layout, finish
 
     def _pack_planned(self, in_pad):

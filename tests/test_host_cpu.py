@@ -232,6 +232,45 @@ def test_pack_plan_equals_per_tensor_packing(n_conv):
     assert torch.equal(plan()['w'], conv.packed(20, 16))
 
 
+def test_pack_plan_of_attention_models_equals_per_tensor_packing():
+    """TransformerConv cells and the attention decoder head through ops.PackPlan: the layer-by-layer matrices of
+    GConvLSTM._pack_multi / TransformerConv.pack_many bit for bit, and every parameter gradient (hidden 8 -> padded planes,
+    6 input channels -> padded rows)."""
+    import torch
+    from model.model import GConvLSTM, TransformerConv
+    from model.seq2seq import Decoder, Encoder
+    from qtmpnn import ops
+    torch.manual_seed(0)
+    cell = GConvLSTM(6, 8, n_conv_layers=3, convolution_type='TransformerConv')
+    for p in cell.parameters():
+        p.data.normal_()
+    assert cell.plannable
+    names = [f'{br}_{g}' for br in ('conv_x', 'conv_h') for g in cell.GATES]
+    ref = cell._pack_multi(names)
+    params = cell.plan_params()
+    assert len(params) == len(list(cell.parameters()))
+    plan = ops.PackPlan(params, lambda T, fill: cell.plan_layout(T, fill, 'r.'))
+    first, cont = cell.pack_from(plan(), 'r.', None, None, (False, True))
+    assert first.multi is cont.multi and first.W is None
+    mats = lambda multi: [w for Ws, We, _ in multi for w in Ws + [We]]
+    for a, b in zip(mats(ref), mats(first.multi)):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert torch.equal(first.wc, torch.cat([cell.w_c_i, cell.w_c_f, cell.w_c_o])) and torch.equal(first.b, torch.cat([cell.b_i, cell.b_f, cell.b_c, cell.b_o]))
+    probe = lambda ms: sum((m * torch.linspace(-1, 1, m.numel()).view_as(m)).sum() for m in ms)
+    gr = torch.autograd.grad(probe(mats(ref)), params, allow_unused=True)
+    gg = torch.autograd.grad(probe(mats(first.multi)), params, allow_unused=True)
+    for a, b, prm in zip(gr, gg, params):
+        assert (a is None and not b.any()) or torch.allclose(a, b, atol=1e-6), prm.shape
+    dec = Decoder(4, 8, 0.1, n_layers=2, concat_layers_dim=1, convolution_type='TransformerConv', n_conv_layers=2)
+    for p in dec.parameters():
+        p.data.normal_()
+    assert dec.plannable and Encoder(6, 8, 0.1, n_layers=2, convolution_type='TransformerConv', n_conv_layers=2).plannable
+    pk = dec.pack(4)
+    assert pk['fc1'] is None and pk['fc2'] is None
+    for a, b in zip(TransformerConv.pack_many([dec.fc_out1, dec.fc_out2]), pk['heads']):
+        assert torch.equal(a.W, b.W) and torch.equal(a.We, b.We)
+
+
 def test_flat_params_views_and_single_tensor_update_equal_per_tensor_update():
     """qtmpnn.flat.FlatParams (CPU, plain torch): every parameter becomes a view of one buffer without changing values, keys
     or shapes; load_state_dict keeps the views; clip_grad_norm_ + Adam on the ONE flat tensor give the same weights as the
