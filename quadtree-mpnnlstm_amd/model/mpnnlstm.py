@@ -345,20 +345,24 @@ class NextFramePredictorS2S(NextFramePredictor):
 
     def train(self, loader_train, loader_test, climatology=None, n_epochs=200, lr=0.01, lr_decay=0.95, mask=None,
               high_interest_region=None, truncated_backprop=45, graph_structure=None, use_graph=False):
-        """The reference's training loop (mpnnlstm.py:186-387).  use_graph=True (beyond the reference; needs
-        truncated_backprop in (0, None)) replays the whole training step as a hipGraph: one graph is captured per
-        distinct batch shape on first sight (that batch's own update runs eagerly just before the capture) and the learning-rate
-        schedule keeps working because the capturable optimizer holds lr in a device tensor that StepLR updates in place."""
+        """The reference's training loop (mpnnlstm.py:186-387).  use_graph=True (beyond the reference) replays the whole training
+        step as a hipGraph: one graph is captured per distinct batch shape on first sight (that batch's own update runs eagerly just
+        before the capture) and the learning-rate schedule keeps working because the capturable optimizer holds lr in a device
+        tensor that StepLR updates in place.  It needs the step to be ONE rollout: truncated_backprop in (0, None), or a truncation
+        length that covers all output steps (the default 45 with the notebook's 10: the truncated loop is then a single chunk over
+        the whole rollout, without gradient clipping -- mpnnlstm.py:311 is commented out -- and that is what is captured)."""
         image_shape = loader_train.dataset.image_shape
         truncate_ = truncated_backprop not in (0, None)
-        if use_graph and truncate_:
-            raise ValueError('use_graph=True needs truncated_backprop=0 (the truncated loop re-runs the encoder per chunk)')
+        single_chunk = truncate_ and truncated_backprop >= self.output_timesteps
+        if use_graph and truncate_ and not single_chunk:
+            raise ValueError('use_graph=True needs truncated_backprop=0 or >= the output steps (the truncated loop re-runs the encoder '
+                             'per chunk)')
         if not self.training_initiated:
             self.initiate_training(lr, lr_decay, capturable=use_graph)
         graphed = {}
         if mask is not None:
             assert mask.shape == image_shape, f'Mask and image shapes do not match. Got {mask.shape} and {image_shape}'
-        truncate = truncated_backprop not in (0, None)
+        truncate = truncate_ and not (use_graph and single_chunk)
         st = time.time()
         batch_step = 0
         for epoch in range(n_epochs):
@@ -376,7 +380,8 @@ class NextFramePredictorS2S(NextFramePredictor):
                     key = (tuple(x.shape), tuple(y.shape), None if concat is None else tuple(concat.shape))
                     if key not in graphed:      # first sight of this batch shape: its update runs eagerly, then the capture
                         graphed[key] = self.make_graphed_step(x, y, concat, mask=mask, high_interest_region=high_interest_region,
-                                                              warmup=1, graph_structure=graph_structure)
+                                                              warmup=1, graph_structure=graph_structure,
+                                                              max_norm=None if single_chunk else 10.0)
                         loss = self.last_warmup_loss
                     else:
                         loss = graphed[key](x, y, concat)

@@ -12,7 +12,7 @@ import torch.nn as nn
 from model.graph_functions import Graph, _criterion
 from model.model import CONVOLUTION_KWARGS, GConvLSTM, _conv_class
 from qtmpnn import ops
-from qtmpnn.flat import flat_params
+from qtmpnn.flat import flat_params, param_list
 from qtmpnn.mesh import build_mesh, build_pixel_mesh
 
 
@@ -298,7 +298,7 @@ class Seq2Seq(nn.Module):
         vector, so the trainer's all-reduce, clip and Adam run on a single flat tensor (qtmpnn.flat)."""
         if not (self.encoder.plannable and self.decoder.plannable):
             return self.encoder.pack(enc_in_pad), None          # the decoder packs itself when the rollout starts
-        params = list(self.parameters())
+        params = param_list(self)
         fp = flat_params(self) if params[0].is_cuda else None
         plans = self.__dict__.setdefault('_plans', {})
         key = (enc_in_pad, params[0].device)

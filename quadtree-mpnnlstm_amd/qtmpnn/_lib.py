@@ -121,7 +121,14 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    """Handle of torch's current stream on the current device (the raw getter when this torch has it: the Stream object of
+    torch.cuda.current_stream() costs ~15 us to build, and an eager training step asks ~200 times)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

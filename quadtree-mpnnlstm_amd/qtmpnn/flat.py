@@ -9,9 +9,29 @@ operations on `FlatParams.param` / `.param.grad`.
 import torch
 
 
+def param_list(module):
+    """list(module.parameters()), remembered on the module: walking ~300 submodules costs ~1.5 ms and an eager training step asks
+    four times.  Every call re-checks that each (submodule, name) slot still holds the remembered Parameter -- 238 dict look-ups --
+    so a re-assigned Parameter is seen (then the list is rebuilt); modules or parameters REGISTERED after the first call are not
+    (nothing here does that: `del module.__dict__['_param_slots']` after such surgery)."""
+    slots = module.__dict__.get('_param_slots')
+    if slots is not None and all(m._parameters.get(n) is p for m, n, p in slots):
+        return [p for _, _, p in slots]
+    seen, slots = set(), []
+    for m in module.modules():
+        for n, p in m._parameters.items():
+            if p is not None and id(p) not in seen:
+                seen.add(id(p))
+                slots.append((m, n, p))
+    ref = list(module.parameters())
+    assert len(ref) == len(slots) and all(a is b[2] for a, b in zip(ref, slots))       # (same order as module.parameters())
+    module.__dict__['_param_slots'] = slots
+    return ref
+
+
 class FlatParams:
     def __init__(self, module):
-        self.params = list(module.parameters())
+        self.params = param_list(module)
         dev, dt = self.params[0].device, self.params[0].dtype
         assert all(p.device == dev and p.dtype == dt for p in self.params), 'parameters must share device and dtype'
         self.sizes = [p.numel() for p in self.params]
@@ -34,7 +54,7 @@ class FlatParams:
         base, es = self.buffer.data_ptr(), self.buffer.element_size()
         ok = all(p.data_ptr() == base + es * o for p, o in zip(self.params, self.offs))
         if ok and module is not None:
-            ps = list(module.parameters())
+            ps = param_list(module)
             ok = len(ps) == len(self.params) and all(a is b for a, b in zip(ps, self.params))
         return ok
 
@@ -65,7 +85,7 @@ def flat_params(module):
     """The module's FlatParams (made on first use, remade when the parameters were moved or replaced), or None when the
     parameters are not fp32 (model.double() / .half(): the packing gather and qt_flat_adam are fp32 kernels -- the callers
     then fall back to per-tensor packing and torch.optim.Adam)."""
-    if any(p.dtype != torch.float32 for p in module.parameters()):
+    if any(p.dtype != torch.float32 for p in param_list(module)):
         return None
     fp = module.__dict__.get('_flat_params')
     if fp is None or not fp.intact(module):

@@ -642,9 +642,12 @@ def test_transformer_rollout_batched_equals_single_and_is_deterministic():
         assert (a.grad is None) == (b.grad is None) and (a.grad is None or torch.equal(a.grad, b.grad))
 
 
-def test_train_loop_with_graph_replay_matches_eager_loop():
+@pytest.mark.parametrize('tb', [0, 45])
+def test_train_loop_with_graph_replay_matches_eager_loop(tb):
     """NextFramePredictorS2S.train(use_graph=True): the reference's epoch loop with the step replayed as a hipGraph gives the
-    eager loop's losses (one update per batch, learning-rate schedule included) on a tiny in-memory loader."""
+    eager loop's losses (one update per batch, learning-rate schedule included) on a tiny in-memory loader.  tb = 45: the
+    default truncation length, longer than the rollout -- the eager loop takes the truncated branch (one chunk, no clipping,
+    mpnnlstm.py:281-315) and the graph captures exactly that."""
     from model.mpnnlstm import NextFramePredictorS2S
     from qtmpnn import synthetic
 
@@ -662,7 +665,7 @@ def test_train_loop_with_graph_replay_matches_eager_loop():
         torch.manual_seed(4)
         nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=3, output_timesteps=2, device=dev(),
                                     model_kwargs=dict(hidden_size=8, dropout=0.0, n_layers=1))
-        nfp.train(Loader(items), Loader(items[:1]), n_epochs=4, lr=0.01, lr_decay=0.5, mask=mask, truncated_backprop=0,
+        nfp.train(Loader(items), Loader(items[:1]), n_epochs=4, lr=0.01, lr_decay=0.5, mask=mask, truncated_backprop=tb,
                   use_graph=use_graph)
         return nfp.train_loss, nfp.test_loss
 
@@ -670,6 +673,11 @@ def test_train_loop_with_graph_replay_matches_eager_loop():
     # (capacity-sized launches sum some reductions in another order than exact-size ones: 1e-4-level drift after 8 updates)
     for a, b in zip(tr_g + te_g, tr_e + te_e):
         assert abs(a - b) <= 1e-3 * abs(b) + 1e-7, (tr_g, tr_e, te_g, te_e)
+    if tb:          # a truncation shorter than the rollout re-runs the encoder per chunk: not one capturable step
+        nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=3, output_timesteps=2, device=dev(),
+                                    model_kwargs=dict(hidden_size=8, dropout=0.0, n_layers=1))
+        with pytest.raises(ValueError, match='use_graph'):
+            nfp.train(Loader(items), Loader(items[:1]), n_epochs=1, mask=mask, truncated_backprop=1, use_graph=True)
 
 
 def test_graphed_step_odd_shape_with_mask():
