@@ -302,9 +302,9 @@ class Seq2Seq(nn.Module):
         fp = flat_params(self) if params[0].is_cuda else None
         plans = self.__dict__.setdefault('_plans', {})
         key = (enc_in_pad, params[0].device)
-        ep, el, ef = self.encoder.plan_spec(enc_in_pad)
-        dp, dl, df = self.decoder.plan_spec(4)
         if key not in plans or not plans[key].same_params(params) or plans[key].flat is not fp:
+            ep, el, ef = self.encoder.plan_spec(enc_in_pad)
+            dp, dl, df = self.decoder.plan_spec(4)
             pos = {id(p): i for i, p in enumerate(params)}
             ei, di = [pos[id(p)] for p in ep], [pos[id(p)] for p in dp]
 
@@ -313,6 +313,8 @@ class Seq2Seq(nn.Module):
                 out.update({'d.' + k: v for k, v in dl([T[i] for i in di], fill).items()})
                 return out
             plans[key] = ops.PackPlan(params, layout, flat=fp)
+            plans[key].finish = (ef, df)        # (the closures depend on the modules and the input width only: kept with the plan)
+        ef, df = plans[key].finish
         outs = plans[key]()
         return (ef({k[2:]: v for k, v in outs.items() if k.startswith('e.')}),
                 df({k[2:]: v for k, v in outs.items() if k.startswith('d.')}))
