@@ -209,6 +209,32 @@ def spmm_roofline(nfp, batch, mask, reps=10, traffic_files=('r05_pmc_traffic.jso
                                           'this is NOT HBM traffic (rounds 1-3 reported it as `frac`)'},
            'bytes_formula': "per launch: k_spmm (one hop) 4(N+1) + 8E' + 8NC (SURVEY 8(d)); fused K-1 hops: forward "
                             "4(N+1) + 8E' + 4NC K, backward 4(N+1) + 8E' + 4NC (K+1)"}
+    # context, not a roof: what a plain streaming launch (torch.add: two operands read, one written) that moves the average launch's
+    # bytes takes under the SAME protocol (`reps` launches back to back in one graph: operands warm in the 256 MB Infinity Cache,
+    # like the recurrence's, whose input the previous launch of the step wrote) -- tools/exp_ceiling.py has the cold figures
+    nel = max(int(tot['bytes'] / n / 12), 1)
+    ca, cb, cc = (torch.randn(nel, device=dev) for _ in range(3))
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        torch.add(ca, cb, out=cc)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+        for _ in range(reps):
+            torch.add(ca, cb, out=cc)
+    g.replay()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    g.replay()
+    b.record()
+    b.synchronize()
+    copy_us = a.elapsed_time(b) * 1e3 / reps
+    del g
+    rec['plain_streaming_launch_same_bytes'] = {
+        'us': round(copy_us, 2), 'gbs': round(12.0 * nel / (copy_us * 1e-6) / 1e9, 1),
+        'kernel_time_over_this': round(tot['us'] / n / copy_us, 2),
+        'note': 'torch.add on operands of the average launch\'s bytes, same replay protocol; the practical ceiling of a launch this '
+                'short, not the 8 TB/s roof that `frac` is priced against'}
     if fused:
         rec['limiter'] = ('not HBM: one CU\'s vector issue + LDS per workgroup (SQ counters: profiles/r05_pmc_clip_sq.json); '
                           '`bound` names the roof the contract prices against')
