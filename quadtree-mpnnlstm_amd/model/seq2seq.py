@@ -23,7 +23,18 @@ def _ln_params(*norms):
     return torch.stack([p for n in norms for p in (n.weight, n.bias)])
 
 
-class Encoder(nn.Module):
+class _NoCachesInPickle:
+    """copy / pickle / torch.save(model) see the module as the reference's: the per-module caches built on first use (packing plans
+    with their closures, the flat parameter buffer's bookkeeping, the remembered parameter list) are dropped and rebuilt."""
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        for k in ('_plans', '_flat_params', '_param_slots'):
+            d.pop(k, None)
+        return d
+
+
+class Encoder(_NoCachesInPickle, nn.Module):
     """model/seq2seq.py:21-82.  Layer 0 continues from (H, C); upper layers restart from zero state on
     every call (:71) and one LayerNorm pair is shared by all layers (:49-50) -- reproduced as is."""
 
@@ -104,7 +115,7 @@ class Encoder(nn.Module):
         return torch.stack(hs), torch.stack(cs)
 
 
-class Decoder(nn.Module):
+class Decoder(_NoCachesInPickle, nn.Module):
     """model/seq2seq.py:84-187: n_layers GConvLSTM (always one conv layer, :106) carrying (H[i], C[i]),
     then norm_o + relu on the top layer's OUTPUT GATE, concat, fc_out1 -> relu -> fc_out2 -> dropout ->
     tanh -> + X[:, [0]]."""
@@ -268,7 +279,7 @@ class Decoder(nn.Module):
         return y, torch.stack(hs), torch.stack(cs)
 
 
-class Seq2Seq(nn.Module):
+class Seq2Seq(_NoCachesInPickle, nn.Module):
     """model/seq2seq.py:190-527 for the quadtree path (finite `thresh`)."""
 
     def __init__(self, hidden_size, dropout, thresh, input_timesteps=3, input_features=4, output_timesteps=5, n_layers=4,

@@ -271,6 +271,29 @@ def test_pack_plan_of_attention_models_equals_per_tensor_packing():
         assert torch.equal(a.W, b.W) and torch.equal(a.We, b.We)
 
 
+def test_model_with_cached_plans_pickles_and_copies():
+    """The per-module caches (packing plans with their closures, flat-buffer bookkeeping, remembered parameter list) stay out of
+    pickle / deepcopy: torch.save(model) and copy.deepcopy(model) work after a forward pass has built them, and the copy builds its own."""
+    import copy, pickle, torch
+    from model.seq2seq import Seq2Seq
+    from qtmpnn.flat import param_list
+    m = Seq2Seq(16, 0.1, 0.1, input_timesteps=3, input_features=1, output_timesteps=2, n_layers=1)
+    m._packs(4)
+    assert '_plans' in m.__dict__ and '_param_slots' in m.__dict__
+    m2 = pickle.loads(pickle.dumps(m))
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    assert not {'_plans', '_flat_params', '_param_slots'} & set(m2.__dict__)
+    m3 = copy.deepcopy(m)
+    m3._packs(4)
+    assert all(a is not b for a, b in zip(param_list(m), param_list(m3)))
+    # a re-assigned Parameter is seen by the remembered list
+    old = m.encoder.rnns[0].b_i
+    m.encoder.rnns[0].b_i = torch.nn.Parameter(torch.zeros(1, 16))
+    ps = param_list(m)
+    assert any(p is m.encoder.rnns[0].b_i for p in ps) and not any(p is old for p in ps)
+    assert all(a is b for a, b in zip(ps, m.parameters()))
+
+
 def test_flat_params_views_and_single_tensor_update_equal_per_tensor_update():
     """qtmpnn.flat.FlatParams (CPU, plain torch): every parameter becomes a view of one buffer without changing values, keys
     or shapes; load_state_dict keeps the views; clip_grad_norm_ + Adam on the ONE flat tensor give the same weights as the
