@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from qtmpnn import ops
-from qtmpnn.mesh import CONDITIONS as _CONDITIONS, Mesh, build_mesh, build_pixel_mesh
+from qtmpnn.mesh import CONDITIONS as _CONDITIONS, Mesh, build_mesh, build_pixel_mesh, host_mask
 
 CONDITIONS = list(_CONDITIONS)
 
@@ -112,7 +112,7 @@ def dist_angle(node0, node1, xx, yy):
 
 def flatten_pixelwise(img, mask):
     if mask is not None:
-        return img[:, ~torch.as_tensor(np.asarray(mask), dtype=torch.bool, device=img.device), :]
+        return img[:, ~torch.as_tensor(host_mask(mask), dtype=torch.bool, device=img.device), :]
     return img.reshape(img.shape[0], -1, img.shape[-1])
 
 
@@ -144,7 +144,7 @@ def unflatten_pixelwise(data, mask, image_shape):
     if mask is None:
         return data.reshape(*image_shape, c)
     img = torch.full((*image_shape, c), float('nan'), device=data.device)
-    img[~torch.as_tensor(np.asarray(mask), dtype=torch.bool, device=data.device), :] = data
+    img[~torch.as_tensor(host_mask(mask), dtype=torch.bool, device=data.device), :] = data
     return img
 
 

@@ -20,7 +20,7 @@ from model.utils import add_positional_encoding, get_n_params, int_to_datetime
 from qtmpnn import ops
 from qtmpnn.dist import allreduce_gradients
 from qtmpnn.flat import flat_params
-from qtmpnn.mesh import check_tile_errors
+from qtmpnn.mesh import check_tile_errors, host_mask
 
 try:                                        # pragma: no cover - optional dependency
     from torch.utils.tensorboard import SummaryWriter
@@ -43,10 +43,11 @@ def masked_mse(outputs, meshes, y, mask=None, binary=False):
     if y.dim() == 4:
         y = y.unsqueeze(0)
     mesh0 = meshes[0]
-    n_valid = mesh0.P if mask is None else int((~np.asarray(mask, dtype=bool)).sum())
+    mask = host_mask(mask)
+    n_valid = mesh0.P if mask is None else int((~mask).sum())
     if binary:
         y_hat = torch.stack([unflatten(o, ms, (ms.n, ms.m)).reshape(ms.B, ms.n, ms.m, 1) for o, ms in zip(outputs, meshes)], 1)
-        keep = torch.ones(mesh0.n, mesh0.m, dtype=torch.bool) if mask is None else ~torch.as_tensor(np.asarray(mask, dtype=bool))
+        keep = torch.ones(mesh0.n, mesh0.m, dtype=torch.bool) if mask is None else ~torch.as_tensor(mask)
         return torch.nn.functional.binary_cross_entropy(y_hat[:, :, keep], y.to(y_hat.device)[:, :, keep])
     y = y.to(outputs[0].device)
     part = ops.rollout_sse_partials(outputs, y, meshes) if y.shape[1] == len(outputs) else None     # all steps in one launch

@@ -13,7 +13,7 @@ from model.graph_functions import Graph, _criterion
 from model.model import CONVOLUTION_KWARGS, GConvLSTM, _conv_class
 from qtmpnn import ops
 from qtmpnn.flat import flat_params, param_list
-from qtmpnn.mesh import build_mesh, build_pixel_mesh
+from qtmpnn.mesh import build_mesh, build_pixel_mesh, host_mask
 
 
 _PROJECT_FC2 = __import__('os').environ.get('QT_NO_PROJECT_FC2') != '1'      # (A/B switch, diagnostics)
@@ -21,6 +21,13 @@ _PROJECT_FC2 = __import__('os').environ.get('QT_NO_PROJECT_FC2') != '1'      # (
 
 def _ln_params(*norms):
     return torch.stack([p for n in norms for p in (n.weight, n.bias)])
+
+
+def _raise_on_nan(t, what):
+    """image_to_graph's ValueError (graph_functions.py:626-627, 654-655) on the hot path's own tensors (one device sync)."""
+    bad = torch.isnan(t)
+    if bool(bad.any()):
+        raise ValueError(f'Found NaNs in {what} data {int(bad.sum())} / {t.numel()}')
 
 
 class _NoCachesInPickle:
@@ -360,6 +367,11 @@ class Seq2Seq(_NoCachesInPickle, nn.Module):
         x = x.float()
         B, T, n, m, c = x.shape
         self.mask = mask
+        if mask is not None and not (torch.is_tensor(mask) and mask.is_cuda) and host_mask(mask).all():
+            raise ValueError('the mask covers every pixel: no node is left to predict')
+        if not self.static_shapes:
+            _raise_on_nan(x, 'image')       # image_to_graph's check (graph_functions.py:626-627); not inside a captured step, where
+                                            # nothing may be read back: there a NaN ends as the reference's 'NaN loss :('
         if self.training:
             ops.advance_dropout_epoch(x.device)        # (a no-op unless an attention convolution with dropout ran before)
         if self.remesh_input:
@@ -540,6 +552,8 @@ class Seq2Seq(_NoCachesInPickle, nn.Module):
             val = ops.pool_image(img0.reshape(old.B, 1, old.P, 1), new, True)[0]
             parts = ops.remesh_transfer([*hidden, *cell], old, new, [h] * (2 * L))
         else:
+            if not self.static_shapes:
+                _raise_on_nan(data, 'image')        # (the reference un-flattens the output and image_to_graph checks the image)
             new = self._mesh_from_nodes(data, old, mask, high_interest_region)
             # rows stay float4-sized: the head's own 4-wide output when `data` is its column 0, else 4 copies
             b4 = data._base

@@ -37,6 +37,16 @@ def _mask_key(a):
     return (arr.shape, hash(arr.tobytes()))
 
 
+def host_mask(a):
+    """A mask as a host bool array (None stays None): numpy arrays, lists, CPU and CUDA tensors alike (a CUDA tensor is read back --
+    callers on a hot path keep the result)."""
+    if a is None:
+        return None
+    if torch.is_tensor(a):
+        a = a.detach().cpu().numpy()
+    return np.asarray(a) != 0
+
+
 def _as_u8(a, device, shape):
     """Device uint8 copy of a host mask, cached per (content, device): the upload happens once, outside any hipGraph capture
     (a warm-up step always precedes capture).  A mask whose content has not been seen before cannot be uploaded while a

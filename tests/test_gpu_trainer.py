@@ -282,3 +282,43 @@ def test_ice_exp_preset_experiments_golden(name):
     pred = nfp.predict(loader(g['x'], g['y'], full, 2, 3), clim_f, mask=mask, graph_structure=gs_f)
     assert pred.shape == g['pred'].shape and np.array_equal(np.isnan(pred), np.isnan(g['pred']))
     np.testing.assert_allclose(np.nan_to_num(pred), np.nan_to_num(g['pred']), rtol=2e-4, atol=2e-5)
+
+
+def test_edge_inputs_run_or_fail_loudly():
+    """Inputs at the edges of what the reference's callers pass: float64 arrays and non-contiguous tensors give the float32 loss; a
+    mask may be a numpy array, a CPU or a CUDA tensor; frames smaller than a base cell (8 x 8, 1 x 7) and constant frames (coarsest
+    possible input mesh) train; NaNs in the input raise image_to_graph's ValueError (graph_functions.py:626-627) on the eager step; a mask
+    that covers every pixel raises instead of dividing by zero nodes."""
+    from model.mpnnlstm import NextFramePredictorS2S
+    from qtmpnn import synthetic
+
+    def fresh(conv='ChebConv'):
+        torch.manual_seed(0)
+        nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=3, output_timesteps=2, device=dev(),
+                                    model_kwargs=dict(hidden_size=8, dropout=0.0, n_layers=1, convolution_type=conv))
+        nfp.initiate_training(lr=1e-3, lr_decay=0.95)
+        nfp.model.train()
+        return nfp
+    x, y = synthetic.make_batch(5, 0, 2, 3, 2, n_digits=1, pixel_noise=0.0)
+    xt, yt = torch.from_numpy(x).to(dev()), torch.from_numpy(y).to(dev())
+    mask = np.zeros((64, 64), dtype=bool)
+    mask[:, 40:] = True
+    base = float(fresh().train_step(xt, yt, None, mask=mask))
+    assert np.isfinite(base)
+    assert float(fresh().train_step(xt.double(), yt.double(), None, mask=mask)) == base
+    swapped = xt.permute(0, 1, 3, 2, 4).contiguous().permute(0, 1, 3, 2, 4)
+    assert not swapped.is_contiguous() and float(fresh().train_step(swapped, yt, None, mask=mask)) == base
+    for m in (torch.from_numpy(mask), torch.from_numpy(mask).to(dev()), mask.astype(np.uint8), mask.tolist()):
+        assert float(fresh().train_step(xt, yt, None, mask=m)) == base
+    for shape in ((8, 8), (1, 7)):
+        xs, ys = torch.rand(2, 3, *shape, 1, device=dev()), torch.rand(2, 2, *shape, 1, device=dev())
+        for conv in ('ChebConv', 'GCNConv', 'TransformerConv'):
+            assert np.isfinite(float(fresh(conv).train_step(xs, ys, None, mask=np.zeros(shape, dtype=bool)))), (shape, conv)
+    for conv in ('ChebConv', 'TransformerConv'):
+        assert np.isfinite(float(fresh(conv).train_step(torch.zeros_like(xt), torch.zeros_like(yt), None, mask=mask)))
+    bad = xt.clone()
+    bad[1, 0, 3, 3, 0] = float('nan')
+    with pytest.raises(ValueError, match='Found NaNs in image data 1 / '):
+        fresh().train_step(bad, yt, None, mask=mask)
+    with pytest.raises(ValueError, match='covers every pixel'):
+        fresh().train_step(xt, yt, None, mask=np.ones((64, 64), dtype=bool))
