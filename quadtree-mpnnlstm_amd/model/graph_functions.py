@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from qtmpnn import ops
+from qtmpnn._lib import on_device
 from qtmpnn.mesh import CONDITIONS as _CONDITIONS, Mesh, build_mesh, build_pixel_mesh, host_mask
 
 CONDITIONS = list(_CONDITIONS)
@@ -116,6 +117,7 @@ def flatten_pixelwise(img, mask):
     return img.reshape(img.shape[0], -1, img.shape[-1])
 
 
+@on_device(lambda img, *a, **k: img)
 def flatten(img, mapping, n_pixels_per_node, mask=None):
     """Image (n_samples, w, h, c) -> node means (n_samples, N, c) (graph_functions.py:391-419).
 
@@ -148,6 +150,7 @@ def unflatten_pixelwise(data, mask, image_shape):
     return img
 
 
+@on_device(lambda data, *a, **k: data)
 def unflatten(data, mapping, image_shape, mask=None):
     """Node values (..., N, c) -> image (..., w, h, c) (graph_functions.py:451-458); masked pixels get 0.
     For a B-clip Mesh the result has a leading clip axis (B, ..., w, h, c)."""
@@ -174,6 +177,7 @@ def unflatten(data, mapping, image_shape, mask=None):
     return img[0] if mesh.B == 1 else img
 
 
+@on_device(lambda img, *a, **k: img)
 def image_to_graph(img, thresh=0.05, max_grid_size=64, mask=None, high_interest_region=None, transform_func=None,
                    condition='max_larger_than', use_edge_attrs=True, resolution=0.25):
     """Quadtree mesh of an image stack (graph_functions.py:590-681).
@@ -225,6 +229,7 @@ def create_static_heterogeneous_graph(image_shape, max_grid_size, mask, high_int
     return g
 
 
+@on_device(lambda *a, device=None, **k: device)
 def create_static_homogeneous_graph(image_shape, max_grid_size, mask, use_edge_attrs=True, resolution=0.25, device=None):
     """Uniform preset mesh with fully masked cells removed (graph_functions.py:707-737)."""
     from qtmpnn.mesh import build_homogeneous_mesh

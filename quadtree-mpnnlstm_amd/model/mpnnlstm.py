@@ -18,8 +18,9 @@ from model.graph_functions import image_to_graph, unflatten, plot_contours
 from model.seq2seq import Seq2Seq
 from model.utils import add_positional_encoding, get_n_params, int_to_datetime
 from qtmpnn import ops
-from qtmpnn.dist import allreduce_gradients
+from qtmpnn.dist import all_reduce_sum, allreduce_gradients
 from qtmpnn.flat import flat_params
+from qtmpnn._lib import on_device
 from qtmpnn.mesh import check_tile_errors, host_mask
 
 try:                                        # pragma: no cover - optional dependency
@@ -124,6 +125,7 @@ class NextFramePredictorS2S(NextFramePredictor):
         plt.suptitle(f'Threshold: {thresh} | Num. nodes: {mesh.N}')
         return fig, axs[0]
 
+    @on_device(lambda self, *a, **k: self.device)
     def initiate_training(self, lr, lr_decay, capturable=False):
         self.loss_func_name = 'MSE' if not self.binary else 'BCE'
         if capturable:      # optimizer.step() inside a hipGraph needs device-side step counters and lr
@@ -175,7 +177,7 @@ class NextFramePredictorS2S(NextFramePredictor):
         if g is None:                          # gradients that did not come from the model-wide packing gather: by copy
             g = self.flat.gather_grads()
         if world > 1 or force:
-            torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=group)
+            all_reduce_sum(g, group)
             g.mul_(1.0 / world)
         self.flat.param.grad = g
         return [self.flat.param]
@@ -195,6 +197,7 @@ class NextFramePredictorS2S(NextFramePredictor):
             return d.get_world_size(self.process_group)
         return d.get_world_size() if d.is_available() and d.is_initialized() else 1
 
+    @on_device(lambda self, *a, **k: self.device)
     def train_step(self, x, y, concat_layers=None, mask=None, high_interest_region=None, graph_structure=None,
                    max_norm=10.0):
         """zero_grad -> forward -> masked MSE -> backward -> [all-reduce] -> clip_grad_norm_(10) -> Adam
@@ -206,6 +209,7 @@ class NextFramePredictorS2S(NextFramePredictor):
         check_tile_errors()          # (reads the device only when this step issued tile-resident launches; raises on a failed one)
         return loss.detach()
 
+    @on_device(lambda self, *a, **k: self.device)
     def truncated_backward(self, x, y, concat_layers, mask, high_interest_region=None, graph_structure=None,
                            truncated_backprop=45):
         """The reference's truncated-BPTT loop (mpnnlstm.py:281-315), quirks included: every chunk re-runs the encoder
@@ -231,6 +235,7 @@ class NextFramePredictorS2S(NextFramePredictor):
             losses.append(loss.detach())
         return losses
 
+    @on_device(lambda self, *a, **k: self.device)
     def make_graphed_step(self, x, y, concat_layers=None, mask=None, high_interest_region=None, max_norm=10.0,
                           warmup=2, graph_structure=None, force_multi=False):
         """Capture one whole training step in hipGraphs and return `step(x, y, concat) -> loss`.
@@ -328,6 +333,7 @@ class NextFramePredictorS2S(NextFramePredictor):
         check_tile_errors(always=uses_tiles)
         replays = [0]
 
+        @on_device(lambda *a, **k: self.device)
         def step(x, y, concat_layers=None):
             sx.copy_(x)
             sy.copy_(y)
@@ -335,7 +341,7 @@ class NextFramePredictorS2S(NextFramePredictor):
                 sc.copy_(concat_layers)
             graph.replay()
             if multi:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+                all_reduce_sum(flat, self.process_group)
                 graph2.replay()
             replays[0] += 1
             if uses_tiles and replays[0] % 64 == 0:
@@ -344,6 +350,7 @@ class NextFramePredictorS2S(NextFramePredictor):
         step.check = lambda: check_tile_errors(always=uses_tiles)
         return step
 
+    @on_device(lambda self, *a, **k: self.device)
     def train(self, loader_train, loader_test, climatology=None, n_epochs=200, lr=0.01, lr_decay=0.95, mask=None,
               high_interest_region=None, truncated_backprop=45, graph_structure=None, use_graph=False):
         """The reference's training loop (mpnnlstm.py:186-387).  use_graph=True (beyond the reference) replays the whole training
@@ -431,6 +438,7 @@ class NextFramePredictorS2S(NextFramePredictor):
                 for t in range(self.output_timesteps)]
         return torch.moveaxis(climatology[:, doys], 0, -1)
 
+    @on_device(lambda self, *a, **k: self.device)
     def predict(self, loader, climatology=None, mask=None, high_interest_region=None, graph_structure=None):
         """Inference over a loader -> (n_clips, T_out, W, H, 1) array (mpnnlstm.py:402-440)."""
         image_shape = loader.dataset.image_shape

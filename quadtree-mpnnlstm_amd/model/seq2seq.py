@@ -12,6 +12,7 @@ import torch.nn as nn
 from model.graph_functions import Graph, _criterion
 from model.model import CONVOLUTION_KWARGS, GConvLSTM, _conv_class
 from qtmpnn import ops
+from qtmpnn._lib import on_device
 from qtmpnn.flat import flat_params, param_list
 from qtmpnn.mesh import build_mesh, build_pixel_mesh, host_mask
 
@@ -358,6 +359,7 @@ class Seq2Seq(_NoCachesInPickle, nn.Module):
                           high_interest_region=hir, max_size=self.max_grid_size, static=self.static_shapes, tiles=False)
 
     # -- encoder ------------------------------------------------------------------------
+    @on_device(lambda self, *a, **k: self.encoder.norm_h.weight)
     def process_inputs(self, x, mask=None, high_interest_region=None, graph_structure=None):
         """model/seq2seq.py:254-336.  x: (T_in, W, H, C) or (B, T_in, W, H, C)."""
         self._single = x.dim() == 4
@@ -453,6 +455,7 @@ class Seq2Seq(_NoCachesInPickle, nn.Module):
         self.graph.pyg.x = rows if (c == 1 and fpad == 0) else torch.cat([rows[:, :1], rows[:, c:c + 3]], dim=1)
 
     # -- decoder + remesh ----------------------------------------------------------------
+    @on_device(lambda self, *a, **k: self.encoder.norm_h.weight)
     def unroll_output(self, unroll_steps, y, concat_layers=None, teacher_forcing_ratio=0.5, mask=None,
                       high_interest_region=None, remesh_every=1):
         """model/seq2seq.py:339-398.  concat_layers: (T_out, W, H, 1) or (B, T_out, W, H, 1)."""
@@ -519,6 +522,7 @@ class Seq2Seq(_NoCachesInPickle, nn.Module):
         else:
             self.update_without_remesh(output, g.hidden, g.cell, teacher_force, teacher_input)
 
+    @on_device(lambda self, *a, **k: self.encoder.norm_h.weight)
     def forward(self, x, y=None, concat_layers=None, teacher_forcing_ratio=0.5, mask=None, high_interest_region=None,
                 graph_structure=None, remesh_every=1):
         self.process_inputs(x, mask=mask, high_interest_region=high_interest_region, graph_structure=graph_structure)

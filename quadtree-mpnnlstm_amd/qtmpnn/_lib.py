@@ -132,6 +132,27 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def on_device(get):
+    """Decorator for the entry points a caller reaches first (trainer methods, Seq2Seq.forward, image_to_graph ...): the library
+    launches on the CURRENT device's current stream, so a model that lives on cuda:1 while the process's current device is cuda:0
+    must switch for the duration of the call, like every torch op does per operand.  get(*args, **kw) -> device | tensor | None."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*a, **k):
+            d = get(*a, **k)
+            d = getattr(d, 'device', d)
+            if d is not None and not isinstance(d, torch.device):
+                d = torch.device(d)
+            if d is None or d.type != 'cuda' or d.index is None or d.index == torch.cuda.current_device():
+                return fn(*a, **k)
+            with torch.cuda.device(d):
+                return fn(*a, **k)
+        return wrapper
+    return deco
+
+
 def call(name, *args):
     """Call an entry point on the current torch stream; raises RuntimeError on a non-zero code."""
     lib = load()

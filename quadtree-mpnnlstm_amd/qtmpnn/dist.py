@@ -49,6 +49,26 @@ class HostBarrier:
             dist.barrier(group=self.group)
 
 
+def _via_host(t, group):
+    """True when a CUDA tensor's collective runs over gloo (the one-GPU rehearsal transport of the tests; RCCL is the product's)."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def all_reduce_sum(t, group=None):
+    """Sum `t` over the group in place, ordered on torch's current stream like any other launch.  Over RCCL that is what
+    dist.all_reduce does.  Over gloo a CUDA tensor is staged through host memory HERE, with plain synchronous copies: gloo's own
+    CUDA staging (pinned buffers on side streams) once handed two ranks that share one GPU a stale gradient (a 1.7 % loss jump in
+    one of ~15 runs of tests/test_gpu_dist.py; the RCCL path is bit-exact against the single-graph step every time)."""
+    if _via_host(t, group):
+        h = t.detach().cpu()                # (synchronises with the producing stream)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        torch.cuda.current_stream().synchronize()
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def shard_range(n_items, rank, world):
     """Contiguous shard [lo, hi) of n_items clips for `rank` (equal sizes; n_items % world == 0)."""
     assert n_items % world == 0, f'{n_items} clips do not split evenly over {world} ranks'
@@ -66,7 +86,7 @@ def allreduce_gradients(params, group=None, force=False):
     if world == 1 and not force:
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_sum(flat, group)
     flat.div_(world)
     off = 0
     for p in params:
@@ -85,7 +105,12 @@ def broadcast_parameters(module, src=0, group=None):
         return
     params = list(module.parameters())
     flat = torch.cat([p.detach().reshape(-1) for p in params])
-    dist.broadcast(flat, src=src, group=group)
+    if _via_host(flat, group):
+        h = flat.cpu()
+        dist.broadcast(h, src=src, group=group)
+        flat.copy_(h)
+    else:
+        dist.broadcast(flat, src=src, group=group)
     off = 0
     with torch.no_grad():
         for p in params:

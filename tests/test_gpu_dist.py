@@ -78,7 +78,7 @@ def test_two_ranks_equal_one_process():
     # steps 2 and 3 of the reference correspond to the two graphed steps; global loss = mean over ranks
     for i in range(2):
         glob = 0.5 * (res[0][1][i] + res[1][1][i])
-        assert abs(glob - ref_losses[i + 1]) <= 1e-4 * abs(ref_losses[i + 1]), (i, glob, ref_losses)
+        assert abs(glob - ref_losses[i + 1]) <= 1e-4 * abs(ref_losses[i + 1]), (i, glob, ref_losses, res[0][1], res[1][1])
     for k in ref:
         np.testing.assert_allclose(res[0][2][k], res[1][2][k], rtol=0, atol=0, err_msg=f'ranks diverged: {k}')
         np.testing.assert_allclose(res[0][2][k], ref[k].numpy(), rtol=2e-3, atol=2e-4, err_msg=k)
