@@ -294,9 +294,22 @@ class Seq2Seq(_NoCachesInPickle, nn.Module):
                  n_conv_layers=2, transform_func=None, condition='max_larger_than', remesh_input=False,
                  convolution_type='ChebConv', rnn_type='LSTM', binary=False, dummy=False, device=None, debug=False):
         super().__init__()
-        if hidden_size % 4:
-            raise ValueError(f'hidden_size={hidden_size}: the HIP path moves node rows as 16-byte vectors, so the hidden size '
-                             'must be a multiple of 4 (the reference scripts use 16 and 32)')
+        # a node's row is spread over hidden / 4 lanes of a 64-lane wave (float4 each): the cell kernels are built for the powers of
+        # two 8 .. 128, the attention kernels for 8, 16 and 32; said here, not by the first launch
+        sizes = (8, 16, 32) if convolution_type == 'TransformerConv' else (8, 16, 32, 64, 128)
+        if hidden_size not in sizes:
+            raise ValueError(f'hidden_size={hidden_size}: the HIP kernels for convolution_type={convolution_type!r} are built for '
+                             f'hidden sizes {sizes} (the reference scripts use 16 and 32)')
+        if convolution_type in ('ChebConv', 'GCNConv'):
+            # the stacked convolutions of a cell are composed into ONE Chebyshev series over [X | H]: its gate GEMM reduces over
+            # (hops + 1) x (input + hidden channels) + bias rows, and the GEMM kernels take at most 512 (csrc/cheb.hip: MAXQ)
+            kc = n_conv_layers * (2 if convolution_type == 'ChebConv' else 1) + 1
+            pad4 = lambda v: v + (-v) % 4
+            widths = [pad4(input_features) + hidden_size, 4 + hidden_size] + ([2 * hidden_size] if n_layers > 1 else [])
+            red = kc * max(widths) + pad4(kc)
+            if red > 512:
+                raise ValueError(f'hidden_size={hidden_size} with n_conv_layers={n_conv_layers}, n_layers={n_layers}: the composed gate '
+                                 f'matrix would have {red} rows, the GEMM kernels take 512 (fewer conv layers or a smaller hidden size)')
         self.encoder = Encoder(input_features, hidden_size, dropout, n_layers=n_layers, convolution_type=convolution_type,
                                rnn_type=rnn_type, n_conv_layers=n_conv_layers, dummy=dummy)
         self.decoder = Decoder(1 + 3, hidden_size, dropout, n_layers=n_layers, concat_layers_dim=1,
@@ -368,6 +381,9 @@ class Seq2Seq(_NoCachesInPickle, nn.Module):
             x = x.unsqueeze(0)
         x = x.float()
         B, T, n, m, c = x.shape
+        if c + 3 != self.encoder.rnns[0].in_channels:
+            raise ValueError(f'the frames have {c} channels, the model was built for input_features = '
+                             f'{self.encoder.rnns[0].in_channels - 3} (+ 2 position channels + the node size)')
         self.mask = mask
         if mask is not None and not (torch.is_tensor(mask) and mask.is_cuda) and host_mask(mask).all():
             raise ValueError('the mask covers every pixel: no node is left to predict')

@@ -322,3 +322,26 @@ def test_edge_inputs_run_or_fail_loudly():
         fresh().train_step(bad, yt, None, mask=mask)
     with pytest.raises(ValueError, match='covers every pixel'):
         fresh().train_step(xt, yt, None, mask=np.ones((64, 64), dtype=bool))
+
+
+@pytest.mark.parametrize('conv,h,nl,nc', [('ChebConv', 8, 1, 2), ('ChebConv', 32, 2, 3), ('ChebConv', 64, 1, 3), ('ChebConv', 128, 1, 1),
+                                          ('ChebConv', 16, 2, 4), ('GCNConv', 16, 1, 2), ('GCNConv', 64, 2, 2), ('GCNConv', 128, 1, 2),
+                                          ('TransformerConv', 8, 1, 2), ('TransformerConv', 16, 2, 1), ('TransformerConv', 32, 1, 2)])
+def test_every_supported_hidden_size_trains(conv, h, nl, nc):
+    """The hidden sizes the kernels are built for, at the largest stacks whose composed gate matrix still fits the GEMM kernels' 512
+    rows (Seq2Seq refuses the others at construction: tests/test_host_cpu.py): one training step through the trainer runs and moves
+    the loss; a frame with the wrong channel count is refused by name."""
+    from model.mpnnlstm import NextFramePredictorS2S
+    from qtmpnn import synthetic
+    torch.manual_seed(0)
+    nfp = NextFramePredictorS2S(thresh=0.1, input_features=1, input_timesteps=3, output_timesteps=2, device=dev(),
+                                model_kwargs=dict(hidden_size=h, dropout=0.0, n_layers=nl, convolution_type=conv, n_conv_layers=nc))
+    nfp.initiate_training(lr=1e-3, lr_decay=0.95)
+    nfp.model.train()
+    x, y = synthetic.make_batch(5, 0, 2, 3, 2, n_digits=1, pixel_noise=0.0)
+    xt, yt = torch.from_numpy(x).to(dev()), torch.from_numpy(y).to(dev())
+    mask = np.zeros((64, 64), dtype=bool)
+    l0, l1 = float(nfp.train_step(xt, yt, None, mask=mask)), float(nfp.train_step(xt, yt, None, mask=mask))
+    assert np.isfinite(l0) and np.isfinite(l1) and l1 != l0
+    with pytest.raises(ValueError, match='channels'):
+        nfp.train_step(torch.cat([xt, xt], dim=-1), yt, None, mask=mask)

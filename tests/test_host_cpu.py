@@ -195,6 +195,16 @@ def test_unsupported_variants_raise_clearly():
         Seq2Seq(16, 0.1, 0.1, convolution_type='GATConv')
     with pytest.raises(AssertionError):
         Seq2Seq(16, 0.1, 0.1, convolution_type='NoSuchConv')
+    for h, conv in ((12, 'ChebConv'), (4, 'GCNConv'), (64, 'TransformerConv'), (20, 'TransformerConv')):
+        with pytest.raises(ValueError, match='hidden_size'):            # (said at construction, not by the first launch)
+            Seq2Seq(h, 0.1, 0.1, convolution_type=conv)
+    for h, conv in ((64, 'ChebConv'), (128, 'GCNConv'), (8, 'TransformerConv')):
+        Seq2Seq(h, 0.1, 0.1, convolution_type=conv, n_layers=1, n_conv_layers=1)
+    with pytest.raises(ValueError, match='gate'):           # 5 hops x (4 + 128) channels: more rows than the gate GEMM takes
+        Seq2Seq(128, 0.1, 0.1, convolution_type='ChebConv', n_layers=1, n_conv_layers=2)
+    with pytest.raises(ValueError, match='gate'):           # upper layers see [H below | H]: 5 x 128
+        Seq2Seq(64, 0.1, 0.1, convolution_type='ChebConv', n_layers=2, n_conv_layers=2)
+    Seq2Seq(32, 0.1, 0.1, convolution_type='ChebConv', n_layers=4, n_conv_layers=3)        # (7 x 64 + 8 = 456)
 
 
 @pytest.mark.parametrize('n_conv', [1, 2])
