@@ -59,7 +59,7 @@ def quadtree_decompose(img, padding=0, thresh=0.05, max_size=8, mask=None, high_
                        transform_func=None, condition='max_larger_than'):
     """Label every pixel with its quadtree leaf (graph_functions.py:145-259); returns an int64 array,
     -1 = masked.  `img` is a 2-D array or tensor; the work happens on the GPU."""
-    assert max_size & (max_size - 1) == 0
+    assert max_size & (max_size - 1) == 0, f'max_size / max_grid_size = {max_size}: must be a power of two'
     assert condition in CONDITIONS
     assert padding == 0, 'padding is unused by the reference call sites'
     dev = _device_of(img)

@@ -44,6 +44,10 @@ def masked_mse(outputs, meshes, y, mask=None, binary=False):
     if y.dim() == 4:
         y = y.unsqueeze(0)
     mesh0 = meshes[0]
+    want = (mesh0.B, len(outputs), mesh0.n, mesh0.m, 1)
+    if tuple(y.shape) != want:      # (the loss kernels read B x P targets per step straight from this buffer)
+        raise ValueError(f'targets of shape {tuple(y.shape)} for {mesh0.B} clip(s) x {len(outputs)} output steps of {mesh0.n} x {mesh0.m} '
+                         f'frames: expected (T_out, W, H, 1) or (B, T_out, W, H, 1) = {want}')
     mask = host_mask(mask)
     n_valid = mesh0.P if mask is None else int((~mask).sum())
     if binary:

@@ -399,6 +399,8 @@ class Seq2Seq(_NoCachesInPickle, nn.Module):
         if graph_structure is not None:
             # preset static mesh (:288-294): node size feature = n_pixels_per_node / 4 ("Don't assume 4 !!" in the reference)
             mesh = graph_structure['mapping'].for_batch(B)
+            if (mesh.n, mesh.m) != (n, m):
+                raise ValueError(f'graph_structure was built for {mesh.n} x {mesh.m} frames, the input frames are {n} x {m}')
             size = (mesh.npix / 4.0).unsqueeze(1)
         elif self.thresh == -np.inf:
             mesh = build_pixel_mesh(B, n, m, mask, x.device)            # every unmasked pixel a node (:629-630)

@@ -251,7 +251,7 @@ def build_mesh(src=None, prev=None, B=1, n=None, m=None, thresh=0.05, condition=
             take that path (K >= 4: the encoder's stacks of two or more ChebConvs).
     """
     assert condition in CONDITIONS, f'unknown condition {condition}'
-    assert max_size & (max_size - 1) == 0
+    assert max_size & (max_size - 1) == 0, f'max_size / max_grid_size = {max_size}: must be a power of two'
     if src is not None:
         _lib.require_cuda(src, 'criterion image')
         src = src.contiguous().float()

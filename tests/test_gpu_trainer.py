@@ -322,6 +322,14 @@ def test_edge_inputs_run_or_fail_loudly():
         fresh().train_step(bad, yt, None, mask=mask)
     with pytest.raises(ValueError, match='covers every pixel'):
         fresh().train_step(xt, yt, None, mask=np.ones((64, 64), dtype=bool))
+    # targets the loss kernels would read out of bounds, and a preset mesh of another frame size: refused by name
+    for bad_y in (torch.zeros(2, 2, 32, 32, 1, device=dev()), yt[..., 0], yt[:, :1], torch.cat([yt, yt], dim=-1)):
+        with pytest.raises(ValueError, match='targets of shape'):
+            fresh().train_step(xt, bad_y, None, mask=mask)
+    from model.graph_functions import create_static_heterogeneous_graph
+    small = create_static_heterogeneous_graph((32, 32), 8, np.zeros((32, 32), dtype=bool), use_edge_attrs=False, device=dev())
+    with pytest.raises(ValueError, match='graph_structure was built for 32 x 32'):
+        fresh().train_step(xt, yt, None, mask=mask, graph_structure=small)
 
 
 @pytest.mark.parametrize('conv,h,nl,nc', [('ChebConv', 8, 1, 2), ('ChebConv', 32, 2, 3), ('ChebConv', 64, 1, 3), ('ChebConv', 128, 1, 1),
