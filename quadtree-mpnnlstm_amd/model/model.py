@@ -63,7 +63,7 @@ class ChebConv(nn.Module):
         return torch.cat([w, tail], dim=0)
 
     def forward(self, x, edge_index, edge_weight=None):
-        mesh = _need_mesh(edge_index)
+        mesh = _need_mesh(edge_index, x)
         pad = (-x.shape[1]) % 4
         xin = nn.functional.pad(x, (0, pad)) if pad else x
         opad = (-self.out_channels) % 4
@@ -171,7 +171,7 @@ class TransformerConv(nn.Module):
         return out
 
     def forward(self, x, edge_index, edge_weight=None, packed=None):
-        mesh = _need_mesh(edge_index)
+        mesh = _need_mesh(edge_index, x)
         cin, cout = self.in_channels, self.out_channels
         cin_p, cp = cin + (-cin) % 4, cout + (-cout) % 4
         x = x[:, :cin] if x.shape[1] > cin_p else x
@@ -191,10 +191,15 @@ class PackedConv:
         self.W, self.We, self.acc, self.acc_e = W, We, acc, acc_e
 
 
-def _need_mesh(edge_index):
+def _need_mesh(edge_index, *node_tensors):
+    """The Mesh a module received in the reference's edge_index slot; node_tensors: (N, c) operands whose rows must be the mesh's
+    nodes -- the kernels walk the mesh's rows and read these buffers unchecked."""
     if not isinstance(edge_index, Mesh):
         raise TypeError('pass the Mesh (graph_structure["mapping"]) where the reference passes edge_index: '
                         'the HIP path keeps adjacency and normalisation in the Mesh')
+    for t in node_tensors:
+        if t is not None and t.shape[0] != edge_index.N:
+            raise ValueError(f'a node tensor of {t.shape[0]} rows for a mesh of {edge_index.N} nodes')
     return edge_index
 
 
@@ -491,7 +496,7 @@ class GConvLSTM(nn.Module):
         pad = (-X.shape[1]) % 4
         if pad:
             X = nn.functional.pad(X, (0, pad))
-        return self.step(X, _need_mesh(edge_index), H, C, self.pack(X.shape[1], None, (H is not None,))[0])
+        return self.step(X, _need_mesh(edge_index, X, H, C), H, C, self.pack(X.shape[1], None, (H is not None,))[0])
 
 
 class PackedCell:

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from model.graph_functions import Graph, _criterion
-from model.model import CONVOLUTION_KWARGS, GConvLSTM, _conv_class
+from model.model import CONVOLUTION_KWARGS, GConvLSTM, _conv_class, _need_mesh
 from qtmpnn import ops
 from qtmpnn._lib import on_device
 from qtmpnn.flat import flat_params, param_list
@@ -119,6 +119,7 @@ class Encoder(_NoCachesInPickle, nn.Module):
         pad = (-X.shape[1]) % 4
         if pad:
             X = nn.functional.pad(X, (0, pad))
+        _need_mesh(edge_index, X, H, C)          # (H, C: the first layer's state, model/seq2seq.py:64-66)
         hs, cs = self.run(X, edge_index, H, C, packed if packed is not None else self.pack(X.shape[1]))
         return torch.stack(hs), torch.stack(cs)
 
@@ -283,6 +284,7 @@ class Decoder(_NoCachesInPickle, nn.Module):
     def forward(self, X, edge_index, edge_weight, concat_layers, H, C, packed=None):
         pad = (-X.shape[1]) % 4
         Xp = nn.functional.pad(X, (0, pad)) if pad else X
+        _need_mesh(edge_index, Xp, concat_layers, *H, *C)
         y, hs, cs, _ = self.run(Xp, edge_index, concat_layers, H, C, packed if packed is not None else self.pack(Xp.shape[1]))
         return y, torch.stack(hs), torch.stack(cs)
 

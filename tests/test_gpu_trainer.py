@@ -353,3 +353,40 @@ def test_every_supported_hidden_size_trains(conv, h, nl, nc):
     assert np.isfinite(l0) and np.isfinite(l1) and l1 != l0
     with pytest.raises(ValueError, match='channels'):
         nfp.train_step(torch.cat([xt, xt], dim=-1), yt, None, mask=mask)
+
+
+def test_modules_refuse_node_tensors_of_another_mesh():
+    """The modules take the Mesh where the reference takes edge_index; their kernels walk the mesh's rows and read the node tensors
+    unchecked, so a tensor with another row count (the reference would die in an index error inside PyG) is refused before a launch."""
+    from model.model import ChebConv, GConvLSTM, TransformerConv
+    from model.seq2seq import Decoder, Encoder
+    from qtmpnn import synthetic
+    from qtmpnn.mesh import build_mesh
+    c = synthetic.make_clip(31, canvas=(64, 64), n_digits=1, n_frames=1, pixel_noise=0.0)
+    mesh = build_mesh(src=torch.from_numpy(c[:, ..., 0]).to(dev()), thresh=0.1, mask=None)
+    N = mesh.N
+    good, short = torch.randn(N, 4, device=dev()), torch.randn(N - 1, 4, device=dev())
+    h_ok, h_bad = torch.randn(N, 8, device=dev()), torch.randn(N + 3, 8, device=dev())
+    for conv in (ChebConv(4, 8).to(dev()), TransformerConv(4, 8).to(dev())):
+        assert conv(good, mesh).shape == (N, 8)
+        with pytest.raises(ValueError, match='rows for a mesh'):
+            conv(short, mesh)
+    cell = GConvLSTM(4, 8, 1, 'ChebConv').to(dev())
+    assert cell(good, mesh, None, h_ok, h_ok)[1].shape == (N, 8)
+    for args in ((short, mesh, None, h_ok, h_ok), (good, mesh, None, h_bad, h_ok), (good, mesh, None, h_ok, h_bad)):
+        with pytest.raises(ValueError, match='rows for a mesh'):
+            cell(*args)
+    enc = Encoder(4, 8, 0.0, n_layers=1, convolution_type='ChebConv', n_conv_layers=1).to(dev())
+    dec = Decoder(4, 8, 0.0, n_layers=1, concat_layers_dim=1, convolution_type='ChebConv', n_conv_layers=1).to(dev())
+    H, C = enc(good, mesh)
+    assert H.shape == (1, N, 8)
+    with pytest.raises(ValueError, match='rows for a mesh'):
+        enc(short, mesh)
+    with pytest.raises(ValueError, match='rows for a mesh'):
+        enc(good, mesh, None, H=h_bad, C=h_ok)
+    y, H2, C2 = dec(good, mesh, None, torch.randn(N, 1, device=dev()), H, C)
+    assert y.shape == (N, 1)
+    with pytest.raises(ValueError, match='rows for a mesh'):
+        dec(good, mesh, None, torch.randn(N - 2, 1, device=dev()), H, C)
+    with pytest.raises(ValueError, match='rows for a mesh'):
+        dec(good, mesh, None, torch.randn(N, 1, device=dev()), H[:, :-1], C)
