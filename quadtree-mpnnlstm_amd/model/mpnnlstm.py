@@ -373,7 +373,8 @@ class NextFramePredictorS2S(NextFramePredictor):
             self.initiate_training(lr, lr_decay, capturable=use_graph)
         graphed = {}
         if mask is not None:
-            assert mask.shape == image_shape, f'Mask and image shapes do not match. Got {mask.shape} and {image_shape}'
+            mshape = tuple(host_mask(mask).shape) if not hasattr(mask, 'shape') else tuple(mask.shape)
+            assert mshape == tuple(image_shape), f'Mask and image shapes do not match. Got {mshape} and {image_shape}'
         truncate = truncate_ and not (use_graph and single_chunk)
         st = time.time()
         batch_step = 0
